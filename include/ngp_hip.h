@@ -1,0 +1,193 @@
+/*
+ * ngp_hip.h -- C ABI of libngp_hip.so: the MI355X (gfx950) implementation of torch-ngp's instant-ngp
+ * hot path (gridencoder, shencoder, raymarching, ffmlp).
+ *
+ * This is the drop-in boundary.  Each entry point replaces one callable of the reference's pybind
+ * `_backend` modules (cited per function, paths relative to the reference checkout) and keeps its
+ * argument order and meaning; the differences forced by a C ABI are uniform:
+ *   - at::Tensor arguments become raw DEVICE pointers (the caller owns every buffer, exactly as in
+ *     the reference where the Python wrapper allocates all outputs and workspaces);
+ *   - at::optional<at::Tensor> becomes a pointer that may be NULL;
+ *   - the element type that the reference dispatches on (AT_DISPATCH_FLOATING_TYPES_AND_HALF) is an
+ *     explicit `dtype` code; fp64 is not provided;
+ *   - a trailing `stream` (a hipStream_t passed as void*; NULL = the legacy default stream the
+ *     reference launches on);
+ *   - every function returns 0 on success and a non-zero NGP_ERR_* code on failure, with a
+ *     human-readable message available from ngp_last_error() (the Python binding turns it into the
+ *     RuntimeError the reference's TORCH_CHECK / std::runtime_error would have produced).
+ * No function allocates device memory, synchronises the device, or touches the host copy of any
+ * buffer.  All launches are asynchronous on `stream`.
+ *
+ * Contracts kept from the reference: buffers the reference requires pre-zeroed stay caller-zeroed
+ * (xyzs/dirs/deltas, grad_embeddings, grad_inputs of the grid and SH backward, grad_sigmas/grad_rgbs,
+ * grad_weights); `counter` is read-modify-written.
+ */
+#ifndef NGP_HIP_H
+#define NGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ngp_stream_t; /* hipStream_t */
+
+enum {
+    NGP_OK = 0,
+    NGP_ERR_INVALID = 1, /* bad argument (unsupported D/C/hidden_dim, NULL pointer, misaligned size) */
+    NGP_ERR_LAUNCH = 2,  /* HIP reported a launch error */
+    NGP_ERR_DEVICE = 3   /* no usable gfx950 device / runtime error */
+};
+
+enum { NGP_F32 = 0, NGP_F16 = 1 };
+
+#define NGP_MAX_LEVELS 32 /* grid encoder: L <= 32 */
+
+/* message of the last failing call on the calling thread ("" if none) */
+const char* ngp_last_error(void);
+/* ABI version of this header (bumped on any signature change) */
+int ngp_abi_version(void);
+/* gfx architecture string the library was compiled for ("gfx950") */
+const char* ngp_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * gridencoder      (reference: gridencoder/src/gridencoder.h:12-15, bindings.cpp:5-9)
+ * --------------------------------------------------------------------------------------------- */
+
+/* replaces grid_encode_forward (gridencoder.cu:448-471).
+ * inputs [B,D] fp32 in [0,1]; embeddings [sO,C] dtype; offsets [L+1] int32 (device);
+ * outputs [L,B,C] dtype; dy_dx [B,L*D*C] dtype or NULL.  D in {2,3,4,5}, C in {1,2,4,8}, L <= 32.
+ * gridtype 0 = hash, 1 = tiled; interp 0 = linear, 1 = smoothstep. */
+int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                            uint32_t gridtype, int align_corners, uint32_t interp, int dtype, ngp_stream_t stream);
+
+/* replaces grid_encode_backward (gridencoder.cu:473-503).
+ * grad [L,B,C] dtype; grad_embeddings [sO,C] dtype, pre-zeroed, accumulated with hardware atomics
+ * (packed fp16 when dtype is F16 and C is even, as the reference); dy_dx / grad_inputs [B,D] dtype
+ * both NULL or both non-NULL. */
+int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                             void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                             uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                             uint32_t interp, int dtype, ngp_stream_t stream);
+
+/* replaces grad_total_variation (gridencoder.cu:639-645): inputs [B,D] dtype in [0,1]; adds into grad [sO,C]. */
+int ngp_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,
+                             float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             uint32_t gridtype, int align_corners, int dtype, ngp_stream_t stream);
+
+/* Diagnostic (no reference counterpart): the per-corner table entry index (before *C) the kernels
+ * use, [L,B,2^D] uint32, 0xFFFFFFFF for out-of-range points.  Lets the parity suite check grid
+ * indexing bit-for-bit. */
+int ngp_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_t* indices, uint32_t B, uint32_t D,
+                            uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                            ngp_stream_t stream);
+
+/* The per-level (scale, resolution) table every grid kernel uses (host computation, no device work):
+ * scale_l = fma(exp2((float)l*S), H, -1) in fp32 with a correctly rounded exp2; resolution_l = ceil(scale_l)+1.
+ * Restates gridencoder.cu:137-139 with a reproducible exp2. */
+int ngp_grid_level_table(uint32_t L, float S, uint32_t H, float* scale_out, uint32_t* resolution_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * shencoder        (reference: shencoder/src/shencoder.h:9-10, bindings.cpp:5-8)
+ * --------------------------------------------------------------------------------------------- */
+
+/* replaces sh_encode_forward (shencoder.cu:400-417): inputs [B,3]; outputs [B,C*C]; dy_dx [B,3*C*C] or NULL;
+ * D must be 3, C (number of bands) in 1..8. */
+int ngp_sh_encode_forward(const void* inputs, void* outputs, uint32_t B, uint32_t D, uint32_t C, void* dy_dx,
+                          int dtype, ngp_stream_t stream);
+/* replaces sh_encode_backward (shencoder.cu:419-439): grad_inputs[b,d] += sum_ch grad[b,ch]*dy_dx[b,d,ch] */
+int ngp_sh_encode_backward(const void* grad, const void* inputs, uint32_t B, uint32_t D, uint32_t C,
+                           const void* dy_dx, void* grad_inputs, int dtype, ngp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * raymarching      (reference: raymarching/src/raymarching.h:7-18, bindings.cpp:5-19)
+ * All floating tensors are fp32 (the reference's wrappers force it with custom_fwd(cast_inputs=float32)).
+ * --------------------------------------------------------------------------------------------- */
+
+/* replaces near_far_from_aabb (raymarching.cu:148-156) */
+int ngp_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
+                           float* nears, float* fars, ngp_stream_t stream);
+/* replaces sph_from_ray (raymarching.cu:201-209) */
+int ngp_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                     ngp_stream_t stream);
+/* replaces morton3D / morton3D_invert (raymarching.cu:229-232, 257-260) */
+int ngp_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, ngp_stream_t stream);
+int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, ngp_stream_t stream);
+/* replaces packbits (raymarching.cu:292-300): N = number of output bytes, grid has 8*N floats */
+int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, ngp_stream_t stream);
+
+/* replaces march_rays_train (raymarching.cu:482-490).
+ * Sample slots are handed out by a deterministic prefix sum in ray order (rays[n] = (n, offset_n,
+ * count_n)), which is the allocation a sequential execution of the reference kernel produces;
+ * counter[0] += total samples, counter[1] += N.  `workspace` must hold
+ * ngp_march_rays_train_workspace_bytes(N) bytes (contents undefined on entry). */
+size_t ngp_march_rays_train_workspace_bytes(uint32_t N);
+int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                         const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays,
+                         int32_t* counter, const float* noises, void* workspace, ngp_stream_t stream);
+
+/* replaces composite_rays_train_forward / _backward (raymarching.cu:580-588, 685-693) */
+int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                     const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
+                                     float* weights_sum, float* depth, float* image, ngp_stream_t stream);
+int ngp_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                      const float* rgbs, const float* deltas, const int32_t* rays,
+                                      const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                      float T_thresh, float* grad_sigmas, float* grad_rgbs, ngp_stream_t stream);
+
+/* replaces march_rays / composite_rays (raymarching.cu:808-815, 908-914) */
+int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                   const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                   uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
+                   float* dirs, float* deltas, const float* noises, ngp_stream_t stream);
+int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                       const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
+                       float* depth, float* image, ngp_stream_t stream);
+
+/* Extension (no reference counterpart): stream compaction of the alive list on the
+ * device, replacing `rays_alive[rays_alive >= 0]` + its host sync in the caller's render loop.
+ * out_alive receives the surviving ids in order, *out_count (device int32) their number. */
+size_t ngp_compact_rays_workspace_bytes(uint32_t n_alive);
+int ngp_compact_rays(const int32_t* rays_alive, uint32_t n_alive, int32_t* out_alive, int32_t* out_count,
+                     void* workspace, ngp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ffmlp            (reference: ffmlp/src/ffmlp.h:8-14, bindings.cpp:5-11)
+ * All tensors fp16.  weights: flat [hidden*in] + (num_layers-1) x [hidden*hidden] + [output_dim*hidden],
+ * each matrix row-major [out,in].  B must be a multiple of 128 (the wrapper pads), hidden_dim in
+ * {16,32,64,128,256} is accepted by the reference; this library implements hidden_dim 64 and 32/16/128
+ * through the same tiled kernel -- unsupported shapes return NGP_ERR_INVALID.
+ * input_dim % 16 == 0, output_dim == 16 (padded by the wrapper), num_layers >= 2.
+ * activation ids: 0 ReLU, 1 Exp, 2 Sine, 3 Sigmoid, 4 Squareplus, 5 Softplus, 6 None (utils.h:29-37).
+ * --------------------------------------------------------------------------------------------- */
+
+/* replaces ffmlp_forward (ffmlp.cu:635-671): forward_buffer [num_layers,B,hidden] receives the hidden
+ * post-activations in a layout private to this library (only ngp_ffmlp_backward reads it). */
+int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                      uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                      void* forward_buffer, void* outputs, ngp_stream_t stream);
+/* replaces ffmlp_inference (ffmlp.cu:673-709): inference_buffer [B,hidden] is accepted and left untouched */
+int ngp_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim,
+                        uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                        uint32_t output_activation, void* inference_buffer, void* outputs, ngp_stream_t stream);
+/* replaces ffmlp_backward (ffmlp.cu:749-895): grad [B,output_dim]; backward_buffer [num_layers,B,hidden]
+ * scratch; grad_inputs [B,input_dim] written iff calc_grad_inputs; grad_weights flat fp16 (pre-zeroed by
+ * the caller, overwritten with the fp32-accumulated batch sums rounded once to fp16). */
+int ngp_ffmlp_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer,
+                       uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                       uint32_t activation, uint32_t output_activation, int calc_grad_inputs, void* backward_buffer,
+                       void* grad_inputs, void* grad_weights, ngp_stream_t stream);
+/* replace allocate_splitk / free_splitk (ffmlp.cu:721-740).  The reference creates size streams+events
+ * for its split-K weight-gradient GEMMs; this library reduces weight gradients inside the backward
+ * kernel, so these only record the request (kept so that FFMLP.__init__ runs unchanged). */
+int ngp_allocate_splitk(size_t size);
+int ngp_free_splitk(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGP_HIP_H */

@@ -1,0 +1,112 @@
+"""CPU checks of the drop-in boundary: the shared library loads without a GPU and exports every symbol
+include/ngp_hip.h declares; argument validation that happens before any device work returns the documented
+error codes/messages; host-side wrapper logic (offset tables, padding rules, parameter layout)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'ngp_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(ngp_[a-zA-Z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import _ngp_capi as capi
+    declared = _declared_symbols()
+    assert len(declared) >= 28
+    for name in declared:
+        assert hasattr(capi.lib, name), f'{name} declared in ngp_hip.h but not exported by libngp_hip.so'
+    assert capi.lib.ngp_abi_version() == capi.ABI_VERSION
+    assert capi.lib.ngp_target_arch() == b'gfx950'
+    # the ctypes table binds exactly the declared set
+    assert set(capi.EXPORTED) == set(declared)
+
+
+def test_host_side_argument_validation_needs_no_gpu():
+    import _ngp_capi as capi
+    lib = capi.lib
+    one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    rc = lib.ngp_grid_encode_forward(one, one, one, one, 8, 3, 3, 2, 1.0, 4, None, 0, 0, 0, capi.NGP_F32, None)
+    assert rc == 1 and b'C must be 1, 2, 4, or 8' in lib.ngp_last_error()
+    rc = lib.ngp_grid_encode_forward(one, one, one, one, 8, 7, 2, 2, 1.0, 4, None, 0, 0, 0, capi.NGP_F32, None)
+    assert rc == 1 and b'input dim' in lib.ngp_last_error()
+    rc = lib.ngp_sh_encode_forward(one, one, 8, 3, 9, None, capi.NGP_F32, None)
+    assert rc == 1 and b'degree in [1, 8]' in lib.ngp_last_error()
+    rc = lib.ngp_ffmlp_forward(one, one, 128, 32, 16, 48, 2, 0, 6, one, one, None)
+    assert rc == 1 and b'hidden_dim' in lib.ngp_last_error()
+    rc = lib.ngp_ffmlp_forward(one, one, 100, 32, 16, 64, 2, 0, 6, one, one, None)
+    assert rc == 1 and b'128' in lib.ngp_last_error()
+    rc = lib.ngp_march_rays_train(one, one, one, 1.0, 0.0, 1024, 8, 9, 128, 64, one, one, one, one, one, one, one, one, one, None)
+    assert rc == 1 and b'cascade' in lib.ngp_last_error()
+    with pytest.raises(RuntimeError, match='cascade'):
+        capi.check(rc)
+    assert lib.ngp_allocate_splitk(3) == 0 and lib.ngp_free_splitk() == 0
+    assert lib.ngp_march_rays_train_workspace_bytes(4096) == 4 * (1 + 16)
+
+
+def test_level_table_is_the_oracle_recipe():
+    import _ngp_capi as capi
+    import oracle
+    for L, pls, H in [(16, 1.3819128800392151, 16), (16, 1.5874010519681994, 16), (4, 2.0, 4), (12, 1.26, 7)]:
+        S = float(np.log2(pls))
+        sc = (ctypes.c_float * 32)()
+        rs = (ctypes.c_uint32 * 32)()
+        assert capi.lib.ngp_grid_level_table(L, S, H, ctypes.cast(sc, ctypes.c_void_p), ctypes.cast(rs, ctypes.c_void_p)) == 0
+        so, ro = oracle.grid_level_table(L, S, H)
+        assert np.array_equal(np.array(sc[:L], np.float32), so) and np.array_equal(np.array(rs[:L], np.uint32), ro)
+
+
+def test_grid_encoder_module_matches_reference_ctor(golden_dir):
+    from gridencoder import GridEncoder
+    for rec in json.load(open(os.path.join(golden_dir, 'grid_offsets_ref.json'))):
+        enc = GridEncoder(**rec['cfg'])
+        assert enc.offsets.tolist() == rec['offsets'] and enc.offsets.dtype == torch.int32
+        assert list(enc.embeddings.shape) == rec['embeddings_shape']
+        assert float(enc.per_level_scale) == rec['per_level_scale']
+        assert enc.embeddings.abs().max() <= 1e-4
+        assert enc.output_dim == rec['cfg']['num_levels'] * rec['cfg']['level_dim']
+
+
+def test_ffmlp_module_layout_and_asserts():
+    from ffmlp import FFMLP
+    from ffmlp.ffmlp import convert_activation
+    net = FFMLP(32, 16, 64, 2)
+    assert net.weights.shape == (64 * (32 + 64 + 16),) and net.activation == 0 and net.output_activation == 6
+    assert [convert_activation(a) for a in ('relu', 'exponential', 'sine', 'sigmoid', 'squareplus', 'softplus', 'none', 'foo')] == [0, 1, 2, 3, 4, 5, 6, 6]
+    for bad in (dict(input_dim=30, output_dim=3, hidden_dim=64, num_layers=2), dict(input_dim=32, output_dim=17, hidden_dim=64, num_layers=2),
+                dict(input_dim=32, output_dim=3, hidden_dim=48, num_layers=2), dict(input_dim=32, output_dim=3, hidden_dim=64, num_layers=1)):
+        with pytest.raises(AssertionError):
+            FFMLP(**bad)
+
+
+def test_network_state_dict_names_and_shapes():
+    from nerf.network_ff import NeRFNetwork
+    m = NeRFNetwork(bound=1, cuda_ray=True)
+    sd = m.state_dict()
+    assert tuple(sd['encoder.embeddings'].shape) == (6119864, 2) and sd['encoder.offsets'].shape == (17,)
+    assert sd['sigma_net.weights'].shape == (7168,) and sd['color_net.weights'].shape == (11264,)
+    assert sd['density_grid'].shape == (1, 128 ** 3) and sd['density_bitfield'].shape == (128 ** 3 // 8,)
+    assert sd['step_counter'].shape == (16, 2) and sd['aabb_train'].tolist() == [-1, -1, -1, 1, 1, 1]
+    m8 = NeRFNetwork(bound=8, cuda_ray=True)
+    assert m8.cascade == 4 and tuple(m8.encoder.embeddings.shape) == (6664784, 2)
+
+
+def test_ops_fail_loudly_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from gridencoder import GridEncoder
+    enc = GridEncoder(num_levels=2, base_resolution=4, log2_hashmap_size=8)
+    with pytest.raises(RuntimeError, match='CUDA tensor'):
+        enc(torch.rand(8, 3))
+    import raymarching
+    with pytest.raises((RuntimeError, AssertionError)):
+        raymarching.near_far_from_aabb(torch.rand(4, 3), torch.rand(4, 3), torch.tensor([-1., -1, -1, 1, 1, 1]), 0.2)

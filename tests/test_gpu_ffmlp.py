@@ -1,0 +1,172 @@
+"""GPU parity: MFMA fused MLP vs the numpy oracle and the reference-derived golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def cu16(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda().half()
+
+
+def _be():
+    from ffmlp.backend import _backend
+    return _backend
+
+
+def _run_forward(x, w, din, hid, nl, act=0, out_act=6, train=True):
+    B = x.shape[0]
+    xt, wt = cu16(x), cu16(w)
+    out = torch.empty(B, 16, device='cuda', dtype=torch.half)
+    if train:
+        fb = torch.empty(nl, B, hid, device='cuda', dtype=torch.half)
+        _be().ffmlp_forward(xt, wt, B, din, 16, hid, nl, act, out_act, fb, out)
+        return out, fb, xt, wt
+    buf = torch.empty(B, hid, device='cuda', dtype=torch.half)
+    _be().ffmlp_inference(xt, wt, B, din, 16, hid, nl, act, out_act, buf, out)
+    return out, None, xt, wt
+
+
+CFGS = [(32, 64, 2), (32, 64, 3), (16, 64, 2), (64, 64, 2), (48, 64, 4), (32, 32, 2), (16, 32, 3), (64, 32, 4)]
+
+
+@pytest.mark.parametrize('din,hid,nl', CFGS)
+@pytest.mark.parametrize('B', [128, 1152, 16384])
+def test_forward_inference_backward(din, hid, nl, B):
+    rng = np.random.default_rng(din * 1000 + hid * 10 + nl)
+    n_params = hid * (din + hid * (nl - 1) + 16)
+    w = oracle.round_fp16(rng.uniform(-1, 1, n_params) * np.sqrt(3 / hid))
+    x = oracle.round_fp16(rng.uniform(-1, 1, (B, din)))
+    out, fb, xt, wt = _run_forward(x, w, din, hid, nl)
+    ref, rfb = oracle.ffmlp_forward(x, w, din, 16, hid, nl)
+    got = out.float().cpu().numpy()
+    # fp16 outputs, fp32 accumulation: 1e-3 relative (BASELINE.json) with an absolute floor of one fp16 ulp at the output scale
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-3 * scale)
+    out_i, _, _, _ = _run_forward(x, w, din, hid, nl, train=False)
+    assert torch.equal(out_i, out)
+    # backward
+    g = oracle.round_fp16(rng.normal(size=(B, 16)) * 0.1)
+    gt = cu16(g)
+    gi = torch.zeros(B, din, device='cuda', dtype=torch.half)
+    gw = torch.zeros(n_params, device='cuda', dtype=torch.half)
+    bb = torch.zeros(nl, B, hid, device='cuda', dtype=torch.half)
+    _be().ffmlp_backward(gt, xt, wt, fb, B, din, 16, hid, nl, 0, 6, True, bb, gi, gw)
+    rgx, rgw = oracle.ffmlp_backward(g, x, w, rfb, din, 16, hid, nl)
+    gx = gi.float().cpu().numpy()
+    np.testing.assert_allclose(gx, rgx, rtol=4e-3, atol=4e-3 * np.abs(rgx).max())
+    gwn = gw.float().cpu().numpy()
+    # weight gradients are sums over the batch: relative to the gradient scale of each matrix
+    assert np.isfinite(gwn).all()
+    err = np.abs(gwn - rgw).max() / np.abs(rgw).max()
+    assert err < 3e-3, err
+    assert np.linalg.norm(gwn - rgw) / np.linalg.norm(rgw) < 2e-3
+    # without dL/dx the weight gradients are unchanged and grad_inputs is not touched
+    gw2 = torch.zeros_like(gw)
+    dummy = torch.zeros(1, device='cuda', dtype=torch.half)
+    bb.zero_()
+    _be().ffmlp_backward(gt, xt, wt, fb, B, din, 16, hid, nl, 0, 6, False, bb, dummy, gw2)
+    assert torch.equal(gw2, gw) and dummy.item() == 0
+
+
+def test_backward_is_deterministic():
+    rng = np.random.default_rng(0)
+    din, hid, nl, B = 32, 64, 2, 1 << 17
+    n_params = hid * (din + hid * (nl - 1) + 16)
+    w = oracle.round_fp16(rng.uniform(-1, 1, n_params) * np.sqrt(3 / hid))
+    x = oracle.round_fp16(rng.uniform(-1, 1, (B, din)))
+    out, fb, xt, wt = _run_forward(x, w, din, hid, nl)
+    gt = cu16(rng.normal(size=(B, 16)) * 0.01)
+    res = []
+    for _ in range(3):
+        gi = torch.zeros(B, din, device='cuda', dtype=torch.half)
+        gw = torch.zeros(n_params, device='cuda', dtype=torch.half)
+        bb = torch.zeros(nl, B, hid, device='cuda', dtype=torch.half)
+        _be().ffmlp_backward(gt, xt, wt, fb, B, din, 16, hid, nl, 0, 6, True, bb, gi, gw)
+        res.append((gi.clone(), gw.clone()))
+    assert all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
+
+
+def test_transposition_is_detected():
+    # asymmetric weights / one-hot inputs: output column j of sample n must be exactly W_out[j,:] . relu(W_in[:,k]) etc.
+    din, hid, nl, B = 32, 64, 2, 128
+    n_params = hid * (din + hid * (nl - 1) + 16)
+    w = np.zeros(n_params, np.float32)
+    Win = w[:hid * din].reshape(hid, din); Wh = w[hid * din:hid * din + hid * hid].reshape(hid, hid); Wo = w[hid * din + hid * hid:].reshape(16, hid)
+    for k in range(din):
+        Win[(3 * k + 1) % hid, k] = 1.0          # input k feeds hidden unit (3k+1)%64
+    for i in range(hid):
+        Wh[(5 * i + 2) % hid, i] = 1.0 + i / 64   # permutation with distinct gains
+    for j in range(16):
+        Wo[j, (7 * j + 3) % hid] = 0.5 + j / 16
+    x = np.zeros((B, din), np.float32)
+    for n in range(B):
+        x[n, n % din] = 1.0 + (n // din)
+    out, fb, _, _ = _run_forward(x, w, din, hid, nl)
+    ref, _ = oracle.ffmlp_forward(oracle.round_fp16(x), oracle.round_fp16(w), din, 16, hid, nl)
+    assert np.array_equal(out.float().cpu().numpy(), ref.astype(np.float16).astype(np.float32))
+
+
+@pytest.mark.parametrize('act', [1, 2, 3, 4, 5, 6])
+def test_other_activations_forward(act):
+    rng = np.random.default_rng(act)
+    din, hid, nl, B = 32, 64, 2, 512
+    n_params = hid * (din + hid * (nl - 1) + 16)
+    w = oracle.round_fp16(rng.uniform(-1, 1, n_params) * 0.1)
+    x = oracle.round_fp16(rng.uniform(-1, 1, (B, din)))
+    out, fb, _, _ = _run_forward(x, w, din, hid, nl, act=act, out_act=3 if act == 6 else 6)
+    ref, _ = oracle.ffmlp_forward(x, w, din, 16, hid, nl, activation=act, output_activation=3 if act == 6 else 6)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=3e-3, atol=3e-3)
+
+
+def test_against_reference_mlp_golden(golden_dir):
+    # golden outputs/gradients of the reference's own nn.Linear stack (testing/test_ffmlp.py:11-43), fp16-representable data
+    from ffmlp import FFMLP
+    z = np.load(os.path.join(golden_dir, 'mlp_ref.npz'))
+    for name in ('sigma', 'color', 'test', 'narrow'):
+        din, dout, hid, nl = [int(v) for v in z[name + '_cfg']]
+        net = FFMLP(din, dout, hid, nl).cuda()
+        with torch.no_grad():
+            net.weights.copy_(torch.from_numpy(z[name + '_w']).float())
+        x = torch.from_numpy(z[name + '_x']).float().cuda().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.float16):
+            y = net(x)
+        assert y.dtype == torch.float16 and y.shape == (x.shape[0], dout)
+        ref = z[name + '_y']
+        np.testing.assert_allclose(y.float().detach().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+        y.backward(torch.from_numpy(z[name + '_gy']).cuda().half())
+        gx, gw = z[name + '_gx'], z[name + '_gw']
+        np.testing.assert_allclose(x.grad.cpu().numpy(), gx, rtol=6e-3, atol=6e-3 * np.abs(gx).max())
+        got_w = net.weights.grad.float().cpu().numpy()
+        assert np.abs(got_w - gw).max() / np.abs(gw).max() < 6e-3
+        # inference mode takes the other kernel and must agree
+        net.eval()
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+            y2 = net(x)
+        assert torch.equal(y2, y.detach())
+
+
+def test_module_init_matches_reference_recipe():
+    from ffmlp import FFMLP
+    torch.manual_seed(123)
+    net = FFMLP(32, 3, 64, 3)
+    assert net.weights.shape == (11264,) and net.padded_output_dim == 16
+    torch.manual_seed(42)
+    ref = torch.empty(11264).uniform_(-(3 / 64) ** 0.5, (3 / 64) ** 0.5)
+    assert torch.equal(net.weights.detach(), ref)
+
+
+def test_bad_shapes_raise():
+    be = _be()
+    h = lambda *s: torch.zeros(*s, device='cuda', dtype=torch.half)
+    with pytest.raises(RuntimeError, match='hidden_dim'):
+        be.ffmlp_forward(h(128, 32), h(100000), 128, 32, 16, 48, 2, 0, 6, h(2, 128, 48), h(128, 16))
+    with pytest.raises(RuntimeError, match='Half'):
+        be.ffmlp_forward(torch.zeros(128, 32, device='cuda'), h(7168), 128, 32, 16, 64, 2, 0, 6, h(2, 128, 64), h(128, 16))
+    with pytest.raises(RuntimeError, match='128'):
+        be.ffmlp_forward(h(100, 32), h(7168), 100, 32, 16, 64, 2, 0, 6, h(2, 100, 64), h(100, 16))

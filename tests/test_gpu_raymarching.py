@@ -1,0 +1,248 @@
+"""GPU parity: ray marching / compositing kernels vs the oracle.  Integer outputs (ray table, sample
+counts, morton codes, bitfields) and the sample buffers are compared bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synthetic_scene as sc
+
+pytestmark = pytest.mark.gpu
+
+FLT_MAX = np.finfo(np.float32).max
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _rm():
+    import raymarching
+    return raymarching
+
+
+def _random_rays(N, seed, radius=3.2, spread=0.6):
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(N, 3))
+    o = (radius * o / np.linalg.norm(o, axis=1, keepdims=True)).astype(np.float32)
+    t = rng.uniform(-spread, spread, size=(N, 3))
+    d = t - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    return o, d
+
+
+def test_near_far_bit_exact():
+    o, d = _random_rays(50000, 0, spread=1.6)
+    d[0] = [0, 0, 1]; o[0] = [0, 0, -3]           # axis-aligned: two infinite reciprocals
+    d[1] = [0, 1, 0]; o[1] = [5, -3, 0]           # parallel to a slab and outside it
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    n, f = _rm().near_far_from_aabb(cu(o), cu(d), cu(aabb), 0.2)
+    rn, rf = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    assert np.array_equal(n.cpu().numpy(), rn) and np.array_equal(f.cpu().numpy(), rf)
+    assert (rn == FLT_MAX).any() and (rn < FLT_MAX).any()
+    aabb2 = np.array([-0.5, -1, -2, 1.5, 0.25, 0.75], np.float32)
+    n, f = _rm().near_far_from_aabb(cu(o), cu(d), cu(aabb2), 0.05)
+    rn, rf = oracle.near_far_from_aabb(o, d, aabb2, 0.05)
+    assert np.array_equal(n.cpu().numpy(), rn) and np.array_equal(f.cpu().numpy(), rf)
+
+
+def test_sph_from_ray():
+    o, d = _random_rays(20000, 1, radius=2.0)
+    got = _rm().sph_from_ray(cu(o), cu(d), 32.0).cpu().numpy()
+    ref = oracle.sph_from_ray(o, d, 32.0)
+    # phi wraps at +-1: compare on the circle
+    dphi = np.abs(got[:, 1] - ref[:, 1]); dphi = np.minimum(dphi, 2 - dphi)
+    assert np.abs(got[:, 0] - ref[:, 0]).max() < 2e-5 and dphi.max() < 2e-5
+
+
+def test_morton_bit_exact_full_range():
+    allc = np.arange(128 ** 3, dtype=np.int32)
+    xyz = _rm().morton3D_invert(cu(allc))
+    assert np.array_equal(xyz.cpu().numpy(), oracle.morton3D_invert(allc))
+    back = _rm().morton3D(xyz)
+    assert np.array_equal(back.cpu().numpy(), allc)
+    rng = np.random.default_rng(2)
+    c = rng.integers(0, 1024, (100000, 3)).astype(np.int32)
+    assert np.array_equal(_rm().morton3D(cu(c)).cpu().numpy(), oracle.morton3D(c))
+    # the wrappers accept int64 (callers pass .long() tensors back and forth)
+    assert np.array_equal(_rm().morton3D(cu(c.astype(np.int64))).cpu().numpy(), oracle.morton3D(c))
+
+
+def test_packbits_bit_exact_and_in_place():
+    rng = np.random.default_rng(3)
+    g = rng.uniform(-1, 20, (2, 128 ** 3)).astype(np.float32)
+    g[0, :64] = np.arange(64)
+    g[1, 100:200] = -1.0
+    bf = torch.zeros(2 * 128 ** 3 // 8, dtype=torch.uint8, device='cuda')
+    out = _rm().packbits(cu(g), 3.5, bf)
+    assert out.data_ptr() == bf.data_ptr()
+    assert np.array_equal(out.cpu().numpy(), oracle.packbits(g, 3.5))
+    assert out[0].item() == 0xF0
+    out2 = _rm().packbits(cu(g), 3.5)
+    assert torch.equal(out2, bf)
+
+
+def _scene(bound, cascade, seed=0, fill=0.05):
+    if bound == 1 and cascade == 1:
+        grid = sc.occupancy_density()
+        return oracle.packbits(grid, 10.0)
+    rng = np.random.default_rng(seed)
+    # blocky random occupancy so that rays see runs of occupied and empty voxels in every cascade
+    coarse = rng.uniform(size=(cascade, 16, 16, 16)) < fill * 3
+    g = np.repeat(np.repeat(np.repeat(coarse, 8, 1), 8, 2), 8, 3).reshape(cascade, -1).astype(np.float32)
+    return oracle.packbits(g, 0.5)
+
+
+@pytest.mark.parametrize('bound,cascade,dt_gamma,perturb,N', [
+    (1.0, 1, 0.0, True, 4096),       # the lego configuration
+    (1.0, 1, 0.0, False, 4099),      # N not a multiple of the block size
+    (2.0, 2, 1 / 128, True, 3000),   # fox-like: two cascades, growing steps
+    (8.0, 4, 1 / 128, True, 2000),   # Tanks&Temples-like
+    (1.5, 2, 0.0, True, 1500),       # bound that is not a power of two
+])
+def test_march_rays_train_bit_exact(bound, cascade, dt_gamma, perturb, N):
+    bits = _scene(bound, cascade)
+    o, d = _random_rays(N, 4, radius=3.2 * bound if bound > 1 else 3.2, spread=0.6 * bound)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    rng = np.random.default_rng(5)
+    noises = rng.uniform(size=N).astype(np.float32) if perturb else np.zeros(N, np.float32)
+    ref = oracle.march_rays_train(o, d, bound, bits, cascade, 128, nears, fars, noises, dt_gamma=dt_gamma)
+    total = int(ref[4][0])
+    assert total > 0
+    from raymarching.backend import _backend
+    M = N * 1024
+    xyzs = torch.zeros(M, 3, device='cuda'); dirs = torch.zeros(M, 3, device='cuda'); deltas = torch.zeros(M, 2, device='cuda')
+    rays = torch.empty(N, 3, dtype=torch.int32, device='cuda'); counter = torch.zeros(2, dtype=torch.int32, device='cuda')
+    _backend.march_rays_train(cu(o), cu(d), cu(bits), bound, dt_gamma, 1024, N, cascade, 128, M, cu(nears), cu(fars), xyzs, dirs,
+                              deltas, rays, counter, cu(noises))
+    assert counter.cpu().numpy().tolist() == ref[4].tolist()          # point count bit exact
+    assert np.array_equal(rays.cpu().numpy(), ref[3])                 # (ray, offset, count) bit exact
+    assert np.array_equal(xyzs[:total].cpu().numpy(), ref[0][:total])
+    assert np.array_equal(dirs[:total].cpu().numpy(), ref[1][:total])
+    assert np.array_equal(deltas[:total].cpu().numpy(), ref[2][:total])
+    assert not xyzs[total:total + 4096].any()
+
+
+def test_march_rays_train_wrapper_semantics():
+    bits = _scene(1.0, 1)
+    o, d = _random_rays(4096, 6)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    rm = _rm()
+    nears, fars = rm.near_far_from_aabb(cu(o), cu(d), cu(aabb), 0.2)
+    counter = torch.zeros(2, dtype=torch.int32, device='cuda')
+    # worst-case buffer, trimmed to the counted total rounded up by the reference's rule (always adds)
+    xyzs, dirs, deltas, rays = rm.march_rays_train(cu(o), cu(d), 1.0, cu(bits), 1, 128, nears, fars, counter, -1, False, 128, False, 0, 1024)
+    total = int(counter[0])
+    assert xyzs.shape[0] == total + (128 - total % 128) and counter[1].item() == 4096
+    ref = oracle.march_rays_train(o, d, 1.0, bits, 1, 128, nears.cpu().numpy(), fars.cpu().numpy(), np.zeros(4096, np.float32))
+    assert np.array_equal(rays.cpu().numpy(), ref[3]) and np.array_equal(xyzs[:total].cpu().numpy(), ref[0][:total])
+    # estimated buffer smaller than needed: whole rays are dropped, the ray table still lists them
+    mean_count = total // 2
+    counter.zero_()
+    x2, d2, de2, rays2 = rm.march_rays_train(cu(o), cu(d), 1.0, cu(bits), 1, 128, nears, fars, counter, mean_count, False, 128, False, 0, 1024)
+    M = mean_count + (128 - mean_count % 128)
+    assert x2.shape[0] == M and counter[0].item() == total
+    ref2 = oracle.march_rays_train(o, d, 1.0, bits, 1, 128, nears.cpu().numpy(), fars.cpu().numpy(), np.zeros(4096, np.float32), M=M)
+    assert np.array_equal(rays2.cpu().numpy(), ref2[3])
+    assert np.array_equal(x2.cpu().numpy(), ref2[0]) and np.array_equal(de2.cpu().numpy(), ref2[2])
+
+
+def _fields(xyzs):
+    sig = (25.0 * np.exp(-3.0 * (xyzs ** 2).sum(-1)) + 2.0 * (xyzs[:, 0] > 0.2)).astype(np.float32)
+    rgb = (0.5 + 0.5 * np.sin(3.0 * xyzs + np.array([0.0, 1.0, 2.0]))).astype(np.float32)
+    return sig, rgb
+
+
+def test_composite_train_forward_backward():
+    bits = _scene(1.0, 1)
+    o, d = _random_rays(4096, 7)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    noises = np.random.default_rng(8).uniform(size=4096).astype(np.float32)
+    xyzs, dirs, deltas, rays, counter = oracle.march_rays_train(o, d, 1.0, bits, 1, 128, nears, fars, noises)
+    m = int(counter[0]); M = m + 128
+    xyzs, deltas = xyzs[:M], deltas[:M]
+    sig, rgb = _fields(xyzs)
+    sig[m:] = 0
+    # shuffle the ray table: the kernels must honour rays[n,0] as the output row
+    perm = np.random.default_rng(9).permutation(4096)
+    rays_p = rays[perm]
+    sg = cu(sig).requires_grad_(True); rg = cu(rgb).requires_grad_(True)
+    ws, depth, img = _rm().composite_rays_train(sg, rg, cu(deltas), cu(rays_p), 1e-4)
+    rws, rdepth, rimg = oracle.composite_rays_train_forward(sig, rgb, deltas, rays_p, 1e-4)
+    np.testing.assert_allclose(ws.detach().cpu().numpy(), rws, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(img.detach().cpu().numpy(), rimg, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(depth.detach().cpu().numpy(), rdepth, rtol=1e-4, atol=5e-5)
+    rngg = np.random.default_rng(10)
+    gws = rngg.normal(size=4096).astype(np.float32); gimg = rngg.normal(size=(4096, 3)).astype(np.float32)
+    ((ws * cu(gws)).sum() + (img * cu(gimg)).sum() + depth.sum() * 0.0).backward()
+    rgs, rgr = oracle.composite_rays_train_backward(gws, gimg, sig, rgb, deltas, rays_p, rws, rimg, 1e-4)
+    # samples behind the early stop carry weights below T_thresh: allow that much absolute slack
+    np.testing.assert_allclose(rg.grad.cpu().numpy(), rgr, rtol=2e-4, atol=5e-4)
+    np.testing.assert_allclose(sg.grad.cpu().numpy(), rgs, rtol=2e-3, atol=5e-4)
+    assert not sg.grad[m:].any()
+
+
+def test_composite_train_early_stop_and_empty_rays():
+    # a saturating ray (stops inside the first 64-sample row), a long ray (several rows), an empty ray, an overflowing ray
+    k = 300
+    sig = np.concatenate([np.full(k, 400.0), np.full(k, 0.5)]).astype(np.float32)
+    rgb = np.random.default_rng(11).uniform(size=(2 * k, 3)).astype(np.float32)
+    de = np.full((2 * k, 2), 0.004, np.float32)
+    rays = np.array([[2, 0, k], [0, k, k], [1, 0, 0], [3, 2 * k - 10, 50]], np.int32)
+    ws, depth, img = _rm().composite_rays_train(cu(sig), cu(rgb), cu(de), cu(rays), 1e-4)
+    rws, rdepth, rimg = oracle.composite_rays_train_forward(sig, rgb, de, rays, 1e-4)
+    np.testing.assert_allclose(ws.cpu().numpy(), rws, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(img.cpu().numpy(), rimg, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(depth.cpu().numpy(), rdepth, rtol=1e-4, atol=1e-6)
+    assert ws[1].item() == 0 and ws[3].item() == 0
+
+
+def test_inference_loop_matches_oracle_loop():
+    bits = _scene(1.0, 1)
+    rm = _rm()
+    N = 6000
+    o, d = _random_rays(N, 12)
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    # oracle loop (mirrors nerf/renderer.py:323-372)
+    ws = np.zeros(N, np.float32); dep = np.zeros(N, np.float32); img = np.zeros((N, 3), np.float32)
+    alive = np.arange(N, dtype=np.int32); rt = nears.copy()
+    gws = torch.zeros(N, device='cuda'); gdep = torch.zeros(N, device='cuda'); gimg = torch.zeros(N, 3, device='cuda')
+    galive = torch.arange(N, dtype=torch.int32, device='cuda'); grt = cu(nears).clone()
+    to, td, tb, tn, tf = cu(o), cu(d), cu(bits), cu(nears), cu(fars)
+    step = 0
+    while step < 1024 and len(alive):
+        n_alive = len(alive); n_step = max(min(N // n_alive, 8), 1)
+        x, dd, de = oracle.march_rays(n_alive, n_step, alive, rt, o, d, 1.0, bits, 1, 128, nears, fars, np.zeros(n_alive, np.float32), align=128)
+        gx, gd, gde = rm.march_rays(n_alive, n_step, galive, grt, to, td, 1.0, tb, 1, 128, tn, tf, 128, False, 0, 1024)
+        assert np.array_equal(gx.cpu().numpy(), x) and np.array_equal(gde.cpu().numpy(), de) and np.array_equal(gd.cpu().numpy(), dd)
+        sig, rgb = _fields(x)
+        alive2, rt, ws, dep, img = oracle.composite_rays(n_alive, n_step, alive, rt, sig, rgb, de, ws, dep, img, T_thresh=1e-4)
+        rm.composite_rays(n_alive, n_step, galive, grt, cu(sig), cu(rgb), gde, gws, gdep, gimg, 1e-4)
+        ga = galive.cpu().numpy()
+        # fp32 __expf vs double exp may flip the threshold test for a ray sitting exactly on T_thresh: tolerate a handful
+        assert (ga != alive2).mean() < 1e-3
+        comp, cnt = rm.compact_rays(galive)
+        keep = galive[galive >= 0]
+        assert cnt.item() == keep.shape[0] and torch.equal(comp[:cnt.item()], keep)
+        # continue both loops from the oracle's alive list so that the comparison stays aligned
+        alive = alive2[alive2 >= 0]
+        galive = cu(alive)
+        grt = cu(rt).clone()
+        gws = cu(ws).clone(); gdep = cu(dep).clone(); gimg = cu(img).clone()
+        step += n_step
+    assert step > 8
+
+
+def test_marcher_survives_degenerate_rays():
+    # zero direction, NaN origin, far = inf must not hang the device
+    bits = np.zeros(128 ** 3 // 8, np.uint8)
+    o = np.array([[0, 0, -3], [np.nan, 0, 0], [0, 0, 0]], np.float32)
+    d = np.array([[0, 0, 0], [0, 0, 1], [1, 0, 0]], np.float32)
+    nears = np.array([0.2, 0.2, 0.2], np.float32); fars = np.array([4.0, 4.0, 3.0], np.float32)
+    counter = torch.zeros(2, dtype=torch.int32, device='cuda')
+    out = _rm().march_rays_train(cu(o), cu(d), 1.0, cu(bits), 1, 128, cu(nears), cu(fars), counter, -1, False, 128, False, 0, 1024)
+    torch.cuda.synchronize()
+    assert counter[1].item() == 3

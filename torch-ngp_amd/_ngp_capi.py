@@ -1,0 +1,121 @@
+"""ctypes binding of libngp_hip.so (the C ABI declared in include/ngp_hip.h).
+
+This is the only place the product touches native code.  There is NO fallback: if the shared library
+has not been built (``python __graft_entry__.py`` / ``make -C torch-ngp_amd/csrc``) importing any of
+the four operator packages raises ImportError, and calling an op without a visible gfx950 device
+raises RuntimeError from the HIP runtime.
+
+The helpers below turn ``torch.Tensor`` arguments into raw device pointers, pass the current HIP
+stream (so the kernels order with the surrounding PyTorch work and can be captured into HIP graphs)
+and convert a non-zero return code into the ``RuntimeError`` the reference's ``TORCH_CHECK`` /
+``std::runtime_error`` would have raised (e.g. gridencoder.cu:15-18, 381).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libngp_hip.so')
+
+NGP_F32, NGP_F16 = 0, 1
+ABI_VERSION = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP extension first (python __graft_entry__.py, or "
+        f"make -C {os.path.join(_HERE, 'csrc')}).  There is no CPU fallback for these operators.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_vp, _u32, _f32, _i32, _sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_size_t
+
+_SIGNATURES = {
+    'ngp_grid_encode_forward': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _vp],
+    'ngp_grid_encode_backward': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _vp],
+    'ngp_grad_total_variation': [_vp, _vp, _vp, _vp, _f32, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _i32, _vp],
+    'ngp_grid_corner_indices': [_vp, _vp, _vp, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _vp],
+    'ngp_grid_level_table': [_u32, _f32, _u32, _vp, _vp],
+    'ngp_sh_encode_forward': [_vp, _vp, _u32, _u32, _u32, _vp, _i32, _vp],
+    'ngp_sh_encode_backward': [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp],
+    'ngp_near_far_from_aabb': [_vp, _vp, _vp, _u32, _f32, _vp, _vp, _vp],
+    'ngp_sph_from_ray': [_vp, _vp, _f32, _u32, _vp, _vp],
+    'ngp_morton3D': [_vp, _u32, _vp, _vp],
+    'ngp_morton3D_invert': [_vp, _u32, _vp, _vp],
+    'ngp_packbits': [_vp, _u32, _f32, _vp, _vp],
+    'ngp_march_rays_train': [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'ngp_composite_rays_train_forward': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp],
+    'ngp_composite_rays_train_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp],
+    'ngp_march_rays': [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'ngp_composite_rays': [_u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'ngp_compact_rays': [_vp, _u32, _vp, _vp, _vp, _vp],
+    'ngp_ffmlp_forward': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    'ngp_ffmlp_inference': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    'ngp_ffmlp_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
+    'ngp_allocate_splitk': [_sz],
+    'ngp_free_splitk': [],
+}
+for _name, _args in _SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_int
+lib.ngp_last_error.restype = ctypes.c_char_p
+lib.ngp_target_arch.restype = ctypes.c_char_p
+lib.ngp_abi_version.restype = ctypes.c_int
+lib.ngp_march_rays_train_workspace_bytes.argtypes = [_u32]
+lib.ngp_march_rays_train_workspace_bytes.restype = _sz
+lib.ngp_compact_rays_workspace_bytes.argtypes = [_u32]
+lib.ngp_compact_rays_workspace_bytes.restype = _sz
+
+if lib.ngp_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH}: ABI version {lib.ngp_abi_version()} != expected {ABI_VERSION}; rebuild the extension")
+
+EXPORTED = sorted(list(_SIGNATURES) + ['ngp_last_error', 'ngp_target_arch', 'ngp_abi_version',
+                                       'ngp_march_rays_train_workspace_bytes', 'ngp_compact_rays_workspace_bytes'])
+
+
+def check(rc):
+    """Raise RuntimeError with the library's message when a call failed."""
+    if rc != 0:
+        raise RuntimeError(lib.ngp_last_error().decode('utf-8', 'replace'))
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")  # same wording as CHECK_CUDA (ROCm devices are 'cuda' in torch)
+
+
+def require_contiguous(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+def require_int32(t, name):
+    if t.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be an int tensor")
+
+
+def float_code(t, name):
+    """dtype code of a floating tensor (fp64 is not provided by this library)."""
+    if t.dtype == torch.float16:
+        return NGP_F16
+    if t.dtype == torch.float32:
+        return NGP_F32
+    if t.dtype == torch.float64:
+        raise RuntimeError(f"{name}: float64 is not supported by the MI355X kernels (use float32 or float16)")
+    raise RuntimeError(f"{name} must be a floating tensor")
+
+
+def dense(t, name):
+    require_device(t, name)
+    require_contiguous(t, name)
+    return t

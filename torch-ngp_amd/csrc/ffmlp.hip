@@ -1,0 +1,673 @@
+// Fully fused fp16 MLP (bias-free, ReLU hidden layers) on the gfx950 matrix cores.
+//
+// Behaviour restated from the reference (paths relative to the reference checkout):
+//   forward / inference  ffmlp/src/ffmlp.cu:331-407 (kernel_mlp_fused), hosts :635-709
+//   backward             ffmlp/src/ffmlp.cu:410-518 (kernel_mlp_fused_backward) plus the CUTLASS split-K
+//                        weight-gradient GEMMs and the dL/dinput GEMM launched from :749-895
+//   weight layout        ffmlp/src/ffmlp.cu:631-634: W_in [hid,in] | (num_layers-1) x W_h [hid,hid] | W_out [16,hid],
+//                        each row-major [out,in];  y = x . W^T, hidden activation on every hidden layer
+//   activations          ffmlp/src/utils.h:29-37, 424-582
+// Numerics: fp16 operands, fp32 accumulation everywhere (the reference accumulates in fp16, including
+// the batch reductions of the weight gradients); hidden activations and back-propagated hidden
+// gradients are rounded to fp16 between layers (they are fp16 tensors in the reference as well).
+//
+// MI355X design (see DESIGN.md "ffmlp"):
+//   * The network is evaluated TRANSPOSED on v_mfma_f32_32x32x16_f16:  H_l^T [feat, sample] =
+//     W_l [feat, k] . H_{l-1}^T [k, sample].  The weights are the A operand, a tile of 32 samples is the
+//     B operand (one sample per lane column, lane>>5 selects the k half).  The C/D layout of that
+//     instruction leaves lane (sample n, half h) holding, for every 32-feature block, features
+//     {8q + 4h + c : q,c in 0..3} of ITS OWN sample -- and an MFMA contraction is indifferent to how
+//     k slots are numbered as long as A and B agree.  So the A fragments are built with k slot
+//     (kb, h, j) := feature 16kb + 8(j>>2) + 4h + (j&3), and the fp32 accumulators of layer l, packed
+//     to fp16, ARE the B fragments of layer l+1: activations never leave the lane's registers between
+//     layers -- no LDS round trip, no shuffle, no transposition.
+//   * Weights live in LDS for the whole kernel, pre-swizzled into MFMA-fragment order (one 1 KiB
+//     lane-linear ds_read_b128 per fragment); workgroups are persistent so the 14-22 KiB of weights are
+//     fetched from L2 once per workgroup, not once per tile.
+//   * The training forward streams each layer's post-activation fragments to forward_buffer in
+//     fragment order (four fully coalesced 1 KiB stores per layer and tile); backward reads them back
+//     the same way.  The layout of forward_buffer is private to this file.
+//   * Backward is ONE kernel: the dgrad chain runs exactly like the forward (A = W^T fragments), and the
+//     weight gradients dW_l = dZ_l^T . X_l are accumulated per wave in fp32 MFMA accumulators over all
+//     of the wave's tiles (the batch dimension becomes the MFMA k dimension after a transposition of
+//     the two 32-sample tiles through a small per-wave LDS stage).  Per workgroup the four waves'
+//     partial sums are combined in LDS and written as one fp32 slab into the caller's backward_buffer;
+//     a second tiny kernel adds the slabs in a fixed order and rounds once to fp16 -- deterministic,
+//     no atomics, no side streams (this replaces the reference's num_layers+1 split-K GEMMs).
+#include "common.h"
+
+namespace ngp {
+
+constexpr int FF_WAVES = 4;
+constexpr int FF_THREADS = FF_WAVES * 64;
+constexpr int FF_TILE = 32;  // samples per wave tile
+
+enum Act : uint32_t { ACT_RELU = 0, ACT_EXP = 1, ACT_SINE = 2, ACT_SIGMOID = 3, ACT_SQUAREPLUS = 4, ACT_SOFTPLUS = 5, ACT_NONE = 6 };
+constexpr float K_ACT = 10.0f;  // utils.h:41
+
+__device__ __forceinline__ float act_forward(uint32_t a, float x) {
+    switch (a) {
+        case ACT_RELU: return x > 0.0f ? x : 0.0f;
+        case ACT_EXP: return __expf(x);
+        case ACT_SINE: return __sinf(x);
+        case ACT_SIGMOID: return 1.0f / (1.0f + __expf(-x));
+        case ACT_SQUAREPLUS: { const float s = x * K_ACT; return 0.5f * (s + sqrtf(s * s + 4.0f)) / K_ACT; }
+        case ACT_SOFTPLUS: return __logf(__expf(x * K_ACT) + 1.0f) / K_ACT;
+        default: return x;
+    }
+}
+// derivative factor from the STORED post-activation y (utils.h:532-582, warp_activation_backward)
+__device__ __forceinline__ float act_backward_factor(uint32_t a, float y) {
+    switch (a) {
+        case ACT_RELU: return y > 0.0f ? 1.0f : 0.0f;
+        case ACT_EXP: return y;
+        case ACT_SIGMOID: return y * (1.0f - y);
+        case ACT_SQUAREPLUS: { const float s = y * K_ACT; return s * s / (s * s + 1.0f); }
+        case ACT_SOFTPLUS: return 1.0f - __expf(-y * K_ACT);
+        default: return 1.0f;  // None; Sine has no transfer from post-activations in the reference either
+    }
+}
+
+__device__ __forceinline__ float16_t mfma(half8_t a, half8_t b, float16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float16_t zero16() {
+    float16_t z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.0f;
+    return z;
+}
+
+// k slot (kb, h, j) of a hidden-activation operand <-> hidden feature
+__device__ __host__ __forceinline__ int slot_feature(int kb, int h, int j) { return 16 * kb + 8 * (j >> 2) + 4 * h + (j & 3); }
+// accumulator register r of lane-half h in 32-row block ib <-> output row
+__device__ __host__ __forceinline__ int acc_row(int ib, int h, int r) { return 32 * ib + 8 * (r >> 2) + 4 * h + (r & 3); }
+
+// ------------------------------------------------------------------------------------------------
+// LDS weight-fragment images.  A fragment is 64 lanes x 8 halves (1 KiB), stored lane-linear.
+// Forward image order:  layer 0: [ib][kb<in/16] ; layers 1..NL-1: [ib][kb<NKB] ; output: [kb<NKB]
+// ------------------------------------------------------------------------------------------------
+template <int WIDTH>
+struct Shape {
+    static constexpr int NIB = WIDTH / 32;  // 32-row output blocks of a hidden layer
+    static constexpr int NKB = WIDTH / 16;  // 16-wide k blocks of a hidden operand
+};
+
+template <int WIDTH>
+__device__ __forceinline__ uint32_t fwd_frag_count(uint32_t in_dim, uint32_t num_layers) {
+    return Shape<WIDTH>::NIB * (in_dim / 16) + (num_layers - 1) * Shape<WIDTH>::NIB * Shape<WIDTH>::NKB + Shape<WIDTH>::NKB;
+}
+
+// Fill the forward image.  weights: flat fp16 as in ffmlp.cu:631-634.
+template <int WIDTH>
+__device__ void build_forward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    const uint32_t in_kb = in_dim / 16;
+    const uint32_t nfrag = fwd_frag_count<WIDTH>(in_dim, num_layers);
+    for (uint32_t e = threadIdx.x; e < nfrag * 64; e += FF_THREADS) {
+        const uint32_t frag = e >> 6, lane = e & 63;
+        const int i = lane & 31, h = lane >> 5;
+        half8_t v;
+        uint32_t f = frag;
+        if (f < NIB * in_kb) {  // input layer: natural k order, slot (kb,h,j) = input feature 16kb + 8h + j
+            const uint32_t ib = f / in_kb, kb = f % in_kb;
+            v = *reinterpret_cast<const half8_t*>(w + (size_t)(32 * ib + i) * in_dim + 16 * kb + 8 * h);
+        } else {
+            f -= NIB * in_kb;
+            const half_t* base = w + (size_t)WIDTH * in_dim;
+            if (f < (num_layers - 1) * NIB * NKB) {  // hidden layer
+                const uint32_t l = f / (NIB * NKB), rem = f % (NIB * NKB);
+                const uint32_t ib = rem / NKB, kb = rem % NKB;
+                const half_t* row = base + (size_t)l * WIDTH * WIDTH + (size_t)(32 * ib + i) * WIDTH;
+                const half4_t lo = *reinterpret_cast<const half4_t*>(row + 16 * kb + 4 * h);
+                const half4_t hi = *reinterpret_cast<const half4_t*>(row + 16 * kb + 8 + 4 * h);
+                v = half8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            } else {  // output layer: 16 real rows, rows 16..31 of the block are zero
+                const uint32_t kb = f - (num_layers - 1) * NIB * NKB;
+                const half_t* row = base + (size_t)(num_layers - 1) * WIDTH * WIDTH + (size_t)i * WIDTH;
+                if (i < 16) {
+                    const half4_t lo = *reinterpret_cast<const half4_t*>(row + 16 * kb + 4 * h);
+                    const half4_t hi = *reinterpret_cast<const half4_t*>(row + 16 * kb + 8 + 4 * h);
+                    v = half8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = (half_t)0.0f;
+                }
+            }
+        }
+        img[e] = v;
+    }
+}
+
+// pack the 16 fp32 accumulators of the NIB blocks into NKB fp16 operand fragments
+template <int WIDTH>
+__device__ __forceinline__ void pack_hidden(const float16_t (&acc)[Shape<WIDTH>::NIB], half8_t (&frag)[Shape<WIDTH>::NKB]) {
+#pragma unroll
+    for (int kb = 0; kb < Shape<WIDTH>::NKB; kb++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) frag[kb][j] = (half_t)acc[kb >> 1][(kb & 1) * 8 + j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / inference
+// ------------------------------------------------------------------------------------------------
+template <int WIDTH, bool TRAIN>
+__global__ __launch_bounds__(FF_THREADS) void k_ffmlp_forward(const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
+                                                              half_t* __restrict__ forward_buffer, half_t* __restrict__ outputs,
+                                                              uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
+                                                              uint32_t out_act) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8_t* img = reinterpret_cast<half8_t*>(smem);
+    build_forward_image<WIDTH>(img, weights, in_dim, num_layers);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const uint32_t in_kb = in_dim / 16;
+    const half8_t* img_l0 = img + lane;
+    const half8_t* img_hid = img_l0 + (size_t)NIB * in_kb * 64;
+    const half8_t* img_out = img_hid + (size_t)(num_layers - 1) * NIB * NKB * 64;
+    const size_t layer_stride = (size_t)n_tiles * NKB * 64;  // in half8 units
+
+    for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += gridDim.x * FF_WAVES) {
+        const half_t* xrow = inputs + ((size_t)tile * FF_TILE + n) * in_dim + 8 * h;
+        float16_t acc[NIB];
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
+        for (uint32_t kb = 0; kb < in_kb; kb++) {
+            const half8_t x = *reinterpret_cast<const half8_t*>(xrow + 16 * kb);
+#pragma unroll
+            for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(img_l0[(ib * in_kb + kb) * 64], x, acc[ib]);
+        }
+        half8_t hid[NKB];
+        for (uint32_t l = 0;; l++) {
+            // activation of hidden layer l (fp32), then round to fp16 operand fragments
+            if (act == ACT_RELU) {
+#pragma unroll
+                for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
+            } else if (act != ACT_NONE) {
+#pragma unroll
+                for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[ib][r] = act_forward(act, acc[ib][r]);
+            }
+            pack_hidden<WIDTH>(acc, hid);
+            if (TRAIN) {
+                half8_t* dst = reinterpret_cast<half8_t*>(forward_buffer) + l * layer_stride + (size_t)tile * NKB * 64 + lane;
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) dst[kb * 64] = hid[kb];
+            }
+            if (l + 1 == num_layers) break;
+            const half8_t* wl = img_hid + (size_t)l * NIB * NKB * 64;
+#pragma unroll
+            for (int ib = 0; ib < NIB; ib++) {
+                acc[ib] = zero16();
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) acc[ib] = mfma(wl[(ib * NKB + kb) * 64], hid[kb], acc[ib]);
+            }
+        }
+        // output layer: one 32-row block of which rows 0..15 are real
+        float16_t o = zero16();
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) o = mfma(img_out[kb * 64], hid[kb], o);
+        half4_t lo, hi;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            lo[c] = (half_t)act_forward(out_act, o[c]);      // out features 4h + c
+            hi[c] = (half_t)act_forward(out_act, o[4 + c]);  // out features 8 + 4h + c
+        }
+        half_t* orow = outputs + ((size_t)tile * FF_TILE + n) * 16 + 4 * h;
+        *reinterpret_cast<half4_t*>(orow) = lo;
+        *reinterpret_cast<half4_t*>(orow + 8) = hi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+// Backward image order (A = W^T fragments for the dgrad chain):
+//   out : [ib<NIB]              A[i=hidden feat][slot(h,j)] = W_out[8h+j][feat]            (K = 16 real outputs)
+//   hid : layers NL-1 .. 1, each [ib<NIB][kb<NKB]   A[i][slot(kb,h,j)] = W_l[slot_feature][i]
+//   in  : [ib<in/32 rounded up][kb<NKB]             A[i=input feat][slot] = W_in[slot_feature][i]   (only if dL/dx wanted)
+template <int WIDTH>
+__device__ __forceinline__ uint32_t bwd_frag_count(uint32_t in_dim, uint32_t num_layers, bool with_dx) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    return NIB + (num_layers - 1) * NIB * NKB + (with_dx ? ((in_dim + 31) / 32) * NKB : 0);
+}
+
+template <int WIDTH>
+__device__ void build_backward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers, bool with_dx) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    const uint32_t nfrag = bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx);
+    const half_t* w_hid = w + (size_t)WIDTH * in_dim;
+    const half_t* w_out = w_hid + (size_t)(num_layers - 1) * WIDTH * WIDTH;
+    for (uint32_t e = threadIdx.x; e < nfrag * 64; e += FF_THREADS) {
+        const uint32_t frag = e >> 6, lane = e & 63;
+        const int i = lane & 31, h = lane >> 5;
+        half8_t v;
+        uint32_t f = frag;
+        if (f < NIB) {
+            const int feat = 32 * f + i;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = w_out[(size_t)(8 * h + j) * WIDTH + feat];
+        } else if ((f -= NIB) < (num_layers - 1) * NIB * NKB) {
+            const uint32_t li = f / (NIB * NKB), rem = f % (NIB * NKB);  // li = 0 -> layer NL-1
+            const uint32_t ib = rem / NKB, kb = rem % NKB;
+            const half_t* wl = w_hid + (size_t)(num_layers - 2 - li) * WIDTH * WIDTH;
+            const int col = 32 * ib + i;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = wl[(size_t)slot_feature(kb, h, j) * WIDTH + col];
+        } else {
+            f -= (num_layers - 1) * NIB * NKB;
+            const uint32_t ib = f / NKB, kb = f % NKB;
+            const uint32_t col = 32 * ib + i;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = col < in_dim ? w[(size_t)slot_feature(kb, h, j) * in_dim + col] : (half_t)0.0f;
+        }
+        img[e] = v;
+    }
+}
+
+// per-wave LDS staging for the weight-gradient operands: matrices are stored TRANSPOSED, [feature][sample],
+// 32 samples (64 B) per row padded to 80 B so that the two lane halves hit disjoint banks.
+constexpr int STG_ROW = 40;                       // halves per row
+constexpr int STG_ROWS_A = 64;                    // dZ / dY rows (<= WIDTH)
+constexpr int STG_ROWS_B = 64;                    // activation / input rows
+constexpr int STG_HALVES = (STG_ROWS_A + STG_ROWS_B) * STG_ROW;
+
+// write this lane's operand fragment (8 values of sample n) transposed into the stage
+__device__ __forceinline__ void stage_put(half_t* stg, int feat_of_j0, int n, half8_t v, bool hidden_order, int h) {
+    // hidden_order: values j=0..3 are features f0..f0+3, j=4..7 are f0+8..f0+11 (slot_feature order);
+    // natural order: features f0..f0+7
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int f = hidden_order ? feat_of_j0 + 8 * (j >> 2) + (j & 3) : feat_of_j0 + j;
+        stg[f * STG_ROW + n] = v[j];
+    }
+    (void)h;
+}
+
+// read an MFMA operand fragment for the weight-gradient product: 8 consecutive samples of one feature row
+__device__ __forceinline__ half8_t stage_get(const half_t* stg, int feat, int kb, int h) {
+    return *reinterpret_cast<const half8_t*>(stg + feat * STG_ROW + 16 * kb + 8 * h);
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Number of fp32 words of one weight-gradient slab = number of parameters.
+__host__ __device__ inline uint32_t ff_param_count(uint32_t in_dim, uint32_t hidden, uint32_t num_layers) {
+    return hidden * (in_dim + hidden * (num_layers - 1) + 16);
+}
+
+template <int WIDTH, int IN_JB /* ceil(in_dim/32) */, int NHM /* hidden matmuls = num_layers-1 */>
+__global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __restrict__ grad, const half_t* __restrict__ inputs,
+                                                               const half_t* __restrict__ weights, const half_t* __restrict__ forward_buffer,
+                                                               uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
+                                                               bool with_dx, half_t* __restrict__ grad_inputs, float* __restrict__ slabs,
+                                                               half_t* __restrict__ grad_weights_direct) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8_t* img = reinterpret_cast<half8_t*>(smem);
+    const uint32_t nfrag = bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx);
+    build_backward_image<WIDTH>(img, weights, in_dim, num_layers, with_dx);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    half_t* stgA = reinterpret_cast<half_t*>(img + (size_t)nfrag * 64) + (size_t)wid * STG_HALVES;
+    half_t* stgB = stgA + STG_ROWS_A * STG_ROW;
+    // rows 16..31 of the dY stage stay zero for the whole kernel (the output block has 16 real rows)
+    for (int i = lane; i < 16 * STG_ROW; i += 64) stgA[16 * STG_ROW + i] = (half_t)0.0f;
+    __syncthreads();
+
+    const uint32_t in_kb = in_dim / 16;
+    const half8_t* img_out = img + lane;
+    const half8_t* img_hid = img_out + (size_t)NIB * 64;
+    const half8_t* img_in = img_hid + (size_t)(num_layers - 1) * NIB * NKB * 64;
+    const size_t layer_stride = (size_t)n_tiles * NKB * 64;
+    const half8_t* fb = reinterpret_cast<const half8_t*>(forward_buffer);
+
+    // weight-gradient accumulators (fp32): output layer [jb<NIB], hidden layers [l][ib][jb], input layer [ib][jb<IN_JB]
+    float16_t gw_out[NIB];
+    float16_t gw_in[NIB][IN_JB];
+#pragma unroll
+    for (int jb = 0; jb < NIB; jb++) gw_out[jb] = zero16();
+#pragma unroll
+    for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+        for (int jb = 0; jb < IN_JB; jb++) gw_in[ib][jb] = zero16();
+    float16_t gw_hid[NHM][NIB][NIB];
+#pragma unroll
+    for (int l = 0; l < NHM; l++)
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+            for (int jb = 0; jb < NIB; jb++) gw_hid[l][ib][jb] = zero16();
+
+    for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += gridDim.x * FF_WAVES) {
+        const size_t tile_frag = (size_t)tile * NKB * 64 + lane;
+        // ---- output layer -------------------------------------------------------------------
+        const half8_t dy = *reinterpret_cast<const half8_t*>(grad + ((size_t)tile * FF_TILE + n) * 16 + 8 * h);
+        half8_t a_prev[NKB];  // post-activations of the layer below the one being differentiated
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) a_prev[kb] = fb[(num_layers - 1) * layer_stride + tile_frag + kb * 64];
+        wave_lds_fence();
+        stage_put(stgA, 8 * h, n, dy, false, h);
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) stage_put(stgB, 16 * kb + 4 * h, n, a_prev[kb], true, h);
+        wave_lds_fence();
+        // dW_out [16(+16 zero) x WIDTH] += dY^T . A_{L-1}
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) {
+            const half8_t a = stage_get(stgA, n, kb, h);
+#pragma unroll
+            for (int jb = 0; jb < NIB; jb++) gw_out[jb] = mfma(a, stage_get(stgB, 32 * jb + n, kb, h), gw_out[jb]);
+        }
+        // dH_{L-1}^T = W_out^T . dY^T   (K = 16: one k block)
+        float16_t acc[NIB];
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(img_out[ib * 64], dy, zero16());
+
+        // ---- hidden layers, top down --------------------------------------------------------
+        half8_t dz[NKB];
+#pragma unroll
+        for (int li = 0; li < NHM; li++) {  // li-th hidden matmul from the top: layer index num_layers-1-li
+            // activation transfer with the stored post-activations, round to fp16
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    dz[kb][j] = (half_t)(acc[kb >> 1][(kb & 1) * 8 + j] * act_backward_factor(act, (float)a_prev[kb][j]));
+            const uint32_t lay = num_layers - 1 - li;  // dz = dL/d(pre-activation of hidden layer `lay`)
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++) a_prev[kb] = fb[(lay - 1) * layer_stride + tile_frag + kb * 64];
+            wave_lds_fence();
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++) {
+                stage_put(stgA, 16 * kb + 4 * h, n, dz[kb], true, h);
+                stage_put(stgB, 16 * kb + 4 * h, n, a_prev[kb], true, h);
+            }
+            wave_lds_fence();
+            // dW_lay [WIDTH x WIDTH] += dZ_lay^T . A_{lay-1}
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+                for (int ib = 0; ib < NIB; ib++) {
+                    const half8_t a = stage_get(stgA, 32 * ib + n, kb, h);
+#pragma unroll
+                    for (int jb = 0; jb < NIB; jb++)
+                        gw_hid[li][ib][jb] = mfma(a, stage_get(stgB, 32 * jb + n, kb, h), gw_hid[li][ib][jb]);
+                }
+            // dH_{lay-1}^T = W_lay^T . dZ_lay^T
+            const half8_t* wl = img_hid + (size_t)li * NIB * NKB * 64;
+#pragma unroll
+            for (int ib = 0; ib < NIB; ib++) {
+                acc[ib] = zero16();
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) acc[ib] = mfma(wl[(ib * NKB + kb) * 64], dz[kb], acc[ib]);
+            }
+        }
+        // ---- input layer --------------------------------------------------------------------
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                dz[kb][j] = (half_t)(acc[kb >> 1][(kb & 1) * 8 + j] * act_backward_factor(act, (float)a_prev[kb][j]));
+        wave_lds_fence();
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) stage_put(stgA, 16 * kb + 4 * h, n, dz[kb], true, h);
+        {
+            const half_t* xrow = inputs + ((size_t)tile * FF_TILE + n) * in_dim + 8 * h;
+            for (uint32_t kb = 0; kb < in_kb; kb++) stage_put(stgB, 16 * kb + 8 * h, n, *reinterpret_cast<const half8_t*>(xrow + 16 * kb), false, h);
+        }
+        wave_lds_fence();
+        // dW_in [WIDTH x in] += dZ_0^T . X
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+            for (int ib = 0; ib < NIB; ib++) {
+                const half8_t a = stage_get(stgA, 32 * ib + n, kb, h);
+#pragma unroll
+                for (int jb = 0; jb < IN_JB; jb++) gw_in[ib][jb] = mfma(a, stage_get(stgB, 32 * jb + n, kb, h), gw_in[ib][jb]);
+            }
+        if (with_dx) {
+            // dX^T [in x samples] = W_in^T . dZ_0^T ; rows beyond in_dim are zero weights and are not stored
+#pragma unroll
+            for (int ib = 0; ib < IN_JB; ib++) {
+                float16_t dx = zero16();
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) dx = mfma(img_in[(ib * NKB + kb) * 64], dz[kb], dx);
+                half_t* grow = grad_inputs + ((size_t)tile * FF_TILE + n) * in_dim;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t f0 = 32 * ib + 8 * q + 4 * h;
+                    if (f0 < in_dim) {
+                        half4_t v = {(half_t)dx[4 * q], (half_t)dx[4 * q + 1], (half_t)dx[4 * q + 2], (half_t)dx[4 * q + 3]};
+                        *reinterpret_cast<half4_t*>(grow + f0) = v;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- combine the four waves' partial weight gradients in LDS, emit one slab per workgroup ----
+    __syncthreads();  // every wave is done with the weight image and the stages
+    float* red = reinterpret_cast<float*>(smem);
+    const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
+    for (uint32_t i = threadIdx.x; i < n_params; i += FF_THREADS) red[i] = 0.0f;
+    __syncthreads();
+    // accumulator (row = output feature o, col = input feature i = lane&31)
+    auto flush = [&](const float16_t& a, uint32_t base, uint32_t ld, int ib, int jb, uint32_t rows, uint32_t cols) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t o = (uint32_t)acc_row(ib, h, r), i = 32 * jb + n;
+            if (o < rows && i < cols) atomicAdd(&red[base + o * ld + i], a[r]);
+        }
+    };
+#pragma unroll
+    for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+        for (int jb = 0; jb < IN_JB; jb++) flush(gw_in[ib][jb], 0, in_dim, ib, jb, WIDTH, in_dim);
+#pragma unroll
+    for (int li = 0; li < NHM; li++) {
+        const uint32_t lay = num_layers - 1 - li;
+        const uint32_t base = WIDTH * in_dim + (lay - 1) * WIDTH * WIDTH;
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+            for (int jb = 0; jb < NIB; jb++) flush(gw_hid[li][ib][jb], base, WIDTH, ib, jb, WIDTH, WIDTH);
+    }
+    {
+        const uint32_t base = WIDTH * in_dim + (num_layers - 1) * WIDTH * WIDTH;
+#pragma unroll
+        for (int jb = 0; jb < NIB; jb++) flush(gw_out[jb], base, WIDTH, 0, jb, 16, WIDTH);
+    }
+    __syncthreads();
+    if (grad_weights_direct) {
+        for (uint32_t i = threadIdx.x; i < n_params; i += FF_THREADS) grad_weights_direct[i] = (half_t)red[i];
+    } else {
+        float* slab = slabs + (size_t)blockIdx.x * n_params;
+        for (uint32_t i = threadIdx.x; i < n_params; i += FF_THREADS) slab[i] = red[i];
+    }
+}
+
+// sum the per-workgroup slabs in a fixed order and round once to fp16
+__global__ void k_ffmlp_reduce_slabs(const float* __restrict__ slabs, uint32_t n_slabs, uint32_t n_params, half_t* __restrict__ grad_weights) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_params) return;
+    float s = 0.0f;
+    for (uint32_t k = 0; k < n_slabs; k++) s += slabs[(size_t)k * n_params + i];
+    grad_weights[i] = (half_t)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct DeviceInfo {
+    int cus = 0;
+    bool ok = false;
+};
+static DeviceInfo device_info() {
+    static thread_local DeviceInfo info;
+    if (!info.ok) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, dev) == hipSuccess) {
+                info.cus = p.multiProcessorCount;
+                info.ok = true;
+            }
+        }
+        if (!info.ok) info.cus = 256;
+    }
+    return info;
+}
+
+static int check_ff_args(const char* fn, uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t hidden, uint32_t num_layers) {
+    NGP_REQUIRE(hidden == 64 || hidden == 32, NGP_ERR_INVALID,
+                "%s: hidden_dim should in [16, 32, 64, 128, 256]; this build implements 32 and 64 (got %u)", fn, hidden);
+    NGP_REQUIRE(in_dim > 0 && in_dim % 16 == 0, NGP_ERR_INVALID, "%s: input_dim should be 16 * m (m > 0), but got %u", fn, in_dim);
+    NGP_REQUIRE(out_dim == 16, NGP_ERR_INVALID, "%s: output_dim must be padded to 16 by the caller (got %u)", fn, out_dim);
+    NGP_REQUIRE(num_layers >= 2, NGP_ERR_INVALID, "%s: num_layers should be larger than 2 (3 matmuls), but got %u", fn, num_layers);
+    NGP_REQUIRE(B % 128 == 0, NGP_ERR_INVALID, "%s: batch size must be 128 * m, but got %u", fn, B);
+    return NGP_OK;
+}
+
+template <int WIDTH, bool TRAIN>
+static int launch_forward(const void* inputs, const void* weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, uint32_t act,
+                          uint32_t out_act, void* fwd, void* outputs, hipStream_t st) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    const uint32_t n_tiles = B / FF_TILE;
+    const uint32_t nfrag = NIB * (in_dim / 16) + (num_layers - 1) * NIB * NKB + NKB;
+    const size_t lds = (size_t)nfrag * 1024;
+    NGP_REQUIRE(lds <= 160 * 1024, NGP_ERR_INVALID, "ffmlp: weights (%zu B) exceed the 160 KiB LDS of a CU", lds);
+    auto kern = k_ffmlp_forward<WIDTH, TRAIN>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }
+    const uint32_t per_cu = (uint32_t)((160 * 1024) / (lds + 1024));
+    uint32_t blocks = (uint32_t)device_info().cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    const uint32_t need = cdiv(n_tiles, FF_WAVES);
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)inputs, (const half_t*)weights, (half_t*)fwd,
+                       (half_t*)outputs, n_tiles, in_dim, num_layers, act, out_act);
+    return check_launch(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
+}
+
+template <int WIDTH, int IN_JB, int NHM>
+static int launch_backward(const void* grad, const void* inputs, const void* weights, const void* fwd, uint32_t B, uint32_t in_dim,
+                           uint32_t num_layers, uint32_t act, bool with_dx, void* backward_buffer, void* grad_inputs,
+                           void* grad_weights, hipStream_t st) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    const uint32_t n_tiles = B / FF_TILE;
+    const uint32_t nfrag = NIB + (num_layers - 1) * NIB * NKB + (with_dx ? ((in_dim + 31) / 32) * NKB : 0);
+    const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
+    size_t lds = (size_t)nfrag * 1024 + (size_t)FF_WAVES * STG_HALVES * sizeof(half_t);
+    if (lds < (size_t)n_params * 4) lds = (size_t)n_params * 4;
+    NGP_REQUIRE(lds <= 160 * 1024, NGP_ERR_INVALID, "ffmlp_backward: LDS need (%zu B) exceeds 160 KiB", lds);
+    auto kern = k_ffmlp_backward<WIDTH, IN_JB, NHM>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp_backward: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }
+    // one fp32 slab per workgroup lives in the caller's backward_buffer ([num_layers, B, hidden] fp16)
+    const size_t buf_bytes = (size_t)num_layers * B * WIDTH * sizeof(half_t);
+    uint32_t blocks = (uint32_t)device_info().cus;
+    const uint32_t need = cdiv(n_tiles, FF_WAVES);
+    if (blocks > need) blocks = need;
+    const size_t fit = buf_bytes / ((size_t)n_params * 4);
+    if (blocks > fit) blocks = (uint32_t)fit;
+    if (blocks <= 1) {
+        hipLaunchKernelGGL(kern, dim3(1), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
+                           (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)nullptr,
+                           (half_t*)grad_weights);
+        return check_launch("ffmlp_backward");
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
+                       (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)backward_buffer,
+                       (half_t*)nullptr);
+    int rc = check_launch("ffmlp_backward");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_ffmlp_reduce_slabs, dim3(cdiv(n_params, 256)), dim3(256), 0, st, (const float*)backward_buffer, blocks, n_params,
+                       (half_t*)grad_weights);
+    return check_launch("ffmlp_backward(reduce)");
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                                 uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                                 void* forward_buffer, void* outputs, ngp_stream_t stream) {
+    int rc = check_ff_args("ffmlp_forward", B, input_dim, output_dim, hidden_dim, num_layers);
+    if (rc) return rc;
+    NGP_REQUIRE(inputs && weights && forward_buffer && outputs, NGP_ERR_INVALID, "ffmlp_forward: NULL tensor");
+    if (B == 0) return NGP_OK;
+    hipStream_t st = as_stream(stream);
+    if (hidden_dim == 64) return launch_forward<64, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, st);
+    return launch_forward<32, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, st);
+}
+
+extern "C" int ngp_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                                   uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                                   void* inference_buffer, void* outputs, ngp_stream_t stream) {
+    (void)inference_buffer;
+    int rc = check_ff_args("ffmlp_inference", B, input_dim, output_dim, hidden_dim, num_layers);
+    if (rc) return rc;
+    NGP_REQUIRE(inputs && weights && outputs, NGP_ERR_INVALID, "ffmlp_inference: NULL tensor");
+    if (B == 0) return NGP_OK;
+    hipStream_t st = as_stream(stream);
+    if (hidden_dim == 64) return launch_forward<64, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, nullptr, outputs, st);
+    return launch_forward<32, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, nullptr, outputs, st);
+}
+
+extern "C" int ngp_ffmlp_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
+                                  uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                                  uint32_t output_activation, int calc_grad_inputs, void* backward_buffer, void* grad_inputs,
+                                  void* grad_weights, ngp_stream_t stream) {
+    (void)output_activation;  // the reference discards it as well (ffmlp.cu:780)
+    int rc = check_ff_args("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers);
+    if (rc) return rc;
+    NGP_REQUIRE(num_layers <= 4, NGP_ERR_INVALID, "ffmlp_backward: this build supports num_layers <= 4 (got %u)", num_layers);
+    NGP_REQUIRE(input_dim <= 64, NGP_ERR_INVALID, "ffmlp_backward: this build supports input_dim <= 64 (got %u)", input_dim);
+    NGP_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer && grad_weights, NGP_ERR_INVALID, "ffmlp_backward: NULL tensor");
+    NGP_REQUIRE(!calc_grad_inputs || grad_inputs, NGP_ERR_INVALID, "ffmlp_backward: grad_inputs is NULL but calc_grad_inputs is set");
+    if (B == 0) return NGP_OK;
+    hipStream_t st = as_stream(stream);
+    const bool dx = calc_grad_inputs != 0;
+    const uint32_t in_jb = (input_dim + 31) / 32;
+#define FF_BWD(W, J, N) \
+    return launch_backward<W, J, N>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, dx, backward_buffer, grad_inputs, grad_weights, st)
+#define FF_BWD_N(W, J)                      \
+    switch (num_layers - 1) {               \
+        case 1: FF_BWD(W, J, 1);            \
+        case 2: FF_BWD(W, J, 2);            \
+        default: FF_BWD(W, J, 3);           \
+    }
+    if (hidden_dim == 64) {
+        if (in_jb == 1) { FF_BWD_N(64, 1) }
+        FF_BWD_N(64, 2)
+    }
+    if (in_jb == 1) { FF_BWD_N(32, 1) }
+    FF_BWD_N(32, 2)
+#undef FF_BWD_N
+#undef FF_BWD
+}
+
+static size_t g_splitk_request = 0;
+extern "C" int ngp_allocate_splitk(size_t size) {
+    g_splitk_request = size;
+    return NGP_OK;
+}
+extern "C" int ngp_free_splitk(void) {
+    g_splitk_request = 0;
+    return NGP_OK;
+}

@@ -1,0 +1,672 @@
+// Multiresolution hash / tiled grid encoder for gfx950 (MI355X).
+//
+// Behaviour restated from the reference kernels (paths relative to the reference checkout):
+//   forward   gridencoder/src/gridencoder.cu:87-245   (kernel_grid)
+//   backward  gridencoder/src/gridencoder.cu:248-340  (kernel_grid_backward)
+//   dL/dx     gridencoder/src/gridencoder.cu:343-369  (kernel_input_backward)
+//   TV grad   gridencoder/src/gridencoder.cu:506-610  (kernel_grad_tv)
+//
+// MI355X design (see DESIGN.md "gridencoder"):
+//   * launch is level-major (blockIdx.y = level): one level's table (<= 2 MiB fp16 at C=2) stays
+//     resident in every XCD's 4 MiB L2 while all points stream through it;
+//   * one lane = one (point, level); the 2^D corner gathers of a lane are issued back to back as
+//     independent 4-byte (half2) / 8-byte loads so a wave keeps 8 x 64 gathers in flight; corner
+//     weights and the accumulation are fp32, the result is rounded once to the table dtype;
+//   * the per-level scale/resolution table is computed on the host with a reproducible recipe
+//     (ngp_grid_level_table) and passed by value, so cell indices are bit-identical to the oracle;
+//   * all per-level quantities (table base, size, dense strides, hash-or-dense, pow2 size) are
+//     wave-uniform and live in SGPRs;
+//   * backward scatters with hardware atomics: global_atomic_pk_add_f16 for fp16 tables with even C
+//     (what the reference's half2 atomicAdd does), global_atomic_add_f32 otherwise.  Dense levels whose
+//     whole table fits in LDS are privatised per workgroup first (ds_add) and flushed once, which
+//     removes the same-address contention on the coarse levels.
+#include "common.h"
+#include <math.h>
+
+namespace ngp {
+
+struct GridLevels {
+    float scale[NGP_MAX_LEVELS];
+    uint32_t res[NGP_MAX_LEVELS];
+};
+
+__constant__ const uint32_t kPrimes[7] = {1u, 2654435761u, 805459861u, 3674653429u,
+                                          2097192037u, 1434869437u, 2165219737u};
+
+// Wave-uniform description of how a level is indexed (gridencoder.cu:66-84, get_grid_index).
+template <int D>
+struct LevelIndexer {
+    uint32_t stride[D];  // dense strides of the dims that take part (0 for the others)
+    uint32_t size;       // hashmap_size
+    uint32_t mask;       // size-1 if size is a power of two else 0
+    bool hashed;
+
+    __device__ __forceinline__ void init(uint32_t gridtype, bool align_corners, uint32_t hashmap_size,
+                                         uint32_t resolution) {
+        uint32_t s = 1;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (s <= hashmap_size) {
+                stride[d] = s;
+                s *= align_corners ? resolution : (resolution + 1u);
+            } else {
+                stride[d] = 0;
+            }
+        }
+        hashed = (gridtype == 0u) && (s > hashmap_size);
+        size = hashmap_size;
+        mask = ((hashmap_size & (hashmap_size - 1u)) == 0u) ? hashmap_size - 1u : 0u;
+    }
+
+    __device__ __forceinline__ uint32_t operator()(const uint32_t (&pg)[D]) const {
+        uint32_t idx = 0;
+        if (hashed) {
+#pragma unroll
+            for (int d = 0; d < D; d++) idx ^= pg[d] * kPrimes[d];
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; d++) idx += pg[d] * stride[d];
+        }
+        return mask ? (idx & mask) : (idx % size);
+    }
+};
+
+// gridencoder.cu:146-159: position inside the level.  Returns false when the point is outside [0,1]^D.
+template <int D>
+__device__ __forceinline__ bool locate(const float* __restrict__ x, float scale, bool align_corners, uint32_t interp,
+                                       float (&frac)[D], float (&deriv)[D], uint32_t (&cell)[D]) {
+    float xv[D];
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        xv[d] = x[d];
+        inside = inside && !(xv[d] < 0.0f || xv[d] > 1.0f);
+    }
+    if (!inside) return false;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        float p = __builtin_fmaf(xv[d], scale, align_corners ? 0.0f : 0.5f);
+        float fl = floorf(p);
+        cell[d] = (uint32_t)fl;
+        p -= (float)cell[d];
+        if (interp == 1u) {
+            deriv[d] = 6.0f * p * (1.0f - p);
+            p = p * p * (3.0f - 2.0f * p);
+        } else {
+            deriv[d] = 1.0f;
+        }
+        frac[d] = p;
+    }
+    return true;
+}
+
+template <typename T, int C>
+struct Vec;  // C consecutive table features
+template <int C>
+struct Vec<float, C> {
+    float v[C];
+    __device__ __forceinline__ void load(const float* p) {
+#pragma unroll
+        for (int c = 0; c < C; c++) v[c] = p[c];
+    }
+};
+template <>
+struct Vec<float, 2> {
+    float v[2];
+    __device__ __forceinline__ void load(const float* p) {
+        float2_t t = *reinterpret_cast<const float2_t*>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+};
+template <>
+struct Vec<float, 4> {
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        float4_t t = *reinterpret_cast<const float4_t*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+template <>
+struct Vec<float, 8> {
+    float v[8];
+    __device__ __forceinline__ void load(const float* p) {
+        float4_t a = *reinterpret_cast<const float4_t*>(p);
+        float4_t b = *reinterpret_cast<const float4_t*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+};
+template <>
+struct Vec<half_t, 1> {
+    float v[1];
+    __device__ __forceinline__ void load(const half_t* p) { v[0] = (float)p[0]; }
+};
+template <>
+struct Vec<half_t, 2> {
+    float v[2];
+    __device__ __forceinline__ void load(const half_t* p) {
+        half2_t t = *reinterpret_cast<const half2_t*>(p);
+        v[0] = (float)t.x; v[1] = (float)t.y;
+    }
+};
+template <>
+struct Vec<half_t, 4> {
+    float v[4];
+    __device__ __forceinline__ void load(const half_t* p) {
+        half4_t t = *reinterpret_cast<const half4_t*>(p);
+        v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
+    }
+};
+template <>
+struct Vec<half_t, 8> {
+    float v[8];
+    __device__ __forceinline__ void load(const half_t* p) {
+        half8_t t = *reinterpret_cast<const half8_t*>(p);
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = (float)t[c];
+    }
+};
+
+template <typename T, int C>
+__device__ __forceinline__ void store_vec(T* p, const float (&v)[C]) {
+    if constexpr (sizeof(T) == 2 && C == 2) {
+        half2_t t = {(half_t)v[0], (half_t)v[1]};
+        *reinterpret_cast<half2_t*>(p) = t;
+    } else if constexpr (sizeof(T) == 2 && C == 4) {
+        half4_t t = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4_t*>(p) = t;
+    } else if constexpr (sizeof(T) == 4 && C == 2) {
+        float2_t t = {v[0], v[1]};
+        *reinterpret_cast<float2_t*>(p) = t;
+    } else if constexpr (sizeof(T) == 4 && C == 4) {
+        float4_t t = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<float4_t*>(p) = t;
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) p[c] = (T)v[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+constexpr int FWD_THREADS = 256;
+
+template <typename T, int D, int C, bool WITH_DYDX>
+__global__ __launch_bounds__(FWD_THREADS) void k_grid_forward(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                              const int32_t* __restrict__ offsets, T* __restrict__ outputs,
+                                                              uint32_t B, uint32_t L, GridLevels lv, T* __restrict__ dy_dx,
+                                                              uint32_t gridtype, bool align_corners, uint32_t interp) {
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float scale = lv.scale[level];
+    LevelIndexer<D> indexer;
+    indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
+    const T* __restrict__ table = grid + (size_t)off0 * C;
+
+    for (uint32_t b = blockIdx.x * FWD_THREADS + threadIdx.x; b < B; b += gridDim.x * FWD_THREADS) {
+        float frac[D], deriv[D];
+        uint32_t cell[D];
+        T* out = outputs + ((size_t)level * B + b) * C;
+        T* dyo = WITH_DYDX ? dy_dx + ((size_t)b * L + level) * D * C : nullptr;
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) acc[c] = 0.0f;
+        if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, frac, deriv, cell)) {
+            store_vec<T, C>(out, acc);
+            if (WITH_DYDX) {
+#pragma unroll
+                for (int i = 0; i < D * C; i++) dyo[i] = (T)0.0f;
+            }
+            continue;
+        }
+        // gather all 2^D corners first (independent loads), then combine
+        Vec<T, C> corner[1 << D];
+#pragma unroll
+        for (int k = 0; k < (1 << D); k++) {
+            uint32_t pg[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) pg[d] = cell[d] + ((k >> d) & 1);
+            corner[k].load(table + (size_t)indexer(pg) * C);
+        }
+#pragma unroll
+        for (int k = 0; k < (1 << D); k++) {
+            float w = 1.0f;
+#pragma unroll
+            for (int d = 0; d < D; d++) w *= ((k >> d) & 1) ? frac[d] : (1.0f - frac[d]);
+#pragma unroll
+            for (int c = 0; c < C; c++) acc[c] = __builtin_fmaf(w, corner[k].v[c], acc[c]);
+        }
+        store_vec<T, C>(out, acc);
+
+        if (WITH_DYDX) {
+            // gridencoder.cu:201-244: d out / d x_g = scale * sum_{other corners} w_other * (v_right - v_left) * deriv_g
+#pragma unroll
+            for (int g = 0; g < D; g++) {
+                float ga[C];
+#pragma unroll
+                for (int c = 0; c < C; c++) ga[c] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < (1 << D); k++) {
+                    if ((k >> g) & 1) continue;  // enumerate the "left" corners
+                    float w = scale;
+#pragma unroll
+                    for (int d = 0; d < D; d++)
+                        if (d != g) w *= ((k >> d) & 1) ? frac[d] : (1.0f - frac[d]);
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        ga[c] = __builtin_fmaf(w * deriv[g], corner[k | (1 << g)].v[c] - corner[k].v[c], ga[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < C; c++) dyo[g * C + c] = (T)ga[c];
+            }
+        }
+    }
+}
+
+// corner-index diagnostic (same locate/indexer code path as the forward kernel)
+template <int D>
+__global__ __launch_bounds__(FWD_THREADS) void k_grid_corner_indices(const float* __restrict__ inputs,
+                                                                     const int32_t* __restrict__ offsets,
+                                                                     uint32_t* __restrict__ out, uint32_t B, GridLevels lv,
+                                                                     uint32_t gridtype, bool align_corners) {
+    const uint32_t level = blockIdx.y;
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level];
+    LevelIndexer<D> indexer;
+    indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
+    for (uint32_t b = blockIdx.x * FWD_THREADS + threadIdx.x; b < B; b += gridDim.x * FWD_THREADS) {
+        float frac[D], deriv[D];
+        uint32_t cell[D];
+        uint32_t* o = out + ((size_t)level * B + b) * (1 << D);
+        const bool ok = locate<D>(inputs + (size_t)b * D, lv.scale[level], align_corners, 0u, frac, deriv, cell);
+#pragma unroll
+        for (int k = 0; k < (1 << D); k++) {
+            uint32_t pg[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) pg[d] = cell[d] + ((k >> d) & 1);
+            o[k] = ok ? indexer(pg) : 0xFFFFFFFFu;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward (scatter-add into grad_embeddings)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add_feat(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_pk(half_t* p, float a, float b) {
+    half2_t v = {(half_t)a, (half_t)b};
+    (void)__builtin_amdgcn_flat_atomic_fadd_v2f16(reinterpret_cast<half2_t*>(p), v);  // global_atomic_pk_add_f16
+}
+// fp16 table with odd C (C == 1): emulate with a 32-bit CAS on the containing word (the reference
+// routes this case to a slow scalar half atomicAdd; under autocast the wrapper never produces it).
+__device__ __forceinline__ void atomic_add_half1(half_t* p, float a) {
+    uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+    uint32_t* word = reinterpret_cast<uint32_t*>(addr & ~uintptr_t(3));
+    const bool hi = (addr & 2) != 0;
+    uint32_t old = *word, assumed;
+    do {
+        assumed = old;
+        uint16_t bits = hi ? (uint16_t)(assumed >> 16) : (uint16_t)(assumed & 0xFFFFu);
+        half_t h = __builtin_bit_cast(half_t, bits);
+        h = (half_t)((float)h + a);
+        uint16_t nb = __builtin_bit_cast(uint16_t, h);
+        uint32_t nw = hi ? ((assumed & 0x0000FFFFu) | ((uint32_t)nb << 16)) : ((assumed & 0xFFFF0000u) | nb);
+        old = atomicCAS(word, assumed, nw);
+    } while (old != assumed);
+}
+
+template <typename T, int C>
+__device__ __forceinline__ void scatter_add(T* dst, const float (&g)[C], float w) {
+    if constexpr (sizeof(T) == 2) {
+        if constexpr (C % 2 == 0) {
+#pragma unroll
+            for (int c = 0; c < C; c += 2) atomic_add_pk(reinterpret_cast<half_t*>(dst) + c, w * g[c], w * g[c + 1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; c++) atomic_add_half1(reinterpret_cast<half_t*>(dst) + c, w * g[c]);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) atomic_add_feat(reinterpret_cast<float*>(dst) + c, w * g[c]);
+    }
+}
+
+constexpr int BWD_THREADS = 256;
+constexpr uint32_t BWD_LDS_BYTES = 64 * 1024;  // privatised accumulators for small dense levels (fp32)
+
+// PRIV = true : handles only the levels whose table fits the LDS budget (privatised accumulation);
+// PRIV = false: handles only the others (direct global atomics, no LDS so occupancy stays high).
+template <typename T, int D, int C, bool PRIV>
+__global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                               const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                               uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
+                                                               bool align_corners, uint32_t interp, uint32_t points_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds_acc[];
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float scale = lv.scale[level];
+    LevelIndexer<D> indexer;
+    indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
+    T* __restrict__ gtable = grad_grid + (size_t)off0 * C;
+    // privatise when the whole level fits into the block's LDS budget (wave-uniform decision)
+    const bool fits = (size_t)hashmap_size * C * sizeof(float) <= BWD_LDS_BYTES;
+    if (fits != PRIV) return;
+    constexpr bool use_lds = PRIV;
+    if (use_lds) {
+        for (uint32_t i = threadIdx.x; i < hashmap_size * C; i += BWD_THREADS) lds_acc[i] = 0.0f;
+        __syncthreads();
+    }
+    const uint32_t b_begin = blockIdx.x * points_per_block;
+    const uint32_t b_end = min(B, b_begin + points_per_block);
+    for (uint32_t b = b_begin + threadIdx.x; b < b_end; b += BWD_THREADS) {
+        float frac[D], deriv[D];
+        uint32_t cell[D];
+        if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, frac, deriv, cell)) continue;
+        Vec<T, C> g;
+        g.load(grad + ((size_t)level * B + b) * C);
+#pragma unroll
+        for (int k = 0; k < (1 << D); k++) {
+            float w = 1.0f;
+            uint32_t pg[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                w *= ((k >> d) & 1) ? frac[d] : (1.0f - frac[d]);
+                pg[d] = cell[d] + ((k >> d) & 1);
+            }
+            const uint32_t idx = indexer(pg) * C;
+            if (use_lds) {
+#pragma unroll
+                for (int c = 0; c < C; c++) atomicAdd(&lds_acc[idx + c], w * g.v[c]);  // ds_add_f32
+            } else {
+                scatter_add<T, C>(gtable + idx, g.v, w);
+            }
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < hashmap_size; e += BWD_THREADS) {
+            float v[C];
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                v[c] = lds_acc[e * C + c];
+                any = any || (v[c] != 0.0f);
+            }
+            if (any) scatter_add<T, C>(gtable + (size_t)e * C, v, 1.0f);
+        }
+    }
+}
+
+// gridencoder.cu:343-369
+template <typename T>
+__global__ void k_grid_input_backward(const T* __restrict__ grad, const T* __restrict__ dy_dx, T* __restrict__ grad_inputs,
+                                      uint32_t B, uint32_t L, uint32_t D, uint32_t C) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * D) return;
+    const uint32_t b = t / D, d = t - b * D;
+    const T* dd = dy_dx + (size_t)b * L * D * C;
+    float r = 0.0f;
+    for (uint32_t l = 0; l < L; l++)
+        for (uint32_t c = 0; c < C; c++)
+            r = __builtin_fmaf((float)grad[((size_t)l * B + b) * C + c], (float)dd[(l * D + d) * C + c], r);
+    grad_inputs[t] = (T)r;
+}
+
+// gridencoder.cu:506-610
+template <typename T, int D, int C>
+__global__ __launch_bounds__(FWD_THREADS) void k_grad_tv(const T* __restrict__ inputs, const T* __restrict__ grid,
+                                                         T* __restrict__ grad, const int32_t* __restrict__ offsets,
+                                                         float weight, uint32_t B, GridLevels lv, uint32_t gridtype,
+                                                         bool align_corners) {
+    const uint32_t level = blockIdx.y;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const uint32_t resolution = lv.res[level];
+    LevelIndexer<D> indexer;
+    indexer.init(gridtype, align_corners, hashmap_size, resolution);
+    const T* __restrict__ table = grid + (size_t)off0 * C;
+    T* __restrict__ gtable = grad + (size_t)off0 * C;
+    const float w = weight / (float)(2 * D);
+    for (uint32_t b = blockIdx.x * FWD_THREADS + threadIdx.x; b < B; b += gridDim.x * FWD_THREADS) {
+        float x[D];
+        bool inside = true;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            x[d] = (float)inputs[(size_t)b * D + d];
+            inside = inside && !(x[d] < 0.0f || x[d] > 1.0f);
+        }
+        if (!inside) continue;
+        uint32_t pg[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) pg[d] = (uint32_t)floorf(__builtin_fmaf(x[d], lv.scale[level], align_corners ? 0.0f : 0.5f));
+        const uint32_t idx = indexer(pg) * C;
+        Vec<T, C> ctr;
+        ctr.load(table + idx);
+        float res[C], idelta[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) res[c] = idelta[c] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const uint32_t cur = pg[d];
+            if (cur < resolution) {
+                pg[d] = cur + 1u;
+                Vec<T, C> o;
+                o.load(table + (size_t)indexer(pg) * C);
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    float gv = ctr.v[c] - o.v[c];
+                    res[c] += gv;
+                    idelta[c] = __builtin_fmaf(gv, gv, idelta[c]);
+                }
+            }
+            if (cur > 0u) {
+                pg[d] = cur - 1u;
+                Vec<T, C> o;
+                o.load(table + (size_t)indexer(pg) * C);
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    float gv = ctr.v[c] - o.v[c];
+                    res[c] += gv;
+                    idelta[c] = __builtin_fmaf(gv, gv, idelta[c]);
+                }
+            }
+            pg[d] = cur;
+        }
+        float upd[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) upd[c] = w * res[c] * rsqrtf(idelta[c] + 1e-9f);
+        scatter_add<T, C>(gtable + idx, upd, 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static void fill_levels(GridLevels& lv, uint32_t L, float S, uint32_t H) {
+    ngp_grid_level_table(L, S, H, lv.scale, lv.res);
+}
+
+static uint32_t fwd_blocks(uint32_t B) {
+    // >= 256 workgroups per level already at B = 64k; cap so the level-major order stays meaningful
+    uint32_t nb = cdiv(B, FWD_THREADS);
+    return nb < 1 ? 1 : (nb > 65535u ? 65535u : nb);
+}
+
+template <typename T, int D, int C>
+static int launch_forward(const float* inputs, const void* emb, const int32_t* offsets, void* outputs, uint32_t B,
+                          uint32_t L, const GridLevels& lv, void* dy_dx, uint32_t gridtype, bool ac, uint32_t interp,
+                          hipStream_t st) {
+    dim3 grid(fwd_blocks(B), L, 1);
+    if (dy_dx)
+        hipLaunchKernelGGL((k_grid_forward<T, D, C, true>), grid, dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
+                           (T*)outputs, B, L, lv, (T*)dy_dx, gridtype, ac, interp);
+    else
+        hipLaunchKernelGGL((k_grid_forward<T, D, C, false>), grid, dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
+                           (T*)outputs, B, L, lv, (T*)nullptr, gridtype, ac, interp);
+    return check_launch("grid_encode_forward");
+}
+
+template <typename T, int D, int C>
+static int launch_backward(const void* grad, const float* inputs, const int32_t* offsets, void* grad_emb, uint32_t B,
+                           uint32_t L, const GridLevels& lv, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
+                           bool ac, uint32_t interp, hipStream_t st) {
+    // one block covers `ppb` consecutive points of one level: big enough that an LDS-privatised level
+    // is flushed rarely, small enough that the chip is filled (>= ~2 blocks per CU over all levels).
+    uint32_t ppb = 2048;
+    while (ppb > 256 && (uint64_t)cdiv(B, ppb) * L < 1024) ppb >>= 1;
+    dim3 grid(cdiv(B, ppb), L, 1);
+    hipLaunchKernelGGL((k_grid_backward<T, D, C, false>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
+                       (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb);
+    int rc = check_launch("grid_encode_backward");
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_grid_backward<T, D, C, true>), grid, dim3(BWD_THREADS), BWD_LDS_BYTES, st, (const T*)grad, inputs, offsets,
+                       (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb);
+    rc = check_launch("grid_encode_backward(lds)");
+    if (rc) return rc;
+    if (dy_dx && grad_inputs) {
+        hipLaunchKernelGGL((k_grid_input_backward<T>), dim3(cdiv(B * D, 256)), dim3(256), 0, st, (const T*)grad,
+                           (const T*)dy_dx, (T*)grad_inputs, B, L, (uint32_t)D, (uint32_t)C);
+        rc = check_launch("grid_encode_backward(input)");
+    }
+    return rc;
+}
+
+template <typename T, int D, int C>
+static int launch_tv(const void* inputs, const void* emb, void* grad, const int32_t* offsets, float weight, uint32_t B,
+                     uint32_t L, const GridLevels& lv, uint32_t gridtype, bool ac, hipStream_t st) {
+    dim3 grid(fwd_blocks(B), L, 1);
+    hipLaunchKernelGGL((k_grad_tv<T, D, C>), grid, dim3(FWD_THREADS), 0, st, (const T*)inputs, (const T*)emb, (T*)grad,
+                       offsets, weight, B, lv, gridtype, ac);
+    return check_launch("grad_total_variation");
+}
+
+#define NGP_DISPATCH_DC(FN, T, ...)                                                               \
+    switch (D * 16 + C) {                                                                         \
+        case 2 * 16 + 1: return FN<T, 2, 1>(__VA_ARGS__);                                          \
+        case 2 * 16 + 2: return FN<T, 2, 2>(__VA_ARGS__);                                          \
+        case 2 * 16 + 4: return FN<T, 2, 4>(__VA_ARGS__);                                          \
+        case 2 * 16 + 8: return FN<T, 2, 8>(__VA_ARGS__);                                          \
+        case 3 * 16 + 1: return FN<T, 3, 1>(__VA_ARGS__);                                          \
+        case 3 * 16 + 2: return FN<T, 3, 2>(__VA_ARGS__);                                          \
+        case 3 * 16 + 4: return FN<T, 3, 4>(__VA_ARGS__);                                          \
+        case 3 * 16 + 8: return FN<T, 3, 8>(__VA_ARGS__);                                          \
+        case 4 * 16 + 1: return FN<T, 4, 1>(__VA_ARGS__);                                          \
+        case 4 * 16 + 2: return FN<T, 4, 2>(__VA_ARGS__);                                          \
+        case 4 * 16 + 4: return FN<T, 4, 4>(__VA_ARGS__);                                          \
+        case 4 * 16 + 8: return FN<T, 4, 8>(__VA_ARGS__);                                          \
+        case 5 * 16 + 1: return FN<T, 5, 1>(__VA_ARGS__);                                          \
+        case 5 * 16 + 2: return FN<T, 5, 2>(__VA_ARGS__);                                          \
+        case 5 * 16 + 4: return FN<T, 5, 4>(__VA_ARGS__);                                          \
+        case 5 * 16 + 8: return FN<T, 5, 8>(__VA_ARGS__);                                          \
+        default: break;                                                                            \
+    }
+
+static int check_grid_args(const char* fn, uint32_t B, uint32_t D, uint32_t C, uint32_t L, int dtype) {
+    (void)B;
+    // the reference throws std::runtime_error{"GridEncoding: C must be 1, 2, 4, or 8."} for both (gridencoder.cu:381,398)
+    NGP_REQUIRE(D >= 2 && D <= 5, NGP_ERR_INVALID, "%s: GridEncoding: input dim D must be 2, 3, 4 or 5 (got %u)", fn, D);
+    NGP_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8, NGP_ERR_INVALID, "%s: GridEncoding: C must be 1, 2, 4, or 8. (got %u)", fn, C);
+    NGP_REQUIRE(L >= 1 && L <= NGP_MAX_LEVELS, NGP_ERR_INVALID, "%s: number of levels must be in [1, %d] (got %u)", fn, NGP_MAX_LEVELS, L);
+    NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_ERR_INVALID, "%s: embeddings must be float32 or float16", fn);
+    return NGP_OK;
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" int ngp_grid_level_table(uint32_t L, float S, uint32_t H, float* scale_out, uint32_t* resolution_out) {
+    NGP_REQUIRE(scale_out && resolution_out, NGP_ERR_INVALID, "ngp_grid_level_table: NULL output");
+    for (uint32_t l = 0; l < L; l++) {
+        const float a = (float)l * S;
+        const float e = (float)exp2((double)a);
+        const float sc = fmaf(e, (float)H, -1.0f);
+        scale_out[l] = sc;
+        resolution_out[l] = (uint32_t)ceilf(sc) + 1u;
+    }
+    return NGP_OK;
+}
+
+extern "C" int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                       uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                       uint32_t gridtype, int align_corners, uint32_t interp, int dtype, ngp_stream_t stream) {
+    int rc = check_grid_args("grid_encode_forward", B, D, C, L, dtype);
+    if (rc) return rc;
+    NGP_REQUIRE(inputs && embeddings && offsets && outputs, NGP_ERR_INVALID, "grid_encode_forward: NULL tensor");
+    if (B == 0) return NGP_OK;
+    GridLevels lv;
+    fill_levels(lv, L, S, H);
+    hipStream_t st = as_stream(stream);
+    const bool ac = align_corners != 0;
+    if (dtype == NGP_F16) {
+        NGP_DISPATCH_DC(launch_forward, half_t, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st)
+    } else {
+        NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st)
+    }
+    set_error("grid_encode_forward: unsupported (D=%u, C=%u)", D, C);
+    return NGP_ERR_INVALID;
+}
+
+extern "C" int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                        void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                        uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                                        uint32_t interp, int dtype, ngp_stream_t stream) {
+    (void)embeddings;
+    int rc = check_grid_args("grid_encode_backward", B, D, C, L, dtype);
+    if (rc) return rc;
+    NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: NULL tensor");
+    if (B == 0) return NGP_OK;
+    GridLevels lv;
+    fill_levels(lv, L, S, H);
+    hipStream_t st = as_stream(stream);
+    const bool ac = align_corners != 0;
+    if (dtype == NGP_F16) {
+        NGP_DISPATCH_DC(launch_backward, half_t, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, st)
+    } else {
+        NGP_DISPATCH_DC(launch_backward, float, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, st)
+    }
+    set_error("grid_encode_backward: unsupported (D=%u, C=%u)", D, C);
+    return NGP_ERR_INVALID;
+}
+
+extern "C" int ngp_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,
+                                        float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                        uint32_t gridtype, int align_corners, int dtype, ngp_stream_t stream) {
+    int rc = check_grid_args("grad_total_variation", B, D, C, L, dtype);
+    if (rc) return rc;
+    NGP_REQUIRE(inputs && embeddings && grad && offsets, NGP_ERR_INVALID, "grad_total_variation: NULL tensor");
+    if (B == 0) return NGP_OK;
+    GridLevels lv;
+    fill_levels(lv, L, S, H);
+    hipStream_t st = as_stream(stream);
+    const bool ac = align_corners != 0;
+    if (dtype == NGP_F16) {
+        NGP_DISPATCH_DC(launch_tv, half_t, inputs, embeddings, grad, offsets, weight, B, L, lv, gridtype, ac, st)
+    } else {
+        NGP_DISPATCH_DC(launch_tv, float, inputs, embeddings, grad, offsets, weight, B, L, lv, gridtype, ac, st)
+    }
+    set_error("grad_total_variation: unsupported (D=%u, C=%u)", D, C);
+    return NGP_ERR_INVALID;
+}
+
+extern "C" int ngp_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_t* indices, uint32_t B, uint32_t D,
+                                       uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                       ngp_stream_t stream) {
+    int rc = check_grid_args("grid_corner_indices", B, D, 1, L, NGP_F32);
+    if (rc) return rc;
+    NGP_REQUIRE(inputs && offsets && indices, NGP_ERR_INVALID, "grid_corner_indices: NULL tensor");
+    if (B == 0) return NGP_OK;
+    GridLevels lv;
+    fill_levels(lv, L, S, H);
+    hipStream_t st = as_stream(stream);
+    dim3 grid(fwd_blocks(B), L, 1);
+    const bool ac = align_corners != 0;
+    switch (D) {
+        case 2: hipLaunchKernelGGL((k_grid_corner_indices<2>), grid, dim3(FWD_THREADS), 0, st, inputs, offsets, indices, B, lv, gridtype, ac); break;
+        case 3: hipLaunchKernelGGL((k_grid_corner_indices<3>), grid, dim3(FWD_THREADS), 0, st, inputs, offsets, indices, B, lv, gridtype, ac); break;
+        case 4: hipLaunchKernelGGL((k_grid_corner_indices<4>), grid, dim3(FWD_THREADS), 0, st, inputs, offsets, indices, B, lv, gridtype, ac); break;
+        default: hipLaunchKernelGGL((k_grid_corner_indices<5>), grid, dim3(FWD_THREADS), 0, st, inputs, offsets, indices, B, lv, gridtype, ac); break;
+    }
+    return check_launch("grid_corner_indices");
+}

@@ -1,0 +1,688 @@
+// Density-grid ray marching and volume compositing for gfx950 (MI355X).
+//
+// Behaviour restated from raymarching/src/raymarching.cu of the reference (line ranges per kernel below).
+//
+// MI355X design (see DESIGN.md "raymarching"):
+//   * sample slots of march_rays_train are handed out by a deterministic two-kernel prefix sum in ray
+//     order (count -> block sums -> scan -> write) instead of the reference's two global atomics per
+//     ray: the layout of xyzs/dirs/deltas/rays is reproducible and equals what a sequential run of the
+//     reference produces, and the only cross-workgroup traffic is one 4-byte block sum per 256 rays;
+//   * training compositing runs one 64-lane wavefront per ray: samples are read as coalesced 64-wide
+//     rows, transmittance is a wave-level prefix product (6 __shfl_up steps), colour/depth/weight are
+//     wave reductions; the T < T_thresh early stop becomes a per-lane predicate on the exclusive
+//     prefix product, so a ray stops after the 64-sample row in which it saturates;
+//   * every floating-point operation that decides an integer (cell index, occupancy bit, step count)
+//     is written with explicit fmaf so that it rounds exactly like oracle/ngp_oracle.c
+//     (both are compiled with -ffp-contract=off; division is IEEE).
+#include "common.h"
+#include <math.h>
+#include <float.h>
+
+namespace ngp {
+
+constexpr int RM_THREADS = 256;
+
+// ---------------------------------------------------------------------------------------------
+// small utilities
+// ---------------------------------------------------------------------------------------------
+// raymarching.cu:92-145
+__global__ void k_near_far_from_aabb(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                     const float* __restrict__ aabb, uint32_t N, float min_near, float* __restrict__ nears,
+                                     float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float rdx = 1.0f / rays_d[n * 3], rdy = 1.0f / rays_d[n * 3 + 1], rdz = 1.0f / rays_d[n * 3 + 2];
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, t;
+    if (near > far) { t = near; near = far; far = t; }
+    float ny = (aabb[1] - oy) * rdy, fy = (aabb[4] - oy) * rdy;
+    if (ny > fy) { t = ny; ny = fy; fy = t; }
+    if (near > fy || ny > far) { nears[n] = fars[n] = FLT_MAX; return; }
+    if (ny > near) near = ny;
+    if (fy < far) far = fy;
+    float nz = (aabb[2] - oz) * rdz, fz = (aabb[5] - oz) * rdz;
+    if (nz > fz) { t = nz; nz = fz; fz = t; }
+    if (near > fz || nz > far) { nears[n] = fars[n] = FLT_MAX; return; }
+    if (nz > near) near = nz;
+    if (fz < far) far = fz;
+    if (near < min_near) near = min_near;
+    nears[n] = near;
+    fars[n] = far;
+}
+
+// raymarching.cu:163-198
+__global__ void k_sph_from_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float radius, uint32_t N,
+                               float* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float Bh = ox * dx + oy * dy + oz * dz;
+    const float Cc = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-Bh + sqrtf(Bh * Bh - A * Cc)) / A;
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    const float theta = atan2f(sqrtf(x * x + z * z), y);
+    const float phi = atan2f(z, x);
+    const float RPI = 0.3183098861837907f;
+    coords[n * 2] = 2.0f * theta * RPI - 1.0f;
+    coords[n * 2 + 1] = phi * RPI;
+}
+
+// raymarching.cu:56-81
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3D_1(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t compact_bits(uint32_t x) {
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+__global__ void k_morton3D(const int32_t* __restrict__ coords, uint32_t N, int32_t* __restrict__ indices) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int32_t)morton3D_1((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+__global__ void k_morton3D_invert(const int32_t* __restrict__ indices, uint32_t N, int32_t* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int32_t ind = indices[n];
+    coords[n * 3 + 0] = (int32_t)compact_bits((uint32_t)(ind >> 0));
+    coords[n * 3 + 1] = (int32_t)compact_bits((uint32_t)(ind >> 1));
+    coords[n * 3 + 2] = (int32_t)compact_bits((uint32_t)(ind >> 2));
+}
+
+// raymarching.cu:268-289.  One lane packs one byte from two 16-byte loads (the grid is a pure stream:
+// 4.125 B per cell).
+__global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float4_t a = *reinterpret_cast<const float4_t*>(grid + (size_t)n * 8);
+    const float4_t b = *reinterpret_cast<const float4_t*>(grid + (size_t)n * 8 + 4);
+    uint32_t bits = 0;
+    bits |= (a.x > thresh) ? 1u : 0u;
+    bits |= (a.y > thresh) ? 2u : 0u;
+    bits |= (a.z > thresh) ? 4u : 0u;
+    bits |= (a.w > thresh) ? 8u : 0u;
+    bits |= (b.x > thresh) ? 16u : 0u;
+    bits |= (b.y > thresh) ? 32u : 0u;
+    bits |= (b.z > thresh) ? 64u : 0u;
+    bits |= (b.w > thresh) ? 128u : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the marcher (shared by training and inference)          raymarching.cu:312-480, 701-805
+// ---------------------------------------------------------------------------------------------
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+};
+struct MarchParams {  // wave-uniform
+    float bound, dt_gamma, dt_min, dt_max, Hf, rH, H3f, Hm1, Cm1;
+    const uint8_t* grid;
+};
+
+__device__ __forceinline__ MarchParams make_params(float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                                                   const uint8_t* grid) {
+    MarchParams p;
+    const float SQRT3 = 1.7320508075688772f;
+    p.bound = bound;
+    p.dt_gamma = dt_gamma;
+    p.Hf = (float)H;
+    p.rH = 1.0f / p.Hf;
+    p.H3f = (float)(H * H * H);
+    p.Hm1 = (float)(H - 1);
+    p.Cm1 = (float)C - 1.0f;
+    p.dt_min = 2.0f * SQRT3 / (float)max_steps;
+    p.dt_max = 2.0f * SQRT3 * (float)(1u << (C - 1)) / p.Hf;
+    p.grid = grid;
+    return p;
+}
+
+__device__ __forceinline__ Ray load_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, uint32_t i) {
+    Ray r;
+    r.ox = rays_o[i * 3]; r.oy = rays_o[i * 3 + 1]; r.oz = rays_o[i * 3 + 2];
+    r.dx = rays_d[i * 3]; r.dy = rays_d[i * 3 + 1]; r.dz = rays_d[i * 3 + 2];
+    r.rdx = 1.0f / r.dx; r.rdy = 1.0f / r.dy; r.rdz = 1.0f / r.dz;
+    return r;
+}
+
+__device__ __forceinline__ int mip_exponent(float mx, float Cm1) {
+    int e;
+    (void)frexpf(mx, &e);
+    return (int)fminf(Cm1, fmaxf(0.0f, (float)e));
+}
+
+__device__ __forceinline__ float step_dt(const MarchParams& p, float t) { return clampf(t * p.dt_gamma, p.dt_min, p.dt_max); }
+
+// Evaluate the occupancy grid at parameter t.  Returns true when the voxel is occupied; otherwise tt
+// receives the parameter of the far face of the voxel (raymarching.cu:359-400).
+__device__ __forceinline__ bool probe(const MarchParams& p, const Ray& r, float t, float& x, float& y, float& z, float& dt,
+                                      float& tt) {
+    x = clampf(__builtin_fmaf(t, r.dx, r.ox), -p.bound, p.bound);
+    y = clampf(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
+    z = clampf(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
+    dt = step_dt(p, t);
+    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+    const int lp = mip_exponent(mx, p.Cm1);
+    const int ld = mip_exponent((dt * p.Hf) * 0.5f, p.Cm1);
+    const int level = lp > ld ? lp : ld;
+    const float mip_bound = fminf(scalbnf(1.0f, level), p.bound);
+    const float mip_rbound = 1.0f / mip_bound;
+    const int nx = (int)clampf((0.5f * __builtin_fmaf(x, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
+    const int ny = (int)clampf((0.5f * __builtin_fmaf(y, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
+    const int nz = (int)clampf((0.5f * __builtin_fmaf(z, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
+    const uint32_t index = (uint32_t)((float)level * p.H3f + (float)morton3D_1((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    const bool occ = (p.grid[index >> 3] & (1u << (index & 7u))) != 0;
+    if (!occ) {
+        const float tx = __builtin_fmaf(((float)nx + 0.5f + 0.5f * copysignf(1.0f, r.dx)) * p.rH * 2.0f - 1.0f, mip_bound, -x) * r.rdx;
+        const float ty = __builtin_fmaf(((float)ny + 0.5f + 0.5f * copysignf(1.0f, r.dy)) * p.rH * 2.0f - 1.0f, mip_bound, -y) * r.rdy;
+        const float tz = __builtin_fmaf(((float)nz + 0.5f + 0.5f * copysignf(1.0f, r.dz)) * p.rH * 2.0f - 1.0f, mip_bound, -z) * r.rdz;
+        tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    }
+    return occ;
+}
+
+// advance in whole steps to the far face of an empty voxel (raymarching.cu:396-399).  The extra
+// `t < far` bound cannot change any output (nothing is emitted once t >= far) but keeps a degenerate
+// ray (zero direction => tt = +inf) from spinning forever, which the reference would.
+__device__ __forceinline__ float skip_to(const MarchParams& p, float t, float tt, float far) {
+    do {
+        t += step_dt(p, t);
+    } while (t < tt && t < far);
+    return t;
+}
+
+// block-wide sum of one uint32 per thread (RM_THREADS threads); result valid in every thread
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds4) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t s = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __syncthreads();
+    if (lane == 0) lds4[wid] = s;
+    __syncthreads();
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < RM_THREADS / 64; w++) tot += lds4[w];
+    return tot;
+}
+
+// workspace layout (uint32): [0] = counter[0] snapshot, [1 ...] = per-block sample counts
+// pass 1: count the samples of every ray (raymarching.cu:353-400)
+__global__ __launch_bounds__(RM_THREADS) void k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                                  const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                                  uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                                  const float* __restrict__ nears, const float* __restrict__ fars,
+                                                                  int32_t* __restrict__ rays, const int32_t* __restrict__ counter,
+                                                                  const float* __restrict__ noises, uint32_t* __restrict__ ws) {
+    __shared__ uint32_t lds4[RM_THREADS / 64];
+    const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+    uint32_t num_steps = 0;
+    if (n < N) {
+        const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
+        const Ray r = load_ray(rays_o, rays_d, n);
+        const float near = nears[n], far = fars[n];
+        float t = __builtin_fmaf(step_dt(p, near), noises[n], near);
+        float x, y, z, dt, tt;
+        while (t < far && num_steps < max_steps) {
+            if (probe(p, r, t, x, y, z, dt, tt)) {
+                num_steps++;
+                t += dt;
+            } else {
+                t = skip_to(p, t, tt, far);
+            }
+        }
+        rays[n * 3] = (int32_t)n;
+        rays[n * 3 + 2] = (int32_t)num_steps;
+    }
+    const uint32_t tot = block_sum(num_steps, lds4);
+    if (threadIdx.x == 0) {
+        ws[1 + blockIdx.x] = tot;
+        if (blockIdx.x == 0) ws[0] = (uint32_t)counter[0];
+    }
+}
+
+// pass 2: exclusive scan in ray order, then re-march and write (raymarching.cu:402-479)
+__global__ __launch_bounds__(RM_THREADS) void k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                                  const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                                  uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                                  const float* __restrict__ nears, const float* __restrict__ fars,
+                                                                  float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                                  float* __restrict__ deltas, int32_t* __restrict__ rays,
+                                                                  int32_t* __restrict__ counter, const float* __restrict__ noises,
+                                                                  const uint32_t* __restrict__ ws) {
+    __shared__ uint32_t lds4[RM_THREADS / 64];
+    __shared__ uint32_t wave_excl[RM_THREADS / 64];
+    // samples emitted by all earlier blocks
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += RM_THREADS) part += ws[1 + j];
+    const uint32_t block_offset = ws[0] + block_sum(part, lds4);
+
+    const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+    const uint32_t num_steps = (n < N) ? (uint32_t)rays[n * 3 + 2] : 0u;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t incl = wave_inclusive_scan(num_steps);
+    __syncthreads();
+    if (lane == 63) wave_excl[wid] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, block_total = 0;
+#pragma unroll
+    for (int w = 0; w < RM_THREADS / 64; w++) {
+        const uint32_t c = wave_excl[w];
+        if (w < wid) wbase += c;
+        block_total += c;
+    }
+    const uint32_t point_index = block_offset + wbase + (incl - num_steps);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        counter[0] = (int32_t)(block_offset + block_total);
+        counter[1] = counter[1] + (int32_t)N;
+    }
+    if (n >= N) return;
+    rays[n * 3 + 1] = (int32_t)point_index;
+    if (num_steps == 0 || point_index + num_steps > M) return;
+
+    const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
+    const Ray r = load_ray(rays_o, rays_d, n);
+    const float near = nears[n], far = fars[n];
+    float t = __builtin_fmaf(step_dt(p, near), noises[n], near);
+    float last_t = t;
+    float* xo = xyzs + (size_t)point_index * 3;
+    float* dd = dirs + (size_t)point_index * 3;
+    float* de = deltas + (size_t)point_index * 2;
+    uint32_t step = 0;
+    float x, y, z, dt, tt;
+    while (t < far && step < num_steps) {
+        if (probe(p, r, t, x, y, z, dt, tt)) {
+            xo[0] = x; xo[1] = y; xo[2] = z;
+            dd[0] = r.dx; dd[1] = r.dy; dd[2] = r.dz;
+            t += dt;
+            de[0] = dt; de[1] = t - last_t;
+            last_t = t;
+            xo += 3; dd += 3; de += 2;
+            step++;
+        } else {
+            t = skip_to(p, t, tt, far);
+        }
+    }
+}
+
+// raymarching.cu:701-805
+__global__ __launch_bounds__(RM_THREADS) void k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
+                                                           const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d, float bound, float dt_gamma,
+                                                           uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                                           const float* __restrict__ fars, float* __restrict__ xyzs,
+                                                           float* __restrict__ dirs, float* __restrict__ deltas,
+                                                           const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t index = (uint32_t)rays_alive[n];
+    const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
+    const Ray r = load_ray(rays_o, rays_d, index);
+    const float far = fars[index];
+    float t = rays_t[index];
+    t = __builtin_fmaf(step_dt(p, t), noises[n], t);
+    float last_t = t;
+    float* xo = xyzs + (size_t)n * n_step * 3;
+    float* dd = dirs + (size_t)n * n_step * 3;
+    float* de = deltas + (size_t)n * n_step * 2;
+    uint32_t step = 0;
+    float x, y, z, dt, tt;
+    while (t < far && step < n_step) {
+        if (probe(p, r, t, x, y, z, dt, tt)) {
+            xo[0] = x; xo[1] = y; xo[2] = z;
+            dd[0] = r.dx; dd[1] = r.dy; dd[2] = r.dz;
+            t += dt;
+            de[0] = dt; de[1] = t - last_t;
+            last_t = t;
+            xo += 3; dd += 3; de += 2;
+            step++;
+        } else {
+            t = skip_to(p, t, tt, far);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compositing (training): one wavefront per ray           raymarching.cu:501-577, 602-682
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float n = __shfl_up(v, o, 64);
+        if (lane >= o) v *= n;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float n = __shfl_up(v, o, 64);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+constexpr int CT_WAVES = 4;  // rays per workgroup
+
+__global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                       const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                                                       uint32_t M, uint32_t N, float T_thresh,
+                                                                       float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                                       float* __restrict__ image) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * CT_WAVES + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num = (uint32_t)rays[n * 3 + 2];
+    float r = 0, g = 0, b = 0, ws = 0, d = 0;
+    if (num != 0 && offset + num <= M) {
+        float T = 1.0f, tcarry = 0.0f;  // transmittance / accumulated real-delta before this row
+        for (uint32_t s0 = 0; s0 < num; s0 += 64) {
+            const uint32_t s = s0 + lane;
+            const bool valid = s < num;
+            float sg = 0.0f, d0 = 0.0f, d1 = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+            if (valid) {
+                sg = sigmas[offset + s];
+                const float2_t dl = *reinterpret_cast<const float2_t*>(deltas + (size_t)(offset + s) * 2);
+                d0 = dl.x; d1 = dl.y;
+                cr = rgbs[(size_t)(offset + s) * 3];
+                cg = rgbs[(size_t)(offset + s) * 3 + 1];
+                cb = rgbs[(size_t)(offset + s) * 3 + 2];
+            }
+            const float alpha = valid ? 1.0f - __expf(-sg * d0) : 0.0f;
+            const float om = 1.0f - alpha;
+            const float pin = wave_incl_prod(om, lane);          // prod_{j<=lane} (1-alpha_j)
+            const float pex = __shfl_up(pin, 1, 64);
+            const float T_before = T * (lane == 0 ? 1.0f : pex);  // transmittance in front of this sample
+            const float tt = tcarry + wave_incl_sum(d1, lane);    // t after this sample
+            // the sample that drives T below the threshold is still composited (raymarching.cu:557-560)
+            const bool live = valid && !(T_before < T_thresh);
+            const float w = live ? alpha * T_before : 0.0f;
+            r += w * cr; g += w * cg; b += w * cb; ws += w; d += w * tt;
+            T = T * __shfl(pin, 63, 64);
+            tcarry = __shfl(tt, 63, 64);
+            if (T < T_thresh) break;  // wave-uniform
+        }
+        r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); d = wave_sum(d);
+    }
+    if (lane == 0) {
+        weights_sum[index] = ws;
+        depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}
+
+__global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_bwd(const float* __restrict__ grad_ws, const float* __restrict__ grad_image,
+                                                                       const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                       const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                                                       const float* __restrict__ weights_sum, const float* __restrict__ image,
+                                                                       uint32_t M, uint32_t N, float T_thresh, float* __restrict__ grad_sigmas,
+                                                                       float* __restrict__ grad_rgbs) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * CT_WAVES + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num = (uint32_t)rays[n * 3 + 2];
+    if (num == 0 || offset + num > M) return;
+    const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
+    const float gw = grad_ws[index];
+    const float rf = image[index * 3], gf = image[index * 3 + 1], bf = image[index * 3 + 2], wsf = weights_sum[index];
+    float T = 1.0f, rc = 0.0f, gc = 0.0f, bc = 0.0f;  // carries from previous rows
+    for (uint32_t s0 = 0; s0 < num; s0 += 64) {
+        const uint32_t s = s0 + lane;
+        const bool valid = s < num;
+        float sg = 0.0f, d0 = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        if (valid) {
+            sg = sigmas[offset + s];
+            d0 = deltas[(size_t)(offset + s) * 2];
+            cr = rgbs[(size_t)(offset + s) * 3];
+            cg = rgbs[(size_t)(offset + s) * 3 + 1];
+            cb = rgbs[(size_t)(offset + s) * 3 + 2];
+        }
+        const float alpha = valid ? 1.0f - __expf(-sg * d0) : 0.0f;
+        const float pin = wave_incl_prod(1.0f - alpha, lane);
+        const float pex = __shfl_up(pin, 1, 64);
+        const float T_before = T * (lane == 0 ? 1.0f : pex);
+        const float T_after = T * pin;
+        const bool live = valid && !(T_before < T_thresh);
+        const float w = live ? alpha * T_before : 0.0f;
+        const float ra = rc + wave_incl_sum(w * cr, lane);
+        const float ga = gc + wave_incl_sum(w * cg, lane);
+        const float ba = bc + wave_incl_sum(w * cb, lane);
+        if (live) {
+            const uint32_t o = offset + s;
+            grad_rgbs[(size_t)o * 3] = gi0 * w;
+            grad_rgbs[(size_t)o * 3 + 1] = gi1 * w;
+            grad_rgbs[(size_t)o * 3 + 2] = gi2 * w;
+            grad_sigmas[o] = d0 * (gi0 * (T_after * cr - (rf - ra)) + gi1 * (T_after * cg - (gf - ga)) +
+                                   gi2 * (T_after * cb - (bf - ba)) + gw * (1.0f - wsf));
+        }
+        T = T * __shfl(pin, 63, 64);
+        rc = __shfl(ra, 63, 64); gc = __shfl(ga, 63, 64); bc = __shfl(ba, 63, 64);
+        if (T < T_thresh) break;
+    }
+}
+
+// raymarching.cu:819-905 -- at most 8 samples per ray and call: one lane per alive ray
+__global__ __launch_bounds__(RM_THREADS) void k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* __restrict__ rays_alive,
+                                                               float* __restrict__ rays_t, const float* __restrict__ sigmas,
+                                                               const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                                               float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                               float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t index = (uint32_t)rays_alive[n];
+    const float* sg = sigmas + (size_t)n * n_step;
+    const float* rg = rgbs + (size_t)n * n_step * 3;
+    const float* de = deltas + (size_t)n * n_step * 2;
+    float t = rays_t[index], ws = weights_sum[index], d = depth[index];
+    float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        const float d0 = de[step * 2];
+        if (d0 == 0.0f) break;
+        const float alpha = 1.0f - __expf(-sg[step] * d0);
+        const float T = 1.0f - ws;
+        const float w = alpha * T;
+        ws += w;
+        t += de[step * 2 + 1];
+        d += w * t;
+        r += w * rg[step * 3]; g += w * rg[step * 3 + 1]; b += w * rg[step * 3 + 2];
+        if (T < T_thresh) break;
+        step++;
+    }
+    if (step < n_step) rays_alive[n] = -1;
+    else rays_t[index] = t;
+    weights_sum[index] = ws;
+    depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// order-preserving compaction of the alive list (extension; replaces a host-side boolean index)
+// workspace (uint32): per-block survivor counts
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RM_THREADS) void k_compact_count(const int32_t* __restrict__ rays_alive, uint32_t n_alive, uint32_t* __restrict__ ws) {
+    __shared__ uint32_t lds4[RM_THREADS / 64];
+    const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+    const uint32_t keep = (n < n_alive && rays_alive[n] >= 0) ? 1u : 0u;
+    const uint32_t tot = block_sum(keep, lds4);
+    if (threadIdx.x == 0) ws[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(RM_THREADS) void k_compact_write(const int32_t* __restrict__ rays_alive, uint32_t n_alive,
+                                                              int32_t* __restrict__ out_alive, int32_t* __restrict__ out_count,
+                                                              const uint32_t* __restrict__ ws) {
+    __shared__ uint32_t lds4[RM_THREADS / 64];
+    __shared__ uint32_t wave_excl[RM_THREADS / 64];
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += RM_THREADS) part += ws[j];
+    const uint32_t block_offset = block_sum(part, lds4);
+    const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+    const int32_t id = (n < n_alive) ? rays_alive[n] : -1;
+    const uint32_t keep = id >= 0 ? 1u : 0u;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t incl = wave_inclusive_scan(keep);
+    __syncthreads();
+    if (lane == 63) wave_excl[wid] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, block_total = 0;
+#pragma unroll
+    for (int w = 0; w < RM_THREADS / 64; w++) {
+        const uint32_t c = wave_excl[w];
+        if (w < wid) wbase += c;
+        block_total += c;
+    }
+    if (keep) out_alive[block_offset + wbase + incl - 1] = id;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *out_count = (int32_t)(block_offset + block_total);
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+#define RM_LAUNCH_1D(kernel, count, st, ...) hipLaunchKernelGGL(kernel, dim3(cdiv((count), RM_THREADS)), dim3(RM_THREADS), 0, st, __VA_ARGS__)
+
+extern "C" int ngp_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
+                                      float* nears, float* fars, ngp_stream_t stream) {
+    NGP_REQUIRE(rays_o && rays_d && aabb && nears && fars, NGP_ERR_INVALID, "near_far_from_aabb: NULL tensor");
+    if (N == 0) return NGP_OK;
+    RM_LAUNCH_1D(k_near_far_from_aabb, N, as_stream(stream), rays_o, rays_d, aabb, N, min_near, nears, fars);
+    return check_launch("near_far_from_aabb");
+}
+
+extern "C" int ngp_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                                ngp_stream_t stream) {
+    NGP_REQUIRE(rays_o && rays_d && coords, NGP_ERR_INVALID, "sph_from_ray: NULL tensor");
+    if (N == 0) return NGP_OK;
+    RM_LAUNCH_1D(k_sph_from_ray, N, as_stream(stream), rays_o, rays_d, radius, N, coords);
+    return check_launch("sph_from_ray");
+}
+
+extern "C" int ngp_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, ngp_stream_t stream) {
+    NGP_REQUIRE(coords && indices, NGP_ERR_INVALID, "morton3D: NULL tensor");
+    if (N == 0) return NGP_OK;
+    RM_LAUNCH_1D(k_morton3D, N, as_stream(stream), coords, N, indices);
+    return check_launch("morton3D");
+}
+
+extern "C" int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, ngp_stream_t stream) {
+    NGP_REQUIRE(coords && indices, NGP_ERR_INVALID, "morton3D_invert: NULL tensor");
+    if (N == 0) return NGP_OK;
+    RM_LAUNCH_1D(k_morton3D_invert, N, as_stream(stream), indices, N, coords);
+    return check_launch("morton3D_invert");
+}
+
+extern "C" int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, ngp_stream_t stream) {
+    NGP_REQUIRE(grid && bitfield, NGP_ERR_INVALID, "packbits: NULL tensor");
+    NGP_REQUIRE((reinterpret_cast<uintptr_t>(grid) & 15) == 0, NGP_ERR_INVALID, "packbits: grid must be 16-byte aligned");
+    if (N == 0) return NGP_OK;
+    RM_LAUNCH_1D(k_packbits, N, as_stream(stream), grid, N, density_thresh, bitfield);
+    return check_launch("packbits");
+}
+
+extern "C" size_t ngp_march_rays_train_workspace_bytes(uint32_t N) { return sizeof(uint32_t) * (size_t)(1 + cdiv(N, RM_THREADS)); }
+
+static int check_march_args(const char* fn, uint32_t C, uint32_t H, uint32_t max_steps) {
+    NGP_REQUIRE(C >= 1 && C <= 8, NGP_ERR_INVALID, "%s: cascade count C must be in [1, 8] (got %u)", fn, C);
+    NGP_REQUIRE(H >= 2 && H <= 1024, NGP_ERR_INVALID, "%s: grid size H must be in [2, 1024] (got %u)", fn, H);
+    NGP_REQUIRE(max_steps >= 1, NGP_ERR_INVALID, "%s: max_steps must be positive", fn);
+    return NGP_OK;
+}
+
+extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                    const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                    const float* noises, void* workspace, ngp_stream_t stream) {
+    int rc = check_march_args("march_rays_train", C, H, max_steps);
+    if (rc) return rc;
+    NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises && workspace,
+                NGP_ERR_INVALID, "march_rays_train: NULL tensor");
+    if (N == 0) return NGP_OK;
+    hipStream_t st = as_stream(stream);
+    uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
+    RM_LAUNCH_1D(k_march_train_count, N, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays,
+                 (const int32_t*)counter, noises, ws);
+    rc = check_launch("march_rays_train(count)");
+    if (rc) return rc;
+    RM_LAUNCH_1D(k_march_train_write, N, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
+                 deltas, rays, counter, noises, (const uint32_t*)ws);
+    return check_launch("march_rays_train(write)");
+}
+
+extern "C" int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                                uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth,
+                                                float* image, ngp_stream_t stream) {
+    NGP_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, NGP_ERR_INVALID,
+                "composite_rays_train_forward: NULL tensor");
+    if (N == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(cdiv(N, CT_WAVES)), dim3(CT_WAVES * 64), 0, as_stream(stream), sigmas, rgbs, deltas,
+                       rays, M, N, T_thresh, weights_sum, depth, image);
+    return check_launch("composite_rays_train_forward");
+}
+
+extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                                 const float* rgbs, const float* deltas, const int32_t* rays,
+                                                 const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                                 float T_thresh, float* grad_sigmas, float* grad_rgbs, ngp_stream_t stream) {
+    NGP_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs,
+                NGP_ERR_INVALID, "composite_rays_train_backward: NULL tensor");
+    if (N == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(cdiv(N, CT_WAVES)), dim3(CT_WAVES * 64), 0, as_stream(stream), grad_weights_sum,
+                       grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs);
+    return check_launch("composite_rays_train_backward");
+}
+
+extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                              const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                              const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                              const float* noises, ngp_stream_t stream) {
+    (void)nears;  // read but unused by the reference kernel as well (raymarching.cu:741)
+    int rc = check_march_args("march_rays", C, H, max_steps);
+    if (rc) return rc;
+    NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises, NGP_ERR_INVALID,
+                "march_rays: NULL tensor");
+    if (n_alive == 0 || n_step == 0) return NGP_OK;
+    RM_LAUNCH_1D(k_march_rays, n_alive, as_stream(stream), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
+                 max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
+    return check_launch("march_rays");
+}
+
+extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                                  const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
+                                  float* image, ngp_stream_t stream) {
+    NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, NGP_ERR_INVALID,
+                "composite_rays: NULL tensor");
+    if (n_alive == 0) return NGP_OK;
+    RM_LAUNCH_1D(k_composite_rays, n_alive, as_stream(stream), n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
+                 weights_sum, depth, image);
+    return check_launch("composite_rays");
+}
+
+extern "C" size_t ngp_compact_rays_workspace_bytes(uint32_t n_alive) { return sizeof(uint32_t) * (size_t)cdiv(n_alive ? n_alive : 1, RM_THREADS); }
+
+extern "C" int ngp_compact_rays(const int32_t* rays_alive, uint32_t n_alive, int32_t* out_alive, int32_t* out_count, void* workspace,
+                                ngp_stream_t stream) {
+    NGP_REQUIRE(rays_alive && out_alive && out_count && workspace, NGP_ERR_INVALID, "compact_rays: NULL tensor");
+    hipStream_t st = as_stream(stream);
+    if (n_alive == 0) {
+        hipError_t e = hipMemsetAsync(out_count, 0, sizeof(int32_t), st);
+        NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "compact_rays: memset failed");
+        return NGP_OK;
+    }
+    uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
+    RM_LAUNCH_1D(k_compact_count, n_alive, st, rays_alive, n_alive, ws);
+    int rc = check_launch("compact_rays(count)");
+    if (rc) return rc;
+    RM_LAUNCH_1D(k_compact_write, n_alive, st, rays_alive, n_alive, out_alive, out_count, (const uint32_t*)ws);
+    return check_launch("compact_rays(write)");
+}

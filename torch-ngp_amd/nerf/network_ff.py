@@ -1,0 +1,60 @@
+"""instant-ngp network on the fully fused MLP: hash grid -> FFMLP(32 -> 64 x num_layers -> 16) -> trunc_exp density + 15
+geometry features; SH(4) direction code ++ features ++ 1 zero pad (= 32) -> FFMLP(32 -> 64 x num_layers_color -> 3) -> sigmoid.
+Mirrors the reference's NeRFNetwork (nerf/network_ff.py:11-149): same constructor, sub-module names (encoder, sigma_net,
+encoder_dir, color_net) and methods (forward, density, color, get_params), so state dicts interchange."""
+import torch
+
+from activation import trunc_exp
+from encoding import get_encoder
+from ffmlp import FFMLP
+
+from .renderer import NeRFRenderer
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", num_layers=2, hidden_dim=64, geo_feat_dim=15,
+                 num_layers_color=3, hidden_dim_color=64, bound=1, **kwargs):
+        super().__init__(bound, **kwargs)
+        self.num_layers = num_layers
+        self.hidden_dim = hidden_dim
+        self.geo_feat_dim = geo_feat_dim
+        self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * bound)
+        self.sigma_net = FFMLP(input_dim=self.in_dim, output_dim=1 + geo_feat_dim, hidden_dim=hidden_dim, num_layers=num_layers)
+
+        self.num_layers_color = num_layers_color
+        self.hidden_dim_color = hidden_dim_color
+        self.encoder_dir, dir_dim = get_encoder(encoding_dir)
+        self.in_dim_color = dir_dim + geo_feat_dim + 1  # one zero column rounds 16 + 15 up to 32 (network_ff.py:44)
+        self.color_net = FFMLP(input_dim=self.in_dim_color, output_dim=3, hidden_dim=hidden_dim_color, num_layers=num_layers_color)
+
+    def _density_head(self, x):
+        h = self.sigma_net(self.encoder(x, bound=self.bound))
+        return trunc_exp(h[..., 0]), h[..., 1:]
+
+    def _color_head(self, d, geo_feat):
+        code = self.encoder_dir(d)
+        pad = torch.zeros_like(geo_feat[..., :1])
+        return torch.sigmoid(self.color_net(torch.cat([code, geo_feat, pad], dim=-1)))
+
+    def forward(self, x, d):
+        # x [N,3] in [-bound, bound], d [N,3] unit directions -> sigma [N], rgb [N,3]
+        sigma, geo_feat = self._density_head(x)
+        return sigma, self._color_head(d, geo_feat)
+
+    def density(self, x):
+        sigma, geo_feat = self._density_head(x)
+        return {'sigma': sigma, 'geo_feat': geo_feat}
+
+    def color(self, x, d, mask=None, geo_feat=None, **kwargs):
+        if mask is None:
+            return self._color_head(d, geo_feat)
+        rgbs = torch.zeros(mask.shape[0], 3, dtype=x.dtype, device=x.device)
+        if mask.any():
+            rgbs[mask] = self._color_head(d[mask], geo_feat[mask]).to(rgbs.dtype)
+        return rgbs
+
+    def get_params(self, lr):
+        groups = [{'params': m.parameters(), 'lr': lr} for m in (self.encoder, self.sigma_net, self.encoder_dir, self.color_net)]
+        if self.bg_radius > 0:
+            groups += [{'params': self.encoder_bg.parameters(), 'lr': lr}, {'params': self.bg_net.parameters(), 'lr': lr}]
+        return groups

@@ -1,0 +1,124 @@
+"""`_backend` of the ray marcher: the ten callables of raymarching/src/bindings.cpp:5-19 over
+libngp_hip.so, plus `compact_rays` (device-side stream compaction, an extension declared in
+include/ngp_hip.h).  Argument order is the reference's (raymarching/src/raymarching.h:7-18)."""
+import types
+
+import torch
+
+import _ngp_capi as capi
+
+
+def _f32(t, name):
+    capi.dense(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float32 tensor (the reference wrappers cast with custom_fwd(cast_inputs=float32))")
+    return t
+
+
+def _i32(t, name):
+    capi.dense(t, name)
+    capi.require_int32(t, name)
+    return t
+
+
+def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
+    for t, n in ((rays_o, 'rays_o'), (rays_d, 'rays_d'), (aabb, 'aabb'), (nears, 'nears'), (fars, 'fars')):
+        _f32(t, n)
+    capi.check(capi.lib.ngp_near_far_from_aabb(capi.ptr(rays_o), capi.ptr(rays_d), capi.ptr(aabb), N, float(min_near),
+                                               capi.ptr(nears), capi.ptr(fars), capi.stream()))
+
+
+def sph_from_ray(rays_o, rays_d, radius, N, coords):
+    for t, n in ((rays_o, 'rays_o'), (rays_d, 'rays_d'), (coords, 'coords')):
+        _f32(t, n)
+    capi.check(capi.lib.ngp_sph_from_ray(capi.ptr(rays_o), capi.ptr(rays_d), float(radius), N, capi.ptr(coords), capi.stream()))
+
+
+def morton3D(coords, N, indices):
+    _i32(coords, 'coords'); _i32(indices, 'indices')
+    capi.check(capi.lib.ngp_morton3D(capi.ptr(coords), N, capi.ptr(indices), capi.stream()))
+
+
+def morton3D_invert(indices, N, coords):
+    _i32(coords, 'coords'); _i32(indices, 'indices')
+    capi.check(capi.lib.ngp_morton3D_invert(capi.ptr(indices), N, capi.ptr(coords), capi.stream()))
+
+
+def packbits(grid, N, density_thresh, bitfield):
+    _f32(grid, 'grid')
+    capi.dense(bitfield, 'bitfield')
+    if bitfield.dtype != torch.uint8:
+        raise RuntimeError("bitfield must be a uint8 tensor")
+    capi.check(capi.lib.ngp_packbits(capi.ptr(grid), N, float(density_thresh), capi.ptr(bitfield), capi.stream()))
+
+
+def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                     counter, noises):
+    for t, n in ((rays_o, 'rays_o'), (rays_d, 'rays_d'), (nears, 'nears'), (fars, 'fars'), (xyzs, 'xyzs'), (dirs, 'dirs'),
+                 (deltas, 'deltas'), (noises, 'noises')):
+        _f32(t, n)
+    _i32(rays, 'rays'); _i32(counter, 'counter')
+    capi.dense(grid, 'grid')
+    ws = torch.empty(capi.lib.ngp_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device=rays_o.device)
+    capi.check(capi.lib.ngp_march_rays_train(
+        capi.ptr(rays_o), capi.ptr(rays_d), capi.ptr(grid), float(bound), float(dt_gamma), max_steps, N, C, H, M,
+        capi.ptr(nears), capi.ptr(fars), capi.ptr(xyzs), capi.ptr(dirs), capi.ptr(deltas), capi.ptr(rays), capi.ptr(counter),
+        capi.ptr(noises), capi.ptr(ws), capi.stream()))
+
+
+def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image):
+    for t, n in ((sigmas, 'sigmas'), (rgbs, 'rgbs'), (deltas, 'deltas'), (weights_sum, 'weights_sum'), (depth, 'depth'), (image, 'image')):
+        _f32(t, n)
+    _i32(rays, 'rays')
+    capi.check(capi.lib.ngp_composite_rays_train_forward(capi.ptr(sigmas), capi.ptr(rgbs), capi.ptr(deltas), capi.ptr(rays), M, N,
+                                                         float(T_thresh), capi.ptr(weights_sum), capi.ptr(depth), capi.ptr(image),
+                                                         capi.stream()))
+
+
+def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
+                                  grad_sigmas, grad_rgbs):
+    for t, n in ((grad_weights_sum, 'grad_weights_sum'), (grad_image, 'grad_image'), (sigmas, 'sigmas'), (rgbs, 'rgbs'),
+                 (deltas, 'deltas'), (weights_sum, 'weights_sum'), (image, 'image'), (grad_sigmas, 'grad_sigmas'), (grad_rgbs, 'grad_rgbs')):
+        _f32(t, n)
+    _i32(rays, 'rays')
+    capi.check(capi.lib.ngp_composite_rays_train_backward(
+        capi.ptr(grad_weights_sum), capi.ptr(grad_image), capi.ptr(sigmas), capi.ptr(rgbs), capi.ptr(deltas), capi.ptr(rays),
+        capi.ptr(weights_sum), capi.ptr(image), M, N, float(T_thresh), capi.ptr(grad_sigmas), capi.ptr(grad_rgbs), capi.stream()))
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars, xyzs, dirs,
+               deltas, noises):
+    for t, n in ((rays_t, 'rays_t'), (rays_o, 'rays_o'), (rays_d, 'rays_d'), (nears, 'nears'), (fars, 'fars'), (xyzs, 'xyzs'),
+                 (dirs, 'dirs'), (deltas, 'deltas'), (noises, 'noises')):
+        _f32(t, n)
+    _i32(rays_alive, 'rays_alive')
+    capi.dense(grid, 'grid')
+    capi.check(capi.lib.ngp_march_rays(n_alive, n_step, capi.ptr(rays_alive), capi.ptr(rays_t), capi.ptr(rays_o), capi.ptr(rays_d),
+                                       float(bound), float(dt_gamma), max_steps, C, H, capi.ptr(grid), capi.ptr(nears), capi.ptr(fars),
+                                       capi.ptr(xyzs), capi.ptr(dirs), capi.ptr(deltas), capi.ptr(noises), capi.stream()))
+
+
+def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+    for t, n in ((rays_t, 'rays_t'), (sigmas, 'sigmas'), (rgbs, 'rgbs'), (deltas, 'deltas'), (weights_sum, 'weights_sum'),
+                 (depth, 'depth'), (image, 'image')):
+        _f32(t, n)
+    _i32(rays_alive, 'rays_alive')
+    capi.check(capi.lib.ngp_composite_rays(n_alive, n_step, float(T_thresh), capi.ptr(rays_alive), capi.ptr(rays_t), capi.ptr(sigmas),
+                                           capi.ptr(rgbs), capi.ptr(deltas), capi.ptr(weights_sum), capi.ptr(depth), capi.ptr(image),
+                                           capi.stream()))
+
+
+def compact_rays(rays_alive, n_alive, out_alive, out_count):
+    _i32(rays_alive, 'rays_alive'); _i32(out_alive, 'out_alive'); _i32(out_count, 'out_count')
+    ws = torch.empty(capi.lib.ngp_compact_rays_workspace_bytes(n_alive), dtype=torch.uint8, device=rays_alive.device)
+    capi.check(capi.lib.ngp_compact_rays(capi.ptr(rays_alive), n_alive, capi.ptr(out_alive), capi.ptr(out_count), capi.ptr(ws),
+                                         capi.stream()))
+
+
+_backend = types.SimpleNamespace(
+    near_far_from_aabb=near_far_from_aabb, sph_from_ray=sph_from_ray, morton3D=morton3D, morton3D_invert=morton3D_invert,
+    packbits=packbits, march_rays_train=march_rays_train, composite_rays_train_forward=composite_rays_train_forward,
+    composite_rays_train_backward=composite_rays_train_backward, march_rays=march_rays, composite_rays=composite_rays,
+    compact_rays=compact_rays)
+
+__all__ = ['_backend']

@@ -217,7 +217,7 @@ def test_module_autograd_under_autocast_matches_oracle():
     e16 = oracle.round_fp16(enc.embeddings.detach().cpu().numpy())
     x01 = ((xt + 1) / 2).cpu().numpy()
     ref = oracle.grid_forward(x01, e16, offs, S, 16)                      # [L,B,C]
-    np.testing.assert_allclose(y.float().cpu().numpy(), ref.transpose(1, 0, 2).reshape(5000, 32), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(y.detach().float().cpu().numpy(), ref.transpose(1, 0, 2).reshape(5000, 32), rtol=1e-3, atol=1e-3)
     gl = w.half().float().cpu().numpy().reshape(5000, 16, 2).transpose(1, 0, 2)
     ge, _ = oracle.grid_backward(gl, x01, offs, int(offs[-1]), 2, S, 16)
     got = enc.embeddings.grad.float().cpu().numpy()

@@ -222,8 +222,9 @@ def test_inference_loop_matches_oracle_loop():
         alive2, rt, ws, dep, img = oracle.composite_rays(n_alive, n_step, alive, rt, sig, rgb, de, ws, dep, img, T_thresh=1e-4)
         rm.composite_rays(n_alive, n_step, galive, grt, cu(sig), cu(rgb), gde, gws, gdep, gimg, 1e-4)
         ga = galive.cpu().numpy()
-        # fp32 __expf vs double exp may flip the threshold test for a ray sitting exactly on T_thresh: tolerate a handful
-        assert (ga != alive2).mean() < 1e-3
+        # fp32 transmittance (1 - weights_sum near 1 resolves 6e-8) vs the oracle's double may flip the T < T_thresh test
+        # of a ray sitting on the threshold: tolerate a couple of rays per step
+        assert (ga != alive2).sum() <= max(2, int(1e-3 * n_alive))
         comp, cnt = rm.compact_rays(galive)
         keep = galive[galive >= 0]
         assert cnt.item() == keep.shape[0] and torch.equal(comp[:cnt.item()], keep)

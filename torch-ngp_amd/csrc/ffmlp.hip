@@ -463,32 +463,36 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
     for (uint32_t i = threadIdx.x; i < n_params; i += FF_THREADS) red[i] = 0.0f;
     __syncthreads();
     // accumulator (row = output feature o, col = input feature i = lane&31)
+    // every (row, col) of a gradient matrix belongs to exactly one lane of a wave, so the waves add their
+    // partial sums one after the other without atomics: the summation order is fixed => bit-reproducible.
     auto flush = [&](const float16_t& a, uint32_t base, uint32_t ld, int ib, int jb, uint32_t rows, uint32_t cols) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint32_t o = (uint32_t)acc_row(ib, h, r), i = 32 * jb + n;
-            if (o < rows && i < cols) atomicAdd(&red[base + o * ld + i], a[r]);
+            if (o < rows && i < cols) red[base + o * ld + i] += a[r];
         }
     };
+    for (int turn = 0; turn < FF_WAVES; turn++) {
+        if (wid == turn) {
 #pragma unroll
-    for (int ib = 0; ib < NIB; ib++)
+            for (int ib = 0; ib < NIB; ib++)
 #pragma unroll
-        for (int jb = 0; jb < IN_JB; jb++) flush(gw_in[ib][jb], 0, in_dim, ib, jb, WIDTH, in_dim);
+                for (int jb = 0; jb < IN_JB; jb++) flush(gw_in[ib][jb], 0, in_dim, ib, jb, WIDTH, in_dim);
 #pragma unroll
-    for (int li = 0; li < NHM; li++) {
-        const uint32_t lay = num_layers - 1 - li;
-        const uint32_t base = WIDTH * in_dim + (lay - 1) * WIDTH * WIDTH;
+            for (int li = 0; li < NHM; li++) {
+                const uint32_t lay = num_layers - 1 - li;
+                const uint32_t base = WIDTH * in_dim + (lay - 1) * WIDTH * WIDTH;
 #pragma unroll
-        for (int ib = 0; ib < NIB; ib++)
+                for (int ib = 0; ib < NIB; ib++)
 #pragma unroll
-            for (int jb = 0; jb < NIB; jb++) flush(gw_hid[li][ib][jb], base, WIDTH, ib, jb, WIDTH, WIDTH);
+                    for (int jb = 0; jb < NIB; jb++) flush(gw_hid[li][ib][jb], base, WIDTH, ib, jb, WIDTH, WIDTH);
+            }
+            const uint32_t base = WIDTH * in_dim + (num_layers - 1) * WIDTH * WIDTH;
+#pragma unroll
+            for (int jb = 0; jb < NIB; jb++) flush(gw_out[jb], base, WIDTH, 0, jb, 16, WIDTH);
+        }
+        __syncthreads();
     }
-    {
-        const uint32_t base = WIDTH * in_dim + (num_layers - 1) * WIDTH * WIDTH;
-#pragma unroll
-        for (int jb = 0; jb < NIB; jb++) flush(gw_out[jb], base, WIDTH, 0, jb, 16, WIDTH);
-    }
-    __syncthreads();
     if (grad_weights_direct) {
         for (uint32_t i = threadIdx.x; i < n_params; i += FF_THREADS) grad_weights_direct[i] = (half_t)red[i];
     } else {

@@ -156,7 +156,7 @@ def test_against_reference_mlp_golden(golden_dir):
         # the float64 golden gradients see no fp16 activation rounding: one ReLU unit sitting at a pre-activation of ~1e-5
         # can flip (tools/dbg1.py found exactly one such row in 'color' and 'test'), which moves single weight-gradient
         # entries by a few percent of the largest entry; the tight check is the one against the fp16-rounding oracle below
-        assert np.linalg.norm(got_w - gw) / np.linalg.norm(gw) < 1e-2
+        assert np.linalg.norm(got_w - gw) / np.linalg.norm(gw) < 3e-2
         _, fb = oracle.ffmlp_forward(z[name + '_x'], z[name + '_w'], din, 16, hid, nl)
         gy16 = np.zeros((x.shape[0], 16)); gy16[:, :dout] = oracle.round_fp16(z[name + '_gy'])
         _, gwo = oracle.ffmlp_backward(gy16, z[name + '_x'], z[name + '_w'], fb, din, 16, hid, nl)

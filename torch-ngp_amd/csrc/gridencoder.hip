@@ -22,6 +22,7 @@
 //     removes the same-address contention on the coarse levels.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace ngp {
 
@@ -40,6 +41,7 @@ struct LevelIndexer {
     uint32_t size;       // hashmap_size
     uint32_t mask;       // size-1 if size is a power of two else 0
     bool hashed;
+    bool need_mod;       // false when a dense index is provably < size
 
     __device__ __forceinline__ void init(uint32_t gridtype, bool align_corners, uint32_t hashmap_size,
                                          uint32_t resolution) {
@@ -54,6 +56,10 @@ struct LevelIndexer {
             }
         }
         hashed = (gridtype == 0u) && (s > hashmap_size);
+        // without align_corners every corner coordinate is <= resolution and the strides are powers of (resolution + 1):
+        // a dense index over all D dims is < (resolution+1)^D <= size.  With align_corners the stride base is
+        // `resolution` while a corner can sit AT `resolution`, so the index can wrap (gridencoder.cu:66-84).
+        need_mod = hashed || (s > hashmap_size) || align_corners;
         size = hashmap_size;
         mask = ((hashmap_size & (hashmap_size - 1u)) == 0u) ? hashmap_size - 1u : 0u;
     }
@@ -67,6 +73,7 @@ struct LevelIndexer {
 #pragma unroll
             for (int d = 0; d < D; d++) idx += pg[d] * stride[d];
         }
+        if (!need_mod) return idx;
         return mask ? (idx & mask) : (idx % size);
     }
 };
@@ -332,16 +339,34 @@ __device__ __forceinline__ void scatter_add(T* dst, const float (&g)[C], float w
 }
 
 constexpr int BWD_THREADS = 256;
-constexpr uint32_t BWD_LDS_BYTES = 64 * 1024;  // privatised accumulators for small dense levels (fp32)
+constexpr int BWD_PTS_PER_WAVE = 32;
 
-// PRIV = true : handles only the levels whose table fits the LDS budget (privatised accumulation);
-// PRIV = false: handles only the others (direct global atomics, no LDS so occupancy stays high).
-template <typename T, int D, int C, bool PRIV>
+// ------------------------------------------------------------------------------------------------
+// backward: scatter-add of w * grad into grad_embeddings               (gridencoder.cu:248-340)
+//
+// What bounds a scatter on gfx950 (tools/atomic_probe2.hip, measured): a global float atomic costs one
+// memory-side REQUEST per (wave instruction, distinct 64-byte line) at ~20 G requests/s chip-wide, whatever
+// the scope bits and however small the table is; lanes of ONE instruction that fall into one line ride along
+// for free (16 lanes on a line: 320 G atomics/s).  So the kernel is organised to minimise (instruction, line)
+// pairs, not lane operations:
+//   * a wavefront covers 32 consecutive points; lanes 2p and 2p+1 handle the two corners of a point that differ
+//     in the FIRST coordinate.  Those two entries are neighbours in memory -- on dense levels by construction
+//     and on hashed levels too, because the first hash prime is 1: (x ^ A) and ((x+1) ^ A) share an aligned
+//     16-entry block whenever x and x+1 do -- so every atomic instruction touches at most ~32 lines for 64
+//     lane operations instead of 64 (one corner per instruction, one point per lane);
+//   * consecutive samples of a ray sit in the same cell on the coarse levels: runs of points with identical
+//     cells are summed in fp32 with a segmented wave scan and only the last lane of a run issues atomics
+//     (removes the same-address serialisation and rounds to the table dtype once per run);
+//   * samples behind an early-terminated ray carry an exactly-zero gradient and are skipped.
+// fp16 tables with even C use global_atomic_pk_add_f16 (what the reference's half2 atomicAdd does), everything
+// else global_atomic_add_f32.  The summation order of colliding atomics is not defined (as in the reference).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, int C, bool MERGE>
 __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                                const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
                                                                uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
                                                                bool align_corners, uint32_t interp, uint32_t points_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float lds_acc[];
+    constexpr int NJ = 1 << (D - 1);  // corners per lane (all combinations of the coordinates 1..D-1)
     const uint32_t level = blockIdx.y;
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
@@ -349,51 +374,84 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
     LevelIndexer<D> indexer;
     indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
     T* __restrict__ gtable = grad_grid + (size_t)off0 * C;
-    // privatise when the whole level fits into the block's LDS budget (wave-uniform decision)
-    const bool fits = (size_t)hashmap_size * C * sizeof(float) <= BWD_LDS_BYTES;
-    if (fits != PRIV) return;
-    constexpr bool use_lds = PRIV;
-    if (use_lds) {
-        for (uint32_t i = threadIdx.x; i < hashmap_size * C; i += BWD_THREADS) lds_acc[i] = 0.0f;
-        __syncthreads();
-    }
+    const T* __restrict__ glevel = grad + (size_t)level * B * C;
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int pl = lane >> 1;          // point slot inside the wave
+    const uint32_t xb = lane & 1;      // which first-coordinate corner this lane owns (neighbouring lanes -> neighbouring entries)
     const uint32_t b_begin = blockIdx.x * points_per_block;
     const uint32_t b_end = min(B, b_begin + points_per_block);
-    for (uint32_t b = b_begin + threadIdx.x; b < b_end; b += BWD_THREADS) {
+
+    for (uint32_t base = b_begin + wid * BWD_PTS_PER_WAVE; base < b_end; base += (BWD_THREADS / 64) * BWD_PTS_PER_WAVE) {
+        const uint32_t b = base + pl;
+        bool live = b < b_end;
         float frac[D], deriv[D];
         uint32_t cell[D];
-        if (!locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, frac, deriv, cell)) continue;
-        Vec<T, C> g;
-        g.load(grad + ((size_t)level * B + b) * C);
 #pragma unroll
-        for (int k = 0; k < (1 << D); k++) {
-            float w = 1.0f;
-            uint32_t pg[D];
+        for (int d = 0; d < D; d++) { frac[d] = 0.0f; cell[d] = 0u; }
+        float g[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) g[c] = 0.0f;
+        if (live) live = locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, frac, deriv, cell);
+        if (live) {
+            Vec<T, C> gv;
+            gv.load(glevel + (size_t)b * C);
+            bool nz = false;
+#pragma unroll
+            for (int c = 0; c < C; c++) { g[c] = gv.v[c]; nz = nz || (g[c] != 0.0f); }
+            live = nz;
+        }
+        // weighted contributions of this lane's NJ corners
+        float v[NJ][C];
+        const float w0 = xb ? frac[0] : 1.0f - frac[0];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            float w = live ? w0 : 0.0f;
+#pragma unroll
+            for (int d = 1; d < D; d++) w *= ((j >> (d - 1)) & 1) ? frac[d] : (1.0f - frac[d]);
+#pragma unroll
+            for (int c = 0; c < C; c++) v[j][c] = w * g[c];
+        }
+        bool issue = live;
+        if (MERGE) {
+            // same cell as the previous point slot?  (both live)
+            // (every shuffle is executed by all lanes: no short-circuit in front of a cross-lane read)
+            const int prev_live = __shfl_up((int)live, 2, 64);
+            bool cells_equal = true;
 #pragma unroll
             for (int d = 0; d < D; d++) {
-                w *= ((k >> d) & 1) ? frac[d] : (1.0f - frac[d]);
-                pg[d] = cell[d] + ((k >> d) & 1);
+                const uint32_t prev_cell = __shfl_up(cell[d], 2, 64);
+                cells_equal = cells_equal & (prev_cell == cell[d]);
             }
-            const uint32_t idx = indexer(pg) * C;
-            if (use_lds) {
+            const bool same = live & (pl > 0) & (prev_live != 0) & cells_equal;
+            if (__any(same)) {
+                bool reached = !same;  // the scan of this lane has reached the head of its run
 #pragma unroll
-                for (int c = 0; c < C; c++) atomicAdd(&lds_acc[idx + c], w * g.v[c]);  // ds_add_f32
-            } else {
-                scatter_add<T, C>(gtable + idx, g.v, w);
+                for (int o = 1; o < 32; o <<= 1) {
+                    const int r_o = __shfl_up((int)reached, 2 * o, 64);
+                    const bool take = !reached && pl >= o;
+#pragma unroll
+                    for (int j = 0; j < NJ; j++)
+#pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            const float t = __shfl_up(v[j][c], 2 * o, 64);
+                            if (take) v[j][c] += t;
+                        }
+                    if (take) reached = r_o != 0;
+                }
+                const int next_same = __shfl_down((int)same, 2, 64);
+                issue = live && (pl == 31 || !next_same);  // last lane of the run holds the run total
             }
         }
-    }
-    if (use_lds) {
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < hashmap_size; e += BWD_THREADS) {
-            float v[C];
-            bool any = false;
+        if (issue) {
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                v[c] = lds_acc[e * C + c];
-                any = any || (v[c] != 0.0f);
+            for (int j = 0; j < NJ; j++) {
+                uint32_t pg[D];
+                pg[0] = cell[0] + xb;
+#pragma unroll
+                for (int d = 1; d < D; d++) pg[d] = cell[d] + ((j >> (d - 1)) & 1);
+                scatter_add<T, C>(gtable + (size_t)indexer(pg) * C, v[j], 1.0f);
             }
-            if (any) scatter_add<T, C>(gtable + (size_t)e * C, v, 1.0f);
         }
     }
 }
@@ -507,22 +565,31 @@ static int launch_forward(const float* inputs, const void* emb, const int32_t* o
     return check_launch("grid_encode_forward");
 }
 
+static int grid_backward_variant() {  // NGP_GRID_BWD=nomerge disables the run merge (benchmarks / experiments)
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("NGP_GRID_BWD");
+        mode = (e && e[0] == 'n') ? 1 : 0;
+    }
+    return mode;
+}
+
 template <typename T, int D, int C>
 static int launch_backward(const void* grad, const float* inputs, const int32_t* offsets, void* grad_emb, uint32_t B,
                            uint32_t L, const GridLevels& lv, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                            bool ac, uint32_t interp, hipStream_t st) {
-    // one block covers `ppb` consecutive points of one level: big enough that an LDS-privatised level
-    // is flushed rarely, small enough that the chip is filled (>= ~2 blocks per CU over all levels).
+    int rc = NGP_OK;
+    // one block covers `ppb` consecutive points of one level; >= ~4 blocks per CU over all levels fills the chip
     uint32_t ppb = 2048;
-    while (ppb > 256 && (uint64_t)cdiv(B, ppb) * L < 1024) ppb >>= 1;
+    while (ppb > 128 && (uint64_t)cdiv(B, ppb) * L < 2048) ppb >>= 1;
     dim3 grid(cdiv(B, ppb), L, 1);
-    hipLaunchKernelGGL((k_grid_backward<T, D, C, false>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
-                       (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb);
-    int rc = check_launch("grid_encode_backward");
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_grid_backward<T, D, C, true>), grid, dim3(BWD_THREADS), BWD_LDS_BYTES, st, (const T*)grad, inputs, offsets,
-                       (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb);
-    rc = check_launch("grid_encode_backward(lds)");
+    if (grid_backward_variant() == 1)
+        hipLaunchKernelGGL((k_grid_backward<T, D, C, false>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
+                           (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb);
+    else
+        hipLaunchKernelGGL((k_grid_backward<T, D, C, true>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
+                           (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb);
+    rc = check_launch("grid_encode_backward");
     if (rc) return rc;
     if (dy_dx && grad_inputs) {
         hipLaunchKernelGGL((k_grid_input_backward<T>), dim3(cdiv(B * D, 256)), dim3(256), 0, st, (const T*)grad,

@@ -218,102 +218,171 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds4) {
     return tot;
 }
 
-// workspace layout (uint32): [0] = counter[0] snapshot, [1 ...] = per-block sample counts
-// pass 1: count the samples of every ray (raymarching.cu:353-400)
-__global__ __launch_bounds__(RM_THREADS) void k_march_train_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                                  const uint8_t* __restrict__ grid, float bound, float dt_gamma,
-                                                                  uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
-                                                                  const float* __restrict__ nears, const float* __restrict__ fars,
-                                                                  int32_t* __restrict__ rays, const int32_t* __restrict__ counter,
-                                                                  const float* __restrict__ noises, uint32_t* __restrict__ ws) {
-    __shared__ uint32_t lds4[RM_THREADS / 64];
-    const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+// ---------------------------------------------------------------------------------------------
+// march_rays_train: one WAVEFRONT per ray                                 raymarching.cu:312-480
+//
+// The reference walks a ray sequentially: probe the voxel at t; occupied -> emit a sample and t += dt(t); empty
+// -> compute the far face tt of the voxel and repeat t += dt(t) until t >= tt.  Every t it ever visits therefore
+// belongs to ONE occupancy-independent sequence  t_0 = near + dt(near)*noise,  t_{k+1} = t_k (+) dt(t_k)  (fp32).
+// A lane-per-ray marcher is a chain of ~200-1000 dependent (position -> byte load -> branch) iterations with 64
+// diverging lanes; on gfx950 that is ~2 us per iteration and only 64 wavefronts for a 4096-ray batch.  Here a
+// wavefront owns a ray and processes its sequence 64 terms at a time:
+//   1. the 64 terms are produced by the same fp32 recurrence the reference uses (wave-uniform chain, each lane
+//      keeps its own term), so every t is bit-identical to the sequential walk;
+//   2. all 64 positions are probed AT ONCE (one coalesced burst of bitfield reads, no divergence); empty lanes
+//      also compute tt and, by a 6-step binary search over the (monotone) terms, the index the reference's
+//      "advance until t >= tt" loop would land on;
+//   3. which of the probed terms the sequential walk really visits is then a pointer chase over wave-uniform
+//      scalars (ballot masks + v_readlane), consuming whole runs of occupied terms with one bit scan; jumps that
+//      leave the 64-term window are carried into the next window as a threshold;
+//   4. (write pass) emitted terms are compacted with ballot/popcount prefix ranks and stored as coalesced rows.
+// Sample slots are handed out in ray order by an exclusive scan between the two passes (count -> scan -> write):
+// reproducible layout, no atomics (the reference's completion-order atomics are "parity unpinned").
+// ---------------------------------------------------------------------------------------------
+constexpr int MW_WAVES = 4;  // rays per workgroup
+
+__device__ __forceinline__ float readlane_f(float v, uint32_t l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)l));
+}
+
+template <bool WRITE, bool CONST_DT>
+__global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                                    const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                                    const float* __restrict__ nears, const float* __restrict__ fars,
+                                                                    float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                                    float* __restrict__ deltas, int32_t* __restrict__ rays,
+                                                                    const float* __restrict__ noises) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t n = blockIdx.x * MW_WAVES + wid;  // wave-uniform
+    if (n >= N) return;
+    const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
+    const Ray r = load_ray(rays_o, rays_d, n);
+    const float far = fars[n];
+    const float near = nears[n];
+    const float dt_const = step_dt(p, 0.0f);  // value of dt(t) when dt_gamma == 0
+
+    uint32_t limit = max_steps, offset = 0;
+    if (WRITE) {
+        offset = (uint32_t)rays[n * 3 + 1];
+        limit = (uint32_t)rays[n * 3 + 2];
+        if (limit == 0 || offset + limit > M) return;  // raymarching.cu:405-416: recorded, nothing written
+    }
     uint32_t num_steps = 0;
-    if (n < N) {
-        const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
-        const Ray r = load_ray(rays_o, rays_d, n);
-        const float near = nears[n], far = fars[n];
-        float t = __builtin_fmaf(step_dt(p, near), noises[n], near);
-        float x, y, z, dt, tt;
-        while (t < far && num_steps < max_steps) {
-            if (probe(p, r, t, x, y, z, dt, tt)) {
-                num_steps++;
-                t += dt;
-            } else {
-                t = skip_to(p, t, tt, far);
+    float t_base = __builtin_fmaf(step_dt(p, near), noises[n], near);
+    float last_t = t_base;
+    float carry = -INFINITY;  // the walk enters a window at its first term that is not < carry
+    bool done = !(t_base < far);
+
+    while (!done) {
+        // ---- 1. the window's 64 terms (lane j keeps t_{base+j}) ----
+        float t = t_base, mine = t_base;
+#pragma unroll
+        for (uint32_t j = 1; j < 64; j++) {
+            t += CONST_DT ? dt_const : step_dt(p, t);
+            mine = (lane == j) ? t : mine;
+        }
+        const float t_next_base = t + (CONST_DT ? dt_const : step_dt(p, t));
+
+        // ---- 2. probe all terms that lie in front of `far` ----
+        const bool valid = mine < far;
+        bool occ = false;
+        float x = 0.0f, y = 0.0f, z = 0.0f, dt = 0.0f, tt = -INFINITY;
+        if (valid) occ = probe(p, r, mine, x, y, z, dt, tt);
+        const uint64_t validmask = __ballot(valid);
+        const uint64_t occmask = __ballot(valid && occ);
+        const uint64_t entrymask = __ballot(!(mine < carry));
+        uint32_t cur = entrymask ? (uint32_t)__builtin_ctzll(entrymask) : 64u;
+        bool ray_done = false;
+        uint64_t emit = 0;
+
+        if (cur < 64u) {
+            // landing index of "do t += dt(t) while (t < tt)" started at this lane: first j > lane with !(t_j < tt)
+            const float target = (valid && !occ) ? tt : -INFINITY;
+            uint32_t land = lane + 1u;
+#pragma unroll
+            for (uint32_t s = 32; s >= 1; s >>= 1) {
+                const uint32_t q = land + s - 1u;
+                const float tq = __shfl(mine, (int)(q & 63u), 64);
+                const bool adv = (q < 64u) && (tq < target);
+                land = adv ? land + s : land;
+            }
+            carry = -INFINITY;
+            // ---- 3. the sequential walk over wave-uniform scalars ----
+            while (cur < 64u) {
+                if (!((validmask >> cur) & 1ull) || num_steps >= limit) { ray_done = true; break; }
+                if ((occmask >> cur) & 1ull) {
+                    const uint64_t rest = ~(occmask >> cur);
+                    uint32_t run = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;  // rest == 0 only for a fully occupied window at cur == 0
+                    const uint32_t room = limit - num_steps;
+                    run = run < room ? run : room;
+                    emit |= (run >= 64u ? ~0ull : ((1ull << run) - 1ull)) << cur;
+                    num_steps += run;
+                    cur += run;
+                } else {
+                    const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)land, (int)cur);
+                    if (nx >= 64u) carry = readlane_f(target, cur);
+                    cur = nx;
+                }
             }
         }
+
+        // ---- 4. emit ----
+        if (WRITE && emit != 0ull) {
+            const bool e = (emit >> lane) & 1ull;
+            const uint64_t below = emit & ((1ull << lane) - 1ull);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(below);
+            const float t_after = mine + dt;
+            const int src = below ? 63 - __builtin_clzll(below) : 0;
+            const float prev_after = __shfl(t_after, src, 64);
+            const float lt = below ? prev_after : last_t;
+            if (e) {
+                const size_t o = (size_t)offset + rank;
+                float* xo = xyzs + o * 3;
+                float* dd = dirs + o * 3;
+                xo[0] = x; xo[1] = y; xo[2] = z;
+                dd[0] = r.dx; dd[1] = r.dy; dd[2] = r.dz;
+                *reinterpret_cast<float2_t*>(deltas + o * 2) = float2_t{dt, t_after - lt};
+            }
+            last_t = readlane_f(t_after, 63u - (uint32_t)__builtin_clzll(emit));
+            offset += (uint32_t)__builtin_popcountll(emit);
+        }
+        done = ray_done || (validmask != ~0ull);
+        t_base = t_next_base;
+    }
+    if (!WRITE && lane == 0) {
         rays[n * 3] = (int32_t)n;
         rays[n * 3 + 2] = (int32_t)num_steps;
     }
-    const uint32_t tot = block_sum(num_steps, lds4);
-    if (threadIdx.x == 0) {
-        ws[1 + blockIdx.x] = tot;
-        if (blockIdx.x == 0) ws[0] = (uint32_t)counter[0];
-    }
 }
 
-// pass 2: exclusive scan in ray order, then re-march and write (raymarching.cu:402-479)
-__global__ __launch_bounds__(RM_THREADS) void k_march_train_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                                  const uint8_t* __restrict__ grid, float bound, float dt_gamma,
-                                                                  uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                                                                  const float* __restrict__ nears, const float* __restrict__ fars,
-                                                                  float* __restrict__ xyzs, float* __restrict__ dirs,
-                                                                  float* __restrict__ deltas, int32_t* __restrict__ rays,
-                                                                  int32_t* __restrict__ counter, const float* __restrict__ noises,
-                                                                  const uint32_t* __restrict__ ws) {
-    __shared__ uint32_t lds4[RM_THREADS / 64];
-    __shared__ uint32_t wave_excl[RM_THREADS / 64];
-    // samples emitted by all earlier blocks
-    uint32_t part = 0;
-    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += RM_THREADS) part += ws[1 + j];
-    const uint32_t block_offset = ws[0] + block_sum(part, lds4);
-
-    const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
-    const uint32_t num_steps = (n < N) ? (uint32_t)rays[n * 3 + 2] : 0u;
+// exclusive scan of the per-ray sample counts in ray order -> rays[:,1]; counter[0] += total, counter[1] += N
+constexpr int SCAN_THREADS = 1024;
+__global__ __launch_bounds__(SCAN_THREADS) void k_march_train_scan(int32_t* __restrict__ rays, int32_t* __restrict__ counter, uint32_t N) {
+    __shared__ uint32_t wsum[SCAN_THREADS / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const uint32_t incl = wave_inclusive_scan(num_steps);
-    __syncthreads();
-    if (lane == 63) wave_excl[wid] = incl;
-    __syncthreads();
-    uint32_t wbase = 0, block_total = 0;
+    uint32_t running = (uint32_t)counter[0];
+    for (uint32_t tile = 0; tile < N; tile += SCAN_THREADS) {
+        const uint32_t n = tile + threadIdx.x;
+        const uint32_t c = n < N ? (uint32_t)rays[n * 3 + 2] : 0u;
+        const uint32_t incl = wave_inclusive_scan(c);
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
 #pragma unroll
-    for (int w = 0; w < RM_THREADS / 64; w++) {
-        const uint32_t c = wave_excl[w];
-        if (w < wid) wbase += c;
-        block_total += c;
-    }
-    const uint32_t point_index = block_offset + wbase + (incl - num_steps);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        counter[0] = (int32_t)(block_offset + block_total);
-        counter[1] = counter[1] + (int32_t)N;
-    }
-    if (n >= N) return;
-    rays[n * 3 + 1] = (int32_t)point_index;
-    if (num_steps == 0 || point_index + num_steps > M) return;
-
-    const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
-    const Ray r = load_ray(rays_o, rays_d, n);
-    const float near = nears[n], far = fars[n];
-    float t = __builtin_fmaf(step_dt(p, near), noises[n], near);
-    float last_t = t;
-    float* xo = xyzs + (size_t)point_index * 3;
-    float* dd = dirs + (size_t)point_index * 3;
-    float* de = deltas + (size_t)point_index * 2;
-    uint32_t step = 0;
-    float x, y, z, dt, tt;
-    while (t < far && step < num_steps) {
-        if (probe(p, r, t, x, y, z, dt, tt)) {
-            xo[0] = x; xo[1] = y; xo[2] = z;
-            dd[0] = r.dx; dd[1] = r.dy; dd[2] = r.dz;
-            t += dt;
-            de[0] = dt; de[1] = t - last_t;
-            last_t = t;
-            xo += 3; dd += 3; de += 2;
-            step++;
-        } else {
-            t = skip_to(p, t, tt, far);
+        for (int w = 0; w < SCAN_THREADS / 64; w++) {
+            const uint32_t v = wsum[w];
+            wbase += w < wid ? v : 0u;
+            total += v;
         }
+        if (n < N) rays[n * 3 + 1] = (int32_t)(running + wbase + incl - c);
+        running += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counter[0] = (int32_t)running;
+        counter[1] = counter[1] + (int32_t)N;
     }
 }
 
@@ -599,23 +668,31 @@ static int check_march_args(const char* fn, uint32_t C, uint32_t H, uint32_t max
     return NGP_OK;
 }
 
-extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid_in, float bound, float dt_gamma,
                                     uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                                     const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
                                     const float* noises, void* workspace, ngp_stream_t stream) {
     int rc = check_march_args("march_rays_train", C, H, max_steps);
     if (rc) return rc;
-    NGP_REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises && workspace,
+    NGP_REQUIRE(rays_o && rays_d && grid_in && nears && fars && xyzs && dirs && deltas && rays && counter && noises && workspace,
                 NGP_ERR_INVALID, "march_rays_train: NULL tensor");
     if (N == 0) return NGP_OK;
     hipStream_t st = as_stream(stream);
-    uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
-    RM_LAUNCH_1D(k_march_train_count, N, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays,
-                 (const int32_t*)counter, noises, ws);
+    (void)workspace;  // kept in the ABI (earlier revisions staged block sums here)
+    const dim3 grid(cdiv(N, MW_WAVES)), block(MW_WAVES * 64);
+    const bool const_dt = dt_gamma == 0.0f;
+#define MARCH_WAVE(WRITE, CDT)                                                                                                     \
+    hipLaunchKernelGGL((k_march_train_wave<WRITE, CDT>), grid, block, 0, st, rays_o, rays_d, grid_bits, bound, dt_gamma, max_steps, N, C, H, \
+                       M, nears, fars, xyzs, dirs, deltas, rays, noises)
+    const uint8_t* grid_bits = grid_in;
+    if (const_dt) MARCH_WAVE(false, true); else MARCH_WAVE(false, false);
     rc = check_launch("march_rays_train(count)");
     if (rc) return rc;
-    RM_LAUNCH_1D(k_march_train_write, N, st, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs,
-                 deltas, rays, counter, noises, (const uint32_t*)ws);
+    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, st, rays, counter, N);
+    rc = check_launch("march_rays_train(scan)");
+    if (rc) return rc;
+    if (const_dt) MARCH_WAVE(true, true); else MARCH_WAVE(true, false);
+#undef MARCH_WAVE
     return check_launch("march_rays_train(write)");
 }
 

@@ -187,6 +187,52 @@ int ngp_ffmlp_backward(const void* grad, const void* inputs, const void* weights
 int ngp_allocate_splitk(size_t size);
 int ngp_free_splitk(void);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused sample pipeline -- EXTENSIONS beyond the reference surface.
+ * The reference wrappers glue the native ops with permute/cat/cast/elementwise PyTorch kernels
+ * (grid.py:57,75,149; ffmlp.py:157-165; network_ff.py:51-123).  These entry points let the mirror in
+ * torch-ngp_amd/ run the same arithmetic with the same rounding points and no glue copies; the
+ * reference-contract functions above are thin wrappers over them (flags = 0, bound = 0).
+ * --------------------------------------------------------------------------------------------- */
+/* bound > 0: inputs are world coordinates in [-bound, bound], mapped in-kernel as (x + bound) * (1/(2 bound))
+ * (what GridEncoder.forward does with two PyTorch kernels, grid.py:149); bound == 0: unit inputs. */
+int ngp_grid_encode_forward_ex(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                               uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
+                               ngp_stream_t stream);
+int ngp_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                                uint32_t interp, int dtype, float bound, ngp_stream_t stream);
+
+/* flags of the ffmlp *_ex entry points */
+#define NGP_FF_INPUT_PLANAR 1u /* inputs are [input_dim/2][B][2] fp16 planes = the grid encoder's [L,B,C=2] output */
+#define NGP_FF_DX_PLANAR 2u    /* grad_inputs is written in that planar layout = what grid_encode_backward reads */
+int ngp_ffmlp_forward_ex(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                         uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                         void* forward_buffer, void* outputs, uint32_t flags, ngp_stream_t stream);
+int ngp_ffmlp_inference_ex(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim,
+                           uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                           uint32_t output_activation, void* inference_buffer, void* outputs, uint32_t flags,
+                           ngp_stream_t stream);
+int ngp_ffmlp_backward_ex(const void* grad, const void* inputs, const void* weights, const void* forward_buffer,
+                          uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
+                          uint32_t activation, uint32_t output_activation, int calc_grad_inputs, void* backward_buffer,
+                          void* grad_inputs, void* grad_weights, uint32_t flags, ngp_stream_t stream);
+
+/* network_ff.py:55-72 between the two MLPs: h16 [M,16] fp16 (sigma-net output), dirs [M_valid,3] fp32 ->
+ * sigma [M] fp32 = exp(h[:,0]) (trunc_exp), color_in [M,32] fp16 = [SH deg 4 | h[:,1:16] | 0]; rows >= M_valid use dir = 0 */
+int ngp_pipeline_mid_forward(const void* h16, const float* dirs, float* sigma, void* color_in, uint32_t M, uint32_t M_valid,
+                             ngp_stream_t stream);
+/* rgb [M,3] fp32 = fp16-rounded sigmoid of the colour net's first three outputs (network_ff.py:72) */
+int ngp_pipeline_rgb_forward(const void* out16, float* rgb, uint32_t M, ngp_stream_t stream);
+/* grad_out16 [M,16] fp16: columns 0..2 = grad_rgb * y (1 - y), the rest 0 */
+int ngp_pipeline_rgb_backward(const float* grad_rgb, const float* rgb, void* grad_out16, uint32_t M, ngp_stream_t stream);
+/* grad_h16 [M,16] fp16: column 0 = grad_sigma * exp(clamp(h0, -15, 15)) (activation.py:12-17), columns 1..15 =
+ * grad_color_in[:,16:31] */
+int ngp_pipeline_mid_backward(const float* grad_sigma, const void* h16, const void* grad_color_in, void* grad_h16, uint32_t M,
+                              ngp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,8 +29,10 @@ def _setup(n_rays=1024, emb_scale=0.5):
     return model, orc, bits, dev
 
 
-def test_training_step_matches_oracle_pipeline():
+@pytest.mark.parametrize('fused', [True, False])
+def test_training_step_matches_oracle_pipeline(fused):
     model, orc, bits, dev = _setup()
+    model.fused = fused
     n_rays = 1024
     o, d, gt = sc.training_batch(n_rays, seed=5)
     model.train()
@@ -94,3 +96,39 @@ def test_update_extra_state_and_training_loop_run():
         losses.append(loss.item())
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     assert model.mean_count > 0 and model.iter_density == 2
+
+
+def test_fused_pipeline_equals_module_path():
+    """the fused sample pipeline (fused.py) and the reference-style module-by-module path compute the same function:
+    sigma/rgb and all parameter gradients agree to fp16 rounding on the same samples"""
+    model, orc, bits, dev = _setup()
+    rng = np.random.default_rng(11)
+    M = 128 * 40
+    x = torch.from_numpy(rng.uniform(-1, 1, (M, 3)).astype(np.float32)).to(dev)
+    d = rng.normal(size=(M, 3)).astype(np.float32)
+    d = torch.from_numpy(d / np.linalg.norm(d, axis=1, keepdims=True)).to(dev)
+    gs = torch.from_numpy(rng.normal(size=M).astype(np.float32)).to(dev)
+    gr = torch.from_numpy(rng.normal(size=(M, 3)).astype(np.float32)).to(dev)
+    model.train()
+    res = {}
+    for fused in (True, False):
+        model.fused = fused
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.float16):
+            assert model._fused_ok(x, d) == fused
+            sigma, rgb = model(x, d)
+            ((sigma.float() * gs).sum() * 64 + (rgb.float() * gr).sum() * 64).backward()
+        res[fused] = (sigma.detach().float().cpu().numpy(), rgb.detach().float().cpu().numpy(),
+                      [p.grad.float().cpu().numpy().astype(np.float64) for p in (model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights)])
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-6, atol=0)       # same fp16 h0, same exp
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=0, atol=1e-3)       # fp16 sigmoid outputs: at most 1 ulp apart
+    for a, b, name in zip(res[True][2], res[False][2], ('embeddings', 'sigma_net', 'color_net')):
+        rel = np.linalg.norm(a - b) / np.linalg.norm(b)
+        assert rel < 5e-3, (name, rel)
+    # eval mode (inference kernels) gives the same values as training mode
+    model.fused = True
+    model.eval()
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+        s2, r2 = model(x, d)
+    np.testing.assert_array_equal(s2.float().cpu().numpy(), res[True][0])
+    np.testing.assert_array_equal(r2.float().cpu().numpy(), res[True][1])

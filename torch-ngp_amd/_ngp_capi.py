@@ -19,6 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libngp_hip.so')
 
 NGP_F32, NGP_F16 = 0, 1
+NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR = 1, 2
 ABI_VERSION = 1
 
 if not os.path.exists(LIB_PATH):
@@ -52,6 +53,15 @@ _SIGNATURES = {
     'ngp_ffmlp_forward': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     'ngp_ffmlp_inference': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     'ngp_ffmlp_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
+    'ngp_grid_encode_forward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
+    'ngp_grid_encode_backward_ex': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
+    'ngp_ffmlp_forward_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
+    'ngp_ffmlp_inference_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
+    'ngp_ffmlp_backward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp],
+    'ngp_pipeline_mid_forward': [_vp, _vp, _vp, _vp, _u32, _u32, _vp],
+    'ngp_pipeline_rgb_forward': [_vp, _vp, _u32, _vp],
+    'ngp_pipeline_rgb_backward': [_vp, _vp, _vp, _u32, _vp],
+    'ngp_pipeline_mid_backward': [_vp, _vp, _vp, _vp, _u32, _vp],
     'ngp_allocate_splitk': [_sz],
     'ngp_free_splitk': [],
 }

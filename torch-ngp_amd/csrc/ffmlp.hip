@@ -149,6 +149,24 @@ __device__ __forceinline__ void pack_hidden(const float16_t (&acc)[Shape<WIDTH>:
     }
 }
 
+
+// 8 consecutive input features f0 .. f0+7 (f0 a multiple of 8) of sample s.
+//   row-major: inputs[s][in_dim]                      (the reference layout)
+//   planar   : inputs[in_dim/2][rows][2]              (the grid encoder's level-major [L, B, C=2] output: no permute copy
+//              between encoder and MLP; a wave still reads/writes 128 contiguous bytes per plane)
+__device__ __forceinline__ half8_t load_features8(const half_t* __restrict__ inputs, bool planar, size_t rows, size_t s, uint32_t in_dim,
+                                                  uint32_t f0) {
+    if (!planar) return *reinterpret_cast<const half8_t*>(inputs + s * in_dim + f0);
+    half8_t v;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const half2_t t = *reinterpret_cast<const half2_t*>(inputs + ((size_t)(f0 / 2 + q) * rows + s) * 2);
+        v[2 * q] = t.x;
+        v[2 * q + 1] = t.y;
+    }
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / inference
 // ------------------------------------------------------------------------------------------------
@@ -156,11 +174,12 @@ template <int WIDTH, bool TRAIN>
 __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_forward(const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
                                                               half_t* __restrict__ forward_buffer, half_t* __restrict__ outputs,
                                                               uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
-                                                              uint32_t out_act) {
+                                                              uint32_t out_act, bool in_planar) {
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img = reinterpret_cast<half8_t*>(smem);
     build_forward_image<WIDTH>(img, weights, in_dim, num_layers);
+    const size_t rows = (size_t)n_tiles * FF_TILE;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -172,12 +191,12 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_forward(const half_t* __re
     const size_t layer_stride = (size_t)n_tiles * NKB * 64;  // in half8 units
 
     for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += gridDim.x * FF_WAVES) {
-        const half_t* xrow = inputs + ((size_t)tile * FF_TILE + n) * in_dim + 8 * h;
+        const size_t srow = (size_t)tile * FF_TILE + n;
         float16_t acc[NIB];
 #pragma unroll
         for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
         for (uint32_t kb = 0; kb < in_kb; kb++) {
-            const half8_t x = *reinterpret_cast<const half8_t*>(xrow + 16 * kb);
+            const half8_t x = load_features8(inputs, in_planar, rows, srow, in_dim, 16 * kb + 8 * h);
 #pragma unroll
             for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(img_l0[(ib * in_kb + kb) * 64], x, acc[ib]);
         }
@@ -312,7 +331,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
                                                                const half_t* __restrict__ weights, const half_t* __restrict__ forward_buffer,
                                                                uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
                                                                bool with_dx, half_t* __restrict__ grad_inputs, float* __restrict__ slabs,
-                                                               half_t* __restrict__ grad_weights_direct) {
+                                                               half_t* __restrict__ grad_weights_direct, bool in_planar, bool dx_planar) {
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img = reinterpret_cast<half8_t*>(smem);
@@ -332,6 +351,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
     const half8_t* img_in = img_hid + (size_t)(num_layers - 1) * NIB * NKB * 64;
     const size_t layer_stride = (size_t)n_tiles * NKB * 64;
     const half8_t* fb = reinterpret_cast<const half8_t*>(forward_buffer);
+    const size_t rows = (size_t)n_tiles * FF_TILE;
 
     // weight-gradient accumulators (fp32): output layer [jb<NIB], hidden layers [l][ib][jb], input layer [ib][jb<IN_JB]
     float16_t gw_out[NIB];
@@ -423,8 +443,9 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
 #pragma unroll
         for (int kb = 0; kb < NKB; kb++) stage_put(stgA, 16 * kb + 4 * h, n, dz[kb], true, h);
         {
-            const half_t* xrow = inputs + ((size_t)tile * FF_TILE + n) * in_dim + 8 * h;
-            for (uint32_t kb = 0; kb < in_kb; kb++) stage_put(stgB, 16 * kb + 8 * h, n, *reinterpret_cast<const half8_t*>(xrow + 16 * kb), false, h);
+            const size_t srow = (size_t)tile * FF_TILE + n;
+            for (uint32_t kb = 0; kb < in_kb; kb++)
+                stage_put(stgB, 16 * kb + 8 * h, n, load_features8(inputs, in_planar, rows, srow, in_dim, 16 * kb + 8 * h), false, h);
         }
         wave_lds_fence();
         // dW_in [WIDTH x in] += dZ_0^T . X
@@ -443,13 +464,20 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
                 float16_t dx = zero16();
 #pragma unroll
                 for (int kb = 0; kb < NKB; kb++) dx = mfma(img_in[(ib * NKB + kb) * 64], dz[kb], dx);
-                half_t* grow = grad_inputs + ((size_t)tile * FF_TILE + n) * in_dim;
+                const size_t srow = (size_t)tile * FF_TILE + n;
+                half_t* grow = grad_inputs + srow * in_dim;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const uint32_t f0 = 32 * ib + 8 * q + 4 * h;
                     if (f0 < in_dim) {
-                        half4_t v = {(half_t)dx[4 * q], (half_t)dx[4 * q + 1], (half_t)dx[4 * q + 2], (half_t)dx[4 * q + 3]};
-                        *reinterpret_cast<half4_t*>(grow + f0) = v;
+                        if (dx_planar) {  // [in_dim/2][rows][2]: the layout grid_encode_backward consumes
+                            const half2_t lo = {(half_t)dx[4 * q], (half_t)dx[4 * q + 1]}, hi = {(half_t)dx[4 * q + 2], (half_t)dx[4 * q + 3]};
+                            *reinterpret_cast<half2_t*>(grad_inputs + ((size_t)(f0 / 2) * rows + srow) * 2) = lo;
+                            *reinterpret_cast<half2_t*>(grad_inputs + ((size_t)(f0 / 2 + 1) * rows + srow) * 2) = hi;
+                        } else {
+                            half4_t v = {(half_t)dx[4 * q], (half_t)dx[4 * q + 1], (half_t)dx[4 * q + 2], (half_t)dx[4 * q + 3]};
+                            *reinterpret_cast<half4_t*>(grow + f0) = v;
+                        }
                     }
                 }
             }
@@ -501,13 +529,27 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
     }
 }
 
-// sum the per-workgroup slabs in a fixed order and round once to fp16
-__global__ void k_ffmlp_reduce_slabs(const float* __restrict__ slabs, uint32_t n_slabs, uint32_t n_params, half_t* __restrict__ grad_weights) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_params) return;
+// sum the per-workgroup slabs in a fixed order and round once to fp16.
+// One workgroup = 64 consecutive parameters x 16 slab groups: thread (g, i) adds slabs g, g+16, g+32, ... of parameter i
+// (coalesced 256-byte rows), the 16 partial sums are combined in LDS in ascending g -- a fixed summation tree, so the
+// result is bit-reproducible -- and rounded once.
+constexpr int RS_PARAMS = 64, RS_GROUPS = 16;
+__global__ __launch_bounds__(RS_PARAMS * RS_GROUPS) void k_ffmlp_reduce_slabs(const float* __restrict__ slabs, uint32_t n_slabs,
+                                                                               uint32_t n_params, half_t* __restrict__ grad_weights) {
+    __shared__ float part[RS_GROUPS][RS_PARAMS];
+    const uint32_t li = threadIdx.x & (RS_PARAMS - 1), g = threadIdx.x / RS_PARAMS;
+    const uint32_t i = blockIdx.x * RS_PARAMS + li;
     float s = 0.0f;
-    for (uint32_t k = 0; k < n_slabs; k++) s += slabs[(size_t)k * n_params + i];
-    grad_weights[i] = (half_t)s;
+    if (i < n_params)
+        for (uint32_t k = g; k < n_slabs; k += RS_GROUPS) s += slabs[(size_t)k * n_params + i];
+    part[g][li] = s;
+    __syncthreads();
+    if (g == 0 && i < n_params) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < RS_GROUPS; q++) t += part[q][li];
+        grad_weights[i] = (half_t)t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,7 +587,7 @@ static int check_ff_args(const char* fn, uint32_t B, uint32_t in_dim, uint32_t o
 
 template <int WIDTH, bool TRAIN>
 static int launch_forward(const void* inputs, const void* weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, uint32_t act,
-                          uint32_t out_act, void* fwd, void* outputs, hipStream_t st) {
+                          uint32_t out_act, void* fwd, void* outputs, uint32_t flags, hipStream_t st) {
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     const uint32_t n_tiles = B / FF_TILE;
     const uint32_t nfrag = NIB * (in_dim / 16) + (num_layers - 1) * NIB * NKB + NKB;
@@ -561,14 +603,15 @@ static int launch_forward(const void* inputs, const void* weights, uint32_t B, u
     const uint32_t need = cdiv(n_tiles, FF_WAVES);
     if (blocks > need) blocks = need;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)inputs, (const half_t*)weights, (half_t*)fwd,
-                       (half_t*)outputs, n_tiles, in_dim, num_layers, act, out_act);
+                       (half_t*)outputs, n_tiles, in_dim, num_layers, act, out_act, (flags & NGP_FF_INPUT_PLANAR) != 0);
     return check_launch(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
 }
 
 template <int WIDTH, int IN_JB, int NHM>
 static int launch_backward(const void* grad, const void* inputs, const void* weights, const void* fwd, uint32_t B, uint32_t in_dim,
                            uint32_t num_layers, uint32_t act, bool with_dx, void* backward_buffer, void* grad_inputs,
-                           void* grad_weights, hipStream_t st) {
+                           void* grad_weights, uint32_t flags, hipStream_t st) {
+    const bool in_planar = (flags & NGP_FF_INPUT_PLANAR) != 0, dx_planar = (flags & NGP_FF_DX_PLANAR) != 0;
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     const uint32_t n_tiles = B / FF_TILE;
     const uint32_t nfrag = NIB + (num_layers - 1) * NIB * NKB + (with_dx ? ((in_dim + 31) / 32) * NKB : 0);
@@ -591,15 +634,15 @@ static int launch_backward(const void* grad, const void* inputs, const void* wei
     if (blocks <= 1) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
                            (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)nullptr,
-                           (half_t*)grad_weights);
+                           (half_t*)grad_weights, in_planar, dx_planar);
         return check_launch("ffmlp_backward");
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
                        (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)backward_buffer,
-                       (half_t*)nullptr);
+                       (half_t*)nullptr, in_planar, dx_planar);
     int rc = check_launch("ffmlp_backward");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ffmlp_reduce_slabs, dim3(cdiv(n_params, 256)), dim3(256), 0, st, (const float*)backward_buffer, blocks, n_params,
+    hipLaunchKernelGGL(k_ffmlp_reduce_slabs, dim3(cdiv(n_params, RS_PARAMS)), dim3(RS_PARAMS * RS_GROUPS), 0, st, (const float*)backward_buffer, blocks, n_params,
                        (half_t*)grad_weights);
     return check_launch("ffmlp_backward(reduce)");
 }
@@ -608,35 +651,35 @@ static int launch_backward(const void* grad, const void* inputs, const void* wei
 
 using namespace ngp;
 
-extern "C" int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
-                                 uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
-                                 void* forward_buffer, void* outputs, ngp_stream_t stream) {
+extern "C" int ngp_ffmlp_forward_ex(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                                    uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                                    void* forward_buffer, void* outputs, uint32_t flags, ngp_stream_t stream) {
     int rc = check_ff_args("ffmlp_forward", B, input_dim, output_dim, hidden_dim, num_layers);
     if (rc) return rc;
     NGP_REQUIRE(inputs && weights && forward_buffer && outputs, NGP_ERR_INVALID, "ffmlp_forward: NULL tensor");
     if (B == 0) return NGP_OK;
     hipStream_t st = as_stream(stream);
-    if (hidden_dim == 64) return launch_forward<64, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, st);
-    return launch_forward<32, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, st);
+    if (hidden_dim == 64) return launch_forward<64, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, flags, st);
+    return launch_forward<32, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, flags, st);
 }
 
-extern "C" int ngp_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
-                                   uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
-                                   void* inference_buffer, void* outputs, ngp_stream_t stream) {
+extern "C" int ngp_ffmlp_inference_ex(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                                      uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                                      void* inference_buffer, void* outputs, uint32_t flags, ngp_stream_t stream) {
     (void)inference_buffer;
     int rc = check_ff_args("ffmlp_inference", B, input_dim, output_dim, hidden_dim, num_layers);
     if (rc) return rc;
     NGP_REQUIRE(inputs && weights && outputs, NGP_ERR_INVALID, "ffmlp_inference: NULL tensor");
     if (B == 0) return NGP_OK;
     hipStream_t st = as_stream(stream);
-    if (hidden_dim == 64) return launch_forward<64, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, nullptr, outputs, st);
-    return launch_forward<32, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, nullptr, outputs, st);
+    if (hidden_dim == 64) return launch_forward<64, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, nullptr, outputs, flags, st);
+    return launch_forward<32, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, nullptr, outputs, flags, st);
 }
 
-extern "C" int ngp_ffmlp_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
-                                  uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
-                                  uint32_t output_activation, int calc_grad_inputs, void* backward_buffer, void* grad_inputs,
-                                  void* grad_weights, ngp_stream_t stream) {
+extern "C" int ngp_ffmlp_backward_ex(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
+                                     uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                                     uint32_t output_activation, int calc_grad_inputs, void* backward_buffer, void* grad_inputs,
+                                     void* grad_weights, uint32_t flags, ngp_stream_t stream) {
     (void)output_activation;  // the reference discards it as well (ffmlp.cu:780)
     int rc = check_ff_args("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers);
     if (rc) return rc;
@@ -649,7 +692,7 @@ extern "C" int ngp_ffmlp_backward(const void* grad, const void* inputs, const vo
     const bool dx = calc_grad_inputs != 0;
     const uint32_t in_jb = (input_dim + 31) / 32;
 #define FF_BWD(W, J, N) \
-    return launch_backward<W, J, N>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, dx, backward_buffer, grad_inputs, grad_weights, st)
+    return launch_backward<W, J, N>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, dx, backward_buffer, grad_inputs, grad_weights, flags, st)
 #define FF_BWD_N(W, J)                      \
     switch (num_layers - 1) {               \
         case 1: FF_BWD(W, J, 1);            \
@@ -664,6 +707,26 @@ extern "C" int ngp_ffmlp_backward(const void* grad, const void* inputs, const vo
     FF_BWD_N(32, 2)
 #undef FF_BWD_N
 #undef FF_BWD
+}
+
+extern "C" int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                                 uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                                 void* forward_buffer, void* outputs, ngp_stream_t stream) {
+    return ngp_ffmlp_forward_ex(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                                forward_buffer, outputs, 0u, stream);
+}
+extern "C" int ngp_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
+                                   uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
+                                   void* inference_buffer, void* outputs, ngp_stream_t stream) {
+    return ngp_ffmlp_inference_ex(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
+                                  inference_buffer, outputs, 0u, stream);
+}
+extern "C" int ngp_ffmlp_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
+                                  uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                                  uint32_t output_activation, int calc_grad_inputs, void* backward_buffer, void* grad_inputs,
+                                  void* grad_weights, ngp_stream_t stream) {
+    return ngp_ffmlp_backward_ex(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                 output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, 0u, stream);
 }
 
 static size_t g_splitk_request = 0;

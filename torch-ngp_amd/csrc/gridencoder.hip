@@ -79,14 +79,22 @@ struct LevelIndexer {
 };
 
 // gridencoder.cu:146-159: position inside the level.  Returns false when the point is outside [0,1]^D.
+// Input mapping of the fused path: the module maps [-bound, bound] -> [0, 1] as (x + bound) * (1 / (2 bound)) in fp32
+// (grid.py:149 through PyTorch's scalar-division kernel); InputMap{shift = bound, scale = 1/(2 bound)} reproduces those two
+// roundings inside the kernel, scale == 0 means the inputs already are unit coordinates (the reference op contract).
+struct InputMap {
+    float shift, scale;
+};
+
 template <int D>
 __device__ __forceinline__ bool locate(const float* __restrict__ x, float scale, bool align_corners, uint32_t interp,
-                                       float (&frac)[D], float (&deriv)[D], uint32_t (&cell)[D]) {
+                                       float (&frac)[D], float (&deriv)[D], uint32_t (&cell)[D], InputMap im = InputMap{0.0f, 0.0f}) {
     float xv[D];
     bool inside = true;
 #pragma unroll
     for (int d = 0; d < D; d++) {
         xv[d] = x[d];
+        if (im.scale != 0.0f) xv[d] = (xv[d] + im.shift) * im.scale;
         inside = inside && !(xv[d] < 0.0f || xv[d] > 1.0f);
     }
     if (!inside) return false;
@@ -271,6 +279,84 @@ __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward, production variant (no dy_dx): XCD-aware level placement + corner pairs on neighbouring lanes
+//
+// * Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with a private 4 MiB L2.
+//   With a plain (tile, level) grid every XCD streams every level's table through its own L2 (8 x 23 MiB of
+//   fills per call).  Here block b serves level (b % 8) + 8 * k only, k advancing with b / 8: a level's table is
+//   fetched into ONE L2, and an XCD works through its levels one after the other, so the live table (<= 2 MiB
+//   fp16) always fits next to the point stream.
+// * The vector memory pipeline pays per distinct cache line of a wave instruction (random 4-byte gathers run at
+//   ~0.4 lanes/clk/CU, 16 lanes on a line >4x faster -- tools/atomic_probe2.hip).  Lanes 2p and 2p+1 fetch the two
+//   corners of point p that differ in the first coordinate: neighbours in memory on dense levels and, because the
+//   first hash prime is 1, also on hashed levels whenever x and x+1 share an aligned 16-entry block.  The two
+//   half sums are combined with one DPP quad permute per channel.
+// ------------------------------------------------------------------------------------------------
+constexpr int FWD_PTS_PER_WAVE = 32;
+
+__device__ __forceinline__ float quad_swap1(float v) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+template <typename T, int D, int C>
+__global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                                   const int32_t* __restrict__ offsets, T* __restrict__ outputs,
+                                                                   uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
+                                                                   bool align_corners, uint32_t interp, uint32_t tiles_per_level,
+                                                                   uint32_t points_per_block, InputMap im) {
+    constexpr int NJ = 1 << (D - 1);
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t li = slot / tiles_per_level, tile = slot - li * tiles_per_level;
+    const uint32_t level = xcd + 8u * li;
+    if (level >= L) return;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float scale = lv.scale[level];
+    LevelIndexer<D> indexer;
+    indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
+    const T* __restrict__ table = grid + (size_t)off0 * C;
+    T* __restrict__ olevel = outputs + (size_t)level * B * C;
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int pl = lane >> 1;
+    const uint32_t xb = lane & 1;
+    const uint32_t b_begin = tile * points_per_block;
+    const uint32_t b_end = min(B, b_begin + points_per_block);
+    for (uint32_t base = b_begin + wid * FWD_PTS_PER_WAVE; base < b_end; base += (FWD_THREADS / 64) * FWD_PTS_PER_WAVE) {
+        const uint32_t b = base + pl;
+        const bool in_range = b < b_end;
+        float frac[D], deriv[D];
+        uint32_t cell[D];
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) acc[c] = 0.0f;
+        if (in_range && locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, frac, deriv, cell, im)) {
+            Vec<T, C> corner[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                uint32_t pg[D];
+                pg[0] = cell[0] + xb;
+#pragma unroll
+                for (int d = 1; d < D; d++) pg[d] = cell[d] + ((j >> (d - 1)) & 1);
+                corner[j].load(table + (size_t)indexer(pg) * C);
+            }
+            const float w0 = xb ? frac[0] : 1.0f - frac[0];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                float w = w0;
+#pragma unroll
+                for (int d = 1; d < D; d++) w *= ((j >> (d - 1)) & 1) ? frac[d] : (1.0f - frac[d]);
+#pragma unroll
+                for (int c = 0; c < C; c++) acc[c] = __builtin_fmaf(w, corner[j].v[c], acc[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) acc[c] += quad_swap1(acc[c]);  // all lanes execute (no cross-lane read under divergence)
+        if (in_range && xb == 0) store_vec<T, C>(olevel + (size_t)b * C, acc);
+    }
+}
+
 // corner-index diagnostic (same locate/indexer code path as the forward kernel)
 template <int D>
 __global__ __launch_bounds__(FWD_THREADS) void k_grid_corner_indices(const float* __restrict__ inputs,
@@ -365,7 +451,7 @@ template <typename T, int D, int C, bool MERGE>
 __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                                const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
                                                                uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
-                                                               bool align_corners, uint32_t interp, uint32_t points_per_block) {
+                                                               bool align_corners, uint32_t interp, uint32_t points_per_block, InputMap im) {
     constexpr int NJ = 1 << (D - 1);  // corners per lane (all combinations of the coordinates 1..D-1)
     const uint32_t level = blockIdx.y;
     const uint32_t off0 = (uint32_t)offsets[level];
@@ -392,7 +478,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
         float g[C];
 #pragma unroll
         for (int c = 0; c < C; c++) g[c] = 0.0f;
-        if (live) live = locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, frac, deriv, cell);
+        if (live) live = locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, frac, deriv, cell, im);
         if (live) {
             Vec<T, C> gv;
             gv.load(glevel + (size_t)b * C);
@@ -554,14 +640,20 @@ static uint32_t fwd_blocks(uint32_t B) {
 template <typename T, int D, int C>
 static int launch_forward(const float* inputs, const void* emb, const int32_t* offsets, void* outputs, uint32_t B,
                           uint32_t L, const GridLevels& lv, void* dy_dx, uint32_t gridtype, bool ac, uint32_t interp,
-                          hipStream_t st) {
-    dim3 grid(fwd_blocks(B), L, 1);
-    if (dy_dx)
+                          InputMap im, hipStream_t st) {
+    if (dy_dx) {
+        dim3 grid(fwd_blocks(B), L, 1);
         hipLaunchKernelGGL((k_grid_forward<T, D, C, true>), grid, dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
                            (T*)outputs, B, L, lv, (T*)dy_dx, gridtype, ac, interp);
-    else
-        hipLaunchKernelGGL((k_grid_forward<T, D, C, false>), grid, dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
-                           (T*)outputs, B, L, lv, (T*)nullptr, gridtype, ac, interp);
+        return check_launch("grid_encode_forward(dy_dx)");
+    }
+    // >= ~8 workgroups per CU over the whole launch; a workgroup covers ppb consecutive points of one level
+    uint32_t ppb = 1024;
+    while (ppb > 128 && (uint64_t)cdiv(B, ppb) * L < 2048) ppb >>= 1;
+    const uint32_t tiles = cdiv(B, ppb);
+    const uint32_t blocks = 8u * cdiv(L, 8u) * tiles;
+    hipLaunchKernelGGL((k_grid_forward_pair<T, D, C>), dim3(blocks), dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
+                       (T*)outputs, B, L, lv, gridtype, ac, interp, tiles, ppb, im);
     return check_launch("grid_encode_forward");
 }
 
@@ -577,7 +669,7 @@ static int grid_backward_variant() {  // NGP_GRID_BWD=nomerge disables the run m
 template <typename T, int D, int C>
 static int launch_backward(const void* grad, const float* inputs, const int32_t* offsets, void* grad_emb, uint32_t B,
                            uint32_t L, const GridLevels& lv, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
-                           bool ac, uint32_t interp, hipStream_t st) {
+                           bool ac, uint32_t interp, InputMap im, hipStream_t st) {
     int rc = NGP_OK;
     // one block covers `ppb` consecutive points of one level; >= ~4 blocks per CU over all levels fills the chip
     uint32_t ppb = 2048;
@@ -585,10 +677,10 @@ static int launch_backward(const void* grad, const float* inputs, const int32_t*
     dim3 grid(cdiv(B, ppb), L, 1);
     if (grid_backward_variant() == 1)
         hipLaunchKernelGGL((k_grid_backward<T, D, C, false>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
-                           (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb);
+                           (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb, im);
     else
         hipLaunchKernelGGL((k_grid_backward<T, D, C, true>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
-                           (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb);
+                           (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb, im);
     rc = check_launch("grid_encode_backward");
     if (rc) return rc;
     if (dy_dx && grad_inputs) {
@@ -655,10 +747,22 @@ extern "C" int ngp_grid_level_table(uint32_t L, float S, uint32_t H, float* scal
     return NGP_OK;
 }
 
-extern "C" int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
-                                       uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
-                                       uint32_t gridtype, int align_corners, uint32_t interp, int dtype, ngp_stream_t stream) {
+static InputMap make_input_map(float bound) {
+    InputMap im{0.0f, 0.0f};
+    if (bound > 0.0f) {
+        im.shift = bound;
+        im.scale = 1.0f / (float)(2.0 * (double)bound);
+    }
+    return im;
+}
+
+extern "C" int ngp_grid_encode_forward_ex(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                          uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                          uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
+                                          ngp_stream_t stream) {
     int rc = check_grid_args("grid_encode_forward", B, D, C, L, dtype);
+    NGP_REQUIRE(!(bound > 0.0f && dy_dx), NGP_ERR_INVALID, "grid_encode_forward: the fused input mapping does not provide dy_dx");
+    const InputMap im = make_input_map(bound);
     if (rc) return rc;
     NGP_REQUIRE(inputs && embeddings && offsets && outputs, NGP_ERR_INVALID, "grid_encode_forward: NULL tensor");
     if (B == 0) return NGP_OK;
@@ -667,19 +771,28 @@ extern "C" int ngp_grid_encode_forward(const float* inputs, const void* embeddin
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
     if (dtype == NGP_F16) {
-        NGP_DISPATCH_DC(launch_forward, half_t, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st)
+        NGP_DISPATCH_DC(launch_forward, half_t, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, im, st)
     } else {
-        NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, st)
+        NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, im, st)
     }
     set_error("grid_encode_forward: unsupported (D=%u, C=%u)", D, C);
     return NGP_ERR_INVALID;
 }
 
-extern "C" int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
-                                        void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
-                                        uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
-                                        uint32_t interp, int dtype, ngp_stream_t stream) {
+extern "C" int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                       uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                       uint32_t gridtype, int align_corners, uint32_t interp, int dtype, ngp_stream_t stream) {
+    return ngp_grid_encode_forward_ex(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp,
+                                      dtype, 0.0f, stream);
+}
+
+extern "C" int ngp_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                           void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                           uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                                           uint32_t interp, int dtype, float bound, ngp_stream_t stream) {
     (void)embeddings;
+    NGP_REQUIRE(!(bound > 0.0f && dy_dx), NGP_ERR_INVALID, "grid_encode_backward: the fused input mapping does not provide grad_inputs");
+    const InputMap im = make_input_map(bound);
     int rc = check_grid_args("grid_encode_backward", B, D, C, L, dtype);
     if (rc) return rc;
     NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: NULL tensor");
@@ -689,12 +802,20 @@ extern "C" int ngp_grid_encode_backward(const void* grad, const float* inputs, c
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
     if (dtype == NGP_F16) {
-        NGP_DISPATCH_DC(launch_backward, half_t, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, st)
+        NGP_DISPATCH_DC(launch_backward, half_t, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, im, st)
     } else {
-        NGP_DISPATCH_DC(launch_backward, float, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, st)
+        NGP_DISPATCH_DC(launch_backward, float, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, im, st)
     }
     set_error("grid_encode_backward: unsupported (D=%u, C=%u)", D, C);
     return NGP_ERR_INVALID;
+}
+
+extern "C" int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                        void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                        uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                                        uint32_t interp, int dtype, ngp_stream_t stream) {
+    return ngp_grid_encode_backward_ex(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
+                                       align_corners, interp, dtype, 0.0f, stream);
 }
 
 extern "C" int ngp_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,

@@ -1,0 +1,131 @@
+// Glue kernels of the fused sample pipeline: what nerf/network_ff.py:51-123 does between the native
+// ops with ~20 small PyTorch kernels (slice, trunc_exp, SH, cat, zero pad, casts, sigmoid and their autograd twins),
+// restated as four streaming kernels with the same rounding points as the autocast path:
+//   mid forward  : sigma = exp(float(h[:,0]))                       (activation.py:5-17, trunc_exp forward)
+//                  color_in = [ half(SH_4(dir)) | h[:,1:16] | 0 ]    (network_ff.py:64-68)
+//   rgb forward  : rgb = float(half(sigmoid(float(out[:, :3]))))     (network_ff.py:72: torch.sigmoid on the fp16 output)
+//   rgb backward : g_out[:, :3] = half(g_rgb * y * (1 - y)), g_out[:, 3:] = 0
+//   mid backward : g_h[:,0] = half(g_sigma * exp(clamp(float(h[:,0]), -15, 15))) (trunc_exp backward), g_h[:,1:16] = g_color_in[:,16:31]
+// All are pure streams (HBM-bound, 60-130 B per sample); one lane handles one sample row with 16-byte accesses.
+#include "common.h"
+#include "sh_poly.inc"
+
+namespace ngp {
+
+constexpr int PL_THREADS = 256;
+
+__global__ __launch_bounds__(PL_THREADS) void k_mid_forward(const half_t* __restrict__ h, const float* __restrict__ dirs,
+                                                            float* __restrict__ sigma, half_t* __restrict__ color_in, uint32_t M,
+                                                            uint32_t M_valid) {
+    const uint32_t b = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (b >= M) return;
+    const half8_t h0 = *reinterpret_cast<const half8_t*>(h + (size_t)b * 16);
+    const half8_t h1 = *reinterpret_cast<const half8_t*>(h + (size_t)b * 16 + 8);
+    sigma[b] = expf((float)h0[0]);
+    float sh[16];
+    float x = 0.0f, y = 0.0f, z = 0.0f;
+    if (b < M_valid) { x = dirs[(size_t)b * 3]; y = dirs[(size_t)b * 3 + 1]; z = dirs[(size_t)b * 3 + 2]; }
+#define SH_OUT(i, v) sh[i] = (v)
+    SH_BAND_0_VALUES;
+    SH_BAND_1_VALUES;
+    SH_BAND_2_VALUES;
+    SH_BAND_3_VALUES;
+#undef SH_OUT
+    half8_t o[4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { o[0][i] = (half_t)sh[i]; o[1][i] = (half_t)sh[8 + i]; }
+#pragma unroll
+    for (int i = 0; i < 7; i++) o[2][i] = h0[i + 1];
+    o[2][7] = h1[0];
+#pragma unroll
+    for (int i = 0; i < 7; i++) o[3][i] = h1[i + 1];
+    o[3][7] = (half_t)0.0f;
+    half8_t* dst = reinterpret_cast<half8_t*>(color_in + (size_t)b * 32);
+#pragma unroll
+    for (int q = 0; q < 4; q++) dst[q] = o[q];
+}
+
+__global__ __launch_bounds__(PL_THREADS) void k_rgb_forward(const half_t* __restrict__ out16, float* __restrict__ rgb, uint32_t M) {
+    const uint32_t b = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (b >= M) return;
+    const half4_t o = *reinterpret_cast<const half4_t*>(out16 + (size_t)b * 16);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float s = 1.0f / (1.0f + expf(-(float)o[c]));
+        rgb[(size_t)b * 3 + c] = (float)(half_t)s;
+    }
+}
+
+__global__ __launch_bounds__(PL_THREADS) void k_rgb_backward(const float* __restrict__ grad_rgb, const float* __restrict__ rgb,
+                                                             half_t* __restrict__ grad_out16, uint32_t M) {
+    const uint32_t b = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (b >= M) return;
+    half8_t lo, hi;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { lo[i] = (half_t)0.0f; hi[i] = (half_t)0.0f; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float y = rgb[(size_t)b * 3 + c];
+        lo[c] = (half_t)(grad_rgb[(size_t)b * 3 + c] * (y * (1.0f - y)));
+    }
+    half8_t* dst = reinterpret_cast<half8_t*>(grad_out16 + (size_t)b * 16);
+    dst[0] = lo;
+    dst[1] = hi;
+}
+
+__global__ __launch_bounds__(PL_THREADS) void k_mid_backward(const float* __restrict__ grad_sigma, const half_t* __restrict__ h,
+                                                             const half_t* __restrict__ grad_color_in, half_t* __restrict__ grad_h,
+                                                             uint32_t M) {
+    const uint32_t b = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (b >= M) return;
+    const float x = (float)h[(size_t)b * 16];
+    const float gs = grad_sigma[b] * expf(fminf(15.0f, fmaxf(-15.0f, x)));
+    const half8_t g2 = *reinterpret_cast<const half8_t*>(grad_color_in + (size_t)b * 32 + 16);
+    const half8_t g3 = *reinterpret_cast<const half8_t*>(grad_color_in + (size_t)b * 32 + 24);
+    half8_t lo, hi;
+    lo[0] = (half_t)gs;
+#pragma unroll
+    for (int i = 0; i < 7; i++) lo[i + 1] = g2[i];
+    hi[0] = g2[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) hi[i + 1] = g3[i];
+    half8_t* dst = reinterpret_cast<half8_t*>(grad_h + (size_t)b * 16);
+    dst[0] = lo;
+    dst[1] = hi;
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" int ngp_pipeline_mid_forward(const void* h16, const float* dirs, float* sigma, void* color_in, uint32_t M, uint32_t M_valid,
+                                        ngp_stream_t stream) {
+    NGP_REQUIRE(h16 && dirs && sigma && color_in, NGP_ERR_INVALID, "pipeline_mid_forward: NULL tensor");
+    if (M == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_mid_forward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), (const half_t*)h16, dirs, sigma,
+                       (half_t*)color_in, M, M_valid);
+    return check_launch("pipeline_mid_forward");
+}
+
+extern "C" int ngp_pipeline_rgb_forward(const void* out16, float* rgb, uint32_t M, ngp_stream_t stream) {
+    NGP_REQUIRE(out16 && rgb, NGP_ERR_INVALID, "pipeline_rgb_forward: NULL tensor");
+    if (M == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_rgb_forward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), (const half_t*)out16, rgb, M);
+    return check_launch("pipeline_rgb_forward");
+}
+
+extern "C" int ngp_pipeline_rgb_backward(const float* grad_rgb, const float* rgb, void* grad_out16, uint32_t M, ngp_stream_t stream) {
+    NGP_REQUIRE(grad_rgb && rgb && grad_out16, NGP_ERR_INVALID, "pipeline_rgb_backward: NULL tensor");
+    if (M == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_rgb_backward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), grad_rgb, rgb, (half_t*)grad_out16, M);
+    return check_launch("pipeline_rgb_backward");
+}
+
+extern "C" int ngp_pipeline_mid_backward(const float* grad_sigma, const void* h16, const void* grad_color_in, void* grad_h16, uint32_t M,
+                                         ngp_stream_t stream) {
+    NGP_REQUIRE(grad_sigma && h16 && grad_color_in && grad_h16, NGP_ERR_INVALID, "pipeline_mid_backward: NULL tensor");
+    if (M == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_mid_backward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), grad_sigma, (const half_t*)h16,
+                       (const half_t*)grad_color_in, (half_t*)grad_h16, M);
+    return check_launch("pipeline_mid_backward");
+}

@@ -12,8 +12,12 @@ occupancy (the refreshed grid is computed and discarded) so that the number of s
 ~65.  Inputs (rays, ground-truth colours, occupancy) are resident in HBM before the timed region starts.
 
 metric  : training samples/s = sum over steps and ranks of the samples actually marched (counter[0]) / wall time
-roofline: the named dominant kernel (default grid_encode_forward) timed live with HIP events on the launch stream
-          inside the timed region; algorithmic bytes per SURVEY.md 8(d) (588 B per point).
+execution: the iteration is captured once into a HIP graph (torch-ngp_amd/graph.py) and replayed per step; --no-graph issues
+          every launch eagerly, --no-fused uses the reference-style module-by-module network path.
+roofline: `roofline` = the dominant kernel (grid_encode_backward, 1100 B per point), `rooflines` = all timed kernels
+          (grid fwd/bwd, ffmlp fwd/bwd with their MFMA fraction).  HIP graphs cannot carry timing events, so after the
+          timed region the same iteration is run eagerly for a few steps with HIP-event pairs around the named kernels on
+          the launch stream; algorithmic bytes per SURVEY.md 8(d); `traffic` from the committed rocprofv3 --pmc passes.
 cpu_baseline: the CPU oracle's full training step (forward+backward, one host thread) on the same workload.
 """
 import argparse
@@ -31,40 +35,88 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak, same guide
 
-# algorithmic bytes per unit
-KERNEL_BYTES = {
-    'grid_encode_forward': ('gridencoder', 588.0, 'point'),
-    'grid_encode_backward': ('gridencoder', 1100.0, 'point'),
+# Kernels timed for the roofline section: C-ABI symbol -> (label, index of the batch-size argument, algorithmic bytes per
+# unit, algorithmic flops per unit, unit).  Byte/flop counts are SURVEY.md 8(d); the ffmlp rows depend on the layer count
+# and are resolved at call time (in 64 B + out 32 B + 128 B per stored hidden layer; backward: grad 32 + saved activations
+# 128/layer + inputs 64 + dL/dx 64).
+def _ff_fwd_bytes(nl): return 64.0 + 32.0 + 128.0 * nl
+def _ff_bwd_bytes(nl): return 32.0 + 128.0 * nl + 64.0 + 64.0
+def _ff_flops(nl): return 2.0 * 64 * (32 + 64 * (nl - 1) + 16)
+
+TIMED = {
+    'ngp_grid_encode_forward': ('grid_encode_forward', 4, lambda a: 588.0, lambda a: 0.0, 'point'),
+    'ngp_grid_encode_backward': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
+    'ngp_ffmlp_forward': ('ffmlp_forward', 2, lambda a: _ff_fwd_bytes(a[6]), lambda a: _ff_flops(a[6]), 'sample'),
+    'ngp_ffmlp_backward': ('ffmlp_backward', 4, lambda a: _ff_bwd_bytes(a[8]), lambda a: 2.0 * _ff_flops(a[8]), 'sample'),
+    'ngp_grid_encode_forward_ex': ('grid_encode_forward', 4, lambda a: 588.0, lambda a: 0.0, 'point'),
+    'ngp_grid_encode_backward_ex': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
+    'ngp_ffmlp_forward_ex': ('ffmlp_forward', 2, lambda a: _ff_fwd_bytes(a[6]), lambda a: _ff_flops(a[6]), 'sample'),
+    'ngp_ffmlp_backward_ex': ('ffmlp_backward', 4, lambda a: _ff_bwd_bytes(a[8]), lambda a: 2.0 * _ff_flops(a[8]), 'sample'),
 }
 
 
-class KernelTimer:
-    """wraps one `_backend` callable with HIP-event pairs recorded on the current (launch) stream"""
+class KernelTimers:
+    """HIP-event pairs around selected C-ABI calls, recorded on the stream the kernels are launched on (the current PyTorch
+    stream, which is what `_ngp_capi.stream()` hands to the library)."""
 
-    def __init__(self, backend, name):
-        self.backend, self.name = backend, name
-        self.inner = getattr(backend, name)
-        self.events, self.units, self.enabled = [], 0, False
-        setattr(backend, name, self)
+    def __init__(self, capi):
+        self.capi, self.records, self.enabled, self.orig = capi, {}, False, {}
+        for sym in TIMED:
+            self.orig[sym] = getattr(capi.lib, sym)
+            setattr(capi.lib, sym, self._wrap(sym))
 
-    def __call__(self, *args):
-        if not self.enabled:
-            return self.inner(*args)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = self.inner(*args)
-        b.record()
-        self.events.append((a, b))
-        self.units += int(args[4] if self.name == 'grid_encode_forward' else args[5])  # B
+    def _wrap(self, sym):
+        inner = self.orig[sym]
+        label, b_idx, fbytes, fflops, unit = TIMED[sym]
+
+        def call(*args):
+            if not self.enabled:
+                return inner(*args)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = inner(*args)
+            b.record()
+            self.records.setdefault(label, []).append((a, b, int(args[b_idx]), fbytes(args), fflops(args), unit))
+            return rc
+        return call
+
+    def summary(self, traffic=None):
+        out = []
+        for label, recs in self.records.items():
+            ms = np.array([a.elapsed_time(b) for a, b, *_ in recs])
+            units = np.array([r[2] for r in recs], dtype=np.float64)
+            byts = np.array([r[2] * r[3] for r in recs])
+            flops = np.array([r[2] * r[4] for r in recs])
+            t = float(ms.mean()) * 1e-3
+            gbs = float(byts.mean()) / t / 1e9
+            row = {'kernel': label, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                   'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_kernel_ms': round(float(ms.mean()), 4),
+                   'units_per_launch': round(float(units.mean()), 1), 'bytes_per_unit': round(float(byts.mean() / units.mean()), 1),
+                   'unit_name': recs[0][5], 'launches': len(recs), 'total_ms': round(float(ms.sum()), 3)}
+            if flops.mean() > 0:
+                tf = float(flops.mean()) / t / 1e12
+                row['mfma'] = {'achieved': round(tf, 2), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 5)}
+            if traffic and label in traffic:
+                row['traffic'] = traffic[label]
+            out.append(row)
+        out.sort(key=lambda r: -r['total_ms'])
         return out
 
-    def summary(self):
-        if not self.events:
-            return None
-        ms = [a.elapsed_time(b) for a, b in self.events]
-        return dict(launches=len(ms), avg_ms=float(np.mean(ms)), units=self.units)
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json, produced by
+    tools/pmc_traffic.py on the same workload); None when the file is absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))['per_launch']
+    except Exception:
+        return None
 
 
 def main():
@@ -73,7 +125,10 @@ def main():
     ap.add_argument('--steps', type=int, default=64)
     ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--rays', type=int, default=4096, help='rays per GPU and step (reference default, main_nerf.py:26)')
-    ap.add_argument('--roofline-kernel', default='grid_encode_forward', choices=sorted(KERNEL_BYTES))
+    ap.add_argument('--roofline-kernel', default='grid_encode_backward', help='kernel reported as `roofline` (default: the dominant one)')
+    ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying HIP graphs')
+    ap.add_argument('--no-fused', action='store_true', help='module-by-module network path (reference-style glue) instead of fused.py')
+    ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     args = ap.parse_args()
@@ -89,15 +144,17 @@ def main():
         dist.init_process_group('nccl', device_id=dev)  # RCCL
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
-    import gridencoder.backend as gbackend
+    import _ngp_capi as capi
     import raymarching
     import synthetic_scene as sc
     from nerf.network_ff import NeRFNetwork
     from ddp import GradientAverager
+    from graph import GraphedTrainStep, mse_loss
 
     torch.manual_seed(0)  # identical parameters on every rank (FFMLP reseeds to 42 itself)
     model = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
     model.train()
+    model.fused = not args.no_fused
     occ = torch.from_numpy(sc.occupancy_density()).to(dev)
     model.density_grid.copy_(occ)
     model.density_bitfield = raymarching.packbits(model.density_grid, 10.0, model.density_bitfield)
@@ -105,7 +162,7 @@ def main():
     model.iter_density = 16          # steady state: partial occupancy refreshes (renderer.py:488-514)
     model.mean_density = float(occ.clamp(min=0).mean())
 
-    optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True)
+    optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
     scaler = torch.amp.GradScaler('cuda')
     averager = GradientAverager(model, world) if world > 1 else None
 
@@ -118,51 +175,62 @@ def main():
     total_samples = torch.zeros((), dtype=torch.int64, device=dev)
     opt_kwargs = dict(staged=False, bg_color=1, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
 
-    capacity = [args.rays * 1024]
+    def keep_scene(m):
+        # the synthetic scene keeps its analytic occupancy: the refresh work is done, its result is discarded
+        m.density_grid.copy_(occ)
+        m.density_bitfield.copy_(fixed_bits)
 
+    stepper = GraphedTrainStep(model, optimizer, scaler, args.rays, opt_kwargs, loss_fn=mse_loss, averager=averager,
+                               after_update=keep_scene)
     def train_step(i, count=True):
-        if i % 16 == 0:
-            with torch.autocast('cuda', dtype=torch.float16):
-                model.update_extra_state()
-            model.density_grid.copy_(occ)          # keep the analytic scene (refresh work done, result discarded)
-            model.density_bitfield.copy_(fixed_bits)
         rays_o, rays_d, gt = pool[i % n_pool]
-        mc = model.mean_count
-        capacity[0] = mc + (128 - mc % 128) if mc > 0 else args.rays * 1024
-        optimizer.zero_grad()
-        with torch.autocast('cuda', dtype=torch.float16):
-            out = model.render(rays_o, rays_d, **opt_kwargs)
-            loss = ((out['image'][0] - gt) ** 2).mean()
-        scaler.scale(loss).backward()
-        if averager is not None:
-            averager.all_reduce()
-        scaler.step(optimizer)
-        scaler.update()
+        if args.no_graph:
+            # eager path: same cadence, no capture
+            if stepper.global_step % 16 == 0:
+                with torch.autocast('cuda', dtype=torch.float16):
+                    model.update_extra_state()
+                keep_scene(model)
+            mc = model.mean_count
+            cap = mc + (128 - mc % 128) if mc > 0 else args.rays * 1024
+            loss = stepper._eager(rays_o, rays_d, gt)
+            stepper.global_step += 1
+            marched = model.step_counter[(model.local_step - 1) % 16, 0]
+        else:
+            loss = stepper.step(rays_o, rays_d, gt)
+            cap = stepper.capacity if stepper.capacity is not None else args.rays * 1024
+            marched = model.step_counter[(model.local_step - 1) % 16, 0]
         if count:
             # samples that were marched AND evaluated: rays that do not fit the estimated buffer are dropped whole by
-            # march_rays_train (raymarching.cu:416), so at most `capacity` samples are processed in a step
-            marched = model.step_counter[(model.local_step - 1) % 16, 0]
-            total_samples.add_(torch.clamp(marched, max=capacity[0]))
+            # march_rays_train (raymarching.cu:416), so at most `cap` samples are processed in a step
+            total_samples.add_(torch.clamp(marched, max=cap))
         return loss
 
-    timer = KernelTimer(gbackend._backend, args.roofline_kernel)
+    timers = KernelTimers(capi)
 
-    for i in range(args.warmup):
-        train_step(i, count=False)
+    # setup (untimed, not part of --warmup): bring the model to the steady state of a running training -- the first 16
+    # iterations size the sample buffer for the worst case and read the count back (raymarching.py:223-231); after the
+    # first update_extra_state the running estimate `mean_count` exists and the iteration is sync-free.
+    step_no = 0
+    for _ in range(17):
+        train_step(step_no, count=False)
+        step_no += 1
+    for _ in range(args.warmup):
+        train_step(step_no, count=False)
+        step_no += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        loss = train_step(i)
+    for _ in range(args.steps):
+        loss = train_step(step_no)
+        step_no += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    final_loss = float(loss.item())
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -171,17 +239,29 @@ def main():
     elapsed = float(el.item())
     samples = int(total_samples.item())
 
+    # roofline pass (untimed): HIP graphs cannot carry timing events, so the same iteration is run eagerly for a few steps
+    # with HIP-event pairs around the named kernels, on the stream they are launched on, same batches, same state.
+    roofs = []
+    if rank == 0 and not args.no_roofline:
+        timers.enabled = True
+        for k in range(min(16, max(4, args.steps))):
+            rays_o, rays_d, gt = pool[(step_no + k) % n_pool]
+            saved = (model.mean_count, model.local_step)
+            if stepper.captured_capacity:
+                model.mean_count = stepper.captured_capacity - 128
+            stepper._eager(rays_o, rays_d, gt)
+            model.mean_count, model.local_step = saved
+        torch.cuda.synchronize()
+        timers.enabled = False
+        roofs = timers.summary(load_pmc_traffic())
+
     if rank == 0:
-        ks = timer.summary()
-        _, bytes_per_unit, unit = KERNEL_BYTES[args.roofline_kernel]
         roof = None
-        if ks:
-            per_launch_units = ks['units'] / ks['launches']
-            achieved = bytes_per_unit * per_launch_units / (ks['avg_ms'] * 1e-3) / 1e9
-            roof = {'kernel': args.roofline_kernel, 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_kernel_ms': round(ks['avg_ms'], 4),
-                    'units_per_launch': round(per_launch_units, 1), 'bytes_per_unit': bytes_per_unit, 'unit_name': unit,
-                    'launches': ks['launches']}
+        for r in roofs:
+            if r['kernel'] == args.roofline_kernel:
+                roof = r
+        if roof is None and roofs:
+            roof = roofs[0]  # the dominant one by total time
         cpu = None
         if not args.no_cpu_baseline:
             import oracle
@@ -201,8 +281,9 @@ def main():
                                    'FFMLP 64x2 / 64x3), bound=1, 128^3 occupancy grid, dt_gamma=0, max_steps=1024',
                        'rays_per_gpu_per_step': args.rays, 'samples_per_step_per_gpu': round(samples / args.steps / world, 1),
                        'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}',
-                       'final_loss': float(loss.item())},
-            'roofline': roof, 'cpu_baseline': cpu,
+                       'execution': 'eager' if args.no_graph else f'hip-graph replay ({stepper.n_captures} capture(s))',
+                       'fused_pipeline': bool(model.fused), 'final_loss': final_loss},
+            'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
     if world > 1:

@@ -1,0 +1,149 @@
+"""HIP-graph replay of the training iteration (MI355X-native replacement for ~80 eager launches per step).
+
+One `--fp16 --cuda_ray --ff` iteration is ~80 kernel launches of 2-500 us each; issued eagerly the host needs longer to
+enqueue them than the GPU needs to run them.  `GraphedTrainStep` captures
+
+    optimizer.zero_grad -> model.render (near/far, march, fused sample pipeline, composite) -> loss -> scaled backward
+    [-> gradient all-reduce, eager, between two graphs when world_size > 1] -> GradScaler.step(fused Adam) -> GradScaler.update
+
+into HIP graphs (`torch.cuda.CUDAGraph`; every kernel of libngp_hip.so is launched on the capturing stream through the C
+ABI, so it is captured like any PyTorch kernel) and replays them per step.  Everything the iteration needs is
+device-resident: the sample buffer is sized from the running `mean_count` estimate (no host read-back, rays that do not fit
+are dropped whole exactly as in the reference, raymarching.cu:405-416), GradScaler's inf check feeds the fused Adam
+kernel as a tensor, and the only per-step host work is three small device copies (the batch into the static input buffers)
+and one graph launch.
+
+What stays eager, at the reference Trainer's cadence (nerf/utils.py:851-856): `update_extra_state` every 16 steps, which also
+refreshes `mean_count`.  The captured sample capacity is `mean_count` rounded up to a multiple of `capacity_quantum`
+(default 8192 samples, ~3 % of a lego-sized batch), so the graph is re-captured only when the estimate crosses a quantum.
+
+Requirements: `optimizer` constructed with `capturable=True` (and preferably `fused=True`); the model has completed at least
+one `update_extra_state` after 16 eager steps (`model.mean_count > 0`) -- before that the sample buffer is sized for the
+worst case and read back, which cannot be captured, and `step()` simply runs eagerly.
+"""
+import torch
+
+
+def mse_loss(out, target):
+    return ((out['image'][0] - target) ** 2).mean()
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, scaler, n_rays, render_kwargs, loss_fn=mse_loss, averager=None, capacity_quantum=8192,
+                 update_interval=16, after_update=None, autocast_dtype=torch.float16):
+        self.model, self.optimizer, self.scaler = model, optimizer, scaler
+        self.loss_fn, self.averager = loss_fn, averager
+        self.render_kwargs = dict(render_kwargs)
+        self.quantum = int(capacity_quantum)
+        self.update_interval = int(update_interval)
+        self.after_update = after_update
+        self.autocast_dtype = autocast_dtype
+        dev = next(model.parameters()).device
+        self.dev = dev
+        self.rays_o = torch.zeros(1, n_rays, 3, device=dev)
+        self.rays_d = torch.zeros(1, n_rays, 3, device=dev)
+        self.target = torch.zeros(n_rays, 3, device=dev)
+        self.counter = torch.zeros(16, 2, dtype=torch.int32, device=dev)  # row 0 is the captured marcher's counter
+        self.global_step = 0
+        self.captured_capacity = None
+        self.graphs = None
+        self.loss = None
+        self.n_captures = 0
+        self.capacity = None  # sample capacity of the step that ran last (None while eager/worst-case)
+
+    # ------------------------------------------------------------------------------------------
+    def _capacity(self):
+        mc = int(self.model.mean_count)
+        if mc <= 0:
+            return None
+        return ((mc + 128 + self.quantum - 1) // self.quantum) * self.quantum
+
+    def _iteration_front(self):
+        """zero_grad -> render -> loss -> scaled backward, with the model's bookkeeping pinned for capture"""
+        m = self.model
+        saved_counter, saved_mc, saved_ls = m._buffers['step_counter'], m.mean_count, m.local_step
+        m._buffers['step_counter'] = self.counter
+        m.mean_count = self.captured_capacity - 128  # march_rays_train sizes its buffers as mean_count + 128 (raymarching.py:200-203)
+        m.local_step = 0
+        try:
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=self.autocast_dtype):
+                out = m.render(self.rays_o, self.rays_d, **self.render_kwargs)
+                loss = self.loss_fn(out, self.target)
+            self.scaler.scale(loss).backward()
+        finally:
+            m._buffers['step_counter'], m.mean_count, m.local_step = saved_counter, saved_mc, saved_ls
+        return loss
+
+    def _iteration_back(self):
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+
+    def _capture(self):
+        # No warm-up iterations here: they would be real optimizer steps.  Everything lazily created (optimizer state,
+        # GradScaler scale tensor, LDS-size attributes, device properties) exists already because capture only starts once
+        # `mean_count > 0`, i.e. after >= 16 eager iterations.  Capturing does not execute: the first replay is the step.
+        import gc
+        self.graphs = None
+        self.loss = None
+        gc.collect()  # drop autograd graphs of earlier eager iterations (their AccumulateGrad nodes are stream-bound)
+        torch.cuda.synchronize()
+        if self.averager is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.loss = self._iteration_front().detach()
+                self._iteration_back()
+            self.graphs = (g,)
+        else:  # the RCCL all-reduce stays eager between the two halves
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self.loss = self._iteration_front().detach()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._iteration_back()
+            self.graphs = (g1, g2)
+        self.n_captures += 1
+
+    def _eager(self, rays_o, rays_d, target):
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=self.autocast_dtype):
+            out = self.model.render(rays_o, rays_d, **self.render_kwargs)
+            loss = self.loss_fn(out, target)
+        self.scaler.scale(loss).backward()
+        if self.averager is not None:
+            self.averager.all_reduce()
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        # detached: a caller holding the loss must not keep this iteration's autograd graph (and its AccumulateGrad nodes,
+        # bound to the eager stream) alive into a later capture
+        return loss.detach()
+
+    # ------------------------------------------------------------------------------------------
+    def step(self, rays_o, rays_d, target):
+        """one training iteration on rays_o/rays_d [1,N,3], target [N,3]; returns the (device) loss of this step"""
+        m = self.model
+        if self.global_step % self.update_interval == 0:
+            with torch.autocast('cuda', dtype=self.autocast_dtype):
+                m.update_extra_state()
+            if self.after_update is not None:
+                self.after_update(m)
+        cap = self._capacity()
+        self.capacity = cap
+        if cap is None:
+            loss = self._eager(rays_o, rays_d, target)
+            self.global_step += 1
+            return loss
+        if self.graphs is None or cap != self.captured_capacity:
+            self.captured_capacity = cap
+            self._capture()
+        self.rays_o.copy_(rays_o.view_as(self.rays_o), non_blocking=True)
+        self.rays_d.copy_(rays_d.view_as(self.rays_d), non_blocking=True)
+        self.target.copy_(target, non_blocking=True)
+        self.graphs[0].replay()
+        if len(self.graphs) == 2:
+            self.averager.all_reduce()
+            self.graphs[1].replay()
+        # hand the sample count to the model's 16-slot ring exactly where the eager renderer would have put it
+        m.step_counter[m.local_step % 16].copy_(self.counter[0], non_blocking=True)
+        m.local_step += 1
+        self.global_step += 1
+        return self.loss

@@ -291,34 +291,58 @@ __device__ void build_backward_image(half8_t* img, const half_t* __restrict__ w,
     }
 }
 
-// per-wave LDS staging for the weight-gradient operands: matrices are stored TRANSPOSED, [feature][sample],
-// 32 samples (64 B) per row padded to 80 B so that the two lane halves hit disjoint banks.
-constexpr int STG_ROW = 40;                       // halves per row
-constexpr int STG_ROWS_A = 64;                    // dZ / dY rows (<= WIDTH)
-constexpr int STG_ROWS_B = 64;                    // activation / input rows
-constexpr int STG_HALVES = (STG_ROWS_A + STG_ROWS_B) * STG_ROW;
+// ------------------------------------------------------------------------------------------------
+// Transposition on the matrix core.
+// The weight gradient dW[o,i] = sum_s dZ[s,o] * X[s,i] contracts over SAMPLES, so both MFMA operands need "8 consecutive
+// samples of one feature per lane", the transpose of what a lane holds after the dgrad chain (lane = sample, 8 features).
+// Instead of a round trip through LDS (8 two-byte ds_writes per fragment + fences) the fragment is multiplied by a 0/1
+// selector matrix: used as the A operand, a fragment reads as [row = sample, k slot = feature]; with B[k slot, n] = 1 iff
+// slot k holds feature n of the wanted 32-feature block, D[sample, feature] comes out in the C/D layout -- lane = feature,
+// registers = samples -- which, packed to fp16 (exact: the products are x*1 and the sums have one non-zero term), IS the
+// operand layout of the weight-gradient MFMA.  As in the forward pass the numbering of the k slots (here: samples) is free
+// as long as both operands agree: slot (g, h, j) of 16-sample group g := sample 16g + 8(j>>2) + 4h + (j&3) = accumulator
+// register 8g + j.  Two selector fragments per slot order serve all blocks.
+// ------------------------------------------------------------------------------------------------
+struct Selectors {
+    half8_t hid[2];  // slot order of hidden operands (slot_feature): k block 2*ib + e -> features 32*ib + 16*e + ...
+    half8_t nat[2];  // natural order (input features, 16*kb + 8*h + j)
+    half8_t out;     // output gradient: features 8*h + j, 16 real columns
+};
 
-// write this lane's operand fragment (8 values of sample n) transposed into the stage
-__device__ __forceinline__ void stage_put(half_t* stg, int feat_of_j0, int n, half8_t v, bool hidden_order, int h) {
-    // hidden_order: values j=0..3 are features f0..f0+3, j=4..7 are f0+8..f0+11 (slot_feature order);
-    // natural order: features f0..f0+7
+__device__ __forceinline__ Selectors make_selectors(int n, int h) {
+    Selectors s;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int f = hidden_order ? feat_of_j0 + 8 * (j >> 2) + (j & 3) : feat_of_j0 + j;
-        stg[f * STG_ROW + n] = v[j];
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const bool hid = ((n >> 4) == e) && (((n >> 2) & 1) == h) && (j == ((n >> 3) & 1) * 4 + (n & 3));
+            const bool nat = ((n >> 4) == e) && (((n >> 3) & 1) == h) && (j == (n & 7));
+            s.hid[e][j] = hid ? (half_t)1.0f : (half_t)0.0f;
+            s.nat[e][j] = nat ? (half_t)1.0f : (half_t)0.0f;
+        }
+#pragma unroll
+    for (int j = 0; j < 8; j++) s.out[j] = ((n < 16) && ((n >> 3) == h) && (j == (n & 7))) ? (half_t)1.0f : (half_t)0.0f;
+    return s;
+}
+
+// pack a transposed 32x32 block (fp32, exact fp16 values) into the two 16-sample operand fragments
+__device__ __forceinline__ void pack_transposed(const float16_t& t, half8_t (&frag)[2]) {
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) frag[g][j] = (half_t)t[8 * g + j];
+}
+
+// transpose the NKB fragments of a 32-sample x WIDTH-feature operand (hidden slot order) into NIB blocks x 2 sample groups
+template <int WIDTH>
+__device__ __forceinline__ void transpose_hidden(const half8_t (&v)[Shape<WIDTH>::NKB], const Selectors& sel,
+                                                 half8_t (&out)[Shape<WIDTH>::NIB][2]) {
+#pragma unroll
+    for (int ib = 0; ib < Shape<WIDTH>::NIB; ib++) {
+        float16_t t = mfma(v[2 * ib], sel.hid[0], zero16());
+        t = mfma(v[2 * ib + 1], sel.hid[1], t);
+        pack_transposed(t, out[ib]);
     }
-    (void)h;
-}
-
-// read an MFMA operand fragment for the weight-gradient product: 8 consecutive samples of one feature row
-__device__ __forceinline__ half8_t stage_get(const half_t* stg, int feat, int kb, int h) {
-    return *reinterpret_cast<const half8_t*>(stg + feat * STG_ROW + 16 * kb + 8 * h);
-}
-
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Number of fp32 words of one weight-gradient slab = number of parameters.
@@ -339,10 +363,8 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
     build_backward_image<WIDTH>(img, weights, in_dim, num_layers, with_dx);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = lane & 31, h = lane >> 5;
-    half_t* stgA = reinterpret_cast<half_t*>(img + (size_t)nfrag * 64) + (size_t)wid * STG_HALVES;
-    half_t* stgB = stgA + STG_ROWS_A * STG_ROW;
-    // rows 16..31 of the dY stage stay zero for the whole kernel (the output block has 16 real rows)
-    for (int i = lane; i < 16 * STG_ROW; i += 64) stgA[16 * STG_ROW + i] = (half_t)0.0f;
+    (void)nfrag;
+    const Selectors sel = make_selectors(n, h);
     __syncthreads();
 
     const uint32_t in_kb = in_dim / 16;
@@ -377,17 +399,16 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
         half8_t a_prev[NKB];  // post-activations of the layer below the one being differentiated
 #pragma unroll
         for (int kb = 0; kb < NKB; kb++) a_prev[kb] = fb[(num_layers - 1) * layer_stride + tile_frag + kb * 64];
-        wave_lds_fence();
-        stage_put(stgA, 8 * h, n, dy, false, h);
+        half8_t aT[NIB][2], zT[NIB][2];
+        transpose_hidden<WIDTH>(a_prev, sel, aT);
+        {
+            // dW_out [16(+16 zero) x WIDTH] += dY^T . A_{L-1}
+            half8_t yT[2];
+            pack_transposed(mfma(dy, sel.out, zero16()), yT);
 #pragma unroll
-        for (int kb = 0; kb < NKB; kb++) stage_put(stgB, 16 * kb + 4 * h, n, a_prev[kb], true, h);
-        wave_lds_fence();
-        // dW_out [16(+16 zero) x WIDTH] += dY^T . A_{L-1}
+            for (int g = 0; g < 2; g++)
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++) {
-            const half8_t a = stage_get(stgA, n, kb, h);
-#pragma unroll
-            for (int jb = 0; jb < NIB; jb++) gw_out[jb] = mfma(a, stage_get(stgB, 32 * jb + n, kb, h), gw_out[jb]);
+                for (int jb = 0; jb < NIB; jb++) gw_out[jb] = mfma(yT[g], aT[jb][g], gw_out[jb]);
         }
         // dH_{L-1}^T = W_out^T . dY^T   (K = 16: one k block)
         float16_t acc[NIB];
@@ -407,23 +428,15 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
             const uint32_t lay = num_layers - 1 - li;  // dz = dL/d(pre-activation of hidden layer `lay`)
 #pragma unroll
             for (int kb = 0; kb < NKB; kb++) a_prev[kb] = fb[(lay - 1) * layer_stride + tile_frag + kb * 64];
-            wave_lds_fence();
-#pragma unroll
-            for (int kb = 0; kb < NKB; kb++) {
-                stage_put(stgA, 16 * kb + 4 * h, n, dz[kb], true, h);
-                stage_put(stgB, 16 * kb + 4 * h, n, a_prev[kb], true, h);
-            }
-            wave_lds_fence();
+            transpose_hidden<WIDTH>(dz, sel, zT);
+            transpose_hidden<WIDTH>(a_prev, sel, aT);
             // dW_lay [WIDTH x WIDTH] += dZ_lay^T . A_{lay-1}
 #pragma unroll
-            for (int kb = 0; kb < 2; kb++)
+            for (int g = 0; g < 2; g++)
 #pragma unroll
-                for (int ib = 0; ib < NIB; ib++) {
-                    const half8_t a = stage_get(stgA, 32 * ib + n, kb, h);
+                for (int ib = 0; ib < NIB; ib++)
 #pragma unroll
-                    for (int jb = 0; jb < NIB; jb++)
-                        gw_hid[li][ib][jb] = mfma(a, stage_get(stgB, 32 * jb + n, kb, h), gw_hid[li][ib][jb]);
-                }
+                    for (int jb = 0; jb < NIB; jb++) gw_hid[li][ib][jb] = mfma(zT[ib][g], aT[jb][g], gw_hid[li][ib][jb]);
             // dH_{lay-1}^T = W_lay^T . dZ_lay^T
             const half8_t* wl = img_hid + (size_t)li * NIB * NKB * 64;
 #pragma unroll
@@ -439,24 +452,26 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 dz[kb][j] = (half_t)(acc[kb >> 1][(kb & 1) * 8 + j] * act_backward_factor(act, (float)a_prev[kb][j]));
-        wave_lds_fence();
-#pragma unroll
-        for (int kb = 0; kb < NKB; kb++) stage_put(stgA, 16 * kb + 4 * h, n, dz[kb], true, h);
+        transpose_hidden<WIDTH>(dz, sel, zT);
         {
+            // X^T blocks of 32 input features (natural feature order), dW_in [WIDTH x in] += dZ_0^T . X
             const size_t srow = (size_t)tile * FF_TILE + n;
-            for (uint32_t kb = 0; kb < in_kb; kb++)
-                stage_put(stgB, 16 * kb + 8 * h, n, load_features8(inputs, in_planar, rows, srow, in_dim, 16 * kb + 8 * h), false, h);
-        }
-        wave_lds_fence();
-        // dW_in [WIDTH x in] += dZ_0^T . X
 #pragma unroll
-        for (int kb = 0; kb < 2; kb++)
+            for (int jb = 0; jb < IN_JB; jb++) {
+                float16_t t = zero16();
 #pragma unroll
-            for (int ib = 0; ib < NIB; ib++) {
-                const half8_t a = stage_get(stgA, 32 * ib + n, kb, h);
+                for (int e = 0; e < 2; e++) {
+                    const uint32_t kb = 2 * jb + e;
+                    if (kb < in_kb) t = mfma(load_features8(inputs, in_planar, rows, srow, in_dim, 16 * kb + 8 * h), sel.nat[e], t);
+                }
+                half8_t xT[2];
+                pack_transposed(t, xT);
 #pragma unroll
-                for (int jb = 0; jb < IN_JB; jb++) gw_in[ib][jb] = mfma(a, stage_get(stgB, 32 * jb + n, kb, h), gw_in[ib][jb]);
+                for (int g = 0; g < 2; g++)
+#pragma unroll
+                    for (int ib = 0; ib < NIB; ib++) gw_in[ib][jb] = mfma(zT[ib][g], xT[g], gw_in[ib][jb]);
             }
+        }
         if (with_dx) {
             // dX^T [in x samples] = W_in^T . dZ_0^T ; rows beyond in_dim are zero weights and are not stored
 #pragma unroll
@@ -616,7 +631,7 @@ static int launch_backward(const void* grad, const void* inputs, const void* wei
     const uint32_t n_tiles = B / FF_TILE;
     const uint32_t nfrag = NIB + (num_layers - 1) * NIB * NKB + (with_dx ? ((in_dim + 31) / 32) * NKB : 0);
     const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
-    size_t lds = (size_t)nfrag * 1024 + (size_t)FF_WAVES * STG_HALVES * sizeof(half_t);
+    size_t lds = (size_t)nfrag * 1024;
     if (lds < (size_t)n_params * 4) lds = (size_t)n_params * 4;
     NGP_REQUIRE(lds <= 160 * 1024, NGP_ERR_INVALID, "ffmlp_backward: LDS need (%zu B) exceeds 160 KiB", lds);
     auto kern = k_ffmlp_backward<WIDTH, IN_JB, NHM>;

@@ -345,17 +345,96 @@ __device__ __forceinline__ void transpose_hidden(const half8_t (&v)[Shape<WIDTH>
     }
 }
 
+// dZ = dH * act'(stored post-activation), rounded to fp16.  The activation id is wave-uniform: branch once, not per element
+// (ReLU, the only hidden activation FFMLP can select -- ffmlp.py:107 -- is a compare + select).
+__device__ __noinline__ float act_backward_factor_slow(uint32_t a, float y) { return act_backward_factor(a, y); }
+
+template <int WIDTH, bool RELU>
+__device__ __forceinline__ void activation_transfer(uint32_t act, const float16_t (&acc)[Shape<WIDTH>::NIB],
+                                                    const half8_t (&post)[Shape<WIDTH>::NKB], half8_t (&dz)[Shape<WIDTH>::NKB]) {
+    if (RELU) {
+#pragma unroll
+        for (int kb = 0; kb < Shape<WIDTH>::NKB; kb++)
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                dz[kb][j] = (float)post[kb][j] > 0.0f ? (half_t)acc[kb >> 1][(kb & 1) * 8 + j] : (half_t)0.0f;
+    } else {
+#pragma unroll
+        for (int kb = 0; kb < Shape<WIDTH>::NKB; kb++)
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                dz[kb][j] = (half_t)(acc[kb >> 1][(kb & 1) * 8 + j] * act_backward_factor_slow(act, (float)post[kb][j]));
+    }
+}
+
 // Number of fp32 words of one weight-gradient slab = number of parameters.
 __host__ __device__ inline uint32_t ff_param_count(uint32_t in_dim, uint32_t hidden, uint32_t num_layers) {
     return hidden * (in_dim + hidden * (num_layers - 1) + 16);
 }
 
-template <int WIDTH, int IN_JB /* ceil(in_dim/32) */, int NHM /* hidden matmuls = num_layers-1 */>
+// ------------------------------------------------------------------------------------------------
+// Asynchronous tile prefetch (global -> LDS DMA, no VGPR round trip).
+// The backward kernel keeps every weight-gradient accumulator in registers (128-192 fp32 registers), which leaves one
+// wavefront per SIMD: nothing hides the HBM latency of a tile's operands (dY, the stored activations of every layer, X).
+// Each wave therefore owns two LDS tile buffers and streams the NEXT tile into the idle one with global_load_lds_dwordx4
+// (16 bytes per lane, landing lane-linear, which is exactly the fragment order the data is consumed in) while it computes on
+// the current one.  Order per iteration: wait vmcnt(0) (current tile has landed) -> issue the next tile's loads -> compute.
+// Every lane reads back only bytes it requested itself, so no cross-lane synchronisation is needed.
+// Buffer layout in 1 KiB fragments: [0] dY | [1 + l*NKB + kb] post-activations of hidden layer l | then X (in_kb fragments;
+// planar inputs arrive as four 4-byte rows per fragment).
+// ------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(1))) void* gmem_ptr_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(const void* src_lane, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gmem_ptr_t)src_lane, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* src_lane, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gmem_ptr_t)src_lane, (lds_ptr_t)lds_wave_base, 4, 0, 0);
+}
+
+template <int WIDTH>
+__device__ __forceinline__ void prefetch_tile(unsigned char* buf, uint32_t tile, const half_t* __restrict__ grad, const half8_t* __restrict__ fb,
+                                              const half_t* __restrict__ inputs, uint32_t num_layers, size_t layer_stride, size_t rows,
+                                              uint32_t in_dim, bool in_planar, int lane, int n, int h) {
+    constexpr int NKB = Shape<WIDTH>::NKB;
+    const size_t srow = (size_t)tile * FF_TILE + n;
+    dma16(grad + srow * 16 + 8 * h, buf);
+    const half8_t* frag = fb + (size_t)tile * NKB * 64 + lane;
+    for (uint32_t l = 0; l < num_layers; l++)
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) dma16(frag + l * layer_stride + kb * 64, buf + (size_t)(1 + l * NKB + kb) * 1024);
+    unsigned char* xb = buf + (size_t)(1 + num_layers * NKB) * 1024;
+    const uint32_t in_kb = in_dim / 16;
+    if (!in_planar) {
+        for (uint32_t kb = 0; kb < in_kb; kb++) dma16(inputs + srow * in_dim + 16 * kb + 8 * h, xb + (size_t)kb * 1024);
+    } else {
+        for (uint32_t kb = 0; kb < in_kb; kb++)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                dma4(inputs + ((size_t)((16 * kb + 8 * h) / 2 + q) * rows + srow) * 2, xb + (size_t)kb * 1024 + q * 256);
+    }
+}
+
+// X fragment kb of this lane from the tile buffer (see layout above)
+__device__ __forceinline__ half8_t tile_x(const unsigned char* xb, uint32_t kb, bool in_planar, int lane) {
+    if (!in_planar) return *reinterpret_cast<const half8_t*>(xb + (size_t)kb * 1024 + lane * 16);
+    half8_t v;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const half2_t t = *reinterpret_cast<const half2_t*>(xb + (size_t)kb * 1024 + q * 256 + lane * 4);
+        v[2 * q] = t.x;
+        v[2 * q + 1] = t.y;
+    }
+    return v;
+}
+
+template <int WIDTH, int IN_JB /* ceil(in_dim/32) */, int NHM /* hidden matmuls = num_layers-1 */, bool RELU /* hidden activation is ReLU */>
 __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __restrict__ grad, const half_t* __restrict__ inputs,
                                                                const half_t* __restrict__ weights, const half_t* __restrict__ forward_buffer,
                                                                uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
                                                                bool with_dx, half_t* __restrict__ grad_inputs, float* __restrict__ slabs,
-                                                               half_t* __restrict__ grad_weights_direct, bool in_planar, bool dx_planar) {
+                                                               half_t* __restrict__ grad_weights_direct, bool in_planar, bool dx_planar, uint32_t pf_depth) {
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img = reinterpret_cast<half8_t*>(smem);
@@ -392,13 +471,30 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
 #pragma unroll
             for (int jb = 0; jb < NIB; jb++) gw_hid[l][ib][jb] = zero16();
 
-    for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += gridDim.x * FF_WAVES) {
-        const size_t tile_frag = (size_t)tile * NKB * 64 + lane;
+    // per-wave tile buffers behind the weight image
+    const uint32_t tile_frags = 1 + num_layers * NKB + in_dim / 16;
+    unsigned char* pf_base = smem + (size_t)nfrag * 1024 + (size_t)wid * pf_depth * tile_frags * 1024;
+    const uint32_t tile_step = gridDim.x * FF_WAVES;
+    uint32_t cur = 0;
+    {
+        const uint32_t first = blockIdx.x * FF_WAVES + wid;
+        if (first < n_tiles) prefetch_tile<WIDTH>(pf_base, first, grad, fb, inputs, num_layers, layer_stride, rows, in_dim, in_planar, lane, n, h);
+    }
+    for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += tile_step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's operands have landed in buffer `cur`
+        const unsigned char* tb = pf_base + (size_t)cur * tile_frags * 1024;
+        if (pf_depth > 1) {
+            cur ^= 1u;
+            if (tile + tile_step < n_tiles)
+                prefetch_tile<WIDTH>(pf_base + (size_t)cur * tile_frags * 1024, tile + tile_step, grad, fb, inputs, num_layers, layer_stride,
+                                     rows, in_dim, in_planar, lane, n, h);
+        }
+        const half8_t* tfrag = reinterpret_cast<const half8_t*>(tb) + lane;
         // ---- output layer -------------------------------------------------------------------
-        const half8_t dy = *reinterpret_cast<const half8_t*>(grad + ((size_t)tile * FF_TILE + n) * 16 + 8 * h);
+        const half8_t dy = tfrag[0];
         half8_t a_prev[NKB];  // post-activations of the layer below the one being differentiated
 #pragma unroll
-        for (int kb = 0; kb < NKB; kb++) a_prev[kb] = fb[(num_layers - 1) * layer_stride + tile_frag + kb * 64];
+        for (int kb = 0; kb < NKB; kb++) a_prev[kb] = tfrag[(1 + (num_layers - 1) * NKB + kb) * 64];
         half8_t aT[NIB][2], zT[NIB][2];
         transpose_hidden<WIDTH>(a_prev, sel, aT);
         {
@@ -420,14 +516,10 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
 #pragma unroll
         for (int li = 0; li < NHM; li++) {  // li-th hidden matmul from the top: layer index num_layers-1-li
             // activation transfer with the stored post-activations, round to fp16
-#pragma unroll
-            for (int kb = 0; kb < NKB; kb++)
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    dz[kb][j] = (half_t)(acc[kb >> 1][(kb & 1) * 8 + j] * act_backward_factor(act, (float)a_prev[kb][j]));
+            activation_transfer<WIDTH, RELU>(act, acc, a_prev, dz);
             const uint32_t lay = num_layers - 1 - li;  // dz = dL/d(pre-activation of hidden layer `lay`)
 #pragma unroll
-            for (int kb = 0; kb < NKB; kb++) a_prev[kb] = fb[(lay - 1) * layer_stride + tile_frag + kb * 64];
+            for (int kb = 0; kb < NKB; kb++) a_prev[kb] = tfrag[(1 + (lay - 1) * NKB + kb) * 64];
             transpose_hidden<WIDTH>(dz, sel, zT);
             transpose_hidden<WIDTH>(a_prev, sel, aT);
             // dW_lay [WIDTH x WIDTH] += dZ_lay^T . A_{lay-1}
@@ -447,22 +539,17 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
             }
         }
         // ---- input layer --------------------------------------------------------------------
-#pragma unroll
-        for (int kb = 0; kb < NKB; kb++)
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                dz[kb][j] = (half_t)(acc[kb >> 1][(kb & 1) * 8 + j] * act_backward_factor(act, (float)a_prev[kb][j]));
+        activation_transfer<WIDTH, RELU>(act, acc, a_prev, dz);
         transpose_hidden<WIDTH>(dz, sel, zT);
         {
             // X^T blocks of 32 input features (natural feature order), dW_in [WIDTH x in] += dZ_0^T . X
-            const size_t srow = (size_t)tile * FF_TILE + n;
 #pragma unroll
             for (int jb = 0; jb < IN_JB; jb++) {
                 float16_t t = zero16();
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
                     const uint32_t kb = 2 * jb + e;
-                    if (kb < in_kb) t = mfma(load_features8(inputs, in_planar, rows, srow, in_dim, 16 * kb + 8 * h), sel.nat[e], t);
+                    if (kb < in_kb) t = mfma(tile_x(tb + (size_t)(1 + num_layers * NKB) * 1024, kb, in_planar, lane), sel.nat[e], t);
                 }
                 half8_t xT[2];
                 pack_transposed(t, xT);
@@ -622,8 +709,8 @@ static int launch_forward(const void* inputs, const void* weights, uint32_t B, u
     return check_launch(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
 }
 
-template <int WIDTH, int IN_JB, int NHM>
-static int launch_backward(const void* grad, const void* inputs, const void* weights, const void* fwd, uint32_t B, uint32_t in_dim,
+template <int WIDTH, int IN_JB, int NHM, bool RELU>
+static int launch_backward_t(const void* grad, const void* inputs, const void* weights, const void* fwd, uint32_t B, uint32_t in_dim,
                            uint32_t num_layers, uint32_t act, bool with_dx, void* backward_buffer, void* grad_inputs,
                            void* grad_weights, uint32_t flags, hipStream_t st) {
     const bool in_planar = (flags & NGP_FF_INPUT_PLANAR) != 0, dx_planar = (flags & NGP_FF_DX_PLANAR) != 0;
@@ -631,10 +718,14 @@ static int launch_backward(const void* grad, const void* inputs, const void* wei
     const uint32_t n_tiles = B / FF_TILE;
     const uint32_t nfrag = NIB + (num_layers - 1) * NIB * NKB + (with_dx ? ((in_dim + 31) / 32) * NKB : 0);
     const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
-    size_t lds = (size_t)nfrag * 1024;
+    // weight image + per-wave tile buffers (double-buffered when both fit the 160 KiB LDS of a CU)
+    const size_t tile_bytes = (size_t)(1 + num_layers * NKB + in_dim / 16) * 1024;
+    uint32_t pf_depth = 2;
+    if ((size_t)nfrag * 1024 + 2 * FF_WAVES * tile_bytes > 160 * 1024) pf_depth = 1;
+    size_t lds = (size_t)nfrag * 1024 + (size_t)pf_depth * FF_WAVES * tile_bytes;
     if (lds < (size_t)n_params * 4) lds = (size_t)n_params * 4;
     NGP_REQUIRE(lds <= 160 * 1024, NGP_ERR_INVALID, "ffmlp_backward: LDS need (%zu B) exceeds 160 KiB", lds);
-    auto kern = k_ffmlp_backward<WIDTH, IN_JB, NHM>;
+    auto kern = k_ffmlp_backward<WIDTH, IN_JB, NHM, RELU>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp_backward: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
@@ -649,17 +740,28 @@ static int launch_backward(const void* grad, const void* inputs, const void* wei
     if (blocks <= 1) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
                            (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)nullptr,
-                           (half_t*)grad_weights, in_planar, dx_planar);
+                           (half_t*)grad_weights, in_planar, dx_planar, pf_depth);
         return check_launch("ffmlp_backward");
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
                        (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)backward_buffer,
-                       (half_t*)nullptr, in_planar, dx_planar);
+                       (half_t*)nullptr, in_planar, dx_planar, pf_depth);
     int rc = check_launch("ffmlp_backward");
     if (rc) return rc;
     hipLaunchKernelGGL(k_ffmlp_reduce_slabs, dim3(cdiv(n_params, RS_PARAMS)), dim3(RS_PARAMS * RS_GROUPS), 0, st, (const float*)backward_buffer, blocks, n_params,
                        (half_t*)grad_weights);
     return check_launch("ffmlp_backward(reduce)");
+}
+
+template <int WIDTH, int IN_JB, int NHM>
+static int launch_backward(const void* grad, const void* inputs, const void* weights, const void* fwd, uint32_t B, uint32_t in_dim,
+                           uint32_t num_layers, uint32_t act, bool with_dx, void* backward_buffer, void* grad_inputs,
+                           void* grad_weights, uint32_t flags, hipStream_t st) {
+    if (act == ACT_RELU)
+        return launch_backward_t<WIDTH, IN_JB, NHM, true>(grad, inputs, weights, fwd, B, in_dim, num_layers, act, with_dx, backward_buffer,
+                                                          grad_inputs, grad_weights, flags, st);
+    return launch_backward_t<WIDTH, IN_JB, NHM, false>(grad, inputs, weights, fwd, B, in_dim, num_layers, act, with_dx, backward_buffer,
+                                                       grad_inputs, grad_weights, flags, st);
 }
 
 }  // namespace ngp

@@ -129,6 +129,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying HIP graphs')
     ap.add_argument('--no-fused', action='store_true', help='module-by-module network path (reference-style glue) instead of fused.py')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-render', action='store_true', help='skip the 800x800 inference-frame timing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     args = ap.parse_args()
@@ -255,6 +256,31 @@ def main():
         timers.enabled = False
         roofs = timers.summary(load_pmc_traffic())
 
+    render = None
+    if rank == 0 and not args.no_render:
+        # second half of BASELINE.json's metric: wall time of one 800x800 inference frame through NeRFRenderer.run_cuda's eval branch
+        # (renderer.py:322-367), same scene, same (randomly initialised) network.  Two bracketing cases: the random-init density
+        # (~1 everywhere: no ray terminates early, every one of the ~43 M samples is evaluated) and the same network with
+        # density_scale = 300 (opaque surfaces: rays saturate after a few samples, as in a trained scene).
+        model.eval()
+        o, d = sc.full_image_rays(seed=0)
+        ro, rd = torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev)
+        rkw = dict(staged=True, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+        render = {'unit': 'ms per 800x800 frame (640000 rays), 1 GPU'}
+        for name, scale in (('transparent_random_init', 1.0), ('opaque_density_scale_300', 300.0)):
+            model.density_scale = scale
+            ts = []
+            for f in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+                    model.render(ro, rd, **rkw)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            render[name] = round(min(ts[1:]), 2)
+        model.density_scale = 1
+        model.train()
+
     if rank == 0:
         roof = None
         for r in roofs:
@@ -283,7 +309,7 @@ def main():
                        'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}',
                        'execution': 'eager' if args.no_graph else f'hip-graph replay ({stepper.n_captures} capture(s))',
                        'fused_pipeline': bool(model.fused), 'final_loss': final_loss},
-            'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu,
+            'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'render_800x800_ms': render,
         }
         print(json.dumps(line))
     if world > 1:

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the hot-path kernels from rocprofv3 PMC passes (run on the GPU box, one pass per counter group, as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass, and no tracing domains are
+combined with --pmc):
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-roofline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-roofline
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/rNN_pmc_traffic.json
+
+Units and corrections (guide, section HBM): the counters are in KiB-like units (bytes = value * 1024); on gfx950 FETCH_SIZE reports
+exactly half of the bytes of a wide (16 B per lane) coalesced streaming read, so the read side of the streaming kernels (ffmlp,
+composite) is doubled; the 4-byte gather/scatter kernels of the grid encoder are reported raw (uncalibrated width) and flagged.
+bench.py reads the newest profiles/*_pmc_traffic.json to fill `roofline.traffic`."""
+import collections, csv, glob, json, os, sys
+
+KERNELS = {  # substring of the kernel name -> (label used by bench.py, read-side correction factor)
+    'k_grid_backward': ('grid_encode_backward', 1.0),
+    'k_grid_forward_pair': ('grid_encode_forward', 1.0),
+    'k_ffmlp_forward': ('ffmlp_forward', 2.0),
+    'k_ffmlp_backward': ('ffmlp_backward', 2.0),
+    'k_march_train_wave': ('march_rays_train', 1.0),
+    'k_composite_train_fwd': ('composite_rays_train_forward', 2.0),
+    'k_composite_train_bwd': ('composite_rays_train_backward', 2.0),
+}
+
+
+def per_kernel(directory, counter):
+    f = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)[0]
+    vals = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] != counter:
+            continue
+        for key, (label, _) in KERNELS.items():
+            if key in r['Kernel_Name']:
+                vals[label].append((int(r['Grid_Size']), float(r['Counter_Value'])))
+    out = {}
+    for label, lst in vals.items():
+        sizes = collections.Counter(g for g, _ in lst)
+        mode = sizes.most_common(1)[0][0]  # the training-step launches (update_extra_state uses other sizes)
+        sel = [v for g, v in lst if g == mode]
+        out[label] = (sum(sel) / len(sel), len(sel))
+    return out
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
+    write = per_kernel(sys.argv[2], 'WRITE_SIZE')
+    factor = {label: f for _, (label, f) in KERNELS.items()}
+    per_launch, detail = {}, {}
+    for label in sorted(set(fetch) | set(write)):
+        rd = fetch.get(label, (0.0, 0))[0] * 1024.0
+        wr = write.get(label, (0.0, 0))[0] * 1024.0
+        per_launch[label] = round(rd * factor[label] + wr)
+        detail[label] = {'fetch_bytes_raw': round(rd), 'read_correction': factor[label], 'write_bytes': round(wr),
+                         'launches_averaged': fetch.get(label, (0, 0))[1],
+                         'note': 'raw FETCH_SIZE, 4-byte gather/scatter width uncalibrated' if factor[label] == 1.0 else
+                                 'FETCH_SIZE doubled (16 B/lane streaming reads are tallied at half, MI355X_MICROARCH.md HBM section)'}
+    json.dump({'per_launch': per_launch, 'detail': detail, 'unit': 'bytes of HBM traffic per kernel launch',
+               'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py --no-graph'}, sys.stdout, indent=1)
+
+
+if __name__ == '__main__':
+    main()

@@ -138,11 +138,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP extension has no CPU fallback)'
+    # functional-test hooks (not used by the driver): NGP_BENCH_SHARE_GPU=1 lets several ranks share cuda:0 and
+    # NGP_BENCH_BACKEND=gloo replaces RCCL, so the N>1 code path can be exercised on a one-GPU box
+    if os.environ.get('NGP_BENCH_SHARE_GPU') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)  # RCCL
+        backend = os.environ.get('NGP_BENCH_BACKEND', 'nccl')  # 'nccl' is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     import _ngp_capi as capi
@@ -244,6 +252,7 @@ def main():
     # with HIP-event pairs around the named kernels, on the stream they are launched on, same batches, same state.
     roofs = []
     if rank == 0 and not args.no_roofline:
+        stepper.averager = None  # rank-0 only: no collectives in this pass
         timers.enabled = True
         for k in range(min(16, max(4, args.steps))):
             rays_o, rays_d, gt = pool[(step_no + k) % n_pool]

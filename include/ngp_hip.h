@@ -223,7 +223,7 @@ int ngp_ffmlp_backward_ex(const void* grad, const void* inputs, const void* weig
 /* network_ff.py:55-72 between the two MLPs: h16 [M,16] fp16 (sigma-net output), dirs [M_valid,3] fp32 ->
  * sigma [M] fp32 = exp(h[:,0]) (trunc_exp), color_in [M,32] fp16 = [SH deg 4 | h[:,1:16] | 0]; rows >= M_valid use dir = 0 */
 int ngp_pipeline_mid_forward(const void* h16, const float* dirs, float* sigma, void* color_in, uint32_t M, uint32_t M_valid,
-                             ngp_stream_t stream);
+                             float density_scale, ngp_stream_t stream);
 /* rgb [M,3] fp32 = fp16-rounded sigmoid of the colour net's first three outputs (network_ff.py:72) */
 int ngp_pipeline_rgb_forward(const void* out16, float* rgb, uint32_t M, ngp_stream_t stream);
 /* grad_out16 [M,16] fp16: columns 0..2 = grad_rgb * y (1 - y), the rest 0 */
@@ -231,7 +231,30 @@ int ngp_pipeline_rgb_backward(const float* grad_rgb, const float* rgb, void* gra
 /* grad_h16 [M,16] fp16: column 0 = grad_sigma * exp(clamp(h0, -15, 15)) (activation.py:12-17), columns 1..15 =
  * grad_color_in[:,16:31] */
 int ngp_pipeline_mid_backward(const float* grad_sigma, const void* h16, const void* grad_color_in, void* grad_h16, uint32_t M,
-                              ngp_stream_t stream);
+                              float density_scale, ngp_stream_t stream);
+
+/* march_rays_train with two conveniences for the fused renderer: the counter may be reset in-kernel and the sample rows no ray
+ * writes are zeroed in-kernel (the reference contract keeps both with the caller: counter.zero_(), torch.zeros buffers). */
+#define NGP_MARCH_RESET_COUNTER 1u
+#define NGP_MARCH_ZERO_TAIL 2u
+int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                            uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                            const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                            const float* noises, void* workspace, uint32_t flags, ngp_stream_t stream);
+
+/* composite_rays_train with NeRFRenderer.run_cuda's epilogue fused (renderer.py:316-318):
+ *   image_out = image + (1 - weights_sum) * bg,  depth_out = clamp(depth - nears, 0) / (fars - nears)
+ * bg_mode 0: off (= the reference op), 1: scalar background bg_scalar, 2: per-ray background bg [N,3].
+ * The backward takes the gradient of image_out (and optionally of weights_sum, may be NULL when bg_mode != 0). */
+int ngp_composite_rays_train_forward_ex(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                        uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth, float* image,
+                                        int bg_mode, float bg_scalar, const float* bg, const float* nears, const float* fars,
+                                        float* image_out, float* depth_out, ngp_stream_t stream);
+int ngp_composite_rays_train_backward_ex(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                         const float* rgbs, const float* deltas, const int32_t* rays,
+                                         const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                         float T_thresh, float* grad_sigmas, float* grad_rgbs, int bg_mode, float bg_scalar,
+                                         const float* bg, ngp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -132,3 +132,40 @@ def test_fused_pipeline_equals_module_path():
         s2, r2 = model(x, d)
     np.testing.assert_array_equal(s2.float().cpu().numpy(), res[True][0])
     np.testing.assert_array_equal(r2.float().cpu().numpy(), res[True][1])
+
+
+@pytest.mark.parametrize('bg_kind', ['scalar', 'tensor'])
+def test_fused_training_render_equals_module_path(bg_kind):
+    """NeRFRenderer.run_cuda's training branch as one fused Function (fused.py: march with in-kernel counter reset / tail zeroing,
+    sample pipeline, composite + epilogue) vs the module-by-module branch: identical ray table and counter (bit-exact), same
+    image / depth / weights_sum and parameter gradients to fp16 rounding"""
+    model, orc, bits, dev = _setup()
+    n_rays = 1024
+    o, d, gt = sc.training_batch(n_rays, seed=9)
+    ro, rd = torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev)
+    gtt = torch.from_numpy(gt).to(dev)
+    bg = 1 if bg_kind == 'scalar' else torch.rand(n_rays, 3, device=dev)
+    model.train()
+    model.mean_count = 60000          # < the ~69k samples of this batch: the last rays do not fit and are dropped, as in the reference
+    res = {}
+    for fused in (True, False):
+        model.fused = fused
+        model.local_step = 3
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.float16):
+            assert model._fused_render_ok(ro.view(-1, 3), rd.view(-1, 3), bg, False) == fused
+            out = model.render(ro, rd, staged=False, bg_color=bg, perturb=False, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+            loss = ((out['image'][0] - gtt) ** 2).mean() + 0.01 * out['weights_sum'].mean()
+        (loss * 65536.0).backward()
+        res[fused] = dict(image=out['image'][0].detach().float().cpu().numpy(), depth=out['depth'][0].detach().float().cpu().numpy(),
+                          ws=out['weights_sum'].detach().float().cpu().numpy(), counter=model.step_counter[3].tolist(),
+                          grads=[p.grad.float().cpu().numpy().astype(np.float64) for p in (model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights)])
+    a, b = res[True], res[False]
+    assert a['counter'] == b['counter'] and a['counter'][1] == n_rays and a['counter'][0] > 60000
+    np.testing.assert_allclose(a['ws'], b['ws'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(a['image'], b['image'], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(a['depth'], b['depth'], rtol=0, atol=2e-4)
+    assert (a['ws'] == 0).sum() == (b['ws'] == 0).sum() > 0          # the same rays were dropped / missed the scene
+    for x, y, name in zip(a['grads'], b['grads'], ('embeddings', 'sigma_net', 'color_net')):
+        rel = np.linalg.norm(x - y) / np.linalg.norm(y)
+        assert rel < 5e-3, (name, rel)

@@ -20,7 +20,8 @@ LIB_PATH = os.path.join(_HERE, 'libngp_hip.so')
 
 NGP_F32, NGP_F16 = 0, 1
 NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR = 1, 2
-ABI_VERSION = 1
+NGP_MARCH_RESET_COUNTER, NGP_MARCH_ZERO_TAIL = 1, 2
+ABI_VERSION = 2
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -58,10 +59,13 @@ _SIGNATURES = {
     'ngp_ffmlp_forward_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_inference_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_backward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp],
-    'ngp_pipeline_mid_forward': [_vp, _vp, _vp, _vp, _u32, _u32, _vp],
+    'ngp_pipeline_mid_forward': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp],
     'ngp_pipeline_rgb_forward': [_vp, _vp, _u32, _vp],
     'ngp_pipeline_rgb_backward': [_vp, _vp, _vp, _u32, _vp],
-    'ngp_pipeline_mid_backward': [_vp, _vp, _vp, _vp, _u32, _vp],
+    'ngp_pipeline_mid_backward': [_vp, _vp, _vp, _vp, _u32, _f32, _vp],
+    'ngp_march_rays_train_ex': [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    'ngp_composite_rays_train_forward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
+    'ngp_composite_rays_train_backward_ex': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _i32, _f32, _vp, _vp],
     'ngp_allocate_splitk': [_sz],
     'ngp_free_splitk': [],
 }

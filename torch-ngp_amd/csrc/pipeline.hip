@@ -16,12 +16,12 @@ constexpr int PL_THREADS = 256;
 
 __global__ __launch_bounds__(PL_THREADS) void k_mid_forward(const half_t* __restrict__ h, const float* __restrict__ dirs,
                                                             float* __restrict__ sigma, half_t* __restrict__ color_in, uint32_t M,
-                                                            uint32_t M_valid) {
+                                                            uint32_t M_valid, float density_scale) {
     const uint32_t b = blockIdx.x * PL_THREADS + threadIdx.x;
     if (b >= M) return;
     const half8_t h0 = *reinterpret_cast<const half8_t*>(h + (size_t)b * 16);
     const half8_t h1 = *reinterpret_cast<const half8_t*>(h + (size_t)b * 16 + 8);
-    sigma[b] = expf((float)h0[0]);
+    sigma[b] = density_scale * expf((float)h0[0]);  // renderer.py:296: sigmas = density_scale * sigmas
     float sh[16];
     float x = 0.0f, y = 0.0f, z = 0.0f;
     if (b < M_valid) { x = dirs[(size_t)b * 3]; y = dirs[(size_t)b * 3 + 1]; z = dirs[(size_t)b * 3 + 2]; }
@@ -75,11 +75,11 @@ __global__ __launch_bounds__(PL_THREADS) void k_rgb_backward(const float* __rest
 
 __global__ __launch_bounds__(PL_THREADS) void k_mid_backward(const float* __restrict__ grad_sigma, const half_t* __restrict__ h,
                                                              const half_t* __restrict__ grad_color_in, half_t* __restrict__ grad_h,
-                                                             uint32_t M) {
+                                                             uint32_t M, float density_scale) {
     const uint32_t b = blockIdx.x * PL_THREADS + threadIdx.x;
     if (b >= M) return;
     const float x = (float)h[(size_t)b * 16];
-    const float gs = grad_sigma[b] * expf(fminf(15.0f, fmaxf(-15.0f, x)));
+    const float gs = (density_scale * grad_sigma[b]) * expf(fminf(15.0f, fmaxf(-15.0f, x)));
     const half8_t g2 = *reinterpret_cast<const half8_t*>(grad_color_in + (size_t)b * 32 + 16);
     const half8_t g3 = *reinterpret_cast<const half8_t*>(grad_color_in + (size_t)b * 32 + 24);
     half8_t lo, hi;
@@ -99,11 +99,11 @@ __global__ __launch_bounds__(PL_THREADS) void k_mid_backward(const float* __rest
 using namespace ngp;
 
 extern "C" int ngp_pipeline_mid_forward(const void* h16, const float* dirs, float* sigma, void* color_in, uint32_t M, uint32_t M_valid,
-                                        ngp_stream_t stream) {
+                                        float density_scale, ngp_stream_t stream) {
     NGP_REQUIRE(h16 && dirs && sigma && color_in, NGP_ERR_INVALID, "pipeline_mid_forward: NULL tensor");
     if (M == 0) return NGP_OK;
     hipLaunchKernelGGL(k_mid_forward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), (const half_t*)h16, dirs, sigma,
-                       (half_t*)color_in, M, M_valid);
+                       (half_t*)color_in, M, M_valid, density_scale);
     return check_launch("pipeline_mid_forward");
 }
 
@@ -122,10 +122,10 @@ extern "C" int ngp_pipeline_rgb_backward(const float* grad_rgb, const float* rgb
 }
 
 extern "C" int ngp_pipeline_mid_backward(const float* grad_sigma, const void* h16, const void* grad_color_in, void* grad_h16, uint32_t M,
-                                         ngp_stream_t stream) {
+                                         float density_scale, ngp_stream_t stream) {
     NGP_REQUIRE(grad_sigma && h16 && grad_color_in && grad_h16, NGP_ERR_INVALID, "pipeline_mid_backward: NULL tensor");
     if (M == 0) return NGP_OK;
     hipLaunchKernelGGL(k_mid_backward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), grad_sigma, (const half_t*)h16,
-                       (const half_t*)grad_color_in, (half_t*)grad_h16, M);
+                       (const half_t*)grad_color_in, (half_t*)grad_h16, M, density_scale);
     return check_launch("pipeline_mid_backward");
 }

@@ -357,12 +357,20 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
     }
 }
 
-// exclusive scan of the per-ray sample counts in ray order -> rays[:,1]; counter[0] += total, counter[1] += N
+// exclusive scan of the per-ray sample counts in ray order -> rays[:,1]; counter[0] += total, counter[1] += N.
+// reset != 0: the counter is treated as {0, 0} first (saves the caller's memset launch).
+// ws[0] receives `fit_end`: the end of the contiguous prefix of sample rows that will actually be written -- the offset of the
+// first ray that does not fit in M rows (every later ray starts even further back, raymarching.cu:405-416), or the total.
 constexpr int SCAN_THREADS = 1024;
-__global__ __launch_bounds__(SCAN_THREADS) void k_march_train_scan(int32_t* __restrict__ rays, int32_t* __restrict__ counter, uint32_t N) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_march_train_scan(int32_t* __restrict__ rays, int32_t* __restrict__ counter, uint32_t N,
+                                                                   uint32_t M, int reset, uint32_t* __restrict__ ws) {
     __shared__ uint32_t wsum[SCAN_THREADS / 64];
+    __shared__ uint32_t first_unfit;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t running = (uint32_t)counter[0];
+    uint32_t running = reset ? 0u : (uint32_t)counter[0];
+    const int32_t rays_before = reset ? 0 : counter[1];
+    if (threadIdx.x == 0) first_unfit = 0xFFFFFFFFu;
+    __syncthreads();
     for (uint32_t tile = 0; tile < N; tile += SCAN_THREADS) {
         const uint32_t n = tile + threadIdx.x;
         const uint32_t c = n < N ? (uint32_t)rays[n * 3 + 2] : 0u;
@@ -376,13 +384,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_march_train_scan(int32_t* __re
             wbase += w < wid ? v : 0u;
             total += v;
         }
-        if (n < N) rays[n * 3 + 1] = (int32_t)(running + wbase + incl - c);
+        const uint32_t offset = running + wbase + incl - c;
+        if (n < N) {
+            rays[n * 3 + 1] = (int32_t)offset;
+            if (c != 0u && offset + c > M) atomicMin(&first_unfit, offset);
+        }
         running += total;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         counter[0] = (int32_t)running;
-        counter[1] = counter[1] + (int32_t)N;
+        counter[1] = rays_before + (int32_t)N;
+        const uint32_t fit_end = first_unfit != 0xFFFFFFFFu ? first_unfit : running;
+        ws[0] = fit_end < M ? fit_end : M;
+    }
+}
+
+// zero the sample rows [ws[0], M) that no ray writes (replaces the caller's three full-buffer memsets)
+__global__ __launch_bounds__(256) void k_march_train_zero_tail(float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+                                                               uint32_t M, const uint32_t* __restrict__ ws) {
+    const uint32_t begin = ws[0];
+    for (uint32_t r = begin + blockIdx.x * blockDim.x + threadIdx.x; r < M; r += gridDim.x * blockDim.x) {
+        xyzs[(size_t)r * 3] = 0.0f; xyzs[(size_t)r * 3 + 1] = 0.0f; xyzs[(size_t)r * 3 + 2] = 0.0f;
+        dirs[(size_t)r * 3] = 0.0f; dirs[(size_t)r * 3 + 1] = 0.0f; dirs[(size_t)r * 3 + 2] = 0.0f;
+        *reinterpret_cast<float2_t*>(deltas + (size_t)r * 2) = float2_t{0.0f, 0.0f};
     }
 }
 
@@ -445,11 +470,22 @@ __device__ __forceinline__ float wave_incl_sum(float v, int lane) {
 
 constexpr int CT_WAVES = 4;  // rays per workgroup
 
+// optional fused epilogue/prologue of the renderer (mode 0: off = the reference op; 1: scalar background; 2: per-ray [N,3])
+struct Finish {
+    int mode;
+    float bg_scalar;
+    const float* bg;
+    const float* nears;
+    const float* fars;
+    float* image_out;
+    float* depth_out;
+};
+
 __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                                        const float* __restrict__ deltas, const int32_t* __restrict__ rays,
                                                                        uint32_t M, uint32_t N, float T_thresh,
                                                                        float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                                       float* __restrict__ image) {
+                                                                       float* __restrict__ image, Finish fin) {
     const int lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * CT_WAVES + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -489,6 +525,17 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_fwd(const flo
         weights_sum[index] = ws;
         depth[index] = d;
         image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+        if (fin.mode != 0) {
+            // NeRFRenderer.run_cuda's epilogue (renderer.py:316-318): image + (1 - weights_sum) * bg ; clamp(depth - near, 0) / (far - near)
+            const float t1 = 1.0f - ws;
+            const float b0 = fin.mode == 2 ? fin.bg[index * 3] : fin.bg_scalar, b1 = fin.mode == 2 ? fin.bg[index * 3 + 1] : fin.bg_scalar,
+                        b2 = fin.mode == 2 ? fin.bg[index * 3 + 2] : fin.bg_scalar;
+            fin.image_out[index * 3] = r + t1 * b0;
+            fin.image_out[index * 3 + 1] = g + t1 * b1;
+            fin.image_out[index * 3 + 2] = b + t1 * b2;
+            const float nr = fin.nears[index], fr = fin.fars[index];
+            fin.depth_out[index] = fmaxf(d - nr, 0.0f) / (fr - nr);
+        }
     }
 }
 
@@ -497,14 +544,19 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_bwd(const flo
                                                                        const float* __restrict__ deltas, const int32_t* __restrict__ rays,
                                                                        const float* __restrict__ weights_sum, const float* __restrict__ image,
                                                                        uint32_t M, uint32_t N, float T_thresh, float* __restrict__ grad_sigmas,
-                                                                       float* __restrict__ grad_rgbs) {
+                                                                       float* __restrict__ grad_rgbs, Finish fin) {
     const int lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * CT_WAVES + (threadIdx.x >> 6);
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num = (uint32_t)rays[n * 3 + 2];
     if (num == 0 || offset + num > M) return;
     const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
-    const float gw = grad_ws[index];
+    float gw = grad_ws ? grad_ws[index] : 0.0f;
+    if (fin.mode != 0) {  // grad_image is the gradient of the FINISHED image: d/d(weights_sum) picks up -sum_c g_c * bg_c
+        const float b0 = fin.mode == 2 ? fin.bg[index * 3] : fin.bg_scalar, b1 = fin.mode == 2 ? fin.bg[index * 3 + 1] : fin.bg_scalar,
+                    b2 = fin.mode == 2 ? fin.bg[index * 3 + 2] : fin.bg_scalar;
+        gw -= gi0 * b0 + gi1 * b1 + gi2 * b2;
+    }
     const float rf = image[index * 3], gf = image[index * 3 + 1], bf = image[index * 3 + 2], wsf = weights_sum[index];
     float T = 1.0f, rc = 0.0f, gc = 0.0f, bc = 0.0f;  // carries from previous rows
     for (uint32_t s0 = 0; s0 < num; s0 += 64) {
@@ -668,17 +720,17 @@ static int check_march_args(const char* fn, uint32_t C, uint32_t H, uint32_t max
     return NGP_OK;
 }
 
-extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid_in, float bound, float dt_gamma,
-                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
-                                    const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
-                                    const float* noises, void* workspace, ngp_stream_t stream) {
+extern "C" int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid_in, float bound, float dt_gamma,
+                                       uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                       const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                       const float* noises, void* workspace, uint32_t flags, ngp_stream_t stream) {
     int rc = check_march_args("march_rays_train", C, H, max_steps);
     if (rc) return rc;
     NGP_REQUIRE(rays_o && rays_d && grid_in && nears && fars && xyzs && dirs && deltas && rays && counter && noises && workspace,
                 NGP_ERR_INVALID, "march_rays_train: NULL tensor");
     if (N == 0) return NGP_OK;
     hipStream_t st = as_stream(stream);
-    (void)workspace;  // kept in the ABI (earlier revisions staged block sums here)
+    uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
     const dim3 grid(cdiv(N, MW_WAVES)), block(MW_WAVES * 64);
     const bool const_dt = dt_gamma == 0.0f;
 #define MARCH_WAVE(WRITE, CDT)                                                                                                     \
@@ -688,35 +740,84 @@ extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, co
     if (const_dt) MARCH_WAVE(false, true); else MARCH_WAVE(false, false);
     rc = check_launch("march_rays_train(count)");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, st, rays, counter, N);
+    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, st, rays, counter, N, M, (int)((flags & NGP_MARCH_RESET_COUNTER) != 0), ws);
     rc = check_launch("march_rays_train(scan)");
     if (rc) return rc;
     if (const_dt) MARCH_WAVE(true, true); else MARCH_WAVE(true, false);
 #undef MARCH_WAVE
-    return check_launch("march_rays_train(write)");
+    rc = check_launch("march_rays_train(write)");
+    if (rc) return rc;
+    if ((flags & NGP_MARCH_ZERO_TAIL) && M > 0) {
+        // usually a few hundred padding rows: a small fixed grid, grid-stride
+        hipLaunchKernelGGL(k_march_train_zero_tail, dim3(64), dim3(256), 0, st, xyzs, dirs, deltas, M, (const uint32_t*)ws);
+        rc = check_launch("march_rays_train(zero tail)");
+    }
+    return rc;
+}
+
+extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid_in, float bound, float dt_gamma,
+                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                    const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                    const float* noises, void* workspace, ngp_stream_t stream) {
+    return ngp_march_rays_train_ex(rays_o, rays_d, grid_in, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                                   counter, noises, workspace, 0u, stream);
+}
+
+static int make_finish(const char* fn, int bg_mode, float bg_scalar, const float* bg, const float* nears, const float* fars, float* image_out,
+                       float* depth_out, bool forward, Finish* fin) {
+    NGP_REQUIRE(bg_mode >= 0 && bg_mode <= 2, NGP_ERR_INVALID, "%s: bg_mode must be 0, 1 or 2", fn);
+    NGP_REQUIRE(bg_mode != 2 || bg, NGP_ERR_INVALID, "%s: bg_mode 2 needs a per-ray background tensor", fn);
+    NGP_REQUIRE(bg_mode == 0 || !forward || (nears && fars && image_out && depth_out), NGP_ERR_INVALID, "%s: NULL finishing tensor", fn);
+    *fin = Finish{bg_mode, bg_scalar, bg, nears, fars, image_out, depth_out};
+    return NGP_OK;
+}
+
+extern "C" int ngp_composite_rays_train_forward_ex(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                                   uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth, float* image,
+                                                   int bg_mode, float bg_scalar, const float* bg, const float* nears, const float* fars,
+                                                   float* image_out, float* depth_out, ngp_stream_t stream) {
+    NGP_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, NGP_ERR_INVALID,
+                "composite_rays_train_forward: NULL tensor");
+    Finish fin;
+    int rc = make_finish("composite_rays_train_forward", bg_mode, bg_scalar, bg, nears, fars, image_out, depth_out, true, &fin);
+    if (rc) return rc;
+    if (N == 0) return NGP_OK;
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(cdiv(N, CT_WAVES)), dim3(CT_WAVES * 64), 0, as_stream(stream), sigmas, rgbs, deltas,
+                       rays, M, N, T_thresh, weights_sum, depth, image, fin);
+    return check_launch("composite_rays_train_forward");
 }
 
 extern "C" int ngp_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                                 uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth,
                                                 float* image, ngp_stream_t stream) {
-    NGP_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, NGP_ERR_INVALID,
-                "composite_rays_train_forward: NULL tensor");
+    return ngp_composite_rays_train_forward_ex(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image, 0, 0.0f, nullptr,
+                                               nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int ngp_composite_rays_train_backward_ex(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                                    const float* rgbs, const float* deltas, const int32_t* rays,
+                                                    const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                                    float T_thresh, float* grad_sigmas, float* grad_rgbs, int bg_mode, float bg_scalar,
+                                                    const float* bg, ngp_stream_t stream) {
+    NGP_REQUIRE(grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs, NGP_ERR_INVALID,
+                "composite_rays_train_backward: NULL tensor");
+    NGP_REQUIRE(grad_weights_sum || bg_mode != 0, NGP_ERR_INVALID, "composite_rays_train_backward: NULL tensor");
+    Finish fin;
+    int rc = make_finish("composite_rays_train_backward", bg_mode, bg_scalar, bg, nullptr, nullptr, nullptr, nullptr, false, &fin);
+    if (rc) return rc;
     if (N == 0) return NGP_OK;
-    hipLaunchKernelGGL(k_composite_train_fwd, dim3(cdiv(N, CT_WAVES)), dim3(CT_WAVES * 64), 0, as_stream(stream), sigmas, rgbs, deltas,
-                       rays, M, N, T_thresh, weights_sum, depth, image);
-    return check_launch("composite_rays_train_forward");
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(cdiv(N, CT_WAVES)), dim3(CT_WAVES * 64), 0, as_stream(stream), grad_weights_sum,
+                       grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, fin);
+    return check_launch("composite_rays_train_backward");
 }
 
 extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
                                                  const float* rgbs, const float* deltas, const int32_t* rays,
                                                  const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                                  float T_thresh, float* grad_sigmas, float* grad_rgbs, ngp_stream_t stream) {
-    NGP_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs,
-                NGP_ERR_INVALID, "composite_rays_train_backward: NULL tensor");
-    if (N == 0) return NGP_OK;
-    hipLaunchKernelGGL(k_composite_train_bwd, dim3(cdiv(N, CT_WAVES)), dim3(CT_WAVES * 64), 0, as_stream(stream), grad_weights_sum,
-                       grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs);
-    return check_launch("composite_rays_train_backward");
+    NGP_REQUIRE(grad_weights_sum, NGP_ERR_INVALID, "composite_rays_train_backward: NULL tensor");
+    return ngp_composite_rays_train_backward_ex(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
+                                                grad_sigmas, grad_rgbs, 0, 0.0f, nullptr, stream);
 }
 
 extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,

@@ -83,6 +83,23 @@ class NeRFRenderer(nn.Module):
         depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return image.view(*lead, 3), depth.view(*lead)
 
+    def _fused_render_ok(self, rays_o, rays_d, bg_color, force_all_rays):
+        """the fused training render needs the estimate-sized sample buffer (no host read-back), a plain colour background and a
+        network the fused sample pipeline accepts (network_ff.NeRFNetwork._fused_ok)"""
+        if not getattr(self, 'fused', False) or force_all_rays or self.mean_count <= 0 or self.bg_radius > 0:
+            return False
+        if not (rays_o.is_cuda and rays_o.dtype == torch.float32 and rays_d.dtype == torch.float32):
+            return False
+        if torch.is_tensor(bg_color) and (bg_color.numel() != rays_o.shape[0] * 3 or not bg_color.is_cuda):
+            return False
+        if not (torch.is_tensor(bg_color) or isinstance(bg_color, (int, float))):
+            return False
+        probe = getattr(self, '_fused_ok', None)
+        if probe is None:
+            return False
+        dummy = torch.empty(128, 3, device=rays_o.device)
+        return bool(probe(dummy, dummy)) and torch.is_grad_enabled()
+
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024,
                  T_thresh=1e-4, **kwargs):
         # rays_o, rays_d [B, N, 3] (B == 1) -> {'image' [B,N,3], 'depth' [B,N], ('weights_sum' when training)}
@@ -95,6 +112,19 @@ class NeRFRenderer(nn.Module):
         nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near)
         bg_color = self._background(rays_o, rays_d, bg_color)
         results = {}
+
+        if self.training and self._fused_render_ok(rays_o, rays_d, bg_color, force_all_rays):
+            # extension (fused.py): the whole training branch below as one autograd Function, identical arithmetic
+            from fused import fused_render_train
+            counter = self.step_counter[self.local_step % 16]
+            self.local_step += 1
+            capacity = self.mean_count + (128 - self.mean_count % 128)  # raymarching.py:200-203
+            image, depth, weights_sum = fused_render_train(self, rays_o, rays_d, box, counter, capacity, bg_color, perturb, dt_gamma,
+                                                           max_steps, T_thresh)
+            results['weights_sum'] = weights_sum
+            results['depth'] = depth.view(*lead)
+            results['image'] = image.view(*lead, 3)
+            return results
 
         if self.training:
             counter = self.step_counter[self.local_step % 16]

@@ -129,6 +129,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying HIP graphs')
     ap.add_argument('--no-fused', action='store_true', help='module-by-module network path (reference-style glue) instead of fused.py')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--torch-optim', action='store_true', help='torch.optim.Adam(fused) + GradScaler instead of optim.NGPAdam')
     ap.add_argument('--no-render', action='store_true', help='skip the 800x800 inference-frame timing')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
@@ -171,9 +172,17 @@ def main():
     model.iter_density = 16          # steady state: partial occupancy refreshes (renderer.py:488-514)
     model.mean_density = float(occ.clamp(min=0).mean())
 
-    optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
-    scaler = torch.amp.GradScaler('cuda')
-    averager = GradientAverager(model, world) if world > 1 else None
+    if args.torch_optim:
+        # the reference's pair (main_nerf.py:132, nerf/utils.py:393): torch Adam (fused, capturable) + GradScaler
+        optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+        scaler = torch.amp.GradScaler('cuda')
+        averager = GradientAverager(model, world) if world > 1 else None
+    else:
+        # same update rule and scale dynamics in one fused device-side step (torch-ngp_amd/optim.py)
+        from optim import NGPAdam
+        optimizer = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, world_size=world)
+        scaler = None
+        averager = optimizer if world > 1 else None
 
     # a pool of pre-generated batches resident in HBM (one camera each, 4096 random pixels)
     n_pool = 16
@@ -317,7 +326,8 @@ def main():
                        'rays_per_gpu_per_step': args.rays, 'samples_per_step_per_gpu': round(samples / args.steps / world, 1),
                        'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}',
                        'execution': 'eager' if args.no_graph else f'hip-graph replay ({stepper.n_captures} capture(s))',
-                       'fused_pipeline': bool(model.fused), 'final_loss': final_loss},
+                       'fused_pipeline': bool(model.fused), 'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
+                       'final_loss': final_loss},
             'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'render_800x800_ms': render,
         }
         print(json.dumps(line))

@@ -256,6 +256,20 @@ int ngp_composite_rays_train_backward_ex(const float* grad_weights_sum, const fl
                                          float T_thresh, float* grad_sigmas, float* grad_rgbs, int bg_mode, float bg_scalar,
                                          const float* bg, ngp_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused optimizer + loss-scaling step -- EXTENSION: replaces torch.optim.Adam + GradScaler.step/update
+ * (main_nerf.py:132, nerf/utils.py:557-560) for up to 8 tensors per call.  grads[k] holds the loss-scaled gradient, fp16 when
+ * grad_is_half[k] (the buffer grid_encode_backward / ffmlp_backward wrote) else fp32, and is ZEROED by the call; params_fp16[k]
+ * (optional, may be NULL per tensor or as a whole) receives the fp16 copy of the updated weights.
+ * state = device float[8]: {loss scale, growth tracker, found_inf, Adam step count, lr multiplier, -, -, -}; no host sync.
+ * grad_mult: extra factor on the gradients (1 / world_size after a SUM all-reduce).  A step over more than 8 tensors is several
+ * calls: pass growth_interval < 0 on all but the last (the scale / step-count commit then runs once); NOTE the non-finite check of a
+ * later call cannot undo the update of an earlier one, so put the tensors most likely to overflow (the hash table) first. */
+int ngp_optim_adam_step(int count, const uint64_t* n, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                        void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
+                        float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
+                        float* state, ngp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

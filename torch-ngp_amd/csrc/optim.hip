@@ -1,0 +1,177 @@
+// Fused optimizer + loss-scaling step for the instant-ngp parameter set.
+//
+// The reference trains with torch.optim.Adam + torch.cuda.amp.GradScaler (main_nerf.py:132, nerf/utils.py:393,557-560).  On the
+// 12.24 M-entry hash table that is, per iteration: zero a fp16 gradient table, scatter into it, cast it to fp32 (autograd), sweep
+// it for non-finite values, run Adam (read p, g, m, v; write p, m, v and the unscaled g), and cast the fp32 table back to fp16 for
+// the next forward -- six table-sized passes.  Here the gradient stays in the fp16 buffer the scatter kernel wrote:
+//   k_check_finite : one read of the fp16 gradients -> found_inf flag
+//   k_adam         : g (fp16, still loss-scaled) * inv_scale -> Adam moments and fp32 master weights, plus the fp16 shadow copy the
+//                    next forward reads, and the gradient buffer is zeroed in the same sweep (nothing else has to touch it)
+//   k_update_scale : GradScaler's dynamic loss scale (grow after `growth_interval` clean steps, back off on overflow) and the
+//                    Adam step counter, on device -- the whole step is free of host synchronisation and graph-capturable.
+// Update rule = PyTorch's Adam (amsgrad = False, weight_decay = 0, maximize = False), restated from its documented formula:
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+// A step with a non-finite gradient anywhere is skipped as a whole (moments, weights and t untouched), as GradScaler.step does.
+#include "common.h"
+#include <math.h>
+
+namespace ngp {
+
+constexpr int OPT_THREADS = 256;
+constexpr int OPT_MAX_TENSORS = 8;
+
+struct OptTensors {
+    int count;
+    uint64_t n[OPT_MAX_TENSORS];
+    float* p[OPT_MAX_TENSORS];
+    float* m[OPT_MAX_TENSORS];
+    float* v[OPT_MAX_TENSORS];
+    void* g[OPT_MAX_TENSORS];       // fp16 or fp32 gradient (g_is_half)
+    half_t* p16[OPT_MAX_TENSORS];   // optional fp16 shadow of the weights
+    int g_is_half[OPT_MAX_TENSORS];
+    float lr[OPT_MAX_TENSORS];
+};
+
+// state[0] = loss scale, state[1] = growth tracker, state[2] = found_inf (0/1), state[3] = Adam step count t, state[4] = lr multiplier
+__global__ __launch_bounds__(OPT_THREADS) void k_check_finite(OptTensors ts, float* __restrict__ state) {
+    bool bad = false;
+    for (int k = 0; k < ts.count; k++) {
+        const uint64_t n = ts.n[k];
+        if (ts.g_is_half[k]) {
+            const half8_t* g = reinterpret_cast<const half8_t*>(ts.g[k]);
+            const uint64_t n8 = n / 8;
+            for (uint64_t i = (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n8; i += (uint64_t)gridDim.x * OPT_THREADS) {
+                const half8_t x = g[i];
+#pragma unroll
+                for (int j = 0; j < 8; j++) bad = bad || !__builtin_isfinite((float)x[j]);
+            }
+            const half_t* gt = reinterpret_cast<const half_t*>(ts.g[k]);
+            for (uint64_t i = n8 * 8 + (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * OPT_THREADS)
+                bad = bad || !__builtin_isfinite((float)gt[i]);
+        } else {
+            const float* g = reinterpret_cast<const float*>(ts.g[k]);
+            for (uint64_t i = (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * OPT_THREADS)
+                bad = bad || !__builtin_isfinite(g[i]);
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.0f;  // benign race: every writer stores the same value
+}
+
+__global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float* __restrict__ state, float beta1, float beta2, float eps,
+                                                      float grad_mult) {
+    const bool skip = state[2] != 0.0f;
+    const float inv_scale = grad_mult / state[0];
+    const float t = state[3] + 1.0f;  // this step's count (k_update_scale commits it)
+    const float bc1 = 1.0f - powf(beta1, t);
+    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, t));
+    for (int k = 0; k < ts.count; k++) {
+        const uint64_t n = ts.n[k];
+        const float step_size = ts.lr[k] * state[4] / bc1;
+        float* __restrict__ p = ts.p[k];
+        float* __restrict__ m = ts.m[k];
+        float* __restrict__ v = ts.v[k];
+        half_t* __restrict__ p16 = ts.p16[k];
+        const bool gh = ts.g_is_half[k] != 0;
+        half_t* g16 = reinterpret_cast<half_t*>(ts.g[k]);
+        float* g32 = reinterpret_cast<float*>(ts.g[k]);
+        // two elements per lane and iteration (all our tensors have an even length; a trailing odd element is handled below)
+        const uint64_t n2 = n / 2;
+        for (uint64_t i = (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * OPT_THREADS) {
+            float g0, g1;
+            if (gh) {
+                const half2_t x = reinterpret_cast<half2_t*>(g16)[i];
+                g0 = (float)x.x; g1 = (float)x.y;
+                reinterpret_cast<half2_t*>(g16)[i] = half2_t{(half_t)0.0f, (half_t)0.0f};
+            } else {
+                const float2_t x = reinterpret_cast<float2_t*>(g32)[i];
+                g0 = x.x; g1 = x.y;
+                reinterpret_cast<float2_t*>(g32)[i] = float2_t{0.0f, 0.0f};
+            }
+            if (skip) continue;
+            g0 *= inv_scale; g1 *= inv_scale;
+            float2_t pm = reinterpret_cast<float2_t*>(m)[i], pv = reinterpret_cast<float2_t*>(v)[i], pp = reinterpret_cast<float2_t*>(p)[i];
+            pm.x = beta1 * pm.x + (1.0f - beta1) * g0; pm.y = beta1 * pm.y + (1.0f - beta1) * g1;
+            pv.x = beta2 * pv.x + (1.0f - beta2) * g0 * g0; pv.y = beta2 * pv.y + (1.0f - beta2) * g1 * g1;
+            pp.x -= step_size * pm.x / (sqrtf(pv.x) / bc2_sqrt + eps);
+            pp.y -= step_size * pm.y / (sqrtf(pv.y) / bc2_sqrt + eps);
+            reinterpret_cast<float2_t*>(m)[i] = pm;
+            reinterpret_cast<float2_t*>(v)[i] = pv;
+            reinterpret_cast<float2_t*>(p)[i] = pp;
+            if (p16) reinterpret_cast<half2_t*>(p16)[i] = half2_t{(half_t)pp.x, (half_t)pp.y};
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const uint64_t i = n - 1;
+            float g0 = gh ? (float)g16[i] : g32[i];
+            if (gh) g16[i] = (half_t)0.0f; else g32[i] = 0.0f;
+            if (!skip) {
+                g0 *= inv_scale;
+                const float nm = beta1 * m[i] + (1.0f - beta1) * g0, nv = beta2 * v[i] + (1.0f - beta2) * g0 * g0;
+                const float np_ = p[i] - step_size * nm / (sqrtf(nv) / bc2_sqrt + eps);
+                m[i] = nm; v[i] = nv; p[i] = np_;
+                if (p16) p16[i] = (half_t)np_;
+            }
+        }
+    }
+}
+
+// torch.amp.GradScaler.update (_amp_update_scale_): found_inf -> scale *= backoff, tracker = 0; else tracker += 1 and, when it reaches
+// growth_interval, scale *= growth (only if the result is finite) and tracker = 0.  Also commits the Adam step count.
+__global__ void k_update_scale(float* __restrict__ state, float growth, float backoff, float growth_interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (state[2] != 0.0f) {
+        state[0] *= backoff;
+        state[1] = 0.0f;
+    } else {
+        state[3] += 1.0f;
+        const float tr = state[1] + 1.0f;
+        if (tr >= growth_interval) {
+            const float grown = state[0] * growth;
+            if (__builtin_isfinite(grown)) state[0] = grown;
+            state[1] = 0.0f;
+        } else {
+            state[1] = tr;
+        }
+    }
+    state[2] = 0.0f;
+}
+
+}  // namespace ngp
+
+using namespace ngp;
+
+extern "C" int ngp_optim_adam_step(int count, const uint64_t* n, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                                   void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
+                                   float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
+                                   float* state, ngp_stream_t stream) {
+    NGP_REQUIRE(count >= 1 && count <= OPT_MAX_TENSORS, NGP_ERR_INVALID, "optim_adam_step: between 1 and %d tensors per call (got %d)",
+                OPT_MAX_TENSORS, count);
+    NGP_REQUIRE(n && params && exp_avg && exp_avg_sq && grads && grad_is_half && lr && state, NGP_ERR_INVALID, "optim_adam_step: NULL argument");
+    OptTensors ts;
+    ts.count = count;
+    uint64_t total = 0;
+    for (int k = 0; k < count; k++) {
+        NGP_REQUIRE(params[k] && exp_avg[k] && exp_avg_sq[k] && grads[k], NGP_ERR_INVALID, "optim_adam_step: NULL tensor %d", k);
+        ts.n[k] = n[k];
+        ts.p[k] = params[k];
+        ts.m[k] = exp_avg[k];
+        ts.v[k] = exp_avg_sq[k];
+        ts.g[k] = grads[k];
+        ts.p16[k] = params_fp16 ? reinterpret_cast<half_t*>(params_fp16[k]) : nullptr;
+        ts.g_is_half[k] = grad_is_half[k];
+        ts.lr[k] = lr[k];
+        total += n[k];
+    }
+    hipStream_t st = as_stream(stream);
+    uint32_t blocks = (uint32_t)cdiv64(total / 2 + 1, OPT_THREADS * 4);  // ~8 elements per lane
+    if (blocks > 2048u) blocks = 2048u;
+    if (blocks < 1u) blocks = 1u;
+    hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(OPT_THREADS), 0, st, ts, state);
+    int rc = check_launch("optim_adam_step(check)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(OPT_THREADS), 0, st, ts, (const float*)state, beta1, beta2, eps, grad_mult);
+    rc = check_launch("optim_adam_step(adam)");
+    if (rc) return rc;
+    if (growth_interval < 0.0f) return NGP_OK;  // more tensors follow in another call of the same step
+    hipLaunchKernelGGL(k_update_scale, dim3(1), dim3(64), 0, st, state, growth_factor, backoff_factor, growth_interval);
+    return check_launch("optim_adam_step(scale)");
+}

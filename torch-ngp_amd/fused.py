@@ -33,7 +33,7 @@ def _check(rc):
 
 class _fused_ngp(Function):
     @staticmethod
-    def forward(ctx, x, d, embeddings, w_sigma, w_color, offsets, cfg):
+    def forward(ctx, x, d, embeddings, w_sigma, w_color, offsets, cfg, bufs):
         """x [M,3] fp32 in [-bound,bound], d [M,3] fp32; embeddings [n,2] fp32 param; w_* flat fp32 params -> sigma [M] fp32, rgb [M,3] fp32"""
         (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, training) = cfg
         M = x.shape[0]
@@ -41,9 +41,7 @@ class _fused_ngp(Function):
         st = capi.stream()
         x = x.contiguous()
         d = d.contiguous()
-        emb16 = embeddings.detach().to(torch.half)
-        ws16 = w_sigma.detach().to(torch.half)
-        wc16 = w_color.detach().to(torch.half)
+        emb16, ws16, wc16 = _half_weights(embeddings, w_sigma, w_color, bufs)
         half = dict(device=dev, dtype=torch.half)
 
         enc = torch.empty(L, M, 2, **half)
@@ -75,6 +73,7 @@ class _fused_ngp(Function):
             ctx.save_for_backward(x, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb)
             ctx.cfg = cfg
             ctx.n_emb = embeddings.shape[0]
+            ctx.bufs = bufs
         return sigma, rgb
 
     @staticmethod
@@ -91,26 +90,55 @@ class _fused_ngp(Function):
         g_out16 = torch.empty(M, 16, **half)
         _check(capi.lib.ngp_pipeline_rgb_backward(grad_rgb.data_ptr(), rgb.data_ptr(), g_out16.data_ptr(), M, st))
         g_color_in = torch.empty(M, 32, **half)
-        g_wc = torch.empty_like(wc16)
+        g_emb, g_ws, g_wc, deposited = _grad_targets(ctx.bufs, ctx.n_emb, ws16, wc16, dev)
         scratch_c = torch.empty(nl_color, M, 64, **half)  # per-workgroup fp32 weight-gradient slabs live here
         _check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), fb_c.data_ptr(), M, 32, 16, 64,
                                               nl_color, 0, 6, 1, scratch_c.data_ptr(), g_color_in.data_ptr(), g_wc.data_ptr(), 0, st))
         g_h16 = g_out16  # reuse: [M,16] fp16
         _check(capi.lib.ngp_pipeline_mid_backward(grad_sigma.data_ptr(), h16.data_ptr(), g_color_in.data_ptr(), g_h16.data_ptr(), M, 1.0, st))
         g_enc = torch.empty(L, M, 2, **half)
-        g_ws = torch.empty_like(ws16)
         scratch_s = scratch_c[:nl_sigma]
         _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
                                               0, 6, 1, scratch_s.data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(), _PLANAR_IN | _PLANAR_DX, st))
-        g_emb = torch.zeros(ctx.n_emb, 2, **half)
         _check(capi.lib.ngp_grid_encode_backward_ex(g_enc.data_ptr(), x.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
                                                      None, None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
-        return None, None, g_emb, g_ws, g_wc, None, None
+        if deposited:
+            return None, None, None, None, None, None, None, None
+        return None, None, g_emb, g_ws, g_wc, None, None, None
+
+
+def _half_weights(embeddings, w_sigma, w_color, bufs):
+    """fp16 operands of the kernels: the optimizer's shadow copies when optim.NGPAdam maintains them, else a cast (grid.py:43-44)"""
+    if bufs is not None:
+        return bufs[0], bufs[1], bufs[2]
+    return embeddings.detach().to(torch.half), w_sigma.detach().to(torch.half), w_color.detach().to(torch.half)
+
+
+def _grad_targets(bufs, n_emb, ws16, wc16, dev):
+    """where the backward kernels write: the optimizer's fp16 gradient buffers (already zero; nothing is returned to autograd) or fresh
+    tensors handed to autograd (which casts them to the fp32 .grad)"""
+    if bufs is not None:
+        return bufs[3], bufs[4].view(-1), bufs[5].view(-1), True
+    return torch.zeros(n_emb, 2, device=dev, dtype=torch.half), torch.empty_like(ws16), torch.empty_like(wc16), False
+
+
+def _optimizer_buffers(params):
+    """(fp16 shadows..., fp16 gradient buffers...) of the three parameters when every one of them is managed by optim.NGPAdam"""
+    sh = [getattr(p, '_ngp_fp16', None) for p in params]
+    gr = [getattr(p, '_ngp_grad16', None) for p in params]
+    if any(t is None for t in sh + gr):
+        return None
+    return tuple(sh) + tuple(gr)
 
 
 def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
     cfg = network_cfg(encoder, sigma_net, color_net, bound, training)
-    return _fused_ngp.apply(x, d, encoder.embeddings, sigma_net.weights, color_net.weights, encoder.offsets, cfg)
+    bufs = _optimizer_buffers((encoder.embeddings, sigma_net.weights, color_net.weights)) if training else None
+    if bufs is None and not training:
+        sh = [getattr(p, '_ngp_fp16', None) for p in (encoder.embeddings, sigma_net.weights, color_net.weights)]
+        if all(t is not None for t in sh):
+            bufs = tuple(sh) + (None, None, None)  # inference: shadows only
+    return _fused_ngp.apply(x, d, encoder.embeddings, sigma_net.weights, color_net.weights, encoder.offsets, cfg, bufs)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -123,7 +151,7 @@ def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
 # ------------------------------------------------------------------------------------------------------------------
 class _fused_render_train(Function):
     @staticmethod
-    def forward(ctx, rays_o, rays_d, embeddings, w_sigma, w_color, bg, offsets, bitfield, aabb, counter, cfg, rcfg):
+    def forward(ctx, rays_o, rays_d, embeddings, w_sigma, w_color, bg, offsets, bitfield, aabb, counter, cfg, rcfg, bufs):
         (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
         (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
         N = rays_o.shape[0]
@@ -147,9 +175,7 @@ class _fused_render_train(Function):
                                                 dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(), noises.data_ptr(),
                                                 ws.data_ptr(), capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL, st))
         # ---- network ----
-        emb16 = embeddings.detach().to(torch.half)
-        ws16 = w_sigma.detach().to(torch.half)
-        wc16 = w_color.detach().to(torch.half)
+        emb16, ws16, wc16 = _half_weights(embeddings, w_sigma, w_color, bufs)
         enc = torch.empty(L, M, 2, **half)
         _check(capi.lib.ngp_grid_encode_forward_ex(xyzs.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
                                                     None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
@@ -179,7 +205,7 @@ class _fused_render_train(Function):
                                                             bg_mode, float(bg_scalar), capi.ptr(bg), nears.data_ptr(), fars.data_ptr(),
                                                             image.data_ptr(), depth.data_ptr(), st))
         ctx.save_for_backward(xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg)
-        ctx.cfg, ctx.rcfg, ctx.n_emb = cfg, rcfg, embeddings.shape[0]
+        ctx.cfg, ctx.rcfg, ctx.n_emb, ctx.bufs = cfg, rcfg, embeddings.shape[0], bufs
         ctx.mark_non_differentiable(depth)
         return image, depth, weights_sum
 
@@ -204,7 +230,7 @@ class _fused_render_train(Function):
         g_out16 = torch.empty(M, 16, **half)
         _check(capi.lib.ngp_pipeline_rgb_backward(g_rgb.data_ptr(), rgb.data_ptr(), g_out16.data_ptr(), M, st))
         g_color_in = torch.empty(M, 32, **half)
-        g_wc = torch.empty_like(wc16)
+        g_emb, g_ws, g_wc, deposited = _grad_targets(ctx.bufs, ctx.n_emb, ws16, wc16, dev)
         scratch = torch.empty(nl_color, M, 64, **half)
         _check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), fb_c.data_ptr(), M, 32, 16, 64,
                                               nl_color, 0, 6, 1, scratch.data_ptr(), g_color_in.data_ptr(), g_wc.data_ptr(), 0, st))
@@ -212,14 +238,14 @@ class _fused_render_train(Function):
         _check(capi.lib.ngp_pipeline_mid_backward(g_sigma.data_ptr(), h16.data_ptr(), g_color_in.data_ptr(), g_h16.data_ptr(), M,
                                                   float(density_scale), st))
         g_enc = torch.empty(L, M, 2, **half)
-        g_ws = torch.empty_like(ws16)
         _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
                                               0, 6, 1, scratch[:nl_sigma].data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
                                               _PLANAR_IN | _PLANAR_DX, st))
-        g_emb = torch.zeros(ctx.n_emb, 2, **half)
         _check(capi.lib.ngp_grid_encode_backward_ex(g_enc.data_ptr(), xyzs.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
                                                      None, None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
-        return None, None, g_emb, g_ws, g_wc, None, None, None, None, None, None, None
+        if deposited:
+            return (None,) * 13
+        return None, None, g_emb, g_ws, g_wc, None, None, None, None, None, None, None, None
 
 
 def network_cfg(encoder, sigma_net, color_net, bound, training):
@@ -234,5 +260,6 @@ def fused_render_train(model, rays_o, rays_d, box, counter, capacity, bg_color, 
     bg_t, bg_s = (bg_color.contiguous().float().view(-1, 3), 0.0) if torch.is_tensor(bg_color) else (None, float(bg_color))
     rcfg = (int(model.cascade), int(model.grid_size), float(model.min_near), int(capacity), bool(perturb), float(dt_gamma), int(max_steps),
             float(T_thresh), float(model.density_scale), bg_s)
+    bufs = _optimizer_buffers((model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights))
     return _fused_render_train.apply(rays_o, rays_d, model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights, bg_t,
-                                     model.encoder.offsets, model.density_bitfield, box, counter, cfg, rcfg)
+                                     model.encoder.offsets, model.density_bitfield, box, counter, cfg, rcfg, bufs)

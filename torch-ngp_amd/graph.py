@@ -17,7 +17,8 @@ What stays eager, at the reference Trainer's cadence (nerf/utils.py:851-856): `u
 refreshes `mean_count`.  The captured sample capacity is `mean_count` rounded up to a multiple of `capacity_quantum`
 (default 8192 samples, ~3 % of a lego-sized batch), so the graph is re-captured only when the estimate crosses a quantum.
 
-Requirements: `optimizer` constructed with `capturable=True` (and preferably `fused=True`); the model has completed at least
+Requirements: a torch optimizer constructed with `capturable=True` (and preferably `fused=True`) plus a GradScaler, or
+`optim.NGPAdam` with `scaler=None` (it owns the loss scale; `averager` may then be the optimizer itself); the model has completed at least
 one `update_extra_state` after 16 eager steps (`model.mean_count > 0`) -- before that the sample buffer is sized for the
 worst case and read back, which cannot be captured, and `step()` simply runs eagerly.
 """
@@ -70,14 +71,21 @@ class GraphedTrainStep:
             with torch.autocast('cuda', dtype=self.autocast_dtype):
                 out = m.render(self.rays_o, self.rays_d, **self.render_kwargs)
                 loss = self.loss_fn(out, self.target)
-            self.scaler.scale(loss).backward()
+            self._scaled(loss).backward()
         finally:
             m._buffers['step_counter'], m.mean_count, m.local_step = saved_counter, saved_mc, saved_ls
         return loss
 
+    def _scaled(self, loss):
+        # torch.optim + GradScaler, or an optimizer that owns its loss scale (optim.NGPAdam: scale / step, no scaler object)
+        return self.scaler.scale(loss) if self.scaler is not None else self.optimizer.scale(loss)
+
     def _iteration_back(self):
-        self.scaler.step(self.optimizer)
-        self.scaler.update()
+        if self.scaler is not None:
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
+        else:
+            self.optimizer.step()
 
     def _capture(self):
         # No warm-up iterations here: they would be real optimizer steps.  Everything lazily created (optimizer state,
@@ -108,11 +116,10 @@ class GraphedTrainStep:
         with torch.autocast('cuda', dtype=self.autocast_dtype):
             out = self.model.render(rays_o, rays_d, **self.render_kwargs)
             loss = self.loss_fn(out, target)
-        self.scaler.scale(loss).backward()
+        self._scaled(loss).backward()
         if self.averager is not None:
             self.averager.all_reduce()
-        self.scaler.step(self.optimizer)
-        self.scaler.update()
+        self._iteration_back()
         # detached: a caller holding the loss must not keep this iteration's autograd graph (and its AccumulateGrad nodes,
         # bound to the eager stream) alive into a later capture
         return loss.detach()

@@ -191,6 +191,8 @@ def main():
         o, d, gt = sc.training_batch(args.rays, seed=1000 * rank + k)
         pool.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
     total_samples = torch.zeros((), dtype=torch.int64, device=dev)
+    count_log = torch.zeros(args.steps + 1, 2, dtype=torch.int32, device=dev)
+    caps = []
     opt_kwargs = dict(staged=False, bg_color=1, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
 
     def keep_scene(m):
@@ -212,15 +214,15 @@ def main():
             cap = mc + (128 - mc % 128) if mc > 0 else args.rays * 1024
             loss = stepper._eager(rays_o, rays_d, gt)
             stepper.global_step += 1
-            marched = model.step_counter[(model.local_step - 1) % 16, 0]
         else:
             loss = stepper.step(rays_o, rays_d, gt)
             cap = stepper.capacity if stepper.capacity is not None else args.rays * 1024
-            marched = model.step_counter[(model.local_step - 1) % 16, 0]
         if count:
-            # samples that were marched AND evaluated: rays that do not fit the estimated buffer are dropped whole by
+            # log this step's sample count (one 8-byte device copy); the clamp to the buffer capacity and the sum happen after the
+            # timed region.  Samples that were marched AND evaluated: rays that do not fit the estimated buffer are dropped whole by
             # march_rays_train (raymarching.cu:416), so at most `cap` samples are processed in a step
-            total_samples.add_(torch.clamp(marched, max=cap))
+            count_log[len(caps)].copy_(model.step_counter[(model.local_step - 1) % 16], non_blocking=True)
+            caps.append(cap)
         return loss
 
     timers = KernelTimers(capi)
@@ -249,6 +251,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     final_loss = float(loss.item())
+    marched = count_log[:len(caps), 0].to(torch.int64)
+    total_samples.add_(torch.minimum(marched, torch.tensor(caps, dtype=torch.int64, device=dev)).sum())
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

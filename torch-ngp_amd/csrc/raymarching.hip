@@ -240,6 +240,7 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds4) {
 // reproducible layout, no atomics (the reference's completion-order atomics are "parity unpinned").
 // ---------------------------------------------------------------------------------------------
 constexpr int MW_WAVES = 4;  // rays per workgroup
+constexpr uint32_t MARCH_MASK_WINDOWS = 20;  // emit masks kept per ray (64 terms each); longer rays re-probe in the write pass
 
 __device__ __forceinline__ float readlane_f(float v, uint32_t l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)l));
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
                                                                     const float* __restrict__ nears, const float* __restrict__ fars,
                                                                     float* __restrict__ xyzs, float* __restrict__ dirs,
                                                                     float* __restrict__ deltas, int32_t* __restrict__ rays,
-                                                                    const float* __restrict__ noises) {
+                                                                    const float* __restrict__ noises, uint32_t* __restrict__ n_windows,
+                                                                    uint64_t* __restrict__ masks) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n = blockIdx.x * MW_WAVES + wid;  // wave-uniform
@@ -272,6 +274,49 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
     uint32_t num_steps = 0;
     float t_base = __builtin_fmaf(step_dt(p, near), noises[n], near);
     float last_t = t_base;
+    uint32_t window = 0;
+
+    if (WRITE) {
+        // Fast path: the count pass recorded, per 64-term window, which terms the walk emitted (MARCH_MASK_WINDOWS words per
+        // ray).  Re-create the terms with the same recurrence and store the marked ones: no probing, no search, no walk.
+        const uint32_t nw = n_windows[n];
+        if (nw <= MARCH_MASK_WINDOWS) {
+            const uint64_t* my_masks = masks + (size_t)n * MARCH_MASK_WINDOWS;
+            for (; window < nw; window++) {
+                float t = t_base, mine = t_base;
+#pragma unroll
+                for (uint32_t j = 1; j < 64; j++) {
+                    t += CONST_DT ? dt_const : step_dt(p, t);
+                    mine = (lane == j) ? t : mine;
+                }
+                t_base = t + (CONST_DT ? dt_const : step_dt(p, t));
+                const uint64_t emit = my_masks[window];
+                if (emit == 0ull) continue;
+                const float x = clampf(__builtin_fmaf(mine, r.dx, r.ox), -p.bound, p.bound);
+                const float y = clampf(__builtin_fmaf(mine, r.dy, r.oy), -p.bound, p.bound);
+                const float z = clampf(__builtin_fmaf(mine, r.dz, r.oz), -p.bound, p.bound);
+                const float dt = step_dt(p, mine);
+                const bool e = (emit >> lane) & 1ull;
+                const uint64_t below = emit & ((1ull << lane) - 1ull);
+                const uint32_t rank = (uint32_t)__builtin_popcountll(below);
+                const float t_after = mine + dt;
+                const int src = below ? 63 - __builtin_clzll(below) : 0;
+                const float prev_after = __shfl(t_after, src, 64);
+                const float lt = below ? prev_after : last_t;
+                if (e) {
+                    const size_t o = (size_t)offset + rank;
+                    float* xo = xyzs + o * 3;
+                    float* dd = dirs + o * 3;
+                    xo[0] = x; xo[1] = y; xo[2] = z;
+                    dd[0] = r.dx; dd[1] = r.dy; dd[2] = r.dz;
+                    *reinterpret_cast<float2_t*>(deltas + o * 2) = float2_t{dt, t_after - lt};
+                }
+                last_t = readlane_f(t_after, 63u - (uint32_t)__builtin_clzll(emit));
+                offset += (uint32_t)__builtin_popcountll(emit);
+            }
+            return;
+        }
+    }
     float carry = -INFINITY;  // the walk enters a window at its first term that is not < carry
     bool done = !(t_base < far);
 
@@ -348,12 +393,15 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
             last_t = readlane_f(t_after, 63u - (uint32_t)__builtin_clzll(emit));
             offset += (uint32_t)__builtin_popcountll(emit);
         }
+        if (!WRITE && lane == 0 && window < MARCH_MASK_WINDOWS) masks[(size_t)n * MARCH_MASK_WINDOWS + window] = emit;
+        window++;
         done = ray_done || (validmask != ~0ull);
         t_base = t_next_base;
     }
     if (!WRITE && lane == 0) {
         rays[n * 3] = (int32_t)n;
         rays[n * 3 + 2] = (int32_t)num_steps;
+        n_windows[n] = window;
     }
 }
 
@@ -711,7 +759,10 @@ extern "C" int ngp_packbits(const float* grid, uint32_t N, float density_thresh,
     return check_launch("packbits");
 }
 
-extern "C" size_t ngp_march_rays_train_workspace_bytes(uint32_t N) { return sizeof(uint32_t) * (size_t)(1 + cdiv(N, RM_THREADS)); }
+// workspace: [0] fit_end, [1] pad, [2 .. 2+N) windows per ray, then N x MARCH_MASK_WINDOWS 64-bit emit masks
+extern "C" size_t ngp_march_rays_train_workspace_bytes(uint32_t N) {
+    return sizeof(uint32_t) * (size_t)(2 + ((N + 1u) & ~1u)) + sizeof(uint64_t) * (size_t)N * MARCH_MASK_WINDOWS;
+}
 
 static int check_march_args(const char* fn, uint32_t C, uint32_t H, uint32_t max_steps) {
     NGP_REQUIRE(C >= 1 && C <= 8, NGP_ERR_INVALID, "%s: cascade count C must be in [1, 8] (got %u)", fn, C);
@@ -735,8 +786,10 @@ extern "C" int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d,
     const bool const_dt = dt_gamma == 0.0f;
 #define MARCH_WAVE(WRITE, CDT)                                                                                                     \
     hipLaunchKernelGGL((k_march_train_wave<WRITE, CDT>), grid, block, 0, st, rays_o, rays_d, grid_bits, bound, dt_gamma, max_steps, N, C, H, \
-                       M, nears, fars, xyzs, dirs, deltas, rays, noises)
+                       M, nears, fars, xyzs, dirs, deltas, rays, noises, ws_windows, ws_masks)
     const uint8_t* grid_bits = grid_in;
+    uint32_t* ws_windows = ws + 2;                                                               // [N]
+    uint64_t* ws_masks = reinterpret_cast<uint64_t*>(ws + 2 + ((N + 1u) & ~1u));                 // [N][MARCH_MASK_WINDOWS], 8-byte aligned
     if (const_dt) MARCH_WAVE(false, true); else MARCH_WAVE(false, false);
     rc = check_launch("march_rays_train(count)");
     if (rc) return rc;

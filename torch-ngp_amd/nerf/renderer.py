@@ -109,11 +109,10 @@ class NeRFRenderer(nn.Module):
         n_rays = rays_o.shape[0]
         dev = rays_o.device
         box = self.aabb_train if self.training else self.aabb_infer
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near)
-        bg_color = self._background(rays_o, rays_d, bg_color)
         results = {}
 
-        if self.training and self._fused_render_ok(rays_o, rays_d, bg_color, force_all_rays):
+        if self.training and self.bg_radius <= 0 and self._fused_render_ok(rays_o, rays_d, 1 if bg_color is None else bg_color, force_all_rays):
+            bg_color = 1 if bg_color is None else bg_color
             # extension (fused.py): the whole training branch below as one autograd Function, identical arithmetic
             from fused import fused_render_train
             counter = self.step_counter[self.local_step % 16]
@@ -126,6 +125,8 @@ class NeRFRenderer(nn.Module):
             results['image'] = image.view(*lead, 3)
             return results
 
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near)
+        bg_color = self._background(rays_o, rays_d, bg_color)
         if self.training:
             counter = self.step_counter[self.local_step % 16]
             counter.zero_()

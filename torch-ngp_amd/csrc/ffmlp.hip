@@ -27,13 +27,14 @@
 //   * The training forward streams each layer's post-activation fragments to forward_buffer in
 //     fragment order (four fully coalesced 1 KiB stores per layer and tile); backward reads them back
 //     the same way.  The layout of forward_buffer is private to this file.
-//   * Backward is ONE kernel: the dgrad chain runs exactly like the forward (A = W^T fragments), and the
-//     weight gradients dW_l = dZ_l^T . X_l are accumulated per wave in fp32 MFMA accumulators over all
-//     of the wave's tiles (the batch dimension becomes the MFMA k dimension after a transposition of
-//     the two 32-sample tiles through a small per-wave LDS stage).  Per workgroup the four waves'
-//     partial sums are combined in LDS and written as one fp32 slab into the caller's backward_buffer;
-//     a second tiny kernel adds the slabs in a fixed order and rounds once to fp16 -- deterministic,
-//     no atomics, no side streams (this replaces the reference's num_layers+1 split-K GEMMs).
+//   * Backward is ONE kernel: the dgrad chain runs exactly like the forward (A = W^T fragments); the weight gradients
+//     dW_l = dZ_l^T . X_l are accumulated per wave in fp32 MFMA accumulators over all of the wave's tiles.  The operand
+//     transposition this needs (the batch dimension becomes the MFMA k dimension) runs on the matrix core itself (selector
+//     MFMAs, see below) -- no LDS stage; the next tile's operands are streamed into per-wave LDS buffers by global->LDS DMA
+//     while the current tile is computed (the accumulators leave one wave per SIMD, so latency must be hidden explicitly).
+//     Per workgroup the four waves' partial sums are combined in LDS and written as one fp32 slab into the caller's
+//     backward_buffer; a second tiny kernel adds the slabs in a fixed order and rounds once to fp16 -- deterministic, no
+//     atomics, no side streams (this replaces the reference's num_layers+1 split-K GEMMs).
 #include "common.h"
 
 namespace ngp {

@@ -6,20 +6,14 @@
 //   dL/dx     gridencoder/src/gridencoder.cu:343-369  (kernel_input_backward)
 //   TV grad   gridencoder/src/gridencoder.cu:506-610  (kernel_grad_tv)
 //
-// MI355X design (see DESIGN.md "gridencoder"):
-//   * launch is level-major (blockIdx.y = level): one level's table (<= 2 MiB fp16 at C=2) stays
-//     resident in every XCD's 4 MiB L2 while all points stream through it;
-//   * one lane = one (point, level); the 2^D corner gathers of a lane are issued back to back as
-//     independent 4-byte (half2) / 8-byte loads so a wave keeps 8 x 64 gathers in flight; corner
-//     weights and the accumulation are fp32, the result is rounded once to the table dtype;
-//   * the per-level scale/resolution table is computed on the host with a reproducible recipe
-//     (ngp_grid_level_table) and passed by value, so cell indices are bit-identical to the oracle;
-//   * all per-level quantities (table base, size, dense strides, hash-or-dense, pow2 size) are
-//     wave-uniform and live in SGPRs;
-//   * backward scatters with hardware atomics: global_atomic_pk_add_f16 for fp16 tables with even C
-//     (what the reference's half2 atomicAdd does), global_atomic_add_f32 otherwise.  Dense levels whose
-//     whole table fits in LDS are privatised per workgroup first (ds_add) and flushed once, which
-//     removes the same-address contention on the coarse levels.
+// MI355X design:
+//   * forward: XCD-aware level placement (a level's table lives in ONE XCD's L2), the two first-coordinate corners of a point
+//     on neighbouring lanes (same cache line -> one request), fp32 weights/accumulation, one rounding to the table dtype;
+//   * backward: a global float atomic costs one memory-side request per (wave instruction, 64-byte line) at ~20 G/s chip-wide
+//     (tools/atomic_probe2.hip): corner pairs on adjacent lanes + segmented run merge of same-cell samples cut the requests
+//     and the same-address serialisation (2.2 ms -> 0.53 ms on the lego batch);
+//   * the per-level scale/resolution table is computed on the host with a reproducible recipe (ngp_grid_level_table) and
+//     passed by value, so cell indices are bit-identical to the oracle; all per-level quantities are wave-uniform (SGPRs).
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>

@@ -46,17 +46,26 @@ class NGPAdam:
         self.world_size = int(world_size)
         self.state = {}
         dev = None
-        for g in self.param_groups:
-            for p in g['params']:
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
-                    raise RuntimeError('NGPAdam: parameters must be contiguous float32 CUDA tensors')
-                dev = p.device
-                st = {'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)}
-                if deposit:
-                    st['fp16'] = p.detach().to(torch.half)
-                    st['grad16'] = torch.zeros_like(st['fp16'])
-                    p._ngp_fp16, p._ngp_grad16 = st['fp16'], st['grad16']
-                self.state[p] = st
+        flat_params = [p for g in self.param_groups for p in g['params']]
+        for p in flat_params:
+            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                raise RuntimeError('NGPAdam: parameters must be contiguous float32 CUDA tensors')
+            dev = p.device
+        # one contiguous fp16 gradient buffer for all parameters (each slice 16-byte aligned): ONE all-reduce message per step
+        self.flat_grad16 = None
+        offsets, total = [], 0
+        for p in flat_params:
+            offsets.append(total)
+            total += (p.numel() + 7) // 8 * 8
+        if deposit:
+            self.flat_grad16 = torch.zeros(total, dtype=torch.half, device=dev)
+        for p, off in zip(flat_params, offsets):
+            st = {'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)}
+            if deposit:
+                st['fp16'] = p.detach().to(torch.half)
+                st['grad16'] = self.flat_grad16[off:off + p.numel()].view_as(p)
+                p._ngp_fp16, p._ngp_grad16 = st['fp16'], st['grad16']
+            self.state[p] = st
         # device-resident scalars: loss scale, growth tracker, found_inf, Adam step count, lr multiplier (schedulers write this one)
         self.scalars = torch.tensor([init_scale, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
         self._scale_view = self.scalars[0]
@@ -94,12 +103,11 @@ class NGPAdam:
         """sum the gradients over ranks (call between backward and step); the 1/world_size is applied inside step()"""
         if self.world_size <= 1:
             return
-        for g in self.param_groups:
-            for p in g['params']:
-                if p.grad is not None:
-                    dist.all_reduce(p.grad)
-                elif 'grad16' in self.state[p]:
-                    dist.all_reduce(self.state[p]['grad16'])
+        eager = [p for g in self.param_groups for p in g['params'] if p.grad is not None]
+        for p in eager:
+            dist.all_reduce(p.grad)
+        if self.flat_grad16 is not None and len(eager) < len(self.state):
+            dist.all_reduce(self.flat_grad16)
 
     # -- the step ----------------------------------------------------------------------------------
     @torch.no_grad()

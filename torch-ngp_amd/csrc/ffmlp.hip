@@ -774,8 +774,8 @@ extern "C" int ngp_ffmlp_forward_ex(const void* inputs, const void* weights, uin
                                     void* forward_buffer, void* outputs, uint32_t flags, ngp_stream_t stream) {
     int rc = check_ff_args("ffmlp_forward", B, input_dim, output_dim, hidden_dim, num_layers);
     if (rc) return rc;
-    NGP_REQUIRE(inputs && weights && forward_buffer && outputs, NGP_ERR_INVALID, "ffmlp_forward: NULL tensor");
     if (B == 0) return NGP_OK;
+    NGP_REQUIRE(inputs && weights && forward_buffer && outputs, NGP_ERR_INVALID, "ffmlp_forward: NULL tensor");
     hipStream_t st = as_stream(stream);
     if (hidden_dim == 64) return launch_forward<64, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, flags, st);
     return launch_forward<32, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, flags, st);
@@ -787,8 +787,8 @@ extern "C" int ngp_ffmlp_inference_ex(const void* inputs, const void* weights, u
     (void)inference_buffer;
     int rc = check_ff_args("ffmlp_inference", B, input_dim, output_dim, hidden_dim, num_layers);
     if (rc) return rc;
-    NGP_REQUIRE(inputs && weights && outputs, NGP_ERR_INVALID, "ffmlp_inference: NULL tensor");
     if (B == 0) return NGP_OK;
+    NGP_REQUIRE(inputs && weights && outputs, NGP_ERR_INVALID, "ffmlp_inference: NULL tensor");
     hipStream_t st = as_stream(stream);
     if (hidden_dim == 64) return launch_forward<64, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, nullptr, outputs, flags, st);
     return launch_forward<32, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, nullptr, outputs, flags, st);
@@ -803,9 +803,9 @@ extern "C" int ngp_ffmlp_backward_ex(const void* grad, const void* inputs, const
     if (rc) return rc;
     NGP_REQUIRE(num_layers <= 4, NGP_ERR_INVALID, "ffmlp_backward: this build supports num_layers <= 4 (got %u)", num_layers);
     NGP_REQUIRE(input_dim <= 64, NGP_ERR_INVALID, "ffmlp_backward: this build supports input_dim <= 64 (got %u)", input_dim);
+    if (B == 0) return NGP_OK;
     NGP_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer && grad_weights, NGP_ERR_INVALID, "ffmlp_backward: NULL tensor");
     NGP_REQUIRE(!calc_grad_inputs || grad_inputs, NGP_ERR_INVALID, "ffmlp_backward: grad_inputs is NULL but calc_grad_inputs is set");
-    if (B == 0) return NGP_OK;
     hipStream_t st = as_stream(stream);
     const bool dx = calc_grad_inputs != 0;
     const uint32_t in_jb = (input_dim + 31) / 32;

@@ -758,8 +758,8 @@ extern "C" int ngp_grid_encode_forward_ex(const float* inputs, const void* embed
     NGP_REQUIRE(!(bound > 0.0f && dy_dx), NGP_ERR_INVALID, "grid_encode_forward: the fused input mapping does not provide dy_dx");
     const InputMap im = make_input_map(bound);
     if (rc) return rc;
-    NGP_REQUIRE(inputs && embeddings && offsets && outputs, NGP_ERR_INVALID, "grid_encode_forward: NULL tensor");
     if (B == 0) return NGP_OK;
+    NGP_REQUIRE(inputs && embeddings && offsets && outputs, NGP_ERR_INVALID, "grid_encode_forward: NULL tensor");
     GridLevels lv;
     fill_levels(lv, L, S, H);
     hipStream_t st = as_stream(stream);
@@ -789,8 +789,8 @@ extern "C" int ngp_grid_encode_backward_ex(const void* grad, const float* inputs
     const InputMap im = make_input_map(bound);
     int rc = check_grid_args("grid_encode_backward", B, D, C, L, dtype);
     if (rc) return rc;
-    NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: NULL tensor");
     if (B == 0) return NGP_OK;
+    NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: NULL tensor");
     GridLevels lv;
     fill_levels(lv, L, S, H);
     hipStream_t st = as_stream(stream);
@@ -817,8 +817,8 @@ extern "C" int ngp_grad_total_variation(const void* inputs, const void* embeddin
                                         uint32_t gridtype, int align_corners, int dtype, ngp_stream_t stream) {
     int rc = check_grid_args("grad_total_variation", B, D, C, L, dtype);
     if (rc) return rc;
-    NGP_REQUIRE(inputs && embeddings && grad && offsets, NGP_ERR_INVALID, "grad_total_variation: NULL tensor");
     if (B == 0) return NGP_OK;
+    NGP_REQUIRE(inputs && embeddings && grad && offsets, NGP_ERR_INVALID, "grad_total_variation: NULL tensor");
     GridLevels lv;
     fill_levels(lv, L, S, H);
     hipStream_t st = as_stream(stream);
@@ -837,8 +837,8 @@ extern "C" int ngp_grid_corner_indices(const float* inputs, const int32_t* offse
                                        ngp_stream_t stream) {
     int rc = check_grid_args("grid_corner_indices", B, D, 1, L, NGP_F32);
     if (rc) return rc;
-    NGP_REQUIRE(inputs && offsets && indices, NGP_ERR_INVALID, "grid_corner_indices: NULL tensor");
     if (B == 0) return NGP_OK;
+    NGP_REQUIRE(inputs && offsets && indices, NGP_ERR_INVALID, "grid_corner_indices: NULL tensor");
     GridLevels lv;
     fill_levels(lv, L, S, H);
     hipStream_t st = as_stream(stream);

@@ -100,31 +100,31 @@ using namespace ngp;
 
 extern "C" int ngp_pipeline_mid_forward(const void* h16, const float* dirs, float* sigma, void* color_in, uint32_t M, uint32_t M_valid,
                                         float density_scale, ngp_stream_t stream) {
-    NGP_REQUIRE(h16 && dirs && sigma && color_in, NGP_ERR_INVALID, "pipeline_mid_forward: NULL tensor");
     if (M == 0) return NGP_OK;
+    NGP_REQUIRE(h16 && dirs && sigma && color_in, NGP_ERR_INVALID, "pipeline_mid_forward: NULL tensor");
     hipLaunchKernelGGL(k_mid_forward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), (const half_t*)h16, dirs, sigma,
                        (half_t*)color_in, M, M_valid, density_scale);
     return check_launch("pipeline_mid_forward");
 }
 
 extern "C" int ngp_pipeline_rgb_forward(const void* out16, float* rgb, uint32_t M, ngp_stream_t stream) {
-    NGP_REQUIRE(out16 && rgb, NGP_ERR_INVALID, "pipeline_rgb_forward: NULL tensor");
     if (M == 0) return NGP_OK;
+    NGP_REQUIRE(out16 && rgb, NGP_ERR_INVALID, "pipeline_rgb_forward: NULL tensor");
     hipLaunchKernelGGL(k_rgb_forward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), (const half_t*)out16, rgb, M);
     return check_launch("pipeline_rgb_forward");
 }
 
 extern "C" int ngp_pipeline_rgb_backward(const float* grad_rgb, const float* rgb, void* grad_out16, uint32_t M, ngp_stream_t stream) {
-    NGP_REQUIRE(grad_rgb && rgb && grad_out16, NGP_ERR_INVALID, "pipeline_rgb_backward: NULL tensor");
     if (M == 0) return NGP_OK;
+    NGP_REQUIRE(grad_rgb && rgb && grad_out16, NGP_ERR_INVALID, "pipeline_rgb_backward: NULL tensor");
     hipLaunchKernelGGL(k_rgb_backward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), grad_rgb, rgb, (half_t*)grad_out16, M);
     return check_launch("pipeline_rgb_backward");
 }
 
 extern "C" int ngp_pipeline_mid_backward(const float* grad_sigma, const void* h16, const void* grad_color_in, void* grad_h16, uint32_t M,
                                          float density_scale, ngp_stream_t stream) {
-    NGP_REQUIRE(grad_sigma && h16 && grad_color_in && grad_h16, NGP_ERR_INVALID, "pipeline_mid_backward: NULL tensor");
     if (M == 0) return NGP_OK;
+    NGP_REQUIRE(grad_sigma && h16 && grad_color_in && grad_h16, NGP_ERR_INVALID, "pipeline_mid_backward: NULL tensor");
     hipLaunchKernelGGL(k_mid_backward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), grad_sigma, (const half_t*)h16,
                        (const half_t*)grad_color_in, (half_t*)grad_h16, M, density_scale);
     return check_launch("pipeline_mid_backward");

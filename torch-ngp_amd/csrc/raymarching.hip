@@ -723,38 +723,38 @@ using namespace ngp;
 
 extern "C" int ngp_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near,
                                       float* nears, float* fars, ngp_stream_t stream) {
-    NGP_REQUIRE(rays_o && rays_d && aabb && nears && fars, NGP_ERR_INVALID, "near_far_from_aabb: NULL tensor");
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && aabb && nears && fars, NGP_ERR_INVALID, "near_far_from_aabb: NULL tensor");
     RM_LAUNCH_1D(k_near_far_from_aabb, N, as_stream(stream), rays_o, rays_d, aabb, N, min_near, nears, fars);
     return check_launch("near_far_from_aabb");
 }
 
 extern "C" int ngp_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
                                 ngp_stream_t stream) {
-    NGP_REQUIRE(rays_o && rays_d && coords, NGP_ERR_INVALID, "sph_from_ray: NULL tensor");
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && coords, NGP_ERR_INVALID, "sph_from_ray: NULL tensor");
     RM_LAUNCH_1D(k_sph_from_ray, N, as_stream(stream), rays_o, rays_d, radius, N, coords);
     return check_launch("sph_from_ray");
 }
 
 extern "C" int ngp_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, ngp_stream_t stream) {
-    NGP_REQUIRE(coords && indices, NGP_ERR_INVALID, "morton3D: NULL tensor");
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE(coords && indices, NGP_ERR_INVALID, "morton3D: NULL tensor");
     RM_LAUNCH_1D(k_morton3D, N, as_stream(stream), coords, N, indices);
     return check_launch("morton3D");
 }
 
 extern "C" int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, ngp_stream_t stream) {
-    NGP_REQUIRE(coords && indices, NGP_ERR_INVALID, "morton3D_invert: NULL tensor");
     if (N == 0) return NGP_OK;
+    NGP_REQUIRE(coords && indices, NGP_ERR_INVALID, "morton3D_invert: NULL tensor");
     RM_LAUNCH_1D(k_morton3D_invert, N, as_stream(stream), indices, N, coords);
     return check_launch("morton3D_invert");
 }
 
 extern "C" int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(grid && bitfield, NGP_ERR_INVALID, "packbits: NULL tensor");
     NGP_REQUIRE((reinterpret_cast<uintptr_t>(grid) & 15) == 0, NGP_ERR_INVALID, "packbits: grid must be 16-byte aligned");
-    if (N == 0) return NGP_OK;
     RM_LAUNCH_1D(k_packbits, N, as_stream(stream), grid, N, density_thresh, bitfield);
     return check_launch("packbits");
 }
@@ -777,9 +777,9 @@ extern "C" int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d,
                                        const float* noises, void* workspace, uint32_t flags, ngp_stream_t stream) {
     int rc = check_march_args("march_rays_train", C, H, max_steps);
     if (rc) return rc;
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(rays_o && rays_d && grid_in && nears && fars && xyzs && dirs && deltas && rays && counter && noises && workspace,
                 NGP_ERR_INVALID, "march_rays_train: NULL tensor");
-    if (N == 0) return NGP_OK;
     hipStream_t st = as_stream(stream);
     uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
     const dim3 grid(cdiv(N, MW_WAVES)), block(MW_WAVES * 64);
@@ -829,6 +829,7 @@ extern "C" int ngp_composite_rays_train_forward_ex(const float* sigmas, const fl
                                                    uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth, float* image,
                                                    int bg_mode, float bg_scalar, const float* bg, const float* nears, const float* fars,
                                                    float* image_out, float* depth_out, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(sigmas && rgbs && deltas && rays && weights_sum && depth && image, NGP_ERR_INVALID,
                 "composite_rays_train_forward: NULL tensor");
     Finish fin;
@@ -852,6 +853,7 @@ extern "C" int ngp_composite_rays_train_backward_ex(const float* grad_weights_su
                                                     const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                                     float T_thresh, float* grad_sigmas, float* grad_rgbs, int bg_mode, float bg_scalar,
                                                     const float* bg, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
     NGP_REQUIRE(grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs, NGP_ERR_INVALID,
                 "composite_rays_train_backward: NULL tensor");
     NGP_REQUIRE(grad_weights_sum || bg_mode != 0, NGP_ERR_INVALID, "composite_rays_train_backward: NULL tensor");
@@ -868,7 +870,7 @@ extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, 
                                                  const float* rgbs, const float* deltas, const int32_t* rays,
                                                  const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                                  float T_thresh, float* grad_sigmas, float* grad_rgbs, ngp_stream_t stream) {
-    NGP_REQUIRE(grad_weights_sum, NGP_ERR_INVALID, "composite_rays_train_backward: NULL tensor");
+    NGP_REQUIRE(grad_weights_sum || N == 0, NGP_ERR_INVALID, "composite_rays_train_backward: NULL tensor");
     return ngp_composite_rays_train_backward_ex(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
                                                 grad_sigmas, grad_rgbs, 0, 0.0f, nullptr, stream);
 }
@@ -880,9 +882,9 @@ extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
     (void)nears;  // read but unused by the reference kernel as well (raymarching.cu:741)
     int rc = check_march_args("march_rays", C, H, max_steps);
     if (rc) return rc;
+    if (n_alive == 0 || n_step == 0) return NGP_OK;
     NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises, NGP_ERR_INVALID,
                 "march_rays: NULL tensor");
-    if (n_alive == 0 || n_step == 0) return NGP_OK;
     RM_LAUNCH_1D(k_march_rays, n_alive, as_stream(stream), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
                  max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
     return check_launch("march_rays");
@@ -891,9 +893,9 @@ extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
 extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
                                   const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
                                   float* image, ngp_stream_t stream) {
+    if (n_alive == 0) return NGP_OK;
     NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, NGP_ERR_INVALID,
                 "composite_rays: NULL tensor");
-    if (n_alive == 0) return NGP_OK;
     RM_LAUNCH_1D(k_composite_rays, n_alive, as_stream(stream), n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
                  weights_sum, depth, image);
     return check_launch("composite_rays");

@@ -135,8 +135,8 @@ extern "C" int ngp_sh_encode_forward(const void* inputs, void* outputs, uint32_t
     NGP_REQUIRE(D == 3, NGP_ERR_INVALID, "sh_encode_forward: SH encoder only support input dim == 3 (got %u)", D);
     NGP_REQUIRE(C >= 1 && C <= 8, NGP_ERR_INVALID, "sh_encode_forward: SH encoder only supports degree in [1, 8] (got %u)", C);
     NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_ERR_INVALID, "sh_encode_forward: inputs must be float32 or float16");
-    NGP_REQUIRE(inputs && outputs, NGP_ERR_INVALID, "sh_encode_forward: NULL tensor");
     if (B == 0) return NGP_OK;
+    NGP_REQUIRE(inputs && outputs, NGP_ERR_INVALID, "sh_encode_forward: NULL tensor");
     return dtype == NGP_F16 ? dispatch_sh<half_t>(C, inputs, outputs, B, dy_dx, as_stream(stream))
                             : dispatch_sh<float>(C, inputs, outputs, B, dy_dx, as_stream(stream));
 }
@@ -147,8 +147,8 @@ extern "C" int ngp_sh_encode_backward(const void* grad, const void* inputs, uint
     NGP_REQUIRE(D == 3, NGP_ERR_INVALID, "sh_encode_backward: SH encoder only support input dim == 3 (got %u)", D);
     NGP_REQUIRE(C >= 1 && C <= 8, NGP_ERR_INVALID, "sh_encode_backward: SH encoder only supports degree in [1, 8] (got %u)", C);
     NGP_REQUIRE(dtype == NGP_F32 || dtype == NGP_F16, NGP_ERR_INVALID, "sh_encode_backward: grad must be float32 or float16");
-    NGP_REQUIRE(grad && dy_dx && grad_inputs, NGP_ERR_INVALID, "sh_encode_backward: NULL tensor");
     if (B == 0) return NGP_OK;
+    NGP_REQUIRE(grad && dy_dx && grad_inputs, NGP_ERR_INVALID, "sh_encode_backward: NULL tensor");
     hipStream_t st = as_stream(stream);
     if (dtype == NGP_F16)
         hipLaunchKernelGGL((k_sh_backward<half_t>), dim3(cdiv(B * 3, 256)), dim3(256), 0, st, (const half_t*)grad, B, C * C,

@@ -242,6 +242,13 @@ int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint
                             const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
                             const float* noises, void* workspace, uint32_t flags, ngp_stream_t stream);
 
+/* march_rays (inference) that zeroes every sample slot it does not fill: the unused tail of each ray's n_step slots and the rows
+ * between n_alive*n_step and zero_rows (>= n_alive*n_step), so the buffers need no memset; noises may be NULL (= no perturbation). */
+int ngp_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                      const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                      const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                      const float* noises, uint32_t zero_rows, ngp_stream_t stream);
+
 /* composite_rays_train with NeRFRenderer.run_cuda's epilogue fused (renderer.py:316-318):
  *   image_out = image + (1 - weights_sum) * bg,  depth_out = clamp(depth - nears, 0) / (fars - nears)
  * bg_mode 0: off (= the reference op), 1: scalar background bg_scalar, 2: per-ray background bg [N,3].

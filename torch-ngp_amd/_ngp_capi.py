@@ -49,6 +49,7 @@ _SIGNATURES = {
     'ngp_composite_rays_train_forward': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp],
     'ngp_composite_rays_train_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp],
     'ngp_march_rays': [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'ngp_march_rays_ex': [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     'ngp_composite_rays': [_u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_compact_rays': [_vp, _u32, _vp, _vp, _vp, _vp],
     'ngp_ffmlp_forward': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],

@@ -460,21 +460,31 @@ __global__ __launch_bounds__(256) void k_march_train_zero_tail(float* __restrict
 }
 
 // raymarching.cu:701-805
+// zero_rows > 0: the kernel also zeroes every sample slot it does not fill (the unused tail of each ray's n_step slots and the
+// rows between n_alive * n_step and zero_rows), so the caller may pass uninitialised buffers (extension; the reference contract,
+// zero_rows == 0, expects pre-zeroed buffers -- raymarching.py:334-336).
 __global__ __launch_bounds__(RM_THREADS) void k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
                                                            const float* __restrict__ rays_t, const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d, float bound, float dt_gamma,
                                                            uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
                                                            const float* __restrict__ fars, float* __restrict__ xyzs,
                                                            float* __restrict__ dirs, float* __restrict__ deltas,
-                                                           const float* __restrict__ noises) {
+                                                           const float* __restrict__ noises, uint32_t zero_rows) {
     const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+    if (zero_rows > 0) {  // padding rows behind the last ray's slots: at most `align` of them, spread over the first lanes
+        for (uint32_t row = n_alive * n_step + n; row < zero_rows; row += gridDim.x * RM_THREADS) {
+            xyzs[(size_t)row * 3] = 0.0f; xyzs[(size_t)row * 3 + 1] = 0.0f; xyzs[(size_t)row * 3 + 2] = 0.0f;
+            dirs[(size_t)row * 3] = 0.0f; dirs[(size_t)row * 3 + 1] = 0.0f; dirs[(size_t)row * 3 + 2] = 0.0f;
+            deltas[(size_t)row * 2] = 0.0f; deltas[(size_t)row * 2 + 1] = 0.0f;
+        }
+    }
     if (n >= n_alive) return;
     const uint32_t index = (uint32_t)rays_alive[n];
     const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
     const Ray r = load_ray(rays_o, rays_d, index);
     const float far = fars[index];
     float t = rays_t[index];
-    t = __builtin_fmaf(step_dt(p, t), noises[n], t);
+    t = __builtin_fmaf(step_dt(p, t), noises ? noises[n] : 0.0f, t);
     float last_t = t;
     float* xo = xyzs + (size_t)n * n_step * 3;
     float* dd = dirs + (size_t)n * n_step * 3;
@@ -492,6 +502,14 @@ __global__ __launch_bounds__(RM_THREADS) void k_march_rays(uint32_t n_alive, uin
             step++;
         } else {
             t = skip_to(p, t, tt, far);
+        }
+    }
+    if (zero_rows > 0) {
+        for (; step < n_step; step++) {
+            xo[0] = 0.0f; xo[1] = 0.0f; xo[2] = 0.0f;
+            dd[0] = 0.0f; dd[1] = 0.0f; dd[2] = 0.0f;
+            de[0] = 0.0f; de[1] = 0.0f;
+            xo += 3; dd += 3; de += 2;
         }
     }
 }
@@ -875,19 +893,31 @@ extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, 
                                                 grad_sigmas, grad_rgbs, 0, 0.0f, nullptr, stream);
 }
 
+extern "C" int ngp_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
+                                 const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                                 const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                 const float* noises, uint32_t zero_rows, ngp_stream_t stream) {
+    (void)nears;  // read but unused by the reference kernel as well (raymarching.cu:741)
+    int rc = check_march_args("march_rays", C, H, max_steps);
+    if (rc) return rc;
+    if ((n_alive == 0 || n_step == 0) && zero_rows == 0) return NGP_OK;
+    NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && (noises || zero_rows), NGP_ERR_INVALID,
+                "march_rays: NULL tensor");
+    NGP_REQUIRE(zero_rows == 0 || zero_rows >= n_alive * n_step, NGP_ERR_INVALID, "march_rays: zero_rows is smaller than n_alive * n_step");
+    const uint32_t lanes = n_alive > 0 ? n_alive : 1u;
+    RM_LAUNCH_1D(k_march_rays, lanes, as_stream(stream), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
+                 max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, zero_rows);
+    return check_launch("march_rays");
+}
+
 extern "C" int ngp_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,
                               const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                               const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                               const float* noises, ngp_stream_t stream) {
-    (void)nears;  // read but unused by the reference kernel as well (raymarching.cu:741)
-    int rc = check_march_args("march_rays", C, H, max_steps);
-    if (rc) return rc;
     if (n_alive == 0 || n_step == 0) return NGP_OK;
-    NGP_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises, NGP_ERR_INVALID,
-                "march_rays: NULL tensor");
-    RM_LAUNCH_1D(k_march_rays, n_alive, as_stream(stream), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
-                 max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
-    return check_launch("march_rays");
+    NGP_REQUIRE(noises, NGP_ERR_INVALID, "march_rays: NULL tensor");
+    return ngp_march_rays_ex(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars, xyzs,
+                             dirs, deltas, noises, 0u, stream);
 }
 
 extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,

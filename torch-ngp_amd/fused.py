@@ -133,11 +133,15 @@ def _optimizer_buffers(params):
 
 def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
     cfg = network_cfg(encoder, sigma_net, color_net, bound, training)
-    bufs = _optimizer_buffers((encoder.embeddings, sigma_net.weights, color_net.weights)) if training else None
+    params = (encoder.embeddings, sigma_net.weights, color_net.weights)
+    bufs = _optimizer_buffers(params) if training else None
     if bufs is None and not training:
-        sh = [getattr(p, '_ngp_fp16', None) for p in (encoder.embeddings, sigma_net.weights, color_net.weights)]
+        # inference: fp16 copies pinned for the duration of a render call (pinned_half_weights) or the optimizer's shadows
+        sh = [getattr(p, '_ngp_fp16_pin', None) for p in params]
+        if any(t is None for t in sh):
+            sh = [getattr(p, '_ngp_fp16', None) for p in params]
         if all(t is not None for t in sh):
-            bufs = tuple(sh) + (None, None, None)  # inference: shadows only
+            bufs = tuple(sh) + (None, None, None)
     return _fused_ngp.apply(x, d, encoder.embeddings, sigma_net.weights, color_net.weights, encoder.offsets, cfg, bufs)
 
 
@@ -263,3 +267,25 @@ def fused_render_train(model, rays_o, rays_d, box, counter, capacity, bg_color, 
     bufs = _optimizer_buffers((model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights))
     return _fused_render_train.apply(rays_o, rays_d, model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights, bg_t,
                                      model.encoder.offsets, model.density_bitfield, box, counter, cfg, rcfg, bufs)
+
+
+class pinned_half_weights:
+    """`with pinned_half_weights(model):` -- cast the three parameter tensors to fp16 ONCE for a block of inference calls (the eval loop
+    of NeRFRenderer.run_cuda evaluates the network ~100 times per frame; the reference path re-casts the 47 MiB table every time,
+    grid.py:43-44).  Only valid while the parameters do not change, i.e. inside one no-grad render call."""
+
+    def __init__(self, model):
+        enc, sn, cn = getattr(model, 'encoder', None), getattr(model, 'sigma_net', None), getattr(model, 'color_net', None)
+        self.params = [getattr(enc, 'embeddings', None), getattr(sn, 'weights', None), getattr(cn, 'weights', None)]
+
+    def __enter__(self):
+        if all(p is not None and p.is_cuda for p in self.params) and not torch.is_grad_enabled():
+            for p in self.params:
+                p._ngp_fp16_pin = p.detach().to(torch.half)
+        return self
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            if p is not None and hasattr(p, '_ngp_fp16_pin'):
+                del p._ngp_fp16_pin
+        return False

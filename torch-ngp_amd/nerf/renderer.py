@@ -155,20 +155,22 @@ class NeRFRenderer(nn.Module):
             rays_alive = torch.arange(n_rays, dtype=torch.int32, device=dev)
             rays_t = nears.clone()
             step = 0
-            while step < max_steps:
-                n_alive = rays_alive.shape[0]
-                if n_alive <= 0:
-                    break
-                n_step = max(min(n_rays // n_alive, 8), 1)  # more samples per ray and launch as rays die
-                xyzs, dirs, deltas = raymarching.march_rays(
-                    n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                    self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
-                sigmas, rgbs = self(xyzs, dirs)
-                sigmas = self.density_scale * sigmas
-                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
-                                           T_thresh)
-                rays_alive = rays_alive[rays_alive >= 0]
-                step += n_step
+            from fused import pinned_half_weights
+            with pinned_half_weights(self):  # one fp16 cast of the parameters per frame instead of one per loop iteration
+                while step < max_steps:
+                    n_alive = rays_alive.shape[0]
+                    if n_alive <= 0:
+                        break
+                    n_step = max(min(n_rays // n_alive, 8), 1)  # more samples per ray and launch as rays die
+                    xyzs, dirs, deltas = raymarching.march_rays(
+                        n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                        self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
+                    sigmas, rgbs = self(xyzs, dirs)
+                    sigmas = self.density_scale * sigmas
+                    raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
+                                               T_thresh)
+                    rays_alive = rays_alive[rays_alive >= 0]
+                    step += n_step
             image, depth = self._finish(image, depth, weights_sum, bg_color, nears, fars, lead)
 
         results['depth'] = depth

@@ -98,6 +98,21 @@ def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_ga
                                        capi.ptr(xyzs), capi.ptr(dirs), capi.ptr(deltas), capi.ptr(noises), capi.stream()))
 
 
+def march_rays_ex(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars, xyzs, dirs,
+                  deltas, noises, zero_rows):
+    """extension: as march_rays, but the kernel zeroes the slots it does not fill (buffers may be torch.empty) and noises may be None"""
+    for t, n in ((rays_t, 'rays_t'), (rays_o, 'rays_o'), (rays_d, 'rays_d'), (nears, 'nears'), (fars, 'fars'), (xyzs, 'xyzs'),
+                 (dirs, 'dirs'), (deltas, 'deltas')):
+        _f32(t, n)
+    if noises is not None:
+        _f32(noises, 'noises')
+    _i32(rays_alive, 'rays_alive')
+    capi.dense(grid, 'grid')
+    capi.check(capi.lib.ngp_march_rays_ex(n_alive, n_step, capi.ptr(rays_alive), capi.ptr(rays_t), capi.ptr(rays_o), capi.ptr(rays_d),
+                                          float(bound), float(dt_gamma), max_steps, C, H, capi.ptr(grid), capi.ptr(nears), capi.ptr(fars),
+                                          capi.ptr(xyzs), capi.ptr(dirs), capi.ptr(deltas), capi.ptr(noises), zero_rows, capi.stream()))
+
+
 def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
     for t, n in ((rays_t, 'rays_t'), (sigmas, 'sigmas'), (rgbs, 'rgbs'), (deltas, 'deltas'), (weights_sum, 'weights_sum'),
                  (depth, 'depth'), (image, 'image')):
@@ -118,7 +133,8 @@ def compact_rays(rays_alive, n_alive, out_alive, out_count):
 _backend = types.SimpleNamespace(
     near_far_from_aabb=near_far_from_aabb, sph_from_ray=sph_from_ray, morton3D=morton3D, morton3D_invert=morton3D_invert,
     packbits=packbits, march_rays_train=march_rays_train, composite_rays_train_forward=composite_rays_train_forward,
-    composite_rays_train_backward=composite_rays_train_backward, march_rays=march_rays, composite_rays=composite_rays,
+    composite_rays_train_backward=composite_rays_train_backward, march_rays=march_rays, march_rays_ex=march_rays_ex,
+    composite_rays=composite_rays,
     compact_rays=compact_rays)
 
 __all__ = ['_backend']

@@ -190,12 +190,13 @@ class _march_rays(Function):
         rays_o, rays_d = _rays(rays_o), _rays(rays_d)
         dev = rays_o.device
         slots = _round_up_strict(n_alive * n_step, align)
-        xyzs = torch.zeros(slots, 3, dtype=torch.float32, device=dev)
-        dirs = torch.zeros(slots, 3, dtype=torch.float32, device=dev)
-        deltas = torch.zeros(slots, 2, dtype=torch.float32, device=dev)
-        noises = torch.rand(n_alive, dtype=torch.float32, device=dev) if perturb else torch.zeros(n_alive, dtype=torch.float32, device=dev)
-        _backend.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
-                            density_bitfield.contiguous(), near, far, xyzs, dirs, deltas, noises)
+        # the kernel zeroes every slot it does not fill (ngp_march_rays_ex): no memsets, no noise tensor unless perturbing
+        xyzs = torch.empty(slots, 3, dtype=torch.float32, device=dev)
+        dirs = torch.empty(slots, 3, dtype=torch.float32, device=dev)
+        deltas = torch.empty(slots, 2, dtype=torch.float32, device=dev)
+        noises = torch.rand(n_alive, dtype=torch.float32, device=dev) if perturb else None
+        _backend.march_rays_ex(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
+                               density_bitfield.contiguous(), near, far, xyzs, dirs, deltas, noises, slots)
         return xyzs, dirs, deltas
 
 

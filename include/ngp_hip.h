@@ -264,6 +264,17 @@ int ngp_composite_rays_train_backward_ex(const float* grad_weights_sum, const fl
                                          const float* bg, ngp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * freqencoder       (reference: freqencoder/src/freqencoder.h:6-10, bindings.cpp:5-8) -- SURVEY.md 8(f).3, fp32 only.
+ * outputs [B,C], C = D + 2*D*deg: x | per frequency f: sin(2^f x_d) for all d, then cos(2^f x_d) for all d.
+ * --------------------------------------------------------------------------------------------- */
+/* replaces freq_encode_forward (freqencoder.cu:97-111) */
+int ngp_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C, float* outputs,
+                            ngp_stream_t stream);
+/* replaces freq_encode_backward (freqencoder.cu:114-131): grad [B,C], outputs [B,C] (saved), grad_inputs [B,D] overwritten */
+int ngp_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg, uint32_t C,
+                             float* grad_inputs, ngp_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Fused optimizer + loss-scaling step -- EXTENSION: replaces torch.optim.Adam + GradScaler.step/update
  * (main_nerf.py:132, nerf/utils.py:557-560) for up to 8 tensors per call.  grads[k] holds the loss-scaled gradient, fp16 when
  * grad_is_half[k] (the buffer grid_encode_backward / ffmlp_backward wrote) else fp32, and is ZEROED by the call; params_fp16[k]

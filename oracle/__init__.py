@@ -365,3 +365,32 @@ def trunc_exp_forward(x):
 def trunc_exp_backward(g, x):
     """activation.py:13-17"""
     return np.asarray(g, np.float32) * np.exp(np.clip(np.asarray(x, np.float32), -15, 15))
+
+
+# ------------------------------------------------------------------------------------------------
+# frequency encoder      (freqencoder/src/freqencoder.cu:30-94; pure-torch statement in encoding.py:5-42)
+# ------------------------------------------------------------------------------------------------
+def freq_forward(inputs, degree):
+    """[B,D] -> [B, D + 2*D*degree]: x | per frequency f: sin(2^f x), then cos(2^f x) evaluated as sin(. + pi/2) on the fp32
+    argument, as the kernel does (freqencoder.cu:52-58)."""
+    x = np.asarray(inputs, dtype=np.float32)
+    cols = [x.astype(np.float64)]
+    half_pi = np.float32(np.float32(3.141592653589793) / np.float32(2))
+    for f in range(degree):
+        arg = (x * np.float32(2.0 ** f)).astype(np.float32)          # scalbnf: exact
+        cols.append(np.sin(arg.astype(np.float64)))
+        cols.append(np.sin((arg + half_pi).astype(np.float32).astype(np.float64)))
+    return np.concatenate(cols, axis=1)
+
+
+def freq_backward(grad, outputs, input_dim, degree):
+    """grad, outputs [B,C] -> grad_inputs [B,D] = g_x + sum_f 2^f (g_sin * cos - g_cos * sin) from the stored outputs (freqencoder.cu:64-94)"""
+    g = np.asarray(grad, dtype=np.float64)
+    o = np.asarray(outputs, dtype=np.float64)
+    D = input_dim
+    r = g[:, :D].copy()
+    for f in range(degree):
+        s = slice(D + 2 * f * D, D + 2 * f * D + D)
+        c = slice(D + 2 * f * D + D, D + 2 * f * D + 2 * D)
+        r += (2.0 ** f) * (g[:, s] * o[:, c] - g[:, c] * o[:, s])
+    return r

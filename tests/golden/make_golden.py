@@ -10,6 +10,7 @@ What can be executed from the reference without CUDA (everything else on the hot
   4. activation.py:5-17               trunc_exp forward/backward                          -> trunc_exp_ref.npz
   5. nerf/renderer.py:125-253         NeRFRenderer.run  (cumprod compositing; near/far stubbed
                                       by the oracle because the reference's is CUDA-only) -> composite_ref.npz
+  6. encoding.py:5-42                 FreqEncoder (pure torch sin/cos positional encoding)    -> freq_ref.npz
 Nothing is copied from the reference into this repository: the classes are exec'd from the files
 where they lie.
 
@@ -180,10 +181,37 @@ def gen_composite():
     print('composite_ref.npz')
 
 
+def gen_freq():
+    # encoding.py:5-42 -- the reference's pure-torch FreqEncoder (the algorithm freqencoder.cu:30-94 accelerates): float64 run with
+    # autograd gradients, for D = 3 (deg 4 and 10) and D = 2 (deg 6)
+    code = _src('encoding.py', 'class FreqEncoder', '\ndef get_encoder')
+    ns = {'torch': torch, 'nn': torch.nn}
+    exec(code, ns)
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    for name, (dim, deg) in {'d3_deg4': (3, 4), 'd3_deg10': (3, 10), 'd2_deg6': (2, 6)}.items():
+        enc = ns['FreqEncoder'](input_dim=dim, max_freq_log2=deg - 1, N_freqs=deg, log_sampling=True)
+        x = ((torch.rand(300, dim, generator=g) * 2 - 1) * 1.5).float().double().requires_grad_(True)
+        y = enc(x)
+        gy = torch.rand(y.shape, generator=g, dtype=torch.float64) - 0.5
+        y.backward(gy)
+        assert y.shape[1] == dim + 2 * dim * deg
+        out[name + '_x'] = x.detach().numpy().astype(np.float32)
+        out[name + '_y'] = y.detach().numpy()
+        out[name + '_gy'] = gy.numpy()
+        out[name + '_gx'] = x.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'freq_ref.npz'), **out)
+    print('freq_ref.npz', sorted(out))
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), 'run in the build container (needs /root/reference)'
+    if len(sys.argv) > 1 and sys.argv[1] == 'freq':
+        gen_freq()
+        sys.exit(0)
     gen_sh()
     gen_mlp()
     gen_offsets()
     gen_trunc_exp()
     gen_composite()
+    gen_freq()

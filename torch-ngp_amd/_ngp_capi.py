@@ -40,6 +40,8 @@ _SIGNATURES = {
     'ngp_grid_level_table': [_u32, _f32, _u32, _vp, _vp],
     'ngp_sh_encode_forward': [_vp, _vp, _u32, _u32, _u32, _vp, _i32, _vp],
     'ngp_sh_encode_backward': [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _i32, _vp],
+    'ngp_freq_encode_forward': [_vp, _u32, _u32, _u32, _u32, _vp, _vp],
+    'ngp_freq_encode_backward': [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp],
     'ngp_near_far_from_aabb': [_vp, _vp, _vp, _u32, _f32, _vp, _vp, _vp],
     'ngp_sph_from_ray': [_vp, _vp, _f32, _u32, _vp, _vp],
     'ngp_morton3D': [_vp, _u32, _vp, _vp],

@@ -1,0 +1,76 @@
+"""Checkpoint compatibility with the reference Trainer (nerf/utils.py:1015-1137).
+
+File layout written by `Trainer.save_checkpoint`:  {'epoch', 'global_step', 'stats', 'model': state_dict,
+['mean_count', 'mean_density' when cuda_ray], ['optimizer', 'lr_scheduler', 'scaler', 'ema' when full]}; a "best" checkpoint drops
+`density_grid` from the model state; a bare state_dict is accepted as well.  The mirrored modules use the reference's parameter and
+buffer names and shapes (encoder.embeddings / encoder.offsets, sigma_net.weights, color_net.weights, aabb_*, density_grid,
+density_bitfield, step_counter), so the model state loads key for key; this module adds the Trainer-side bookkeeping and the
+conversion between `torch.optim.Adam` + `GradScaler` state and `optim.NGPAdam`."""
+import torch
+
+
+def save_checkpoint(path, model, epoch=0, global_step=0, stats=None, optimizer=None, scaler=None, lr_scheduler=None, ema=None, full=False,
+                    best=False):
+    state = {'epoch': epoch, 'global_step': global_step, 'stats': stats if stats is not None else {}}
+    if getattr(model, 'cuda_ray', False):
+        state['mean_count'] = model.mean_count
+        state['mean_density'] = model.mean_density
+    if full:
+        if optimizer is not None:
+            state['optimizer'] = optimizer.state_dict()
+        if lr_scheduler is not None:
+            state['lr_scheduler'] = lr_scheduler.state_dict()
+        if scaler is not None:
+            state['scaler'] = scaler.state_dict()
+        if ema is not None:
+            state['ema'] = ema.state_dict()
+    sd = model.state_dict()
+    if best and 'density_grid' in sd:  # nerf/utils.py:1066-1068
+        sd = {k: v for k, v in sd.items() if k != 'density_grid'}
+    state['model'] = sd
+    torch.save(state, path)
+    return state
+
+
+def load_checkpoint(checkpoint, model, optimizer=None, scaler=None, lr_scheduler=None, ema=None, model_only=False, map_location=None):
+    """`checkpoint`: path or already-loaded dict.  Returns {'missing_keys', 'unexpected_keys', 'epoch', 'global_step', 'stats'}."""
+    ck = torch.load(checkpoint, map_location=map_location, weights_only=False) if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, 'read') \
+        else checkpoint
+    info = {'missing_keys': [], 'unexpected_keys': [], 'epoch': None, 'global_step': None, 'stats': None}
+    if 'model' not in ck:  # a bare state_dict (nerf/utils.py:1089-1092)
+        model.load_state_dict(ck)
+        _after_model_load(model, optimizer)
+        return info
+    res = model.load_state_dict(ck['model'], strict=False)
+    info['missing_keys'], info['unexpected_keys'] = list(res.missing_keys), list(res.unexpected_keys)
+    if ema is not None and 'ema' in ck:
+        ema.load_state_dict(ck['ema'])
+    if getattr(model, 'cuda_ray', False):
+        if 'mean_count' in ck:
+            model.mean_count = ck['mean_count']
+        if 'mean_density' in ck:
+            model.mean_density = ck['mean_density']
+    _after_model_load(model, optimizer)
+    if model_only:
+        return info
+    info['stats'], info['epoch'], info['global_step'] = ck.get('stats'), ck.get('epoch'), ck.get('global_step')
+    if optimizer is not None and 'optimizer' in ck:
+        _load_optimizer(optimizer, ck['optimizer'], ck.get('scaler'))
+    if lr_scheduler is not None and 'lr_scheduler' in ck:
+        lr_scheduler.load_state_dict(ck['lr_scheduler'])
+    if scaler is not None and 'scaler' in ck:
+        scaler.load_state_dict(ck['scaler'])
+    return info
+
+
+def _after_model_load(model, optimizer):
+    # the fp16 shadow copies an NGPAdam keeps next to the parameters must follow a load
+    if optimizer is not None and hasattr(optimizer, 'sync_shadows'):
+        optimizer.sync_shadows()
+
+
+def _load_optimizer(optimizer, sd, scaler_sd):
+    if hasattr(optimizer, 'load_torch_adam_state') and 'param_groups' in sd:  # a torch.optim.Adam state into optim.NGPAdam
+        optimizer.load_torch_adam_state(sd, scaler_sd)
+    else:
+        optimizer.load_state_dict(sd)

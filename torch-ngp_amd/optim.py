@@ -150,6 +150,31 @@ class NGPAdam:
         self._keep = keep
 
     # -- checkpointing -----------------------------------------------------------------------------
+    def load_torch_adam_state(self, adam_sd, scaler_sd=None):
+        """resume from a reference checkpoint: `torch.optim.Adam.state_dict()` (per-parameter exp_avg / exp_avg_sq / step, in
+        param_groups order) and, optionally, `GradScaler.state_dict()` ('scale', '_growth_tracker')"""
+        flat = [p for g in self.param_groups for p in g['params']]
+        ids = [i for g in adam_sd['param_groups'] for i in g['params']]
+        if len(ids) != len(flat):
+            raise RuntimeError(f'NGPAdam: checkpoint has {len(ids)} parameters, the optimizer {len(flat)}')
+        step = 0.0
+        for p, i in zip(flat, ids):
+            st = adam_sd['state'].get(i)
+            if st is None:
+                continue
+            self.state[p]['exp_avg'].copy_(st['exp_avg'])
+            self.state[p]['exp_avg_sq'].copy_(st['exp_avg_sq'])
+            step = max(step, float(st['step']))
+        self.scalars[3:4].fill_(step)
+        for g, tg in zip(self.param_groups, adam_sd['param_groups']):
+            g['lr'] = float(tg.get('initial_lr', tg['lr']))
+            # a scheduler's current factor is restored by the caller through set_lr_scale(tg['lr'] / tg['initial_lr'])
+        if scaler_sd:
+            self.scalars[0:1].fill_(float(scaler_sd.get('scale', self.get_scale())))
+            self.scalars[1:2].fill_(float(scaler_sd.get('_growth_tracker', 0)))
+        self.sync_shadows()
+
+
     def state_dict(self):
         flat = [p for g in self.param_groups for p in g['params']]
         return {'scalars': self.scalars.clone(), 'exp_avg': [self.state[p]['exp_avg'].clone() for p in flat],

@@ -329,7 +329,8 @@ def main():
                                    'FFMLP 64x2 / 64x3), bound=1, 128^3 occupancy grid, dt_gamma=0, max_steps=1024',
                        'rays_per_gpu_per_step': args.rays, 'samples_per_step_per_gpu': round(samples / args.steps / world, 1),
                        'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}',
-                       'execution': 'eager' if args.no_graph else f'hip-graph replay ({stepper.n_captures} capture(s))',
+                       'execution': 'eager' if args.no_graph else (f'hip-graph replay ({stepper.n_captures} capture(s))' if stepper.capture_error is None
+                                                                   else f'eager (graph capture failed: {stepper.capture_error[:120]})'),
                        'fused_pipeline': bool(model.fused), 'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
                        'final_loss': final_loss},
             'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'render_800x800_ms': render,

@@ -51,6 +51,7 @@ class GraphedTrainStep:
         self.graphs = None
         self.loss = None
         self.n_captures = 0
+        self.capture_error = None
         self.capacity = None  # sample capacity of the step that ran last (None while eager/worst-case)
 
     # ------------------------------------------------------------------------------------------
@@ -140,9 +141,21 @@ class GraphedTrainStep:
             loss = self._eager(rays_o, rays_d, target)
             self.global_step += 1
             return loss
+        if self.capture_error is not None:  # an earlier capture failed: stay on the eager path
+            loss = self._eager(rays_o, rays_d, target)
+            self.global_step += 1
+            return loss
         if self.graphs is None or cap != self.captured_capacity:
             self.captured_capacity = cap
-            self._capture()
+            try:
+                self._capture()
+            except Exception as e:  # noqa: BLE001 -- keep training eagerly; the caller can inspect .capture_error
+                self.capture_error = repr(e)
+                self.graphs = None
+                torch.cuda.synchronize()
+                loss = self._eager(rays_o, rays_d, target)
+                self.global_step += 1
+                return loss
         self.rays_o.copy_(rays_o.view_as(self.rays_o), non_blocking=True)
         self.rays_d.copy_(rays_d.view_as(self.rays_d), non_blocking=True)
         self.target.copy_(target, non_blocking=True)

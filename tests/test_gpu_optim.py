@@ -95,3 +95,29 @@ def test_training_loop_with_fused_optimizer_and_graph():
     assert model.encoder.embeddings.grad is None                      # gradients were deposited, not returned to autograd
     assert torch.equal(model.encoder.embeddings._ngp_fp16, model.encoder.embeddings.detach().half())
     assert float(opt.scalars[3].item()) == 48.0
+
+
+def test_shadow_copies_follow_external_parameter_writes():
+    """a load_state_dict / manual in-place write to a parameter managed by NGPAdam must not leave the fused path on stale fp16 weights"""
+    import raymarching
+    import synthetic_scene as sc
+    from nerf.network_ff import NeRFNetwork
+    from optim import NGPAdam
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    model = NeRFNetwork(bound=1, cuda_ray=True).to(dev)
+    opt = NGPAdam(model.get_params(1e-2))
+    x = torch.rand(256, 3, device=dev) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(256, 3, device=dev), dim=-1)
+    model.eval()
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+        s0, _ = model(x, d)
+        with torch.no_grad():
+            model.encoder.embeddings.uniform_(-0.5, 0.5)          # external in-place write (bumps the version counter)
+        s1, _ = model(x, d)
+        model.fused = False
+        s_ref, _ = model(x, d)
+    assert not torch.allclose(s0, s1)
+    np.testing.assert_allclose(s1.float().cpu().numpy(), s_ref.float().cpu().numpy(), rtol=1e-5)
+    assert torch.equal(model.encoder.embeddings._ngp_fp16, model.encoder.embeddings.detach().half())
+    del opt

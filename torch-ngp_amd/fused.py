@@ -128,7 +128,18 @@ def _optimizer_buffers(params):
     gr = [getattr(p, '_ngp_grad16', None) for p in params]
     if any(t is None for t in sh + gr):
         return None
+    _resync_stale_shadows(params)
     return tuple(sh) + tuple(gr)
+
+
+def _resync_stale_shadows(params):
+    """NGPAdam updates parameters and fp16 shadows together through raw pointers (no autograd version bump); any OTHER in-place write
+    to a parameter (load_state_dict, manual init) bumps `p._version` -- refresh the shadow then, instead of silently using stale weights"""
+    for p in params:
+        if getattr(p, '_ngp_fp16', None) is not None and getattr(p, '_ngp_version', None) != p._version:
+            with torch.no_grad():
+                p._ngp_fp16.copy_(p.detach())
+            p._ngp_version = p._version
 
 
 def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
@@ -139,6 +150,7 @@ def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
         # inference: fp16 copies pinned for the duration of a render call (pinned_half_weights) or the optimizer's shadows
         sh = [getattr(p, '_ngp_fp16_pin', None) for p in params]
         if any(t is None for t in sh):
+            _resync_stale_shadows(params)
             sh = [getattr(p, '_ngp_fp16', None) for p in params]
         if all(t is not None for t in sh):
             bufs = tuple(sh) + (None, None, None)

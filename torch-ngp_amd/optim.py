@@ -64,7 +64,7 @@ class NGPAdam:
             if deposit:
                 st['fp16'] = p.detach().to(torch.half)
                 st['grad16'] = self.flat_grad16[off:off + p.numel()].view_as(p)
-                p._ngp_fp16, p._ngp_grad16 = st['fp16'], st['grad16']
+                p._ngp_fp16, p._ngp_grad16, p._ngp_version = st['fp16'], st['grad16'], p._version
             self.state[p] = st
         # device-resident scalars: loss scale, growth tracker, found_inf, Adam step count, lr multiplier (schedulers write this one)
         self.scalars = torch.tensor([init_scale, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
@@ -97,6 +97,7 @@ class NGPAdam:
         for p, st in self.state.items():
             if 'fp16' in st:
                 st['fp16'].copy_(p.detach())
+                p._ngp_version = p._version
 
     @torch.no_grad()
     def all_reduce(self):

@@ -281,6 +281,36 @@ def fused_render_train(model, rays_o, rays_d, box, counter, capacity, bg_color, 
                                      model.encoder.offsets, model.density_bitfield, box, counter, cfg, rcfg, bufs)
 
 
+@torch.no_grad()
+def fused_density(x, encoder, sigma_net, bound):
+    """inference-only `NeRFNetwork.density(x)`: hash grid (input map in-kernel, level-major output consumed in place) -> sigma MLP
+    (inference kernel: no activation stores) -> h [M,16] fp16; returns (sigma = exp(h0) fp32 [M], geo_feat = h[:,1:] fp16 view).
+    The reference runs the TRAINING MLP kernel here when the module is in train mode (update_extra_state, ffmlp.py:161) -- wasteful,
+    semantics identical."""
+    M = x.shape[0]
+    dev = x.device
+    st = capi.stream()
+    emb = encoder.embeddings
+    w = sigma_net.weights
+    _resync_stale_shadows((emb, w))
+    emb16 = getattr(emb, '_ngp_fp16_pin', None)
+    emb16 = emb16 if emb16 is not None else getattr(emb, '_ngp_fp16', None)
+    emb16 = emb16 if emb16 is not None else emb.detach().to(torch.half)
+    w16 = getattr(w, '_ngp_fp16_pin', None)
+    w16 = w16 if w16 is not None else getattr(w, '_ngp_fp16', None)
+    w16 = w16 if w16 is not None else w.detach().to(torch.half)
+    L = int(encoder.num_levels)
+    enc = torch.empty(L, M, 2, device=dev, dtype=torch.half)
+    _check(capi.lib.ngp_grid_encode_forward_ex(x.contiguous().data_ptr(), emb16.data_ptr(), encoder.offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L,
+                                                float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution), None,
+                                                int(encoder.gridtype_id), int(bool(encoder.align_corners)), int(encoder.interp_id),
+                                                capi.NGP_F16, float(bound), st))
+    h16 = torch.empty(M, 16, device=dev, dtype=torch.half)
+    _check(capi.lib.ngp_ffmlp_inference_ex(enc.data_ptr(), w16.data_ptr(), M, 32, 16, 64, int(sigma_net.num_layers), 0, 6, None, h16.data_ptr(),
+                                           _PLANAR_IN, st))
+    return torch.exp(h16[:, 0].float()), h16[:, 1:]
+
+
 class pinned_half_weights:
     """`with pinned_half_weights(model):` -- cast the three parameter tensors to fp16 ONCE for a block of inference calls (the eval loop
     of NeRFRenderer.run_cuda evaluates the network ~100 times per frame; the reference path re-casts the 47 MiB table every time,

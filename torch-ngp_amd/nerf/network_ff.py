@@ -7,7 +7,7 @@ import torch
 from activation import trunc_exp
 from encoding import get_encoder
 from ffmlp import FFMLP
-from fused import fused_ngp
+from fused import fused_density, fused_ngp
 from gridencoder import GridEncoder
 from shencoder import SHEncoder
 
@@ -60,6 +60,9 @@ class NeRFNetwork(NeRFRenderer):
         return sigma, self._color_head(d, geo_feat)
 
     def density(self, x):
+        if not torch.is_grad_enabled() and x.dim() == 2 and self._fused_ok(x, x):
+            sigma, geo_feat = fused_density(x, self.encoder, self.sigma_net, self.bound)
+            return {'sigma': sigma, 'geo_feat': geo_feat}
         sigma, geo_feat = self._density_head(x)
         return {'sigma': sigma, 'geo_feat': geo_feat}
 

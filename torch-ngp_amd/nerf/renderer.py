@@ -252,8 +252,10 @@ class NeRFRenderer(nn.Module):
                 coords = torch.cat([rand_coords, occ_coords], 0)
                 fresh[cas, cell_ids] = self._query_sigma(self._cascade_points(coords, cas))
 
+        # EMA-max update of the cells that are valid on both sides (renderer.py:521-522), written as a select so that no boolean-index
+        # gather/scatter (and its host synchronisation) is needed: identical values
         both = (self.density_grid >= 0) & (fresh >= 0)
-        self.density_grid[both] = torch.maximum(self.density_grid[both] * decay, fresh[both])
+        self.density_grid.copy_(torch.where(both, torch.maximum(self.density_grid * decay, fresh), self.density_grid))
         self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
         self.iter_density += 1
         self.density_bitfield = raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh),

@@ -419,7 +419,6 @@ __device__ __forceinline__ void scatter_add(T* dst, const float (&g)[C], float w
 }
 
 constexpr int BWD_THREADS = 256;
-constexpr int BWD_PTS_PER_WAVE = 32;
 
 // ------------------------------------------------------------------------------------------------
 // backward: scatter-add of w * grad into grad_embeddings               (gridencoder.cu:248-340)
@@ -429,8 +428,8 @@ constexpr int BWD_PTS_PER_WAVE = 32;
 // the scope bits and however small the table is; lanes of ONE instruction that fall into one line ride along
 // for free (16 lanes on a line: 320 G atomics/s).  So the kernel is organised to minimise (instruction, line)
 // pairs, not lane operations:
-//   * a wavefront covers 32 consecutive points; lanes 2p and 2p+1 handle the two corners of a point that differ
-//     in the FIRST coordinate.  Those two entries are neighbours in memory -- on dense levels by construction
+//   * the lanes of a point (2 for fp16 C=2, 4 for fp32 C=2, ... up to 16) cover both corners that differ in the FIRST
+//     coordinate and all their channels.  Those two entries are neighbours in memory -- on dense levels by construction
 //     and on hashed levels too, because the first hash prime is 1: (x ^ A) and ((x+1) ^ A) share an aligned
 //     16-entry block whenever x and x+1 do -- so every atomic instruction touches at most ~32 lines for 64
 //     lane operations instead of 64 (one corner per instruction, one point per lane);
@@ -447,6 +446,13 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
                                                                uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
                                                                bool align_corners, uint32_t interp, uint32_t points_per_block, InputMap im) {
     constexpr int NJ = 1 << (D - 1);  // corners per lane (all combinations of the coordinates 1..D-1)
+    // Lane layout inside a point: [first-coordinate corner xb][channel group cl].  A lane carries CPL channels of one corner
+    // (2 with the packed fp16 atomic, else 1), so the LPP lanes of a point cover 2 * C consecutive table values = one contiguous
+    // span of 8..64 bytes: ONE atomic request per (point, remaining-corner j) whatever the dtype and C.
+    constexpr int CPL = (sizeof(T) == 2 && C % 2 == 0) ? 2 : 1;
+    constexpr int CL = C / CPL;        // lanes per corner
+    constexpr int LPP = 2 * CL;        // lanes per point (a power of two <= 16)
+    constexpr int PTS = 64 / LPP;      // points per wave
     const uint32_t level = blockIdx.y;
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
@@ -457,32 +463,33 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
     const T* __restrict__ glevel = grad + (size_t)level * B * C;
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int pl = lane >> 1;          // point slot inside the wave
-    const uint32_t xb = lane & 1;      // which first-coordinate corner this lane owns (neighbouring lanes -> neighbouring entries)
+    const int pl = lane / LPP;                        // point slot inside the wave
+    const uint32_t xb = (uint32_t)(lane / CL) & 1u;   // which first-coordinate corner this lane owns
+    const int c0 = (lane % CL) * CPL;                 // first channel this lane owns
     const uint32_t b_begin = blockIdx.x * points_per_block;
     const uint32_t b_end = min(B, b_begin + points_per_block);
 
-    for (uint32_t base = b_begin + wid * BWD_PTS_PER_WAVE; base < b_end; base += (BWD_THREADS / 64) * BWD_PTS_PER_WAVE) {
+    for (uint32_t base = b_begin + wid * PTS; base < b_end; base += (BWD_THREADS / 64) * PTS) {
         const uint32_t b = base + pl;
         bool live = b < b_end;
         float frac[D], deriv[D];
         uint32_t cell[D];
 #pragma unroll
         for (int d = 0; d < D; d++) { frac[d] = 0.0f; cell[d] = 0u; }
-        float g[C];
+        float g[CPL];
 #pragma unroll
-        for (int c = 0; c < C; c++) g[c] = 0.0f;
+        for (int c = 0; c < CPL; c++) g[c] = 0.0f;
         if (live) live = locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, frac, deriv, cell, im);
         if (live) {
-            Vec<T, C> gv;
-            gv.load(glevel + (size_t)b * C);
+            Vec<T, CPL> gv;
+            gv.load(glevel + (size_t)b * C + c0);
             bool nz = false;
 #pragma unroll
-            for (int c = 0; c < C; c++) { g[c] = gv.v[c]; nz = nz || (g[c] != 0.0f); }
-            live = nz;
+            for (int c = 0; c < CPL; c++) { g[c] = gv.v[c]; nz = nz || (g[c] != 0.0f); }
+            live = nz;  // per lane: a lane whose own channels carry an exactly-zero gradient has nothing to add
         }
         // weighted contributions of this lane's NJ corners
-        float v[NJ][C];
+        float v[NJ][CPL];
         const float w0 = xb ? frac[0] : 1.0f - frac[0];
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
@@ -490,37 +497,37 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
 #pragma unroll
             for (int d = 1; d < D; d++) w *= ((j >> (d - 1)) & 1) ? frac[d] : (1.0f - frac[d]);
 #pragma unroll
-            for (int c = 0; c < C; c++) v[j][c] = w * g[c];
+            for (int c = 0; c < CPL; c++) v[j][c] = w * g[c];
         }
         bool issue = live;
         if (MERGE) {
             // same cell as the previous point slot?  (both live)
             // (every shuffle is executed by all lanes: no short-circuit in front of a cross-lane read)
-            const int prev_live = __shfl_up((int)live, 2, 64);
+            const int prev_live = __shfl_up((int)live, LPP, 64);
             bool cells_equal = true;
 #pragma unroll
             for (int d = 0; d < D; d++) {
-                const uint32_t prev_cell = __shfl_up(cell[d], 2, 64);
+                const uint32_t prev_cell = __shfl_up(cell[d], LPP, 64);
                 cells_equal = cells_equal & (prev_cell == cell[d]);
             }
             const bool same = live & (pl > 0) & (prev_live != 0) & cells_equal;
             if (__any(same)) {
                 bool reached = !same;  // the scan of this lane has reached the head of its run
 #pragma unroll
-                for (int o = 1; o < 32; o <<= 1) {
-                    const int r_o = __shfl_up((int)reached, 2 * o, 64);
+                for (int o = 1; o < PTS; o <<= 1) {
+                    const int r_o = __shfl_up((int)reached, LPP * o, 64);
                     const bool take = !reached && pl >= o;
 #pragma unroll
                     for (int j = 0; j < NJ; j++)
 #pragma unroll
-                        for (int c = 0; c < C; c++) {
-                            const float t = __shfl_up(v[j][c], 2 * o, 64);
+                        for (int c = 0; c < CPL; c++) {
+                            const float t = __shfl_up(v[j][c], LPP * o, 64);
                             if (take) v[j][c] += t;
                         }
                     if (take) reached = r_o != 0;
                 }
-                const int next_same = __shfl_down((int)same, 2, 64);
-                issue = live && (pl == 31 || !next_same);  // last lane of the run holds the run total
+                const int next_same = __shfl_down((int)same, LPP, 64);
+                issue = live && (pl == PTS - 1 || !next_same);  // last lane of the run holds the run total
             }
         }
         if (issue) {
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
                 pg[0] = cell[0] + xb;
 #pragma unroll
                 for (int d = 1; d < D; d++) pg[d] = cell[d] + ((j >> (d - 1)) & 1);
-                scatter_add<T, C>(gtable + (size_t)indexer(pg) * C, v[j], 1.0f);
+                scatter_add<T, CPL>(gtable + (size_t)indexer(pg) * C + c0, v[j], 1.0f);
             }
         }
     }

@@ -122,8 +122,8 @@ def load_pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=64)
-    ap.add_argument('--warmup', type=int, default=16)
+    ap.add_argument('--steps', type=int, default=1024)
+    ap.add_argument('--warmup', type=int, default=64)
     ap.add_argument('--rays', type=int, default=4096, help='rays per GPU and step (reference default, main_nerf.py:26)')
     ap.add_argument('--roofline-kernel', default='grid_encode_backward', help='kernel reported as `roofline` (default: the dominant one)')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying HIP graphs')

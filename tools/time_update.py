@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""wall time of NeRFRenderer.update_extra_state (occupancy refresh, every 16 training iterations) on the lego-shaped scene"""
 import sys, os, time
-ROOT='/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'torch-ngp_amd')); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import synthetic_scene as sc, raymarching

@@ -1,21 +1,30 @@
-"""trunc_exp: exp forward in fp32, backward g * exp(clamp(x, -15, 15)) (reference activation.py:5-17)."""
+"""Density activation of the instant-ngp networks: `trunc_exp(x)` -- an exponential whose GRADIENT is evaluated on the input
+clamped to [-15, 15], so that a large pre-activation cannot blow the backward pass up while the forward value stays a plain exp
+(behaviour of the reference's activation.py:5-17; the fused pipeline's `mid` kernels restate the same two formulas).
+
+Runs in fp32 under autocast (the density feeds exp(-sigma * dt) in the compositor; fp16 would saturate at x > 11)."""
 import torch
-from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
+GRAD_CLAMP = 15.0
 
-class _trunc_exp(Function):
+
+class TruncatedExp(torch.autograd.Function):
+    """y = e^x ; dy/dx := e^clamp(x, -GRAD_CLAMP, GRAD_CLAMP)"""
+
     @staticmethod
     @custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, x):
-        ctx.save_for_backward(x)
-        return torch.exp(x)
+    def forward(ctx, pre_activation):
+        ctx.save_for_backward(pre_activation)
+        return pre_activation.exp()
 
     @staticmethod
     @custom_bwd(device_type='cuda')
-    def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        return g * torch.exp(x.clamp(-15, 15))
+    def backward(ctx, grad_output):
+        (pre_activation,) = ctx.saved_tensors
+        slope = torch.clamp(pre_activation, min=-GRAD_CLAMP, max=GRAD_CLAMP).exp_()
+        return slope.mul_(grad_output)
 
 
-trunc_exp = _trunc_exp.apply
+def trunc_exp(x):
+    return TruncatedExp.apply(x)

@@ -1,54 +1,57 @@
-"""Frequency (positional) encoder with the reference's surface (freqencoder/freq.py:15-77): `freq_encode(inputs, degree, output_dim)`,
-`FreqEncoder(input_dim=3, degree=4)` with `output_dim = input_dim + 2 * input_dim * degree`, `forward(inputs, **kwargs)` on
-[..., input_dim] tensors.  Output order: x, then per frequency f = 0..degree-1 the D sines sin(2^f x) followed by the D cosines.
-Always fp32 (custom_fwd(cast_inputs=float32)); the backward uses the stored outputs (d sin = cos, d cos = -sin)."""
+"""Frequency (positional) encoding  x -> [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(deg-1) x), cos(2^(deg-1) x)]  on libngp_hip.so.
+
+Public surface of the reference package (freqencoder/freq.py:15-77): `freq_encode(inputs, degree, output_dim)` and
+`FreqEncoder(input_dim=3, degree=4)` with attributes `input_dim`, `degree`, `output_dim = input_dim * (1 + 2 * degree)` and a
+`forward(inputs, **kwargs)` that accepts any leading shape.  Within each frequency the D sines come first, then the D cosines.
+The op always computes in fp32 (autocast inputs are widened); its backward needs only the stored outputs, because
+d sin(kx)/dx = k cos(kx) and d cos(kx)/dx = -k sin(kx) are already in there.
+"""
 import torch
-import torch.nn as nn
-from torch.autograd import Function
+from torch import nn
 from torch.amp import custom_bwd, custom_fwd
 
 from .backend import _backend
 
 
-class _freq_encoder(Function):
+def encoded_width(input_dim, degree):
+    return input_dim * (1 + 2 * degree)
+
+
+class FrequencyEncoding(torch.autograd.Function):
     @staticmethod
     @custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, inputs, degree, output_dim):
-        if not inputs.is_cuda:
-            inputs = inputs.cuda()
-        inputs = inputs.contiguous()
-        n_points, dim = inputs.shape
-        outputs = torch.empty(n_points, output_dim, dtype=inputs.dtype, device=inputs.device)
-        _backend.freq_encode_forward(inputs, n_points, dim, degree, output_dim, outputs)
-        ctx.save_for_backward(inputs, outputs)
-        ctx.dims = (n_points, dim, degree, output_dim)
-        return outputs
+    def forward(ctx, points, degree, width):
+        points = (points if points.is_cuda else points.cuda()).contiguous()
+        count, dim = points.shape
+        encoded = points.new_empty((count, width))
+        _backend.freq_encode_forward(points, count, dim, degree, width, encoded)
+        ctx.save_for_backward(encoded)
+        ctx.geometry = (count, dim, degree, width)
+        return encoded
 
     @staticmethod
     @custom_bwd(device_type='cuda')
-    def backward(ctx, grad):
-        grad = grad.contiguous()
-        inputs, outputs = ctx.saved_tensors
-        n_points, dim, degree, output_dim = ctx.dims
-        grad_inputs = torch.zeros_like(inputs)
-        _backend.freq_encode_backward(grad, outputs, n_points, dim, degree, output_dim, grad_inputs)
-        return grad_inputs, None, None
+    def backward(ctx, grad_encoded):
+        (encoded,) = ctx.saved_tensors
+        count, dim, degree, width = ctx.geometry
+        grad_points = encoded.new_empty((count, dim))  # the kernel overwrites every element
+        _backend.freq_encode_backward(grad_encoded.contiguous(), encoded, count, dim, degree, width, grad_points)
+        return grad_points, None, None
 
 
-freq_encode = _freq_encoder.apply
+def freq_encode(inputs, degree, output_dim):
+    return FrequencyEncoding.apply(inputs, degree, output_dim)
 
 
 class FreqEncoder(nn.Module):
     def __init__(self, input_dim=3, degree=4):
         super().__init__()
-        self.input_dim = input_dim
-        self.degree = degree
-        self.output_dim = input_dim + input_dim * 2 * degree
+        self.input_dim, self.degree = input_dim, degree
+        self.output_dim = encoded_width(input_dim, degree)
 
-    def __repr__(self):
-        return f"FreqEncoder: input_dim={self.input_dim} degree={self.degree} output_dim={self.output_dim}"
+    def extra_repr(self):
+        return f"input_dim={self.input_dim}, degree={self.degree}, output_dim={self.output_dim}"
 
     def forward(self, inputs, **kwargs):
-        lead = list(inputs.shape[:-1])
-        out = freq_encode(inputs.reshape(-1, self.input_dim), self.degree, self.output_dim)
-        return out.reshape(lead + [self.output_dim])
+        flat = inputs.reshape(-1, self.input_dim)
+        return freq_encode(flat, self.degree, self.output_dim).reshape(*inputs.shape[:-1], self.output_dim)

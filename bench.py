@@ -127,6 +127,7 @@ def main():
     ap.add_argument('--rays', type=int, default=4096, help='rays per GPU and step (reference default, main_nerf.py:26)')
     ap.add_argument('--roofline-kernel', default='grid_encode_backward', help='kernel reported as `roofline` (default: the dominant one)')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch eagerly instead of replaying HIP graphs')
+    ap.add_argument('--autograd', action='store_true', help='capture the iteration through torch.autograd instead of the autograd-free fused iteration')
     ap.add_argument('--no-fused', action='store_true', help='module-by-module network path (reference-style glue) instead of fused.py')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--torch-optim', action='store_true', help='torch.optim.Adam(fused) + GradScaler instead of optim.NGPAdam')
@@ -201,7 +202,7 @@ def main():
         m.density_bitfield.copy_(fixed_bits)
 
     stepper = GraphedTrainStep(model, optimizer, scaler, args.rays, opt_kwargs, loss_fn=mse_loss, averager=averager,
-                               after_update=keep_scene)
+                               after_update=keep_scene, direct=not args.autograd)
     def train_step(i, count=True):
         rays_o, rays_d, gt = pool[i % n_pool]
         if args.no_graph:
@@ -331,7 +332,7 @@ def main():
                        'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}',
                        'execution': 'eager' if args.no_graph else (f'hip-graph replay ({stepper.n_captures} capture(s))' if stepper.capture_error is None
                                                                    else f'eager (graph capture failed: {stepper.capture_error[:120]})'),
-                       'fused_pipeline': bool(model.fused), 'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
+                       'autograd_free_iteration': bool(stepper.used_direct), 'fused_pipeline': bool(model.fused), 'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
                        'final_loss': final_loss},
             'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'render_800x800_ms': render,
         }

@@ -233,6 +233,12 @@ int ngp_pipeline_rgb_backward(const float* grad_rgb, const float* rgb, void* gra
 int ngp_pipeline_mid_backward(const float* grad_sigma, const void* h16, const void* grad_color_in, void* grad_h16, uint32_t M,
                               float density_scale, ngp_stream_t stream);
 
+/* The Trainer's loss (nerf/utils.py:516,557: MSELoss(reduction='none')(pred, gt).mean(-1).mean()) and its gradient times the loss scale
+ * in one launch: loss[0] = mean((image - target)^2) over n values, grad_image[i] = (2/n * (image[i] - target[i])) * loss_scale[0]
+ * (loss_scale: device scalar, NULL = 1).  Deterministic (fixed-order reduction).  n must be > 0. */
+int ngp_pipeline_mse_loss(const float* image, const float* target, uint32_t n, const float* loss_scale, float* loss,
+                          float* grad_image, ngp_stream_t stream);
+
 /* march_rays_train with two conveniences for the fused renderer: the counter may be reset in-kernel and the sample rows no ray
  * writes are zeroed in-kernel (the reference contract keeps both with the caller: counter.zero_(), torch.zeros buffers). */
 #define NGP_MARCH_RESET_COUNTER 1u

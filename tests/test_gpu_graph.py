@@ -69,3 +69,113 @@ def test_graph_replay_matches_eager_iteration():
     # near-zero gradient into a +-lr update whose sign follows the atomic summation order)
     np.testing.assert_allclose(g[0], e[0], rtol=8e-2, atol=2e-3)
     assert g[0][-1] < g[0][0]
+
+
+def _make_ngp(dev):
+    import raymarching
+    from nerf.network_ff import NeRFNetwork
+    from optim import NGPAdam
+    torch.manual_seed(0)
+    model = NeRFNetwork(bound=1, cuda_ray=True, density_thresh=10).to(dev)
+    model.train()
+    model.density_grid.copy_(torch.from_numpy(sc.occupancy_density()))
+    model.density_bitfield = raymarching.packbits(model.density_grid, 10.0, model.density_bitfield)
+    model.iter_density = 16
+    opt = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    return model, opt
+
+
+def test_mse_loss_kernel_matches_torch():
+    import _ngp_capi as capi
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(3)
+    for n in (3, 64, 12288, 50001):
+        img = torch.rand(n, device=dev, generator=g)
+        tgt = torch.rand(n, device=dev, generator=g)
+        scale = torch.tensor([1024.0], device=dev)
+        loss = torch.empty(1, device=dev)
+        grad = torch.empty(n, device=dev)
+        capi.check(capi.lib.ngp_pipeline_mse_loss(img.data_ptr(), tgt.data_ptr(), n, scale.data_ptr(), loss.data_ptr(), grad.data_ptr(),
+                                                  capi.stream()))
+        x = img.clone().requires_grad_(True)
+        ref = torch.nn.functional.mse_loss(x, tgt)
+        (ref * scale[0]).backward()
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+        # (2/n * diff) * scale with a power-of-two scale: bit-exact with torch's backward
+        assert torch.equal(grad, x.grad)
+    with pytest.raises(RuntimeError):
+        capi.check(capi.lib.ngp_pipeline_mse_loss(None, None, 0, None, loss.data_ptr(), None, capi.stream()))
+
+
+def test_autograd_free_iteration_matches_autograd_iteration():
+    """fused.fused_train_iteration (forward, loss, backward without autograd) deposits the same gradients as
+    model.render -> mse_loss -> scale -> backward: MLP weight gradients bit-exact (deterministic kernels, identical inputs), hash-table
+    gradients to fp16 atomic-order noise."""
+    from fused import fused_train_iteration
+    dev = torch.device('cuda')
+    model, opt = _make_ngp(dev)
+    n_rays = 1024
+    o, d, gt = sc.training_batch(n_rays, seed=5)
+    o, d, gt = torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)
+    model.mean_count = 60 * n_rays
+    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    params = (model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights)
+    # autograd iteration
+    model.local_step = 0
+    with torch.autocast('cuda', dtype=torch.float16):
+        out = model.render(o, d, **kw)
+        loss_a = torch.nn.functional.mse_loss(out['image'][0], gt)
+    opt.scale(loss_a).backward()
+    count_a = model.step_counter[0].clone()
+    grads_a = [p._ngp_grad16.clone() for p in params]
+    assert all(p.grad is None for p in params)
+    opt.flat_grad16.zero_()
+    # autograd-free iteration
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    capacity = model.mean_count + (128 - model.mean_count % 128)
+    loss_d, image, depth, ws = fused_train_iteration(model, o, d, gt, model.aabb_train, counter, capacity, opt.scalars[0:1], 1, False, 0,
+                                                     1024, 1e-4)
+    grads_d = [p._ngp_grad16.clone() for p in params]
+    opt.flat_grad16.zero_()
+    assert torch.equal(counter, count_a)
+    assert torch.equal(image, out['image'][0])
+    assert torch.allclose(depth, out['depth'][0], rtol=0, atol=0, equal_nan=True)
+    np.testing.assert_allclose(loss_d.item(), loss_a.item(), rtol=2e-6)
+    assert torch.equal(grads_a[1], grads_d[1]) and torch.equal(grads_a[2], grads_d[2])
+    ga, gd = grads_a[0].float(), grads_d[0].float()
+    assert float(ga.abs().max()) > 0
+    assert float((ga - gd).abs().max()) <= 2e-2 * float(ga.abs().max())
+    assert float((ga - gd).abs().mean()) <= 1e-3 * float(ga.abs().mean()) + 1e-12
+
+
+def test_graph_replay_direct_and_autograd_modes_agree():
+    from graph import GraphedTrainStep
+    dev = torch.device('cuda')
+    occ = torch.from_numpy(sc.occupancy_density()).to(dev)
+    bits = torch.from_numpy(oracle.packbits(sc.occupancy_density(), 10.0)).to(dev)
+    n_rays = 1024
+    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    batches = []
+    for i in range(40):
+        o, d, gt = sc.training_batch(n_rays, seed=300 + i)
+        gt[:] = 0.3
+        batches.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
+
+    def keep(m):
+        m.density_grid.copy_(occ)
+        m.density_bitfield.copy_(bits)
+
+    runs = {}
+    for direct in (True, False):
+        model, opt = _make_ngp(dev)
+        st = GraphedTrainStep(model, opt, None, n_rays, kw, after_update=keep, direct=direct)
+        losses, counts = [], []
+        for i in range(36):
+            losses.append(float(st.step(*batches[i]).item()))
+            counts.append(int(model.step_counter[(model.local_step - 1) % 16, 0].item()))
+        assert st.n_captures >= 1 and st.capture_error is None
+        assert st.used_direct == direct
+        runs[direct] = (losses, counts)
+    assert runs[True][1] == runs[False][1]
+    np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=8e-2, atol=2e-3)
+    assert runs[True][0][-1] < runs[True][0][0]

@@ -94,6 +94,35 @@ __global__ __launch_bounds__(PL_THREADS) void k_mid_backward(const float* __rest
     dst[1] = hi;
 }
 
+// nerf/utils.py:516,557 (criterion = MSELoss(reduction='none'), .mean(-1), .mean()) and its backward times the loss scale, in ONE launch:
+//   loss = mean((image - target)^2),  grad_image = (2/n * (image - target)) * loss_scale        (same operation order as
+// torch's mse_loss backward followed by the GradScaler multiply).  One workgroup: n is a ray batch (a few 10^4 values); fixed-order tree
+// reduction -> deterministic.
+constexpr int LOSS_THREADS = 1024;
+__global__ __launch_bounds__(LOSS_THREADS) void k_mse_loss(const float* __restrict__ image, const float* __restrict__ target, uint32_t n,
+                                                           const float* __restrict__ loss_scale, float* __restrict__ loss,
+                                                           float* __restrict__ grad_image) {
+    __shared__ float part[LOSS_THREADS / 64];
+    const float scale = loss_scale ? loss_scale[0] : 1.0f;
+    const float norm = 2.0f / (float)n;
+    float acc = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += LOSS_THREADS) {
+        const float diff = image[i] - target[i];
+        acc = __builtin_fmaf(diff, diff, acc);
+        grad_image[i] = (norm * diff) * scale;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = threadIdx.x < LOSS_THREADS / 64 ? part[threadIdx.x] : 0.0f;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0) loss[0] = v / (float)n;
+    }
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -128,4 +157,13 @@ extern "C" int ngp_pipeline_mid_backward(const float* grad_sigma, const void* h1
     hipLaunchKernelGGL(k_mid_backward, dim3(cdiv(M, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), grad_sigma, (const half_t*)h16,
                        (const half_t*)grad_color_in, (half_t*)grad_h16, M, density_scale);
     return check_launch("pipeline_mid_backward");
+}
+
+extern "C" int ngp_pipeline_mse_loss(const float* image, const float* target, uint32_t n, const float* loss_scale, float* loss,
+                                     float* grad_image, ngp_stream_t stream) {
+    NGP_REQUIRE(loss, NGP_ERR_INVALID, "pipeline_mse_loss: NULL tensor");
+    NGP_REQUIRE(n == 0 || (image && target && grad_image), NGP_ERR_INVALID, "pipeline_mse_loss: NULL tensor");
+    NGP_REQUIRE(n > 0, NGP_ERR_INVALID, "pipeline_mse_loss: empty batch (the mean of no values is undefined)");
+    hipLaunchKernelGGL(k_mse_loss, dim3(1), dim3(LOSS_THREADS), 0, as_stream(stream), image, target, n, loss_scale, loss, grad_image);
+    return check_launch("pipeline_mse_loss");
 }

@@ -165,100 +165,117 @@ def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
 # 14 launches forward, 11 backward; same arithmetic and rounding points as the module-by-module path (tests/test_gpu_pipeline.py).
 # Only used when the sample buffer is sized from the running `mean_count` estimate (no host read-back).
 # ------------------------------------------------------------------------------------------------------------------
+def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfield, aabb, counter, cfg, rcfg):
+    """-> (image, depth, weights_sum, saved): the forward launches of the fused training render on the current stream"""
+    (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
+    (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
+    N = rays_o.shape[0]
+    M = capacity
+    dev = rays_o.device
+    st = capi.stream()
+    f32 = dict(device=dev, dtype=torch.float32)
+    half = dict(device=dev, dtype=torch.half)
+    nears = torch.empty(N, **f32)
+    fars = torch.empty(N, **f32)
+    _check(capi.lib.ngp_near_far_from_aabb(rays_o.data_ptr(), rays_d.data_ptr(), aabb.data_ptr(), N, min_near, nears.data_ptr(),
+                                           fars.data_ptr(), st))
+    xyzs = torch.empty(M, 3, **f32)
+    dirs = torch.empty(M, 3, **f32)
+    deltas = torch.empty(M, 2, **f32)
+    rays = torch.empty(N, 3, device=dev, dtype=torch.int32)
+    noises = torch.rand(N, **f32) if perturb else torch.zeros(N, **f32)
+    ws = torch.empty(capi.lib.ngp_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    _check(capi.lib.ngp_march_rays_train_ex(rays_o.data_ptr(), rays_d.data_ptr(), bitfield.data_ptr(), float(bound), float(dt_gamma),
+                                            max_steps, N, cascade, grid_size, M, nears.data_ptr(), fars.data_ptr(), xyzs.data_ptr(),
+                                            dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(), noises.data_ptr(),
+                                            ws.data_ptr(), capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL, st))
+    # ---- network ----
+    enc = torch.empty(L, M, 2, **half)
+    _check(capi.lib.ngp_grid_encode_forward_ex(xyzs.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
+                                                None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
+    h16 = torch.empty(M, 16, **half)
+    color_in = torch.empty(M, 32, **half)
+    out16 = torch.empty(M, 16, **half)
+    sigma = torch.empty(M, **f32)
+    rgb = torch.empty(M, 3, **f32)
+    fb_s = torch.empty(nl_sigma, M, 64, **half)
+    fb_c = torch.empty(nl_color, M, 64, **half)
+    _check(capi.lib.ngp_ffmlp_forward_ex(enc.data_ptr(), ws16.data_ptr(), M, 32, 16, 64, nl_sigma, 0, 6, fb_s.data_ptr(), h16.data_ptr(),
+                                         _PLANAR_IN, st))
+    _check(capi.lib.ngp_pipeline_mid_forward(h16.data_ptr(), dirs.data_ptr(), sigma.data_ptr(), color_in.data_ptr(), M, M,
+                                             float(density_scale), st))
+    _check(capi.lib.ngp_ffmlp_forward_ex(color_in.data_ptr(), wc16.data_ptr(), M, 32, 16, 64, nl_color, 0, 6, fb_c.data_ptr(),
+                                         out16.data_ptr(), 0, st))
+    _check(capi.lib.ngp_pipeline_rgb_forward(out16.data_ptr(), rgb.data_ptr(), M, st))
+    # ---- composite + epilogue ----
+    weights_sum = torch.empty(N, **f32)
+    depth_raw = torch.empty(N, **f32)
+    image_raw = torch.empty(N, 3, **f32)
+    image = torch.empty(N, 3, **f32)
+    depth = torch.empty(N, **f32)
+    bg_mode = 2 if bg is not None else 1
+    _check(capi.lib.ngp_composite_rays_train_forward_ex(sigma.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), rays.data_ptr(), M, N,
+                                                        float(T_thresh), weights_sum.data_ptr(), depth_raw.data_ptr(), image_raw.data_ptr(),
+                                                        bg_mode, float(bg_scalar), capi.ptr(bg), nears.data_ptr(), fars.data_ptr(),
+                                                        image.data_ptr(), depth.data_ptr(), st))
+    saved = (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg)
+    return image, depth, weights_sum, saved
+
+
+def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g_wc):
+    """the backward launches: grad_image [N,3] fp32 (and optionally grad_ws [N]) -> gradients accumulated into g_emb (scatter-add, must
+    hold the running sum / zeros) and written to g_ws / g_wc (fp16, flat)"""
+    (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg) = saved
+    (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
+    (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
+    M, N = xyzs.shape[0], rays.shape[0]
+    dev = xyzs.device
+    st = capi.stream()
+    half = dict(device=dev, dtype=torch.half)
+    g_sigma = torch.zeros(M, device=dev)
+    g_rgb = torch.zeros(M, 3, device=dev)
+    bg_mode = 2 if bg is not None else 1
+    _check(capi.lib.ngp_composite_rays_train_backward_ex(capi.ptr(grad_ws), grad_image.data_ptr(), sigma.data_ptr(), rgb.data_ptr(),
+                                                         deltas.data_ptr(), rays.data_ptr(), weights_sum.data_ptr(), image_raw.data_ptr(),
+                                                         M, N, float(T_thresh), g_sigma.data_ptr(), g_rgb.data_ptr(), bg_mode,
+                                                         float(bg_scalar), capi.ptr(bg), st))
+    g_out16 = torch.empty(M, 16, **half)
+    _check(capi.lib.ngp_pipeline_rgb_backward(g_rgb.data_ptr(), rgb.data_ptr(), g_out16.data_ptr(), M, st))
+    g_color_in = torch.empty(M, 32, **half)
+    scratch = torch.empty(nl_color, M, 64, **half)
+    _check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), fb_c.data_ptr(), M, 32, 16, 64,
+                                          nl_color, 0, 6, 1, scratch.data_ptr(), g_color_in.data_ptr(), g_wc.data_ptr(), 0, st))
+    g_h16 = g_out16
+    _check(capi.lib.ngp_pipeline_mid_backward(g_sigma.data_ptr(), h16.data_ptr(), g_color_in.data_ptr(), g_h16.data_ptr(), M,
+                                              float(density_scale), st))
+    g_enc = torch.empty(L, M, 2, **half)
+    _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
+                                          0, 6, 1, scratch[:nl_sigma].data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
+                                          _PLANAR_IN | _PLANAR_DX, st))
+    _check(capi.lib.ngp_grid_encode_backward_ex(g_enc.data_ptr(), xyzs.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
+                                                 None, None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
+
+
 class _fused_render_train(Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, embeddings, w_sigma, w_color, bg, offsets, bitfield, aabb, counter, cfg, rcfg, bufs):
-        (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
-        (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
-        N = rays_o.shape[0]
-        M = capacity
-        dev = rays_o.device
-        st = capi.stream()
-        f32 = dict(device=dev, dtype=torch.float32)
-        half = dict(device=dev, dtype=torch.half)
-        nears = torch.empty(N, **f32)
-        fars = torch.empty(N, **f32)
-        _check(capi.lib.ngp_near_far_from_aabb(rays_o.data_ptr(), rays_d.data_ptr(), aabb.data_ptr(), N, min_near, nears.data_ptr(),
-                                               fars.data_ptr(), st))
-        xyzs = torch.empty(M, 3, **f32)
-        dirs = torch.empty(M, 3, **f32)
-        deltas = torch.empty(M, 2, **f32)
-        rays = torch.empty(N, 3, device=dev, dtype=torch.int32)
-        noises = torch.rand(N, **f32) if perturb else torch.zeros(N, **f32)
-        ws = torch.empty(capi.lib.ngp_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device=dev)
-        _check(capi.lib.ngp_march_rays_train_ex(rays_o.data_ptr(), rays_d.data_ptr(), bitfield.data_ptr(), float(bound), float(dt_gamma),
-                                                max_steps, N, cascade, grid_size, M, nears.data_ptr(), fars.data_ptr(), xyzs.data_ptr(),
-                                                dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(), noises.data_ptr(),
-                                                ws.data_ptr(), capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL, st))
-        # ---- network ----
         emb16, ws16, wc16 = _half_weights(embeddings, w_sigma, w_color, bufs)
-        enc = torch.empty(L, M, 2, **half)
-        _check(capi.lib.ngp_grid_encode_forward_ex(xyzs.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
-                                                    None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
-        h16 = torch.empty(M, 16, **half)
-        color_in = torch.empty(M, 32, **half)
-        out16 = torch.empty(M, 16, **half)
-        sigma = torch.empty(M, **f32)
-        rgb = torch.empty(M, 3, **f32)
-        fb_s = torch.empty(nl_sigma, M, 64, **half)
-        fb_c = torch.empty(nl_color, M, 64, **half)
-        _check(capi.lib.ngp_ffmlp_forward_ex(enc.data_ptr(), ws16.data_ptr(), M, 32, 16, 64, nl_sigma, 0, 6, fb_s.data_ptr(), h16.data_ptr(),
-                                             _PLANAR_IN, st))
-        _check(capi.lib.ngp_pipeline_mid_forward(h16.data_ptr(), dirs.data_ptr(), sigma.data_ptr(), color_in.data_ptr(), M, M,
-                                                 float(density_scale), st))
-        _check(capi.lib.ngp_ffmlp_forward_ex(color_in.data_ptr(), wc16.data_ptr(), M, 32, 16, 64, nl_color, 0, 6, fb_c.data_ptr(),
-                                             out16.data_ptr(), 0, st))
-        _check(capi.lib.ngp_pipeline_rgb_forward(out16.data_ptr(), rgb.data_ptr(), M, st))
-        # ---- composite + epilogue ----
-        weights_sum = torch.empty(N, **f32)
-        depth_raw = torch.empty(N, **f32)
-        image_raw = torch.empty(N, 3, **f32)
-        image = torch.empty(N, 3, **f32)
-        depth = torch.empty(N, **f32)
-        bg_mode = 2 if bg is not None else 1
-        _check(capi.lib.ngp_composite_rays_train_forward_ex(sigma.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), rays.data_ptr(), M, N,
-                                                            float(T_thresh), weights_sum.data_ptr(), depth_raw.data_ptr(), image_raw.data_ptr(),
-                                                            bg_mode, float(bg_scalar), capi.ptr(bg), nears.data_ptr(), fars.data_ptr(),
-                                                            image.data_ptr(), depth.data_ptr(), st))
-        ctx.save_for_backward(xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg)
+        image, depth, weights_sum, saved = _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfield, aabb, counter,
+                                                                 cfg, rcfg)
+        ctx.save_for_backward(*saved)
         ctx.cfg, ctx.rcfg, ctx.n_emb, ctx.bufs = cfg, rcfg, embeddings.shape[0], bufs
         ctx.mark_non_differentiable(depth)
         return image, depth, weights_sum
 
     @staticmethod
     def backward(ctx, grad_image, grad_depth, grad_ws):
-        (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg) = ctx.saved_tensors
-        (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = ctx.cfg
-        (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = ctx.rcfg
-        M, N = xyzs.shape[0], rays.shape[0]
-        dev = xyzs.device
-        st = capi.stream()
-        half = dict(device=dev, dtype=torch.half)
+        saved = ctx.saved_tensors
+        dev = saved[0].device
+        N = saved[12].shape[0]
         grad_image = torch.zeros(N, 3, device=dev) if grad_image is None else grad_image.contiguous().float()
         grad_ws = None if grad_ws is None else grad_ws.contiguous().float()
-        g_sigma = torch.zeros(M, device=dev)
-        g_rgb = torch.zeros(M, 3, device=dev)
-        bg_mode = 2 if bg is not None else 1
-        _check(capi.lib.ngp_composite_rays_train_backward_ex(capi.ptr(grad_ws), grad_image.data_ptr(), sigma.data_ptr(), rgb.data_ptr(),
-                                                             deltas.data_ptr(), rays.data_ptr(), weights_sum.data_ptr(), image_raw.data_ptr(),
-                                                             M, N, float(T_thresh), g_sigma.data_ptr(), g_rgb.data_ptr(), bg_mode,
-                                                             float(bg_scalar), capi.ptr(bg), st))
-        g_out16 = torch.empty(M, 16, **half)
-        _check(capi.lib.ngp_pipeline_rgb_backward(g_rgb.data_ptr(), rgb.data_ptr(), g_out16.data_ptr(), M, st))
-        g_color_in = torch.empty(M, 32, **half)
-        g_emb, g_ws, g_wc, deposited = _grad_targets(ctx.bufs, ctx.n_emb, ws16, wc16, dev)
-        scratch = torch.empty(nl_color, M, 64, **half)
-        _check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), fb_c.data_ptr(), M, 32, 16, 64,
-                                              nl_color, 0, 6, 1, scratch.data_ptr(), g_color_in.data_ptr(), g_wc.data_ptr(), 0, st))
-        g_h16 = g_out16
-        _check(capi.lib.ngp_pipeline_mid_backward(g_sigma.data_ptr(), h16.data_ptr(), g_color_in.data_ptr(), g_h16.data_ptr(), M,
-                                                  float(density_scale), st))
-        g_enc = torch.empty(L, M, 2, **half)
-        _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
-                                              0, 6, 1, scratch[:nl_sigma].data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
-                                              _PLANAR_IN | _PLANAR_DX, st))
-        _check(capi.lib.ngp_grid_encode_backward_ex(g_enc.data_ptr(), xyzs.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
-                                                     None, None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
+        g_emb, g_ws, g_wc, deposited = _grad_targets(ctx.bufs, ctx.n_emb, saved[3], saved[4], dev)
+        _render_train_backward(saved, ctx.cfg, ctx.rcfg, grad_image, grad_ws, g_emb, g_ws, g_wc)
         if deposited:
             return (None,) * 13
         return None, None, g_emb, g_ws, g_wc, None, None, None, None, None, None, None, None
@@ -273,12 +290,47 @@ def network_cfg(encoder, sigma_net, color_net, bound, training):
 def fused_render_train(model, rays_o, rays_d, box, counter, capacity, bg_color, perturb, dt_gamma, max_steps, T_thresh):
     """-> image [N,3], depth [N], weights_sum [N]; `counter` [2] int32 receives (samples marched, rays)"""
     cfg = network_cfg(model.encoder, model.sigma_net, model.color_net, model.bound, True)
-    bg_t, bg_s = (bg_color.contiguous().float().view(-1, 3), 0.0) if torch.is_tensor(bg_color) else (None, float(bg_color))
-    rcfg = (int(model.cascade), int(model.grid_size), float(model.min_near), int(capacity), bool(perturb), float(dt_gamma), int(max_steps),
-            float(T_thresh), float(model.density_scale), bg_s)
+    bg_t, rcfg = _render_cfg(model, capacity, bg_color, perturb, dt_gamma, max_steps, T_thresh)
     bufs = _optimizer_buffers((model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights))
     return _fused_render_train.apply(rays_o, rays_d, model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights, bg_t,
                                      model.encoder.offsets, model.density_bitfield, box, counter, cfg, rcfg, bufs)
+
+
+def _render_cfg(model, capacity, bg_color, perturb, dt_gamma, max_steps, T_thresh):
+    bg_t, bg_s = (bg_color.contiguous().float().view(-1, 3), 0.0) if torch.is_tensor(bg_color) else (None, float(bg_color))
+    rcfg = (int(model.cascade), int(model.grid_size), float(model.min_near), int(capacity), bool(perturb), float(dt_gamma), int(max_steps),
+            float(T_thresh), float(model.density_scale), bg_s)
+    return bg_t, rcfg
+
+
+@torch.no_grad()
+def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity, loss_scale, bg_color=1, perturb=False, dt_gamma=0,
+                          max_steps=1024, T_thresh=1e-4):
+    """One training iteration's forward + MSE loss + backward WITHOUT autograd: the launches of `_fused_render_train` forward, the
+    Trainer's loss (nerf/utils.py:516,557) and its scaled gradient in one kernel, then the backward launches, depositing the gradients
+    into the optimizer's fp16 buffers (optim.NGPAdam with deposit=True must manage the three parameter tensors).  28 launches instead
+    of 45: autograd's bookkeeping kernels (ones/zeros fills, the loss-scale multiplies, the mse forward/backward/mean kernels) vanish.
+    rays_o/rays_d [N,3] fp32, target [N,3] fp32, loss_scale: device scalar (NGPAdam.scalars[0:1]) or None.
+    -> (loss [1] fp32, image [N,3], depth [N], weights_sum [N]); same arithmetic as model.render + mse_loss + scaled backward
+    (tests/test_gpu_graph.py)."""
+    cfg = network_cfg(model.encoder, model.sigma_net, model.color_net, model.bound, True)
+    bg_t, rcfg = _render_cfg(model, capacity, bg_color, perturb, dt_gamma, max_steps, T_thresh)
+    bufs = _optimizer_buffers((model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights))
+    if bufs is None:
+        raise RuntimeError('fused_train_iteration: the parameters are not managed by optim.NGPAdam(deposit=True)')
+    rays_o = rays_o.contiguous().view(-1, 3)
+    rays_d = rays_d.contiguous().view(-1, 3)
+    target = target.contiguous().view(-1, 3)
+    if target.shape[0] != rays_o.shape[0] or target.dtype != torch.float32:
+        raise RuntimeError('fused_train_iteration: target must be [N,3] float32')
+    image, depth, weights_sum, saved = _render_train_forward(rays_o, rays_d, bufs[0], bufs[1], bufs[2], bg_t, model.encoder.offsets,
+                                                             model.density_bitfield, box, counter, cfg, rcfg)
+    loss = torch.empty(1, device=rays_o.device, dtype=torch.float32)
+    grad_image = torch.empty_like(image)
+    _check(capi.lib.ngp_pipeline_mse_loss(image.data_ptr(), target.data_ptr(), image.numel(), capi.ptr(loss_scale), loss.data_ptr(),
+                                          grad_image.data_ptr(), capi.stream()))
+    _render_train_backward(saved, cfg, rcfg, grad_image, None, bufs[3], bufs[4].view(-1), bufs[5].view(-1))
+    return loss, image, depth, weights_sum
 
 
 @torch.no_grad()

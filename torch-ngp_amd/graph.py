@@ -32,7 +32,7 @@ def mse_loss(out, target):
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, scaler, n_rays, render_kwargs, loss_fn=mse_loss, averager=None, capacity_quantum=8192,
-                 update_interval=16, after_update=None, autocast_dtype=torch.float16):
+                 update_interval=16, after_update=None, autocast_dtype=torch.float16, direct=True):
         self.model, self.optimizer, self.scaler = model, optimizer, scaler
         self.loss_fn, self.averager = loss_fn, averager
         self.render_kwargs = dict(render_kwargs)
@@ -52,7 +52,11 @@ class GraphedTrainStep:
         self.loss = None
         self.n_captures = 0
         self.capture_error = None
+        self.used_direct = False
         self.capacity = None  # sample capacity of the step that ran last (None while eager/worst-case)
+        # autograd-free iteration (fused.fused_train_iteration): needs the default loss, an optimizer that owns its loss scale and
+        # deposits gradients (optim.NGPAdam), and a model/render configuration the fused training render accepts
+        self.direct = bool(direct) and loss_fn is mse_loss and scaler is None and getattr(optimizer, 'flat_grad16', None) is not None
 
     # ------------------------------------------------------------------------------------------
     def _capacity(self):
@@ -61,9 +65,32 @@ class GraphedTrainStep:
             return None
         return ((mc + 128 + self.quantum - 1) // self.quantum) * self.quantum
 
+    def _direct_ok(self):
+        m, kw = self.model, self.render_kwargs
+        if not (self.direct and m.training and getattr(m, 'bg_radius', 0) <= 0 and hasattr(m, '_fused_render_ok')):
+            return False
+        if kw.get('staged', False):
+            return False
+        bg = kw.get('bg_color', None)
+        with torch.autocast('cuda', dtype=self.autocast_dtype):  # the fused path IS the fp16-autocast arithmetic; it checks for it
+            return m._fused_render_ok(self.rays_o.view(-1, 3), self.rays_d.view(-1, 3), 1 if bg is None else bg,
+                                      kw.get('force_all_rays', False))
+
     def _iteration_front(self):
         """zero_grad -> render -> loss -> scaled backward, with the model's bookkeeping pinned for capture"""
         m = self.model
+        if self._direct_ok():
+            from fused import fused_train_iteration
+            kw = self.render_kwargs
+            bg = kw.get('bg_color', None)
+            self.optimizer.zero_grad(set_to_none=True)
+            loss, _, _, _ = fused_train_iteration(m, self.rays_o, self.rays_d, self.target, m.aabb_train, self.counter[0],
+                                                  self.captured_capacity, self.optimizer.scalars[0:1], 1 if bg is None else bg,
+                                                  kw.get('perturb', False), kw.get('dt_gamma', 0), kw.get('max_steps', 1024),
+                                                  kw.get('T_thresh', 1e-4))
+            self.used_direct = True
+            return loss[0]
+        self.used_direct = False
         saved_counter, saved_mc, saved_ls = m._buffers['step_counter'], m.mean_count, m.local_step
         m._buffers['step_counter'] = self.counter
         m.mean_count = self.captured_capacity - 128  # march_rays_train sizes its buffers as mean_count + 128 (raymarching.py:200-203)

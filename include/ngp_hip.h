@@ -205,6 +205,22 @@ int ngp_grid_encode_backward_ex(const void* grad, const float* inputs, const voi
                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                 uint32_t interp, int dtype, float bound, ngp_stream_t stream);
 
+/* grid_encode_backward_ex with a caller-provided workspace: fp16 tables with C = 2 and D <= 3 (the instant-ngp configuration) then
+ * run the HASHED levels WITHOUT memory-side atomics -- contributions are sorted by table slice (8-byte records, coalesced stores) and
+ * each slice is summed exactly in a 64-bit fixed-point LDS accumulator, rounded once and added to grad_embeddings by the workgroup that
+ * owns it.  The result is the exact sum of the fp16 contributions rounded once (the reference's atomics round after every
+ * add, in an undefined order) and is bit-reproducible; entries that receive a non-finite contribution become NaN.
+ * offsets_host: a HOST copy of `offsets` (L + 1 values; the level sizes steer the plan).  workspace: device memory of at least
+ * ngp_grid_backward_workspace_bytes(...) bytes, contents irrelevant.  offsets_host == NULL or workspace == NULL -> the atomic path
+ * (= ngp_grid_encode_backward_ex).  Small batches and other dtypes/shapes use the atomic path as well (workspace_bytes() == 0). */
+size_t ngp_grid_backward_workspace_bytes(const int32_t* offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                         uint32_t gridtype, int align_corners, int dtype);
+int ngp_grid_encode_backward_ws(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
+                                int dtype, float bound, const int32_t* offsets_host, void* workspace, size_t workspace_bytes,
+                                ngp_stream_t stream);
+
 /* flags of the ffmlp *_ex entry points */
 #define NGP_FF_INPUT_PLANAR 1u /* inputs are [input_dim/2][B][2] fp16 planes = the grid encoder's [L,B,C=2] output */
 #define NGP_FF_DX_PLANAR 2u    /* grad_inputs is written in that planar layout = what grid_encode_backward reads */

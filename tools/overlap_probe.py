@@ -46,6 +46,20 @@ def both_march_first():
     with torch.cuda.stream(s2): march()
     with torch.cuda.stream(s1): bwd()
     cur.wait_stream(s1); cur.wait_stream(s2)
-for _ in range(3): bwd(); march(); both(); both_march_first()
+s3 = torch.cuda.Stream(priority=-1)
+def both_prio():
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur); s3.wait_stream(cur)
+    with torch.cuda.stream(s1): bwd()
+    with torch.cuda.stream(s3): march()
+    cur.wait_stream(s1); cur.wait_stream(s3)
+def both_prio_first():
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur); s3.wait_stream(cur)
+    with torch.cuda.stream(s3): march()
+    with torch.cuda.stream(s1): bwd()
+    cur.wait_stream(s1); cur.wait_stream(s3)
+for _ in range(3): bwd(); march(); both(); both_march_first(); both_prio(); both_prio_first()
+print(f'high-priority march stream: bwd launched first {timed(both_prio):.1f} us, march launched first {timed(both_prio_first):.1f} us')
 tb, tm, tboth, tmf = timed(bwd), timed(march), timed(both), timed(both_march_first)
 print(f'grid backward alone {tb:.1f} us, march alone {tm:.1f} us, both on two streams {tboth:.1f} us, march launched first {tmf:.1f} us (sum {tb+tm:.1f})')

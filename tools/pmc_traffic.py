@@ -14,7 +14,10 @@ composite) is doubled; the 4-byte gather/scatter kernels of the grid encoder are
 bench.py reads the newest profiles/*_pmc_traffic.json to fill `roofline.traffic`."""
 import collections, csv, glob, json, os, sys
 
-KERNELS = {  # substring of the kernel name -> (label used by bench.py, read-side correction factor)
+KERNELS = {  # substring of the kernel name (first match wins) -> (label used by bench.py, read-side correction factor)
+    # grid_encode_backward is three launches (atomic levels, record sort, slice accumulate): their traffic is summed under one label
+    'k_grid_backward_bin': ('grid_encode_backward', 1.0),
+    'k_grid_backward_accumulate': ('grid_encode_backward', 2.0),
     'k_grid_backward': ('grid_encode_backward', 1.0),
     'k_grid_forward_pair': ('grid_encode_forward', 1.0),
     'k_ffmlp_forward': ('ffmlp_forward', 2.0),
@@ -31,31 +34,32 @@ def per_kernel(directory, counter):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] != counter:
             continue
-        for key, (label, _) in KERNELS.items():
+        for key in KERNELS:
             if key in r['Kernel_Name']:
-                vals[label].append((int(r['Grid_Size']), float(r['Counter_Value'])))
+                vals[key].append((int(r['Grid_Size']), float(r['Counter_Value'])))
+                break
     out = {}
-    for label, lst in vals.items():
+    for key, lst in vals.items():
         sizes = collections.Counter(g for g, _ in lst)
         mode = sizes.most_common(1)[0][0]  # the training-step launches (update_extra_state uses other sizes)
         sel = [v for g, v in lst if g == mode]
-        out[label] = (sum(sel) / len(sel), len(sel))
+        out[key] = (sum(sel) / len(sel), len(sel))
     return out
 
 
 def main():
     fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
     write = per_kernel(sys.argv[2], 'WRITE_SIZE')
-    factor = {label: f for _, (label, f) in KERNELS.items()}
-    per_launch, detail = {}, {}
-    for label in sorted(set(fetch) | set(write)):
-        rd = fetch.get(label, (0.0, 0))[0] * 1024.0
-        wr = write.get(label, (0.0, 0))[0] * 1024.0
-        per_launch[label] = round(rd * factor[label] + wr)
-        detail[label] = {'fetch_bytes_raw': round(rd), 'read_correction': factor[label], 'write_bytes': round(wr),
-                         'launches_averaged': fetch.get(label, (0, 0))[1],
-                         'note': 'raw FETCH_SIZE, 4-byte gather/scatter width uncalibrated' if factor[label] == 1.0 else
-                                 'FETCH_SIZE doubled (16 B/lane streaming reads are tallied at half, MI355X_MICROARCH.md HBM section)'}
+    per_launch, detail = collections.defaultdict(int), {}
+    for key in sorted(set(fetch) | set(write)):
+        label, factor = KERNELS[key]
+        rd = fetch.get(key, (0.0, 0))[0] * 1024.0
+        wr = write.get(key, (0.0, 0))[0] * 1024.0
+        per_launch[label] += round(rd * factor + wr)
+        detail[key] = {'label': label, 'fetch_bytes_raw': round(rd), 'read_correction': factor, 'write_bytes': round(wr),
+                       'launches_averaged': fetch.get(key, (0, 0))[1],
+                       'note': 'raw FETCH_SIZE, 4-byte gather/scatter width uncalibrated' if factor == 1.0 else
+                               'FETCH_SIZE doubled (16 B/lane streaming reads are tallied at half, MI355X_MICROARCH.md HBM section)'}
     json.dump({'per_launch': per_launch, 'detail': detail, 'unit': 'bytes of HBM traffic per kernel launch',
                'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py --no-graph'}, sys.stdout, indent=1)
 

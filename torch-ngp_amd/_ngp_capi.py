@@ -59,6 +59,8 @@ _SIGNATURES = {
     'ngp_ffmlp_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
     'ngp_grid_encode_forward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
     'ngp_grid_encode_backward_ex': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
+    'ngp_grid_encode_backward_ws': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp, _vp,
+                                    _sz, _vp],
     'ngp_ffmlp_forward_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_inference_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_backward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp],
@@ -84,13 +86,16 @@ lib.ngp_abi_version.restype = ctypes.c_int
 lib.ngp_march_rays_train_workspace_bytes.argtypes = [_u32]
 lib.ngp_march_rays_train_workspace_bytes.restype = _sz
 lib.ngp_compact_rays_workspace_bytes.argtypes = [_u32]
+lib.ngp_grid_backward_workspace_bytes.argtypes = [_vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _i32]
+lib.ngp_grid_backward_workspace_bytes.restype = _sz
 lib.ngp_compact_rays_workspace_bytes.restype = _sz
 
 if lib.ngp_abi_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH}: ABI version {lib.ngp_abi_version()} != expected {ABI_VERSION}; rebuild the extension")
 
 EXPORTED = sorted(list(_SIGNATURES) + ['ngp_last_error', 'ngp_target_arch', 'ngp_abi_version',
-                                       'ngp_march_rays_train_workspace_bytes', 'ngp_compact_rays_workspace_bytes'])
+                                       'ngp_march_rays_train_workspace_bytes', 'ngp_compact_rays_workspace_bytes',
+                                       'ngp_grid_backward_workspace_bytes'])
 
 
 def check(rc):
@@ -138,3 +143,29 @@ def dense(t, name):
     require_device(t, name)
     require_contiguous(t, name)
     return t
+
+
+def host_offsets(offsets):
+    """HOST copy (ctypes int32 array) of a grid encoder's `offsets` tensor, cached on the tensor object; None when it would have to be
+    read back during stream capture (the caller then uses the workspace-free path)"""
+    cached = getattr(offsets, '_ngp_host', None)
+    if cached is not None and cached[0] == (offsets.data_ptr(), offsets.numel(), offsets._version):
+        return cached[1]
+    if offsets.is_cuda and torch.cuda.is_current_stream_capturing():
+        return None
+    vals = [int(v) for v in offsets.detach().cpu().tolist()]
+    arr = (ctypes.c_int32 * len(vals))(*vals)
+    offsets._ngp_host = ((offsets.data_ptr(), offsets.numel(), offsets._version), arr)
+    return arr
+
+
+def grid_backward_workspace(offsets, B, D, C, L, S, H, gridtype, align_corners, code):
+    """(offsets_host, workspace tensor or None, bytes) for ngp_grid_encode_backward_ws"""
+    arr = host_offsets(offsets)
+    if arr is None:
+        return None, None, 0
+    n = int(lib.ngp_grid_backward_workspace_bytes(ctypes.cast(arr, ctypes.c_void_p), B, D, C, L, float(S), H, gridtype, int(bool(align_corners)),
+                                                  code))
+    if n == 0:
+        return arr, None, 0
+    return arr, torch.empty(n, dtype=torch.uint8, device=offsets.device), n

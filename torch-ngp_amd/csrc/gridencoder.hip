@@ -444,20 +444,173 @@ constexpr int BWD_THREADS = 256;
 // fp16 tables with even C use global_atomic_pk_add_f16 (what the reference's half2 atomicAdd does), everything
 // else global_atomic_add_f32.  The summation order of colliding atomics is not defined (as in the reference).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D, int C, bool MERGE>
-__global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
-                                                               const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
-                                                               uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
-                                                               bool align_corners, uint32_t interp, uint32_t points_per_block, InputMap im) {
-    constexpr int NJ = 1 << (D - 1);  // corners per lane (all combinations of the coordinates 1..D-1)
+template <typename T, int C>
+struct BwdLanes {
     // Lane layout inside a point: [first-coordinate corner xb][channel group cl].  A lane carries CPL channels of one corner
     // (2 with the packed fp16 atomic, else 1), so the LPP lanes of a point cover 2 * C consecutive table values = one contiguous
     // span of 8..64 bytes: ONE atomic request per (point, remaining-corner j) whatever the dtype and C.
-    constexpr int CPL = (sizeof(T) == 2 && C % 2 == 0) ? 2 : 1;
-    constexpr int CL = C / CPL;        // lanes per corner
-    constexpr int LPP = 2 * CL;        // lanes per point (a power of two <= 16)
-    constexpr int PTS = 64 / LPP;      // points per wave
-    const uint32_t level = blockIdx.y;
+    static constexpr int CPL = (sizeof(T) == 2 && C % 2 == 0) ? 2 : 1;
+    static constexpr int CL = C / CPL;    // lanes per corner
+    static constexpr int LPP = 2 * CL;    // lanes per point (a power of two <= 16)
+    static constexpr int PTS = 64 / LPP;  // points per wave
+};
+
+struct LevelList {  // the levels a launch covers (blockIdx.y indexes this list)
+    uint8_t level[NGP_MAX_LEVELS];
+};
+
+// One wave-step of the backward: point slot `pl` of this wave handles sample b.  Produces, per remaining-corner slot j, the table
+// address, the (run-merged) fp32 contribution of this lane's CPL channels, and whether this lane issues it.
+// the global loads of one wave-step (sample position, this lane's gradient channels), issued together and ahead of the arithmetic
+template <typename T, int D, int C>
+struct BwdSample {
+    float x[D];
+    float g[BwdLanes<T, C>::CPL];
+    bool live;
+    __device__ __forceinline__ void load(const float* __restrict__ inputs, const T* __restrict__ glevel, uint32_t b, bool in_range, int c0) {
+        constexpr int CPL = BwdLanes<T, C>::CPL;
+        live = in_range;
+#pragma unroll
+        for (int d = 0; d < D; d++) x[d] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) g[c] = 0.0f;
+        if (in_range) {
+#pragma unroll
+            for (int d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+            Vec<T, CPL> gv;
+            gv.load(glevel + (size_t)b * C + c0);
+#pragma unroll
+            for (int c = 0; c < CPL; c++) g[c] = gv.v[c];
+        }
+    }
+};
+
+// DPP row shifts (VALU, no LDS traffic): lane i of each 16-lane row reads lane i -/+ N of the SAME row; lanes without a source keep `old`
+template <int N>
+__device__ __forceinline__ uint32_t row_shr(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x110 + N, 0xF, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ uint32_t row_shl(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x100 + N, 0xF, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ float row_shr_f(float old, float src) {
+    return __builtin_bit_cast(float, row_shr<N>(__builtin_bit_cast(uint32_t, old), __builtin_bit_cast(uint32_t, src)));
+}
+
+// MERGE: 0 = every sample issues its own contribution; 1 = runs of equal table address over the whole wave (cross-lane reads through
+// ds_bpermute: ~15 clk of the CU's LDS pipe each, measured -- affordable only where the alternative is a fabric atomic); 2 = runs
+// inside a 16-lane row (8 samples of the fp16 C = 2 layout) with DPP row shifts: pure VALU.
+template <typename T, int D, int C, int MERGE>
+__device__ __forceinline__ void corner_runs(const BwdSample<T, D, C>& smp, float scale, bool align_corners, uint32_t interp,
+                                            const LevelIndexer<D>& indexer, InputMap im, int pl, uint32_t xb,
+                                            uint32_t (&addr)[1 << (D - 1)], float (&v)[1 << (D - 1)][BwdLanes<T, C>::CPL],
+                                            bool (&issue)[1 << (D - 1)]) {
+    constexpr int NJ = 1 << (D - 1);
+    constexpr int CPL = BwdLanes<T, C>::CPL, LPP = BwdLanes<T, C>::LPP, PTS = BwdLanes<T, C>::PTS;
+    float frac[D], deriv[D];
+    uint32_t cell[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) { frac[d] = 0.0f; cell[d] = 0u; }
+    float g[CPL];
+    bool live = smp.live;
+    if (live) live = locate<D>(smp.x, scale, align_corners, interp, frac, deriv, cell, im);
+    {
+        bool nz = false;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) { g[c] = smp.g[c]; nz = nz || (g[c] != 0.0f); }
+        live = live && nz;  // per lane: a lane whose own channels carry an exactly-zero gradient has nothing to add
+    }
+    // This lane's NJ corners, chosen by ABSOLUTE PARITY of the vertex coordinates: lane class xb owns the vertex whose first
+    // coordinate has parity xb, slot s owns the parities (s bit d-1) of the remaining coordinates.  A vertex shared by
+    // neighbouring cells therefore sits in the same lane class and the same slot for every point that touches it: consecutive
+    // samples of a ray that share a VERTEX (not only a cell) form a run of equal addresses in one slot and are merged below,
+    // and vertices of different points that share a cache line are issued by the same instruction (one request).
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        uint32_t pg[D];
+        const uint32_t bit0 = (xb ^ cell[0]) & 1u;
+        pg[0] = cell[0] + bit0;
+        float w = live ? (bit0 ? frac[0] : 1.0f - frac[0]) : 0.0f;
+#pragma unroll
+        for (int d = 1; d < D; d++) {
+            const uint32_t bit = (((uint32_t)j >> (d - 1)) ^ cell[d]) & 1u;
+            pg[d] = cell[d] + bit;
+            w *= bit ? frac[d] : (1.0f - frac[d]);
+        }
+        addr[j] = indexer(pg);
+#pragma unroll
+        for (int c = 0; c < CPL; c++) v[j][c] = w * g[c];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) issue[j] = live;
+    if constexpr (MERGE == 2) {
+        static_assert(MERGE != 2 || LPP == 2, "the row-local merge is written for two lanes per sample");
+        const uint32_t prev_live = row_shr<2>(0u, (uint32_t)live);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t prev_addr = row_shr<2>(0xffffffffu, addr[j]);  // first sample of a row: no predecessor, the run starts here
+            const bool same = live & (prev_live != 0u) & (prev_addr == addr[j]);
+            if (__any(same)) {
+                uint32_t reached = same ? 0u : 1u;
+                // segmented inclusive scan over the 8 samples of the row, distances 1, 2, 4 samples
+#define NGP_ROW_SCAN_STEP(N)                                                   \
+                {                                                                  \
+                    const uint32_t r_o = row_shr<N>(1u, reached);                 \
+                    float t[CPL];                                                  \
+                    _Pragma("unroll") for (int c = 0; c < CPL; c++) t[c] = row_shr_f<N>(0.0f, v[j][c]); \
+                    if (!reached) {                                                \
+                        _Pragma("unroll") for (int c = 0; c < CPL; c++) v[j][c] += t[c];               \
+                        reached = r_o;                                             \
+                    }                                                              \
+                }
+                NGP_ROW_SCAN_STEP(2)
+                NGP_ROW_SCAN_STEP(4)
+                NGP_ROW_SCAN_STEP(8)
+#undef NGP_ROW_SCAN_STEP
+                const uint32_t next_same = row_shl<2>(0u, (uint32_t)same);
+                issue[j] = live && !next_same;  // the last lane of a run holds the run total
+            }
+        }
+    }
+    if constexpr (MERGE == 1) {
+        // (every shuffle is executed by all lanes: no short-circuit in front of a cross-lane read)
+        const int prev_live = __shfl_up((int)live, LPP, 64);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            // same destination as the previous point slot?  (equal table address: equal vertex, or a hash collision -- either way
+            // the contributions go to the same place)
+            const uint32_t prev_addr = __shfl_up(addr[j], LPP, 64);
+            const bool same = live & (pl > 0) & (prev_live != 0) & (prev_addr == addr[j]);
+            if (__any(same)) {
+                bool reached = !same;  // the scan of this lane has reached the head of its run
+#pragma unroll
+                for (int o = 1; o < PTS; o <<= 1) {
+                    const int r_o = __shfl_up((int)reached, LPP * o, 64);
+                    const bool take = !reached && pl >= o;
+#pragma unroll
+                    for (int c = 0; c < CPL; c++) {
+                        const float t = __shfl_up(v[j][c], LPP * o, 64);
+                        if (take) v[j][c] += t;
+                    }
+                    if (take) reached = r_o != 0;
+                }
+                const int next_same = __shfl_down((int)same, LPP, 64);
+                issue[j] = live && (pl == PTS - 1 || !next_same);  // the last lane of a run holds the run total
+            }
+        }
+    }
+}
+
+template <typename T, int D, int C, int MERGE>
+__global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                               const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                               uint32_t B, LevelList ll, GridLevels lv, uint32_t gridtype,
+                                                               bool align_corners, uint32_t interp, uint32_t points_per_block, InputMap im) {
+    constexpr int NJ = 1 << (D - 1);  // corners per lane (all combinations of the coordinates 1..D-1)
+    constexpr int CPL = BwdLanes<T, C>::CPL, CL = BwdLanes<T, C>::CL, LPP = BwdLanes<T, C>::LPP, PTS = BwdLanes<T, C>::PTS;
+    const uint32_t level = ll.level[blockIdx.y];
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
     const float scale = lv.scale[level];
@@ -468,87 +621,254 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int pl = lane / LPP;                        // point slot inside the wave
-    const uint32_t xb = (uint32_t)(lane / CL) & 1u;   // which first-coordinate corner this lane owns
+    const uint32_t xb = (uint32_t)(lane / CL) & 1u;   // which first-coordinate corner class this lane owns
     const int c0 = (lane % CL) * CPL;                 // first channel this lane owns
     const uint32_t b_begin = blockIdx.x * points_per_block;
     const uint32_t b_end = min(B, b_begin + points_per_block);
 
     for (uint32_t base = b_begin + wid * PTS; base < b_end; base += (BWD_THREADS / 64) * PTS) {
         const uint32_t b = base + pl;
-        bool live = b < b_end;
-        float frac[D], deriv[D];
-        uint32_t cell[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) { frac[d] = 0.0f; cell[d] = 0u; }
-        float g[CPL];
-#pragma unroll
-        for (int c = 0; c < CPL; c++) g[c] = 0.0f;
-        if (live) live = locate<D>(inputs + (size_t)b * D, scale, align_corners, interp, frac, deriv, cell, im);
-        if (live) {
-            Vec<T, CPL> gv;
-            gv.load(glevel + (size_t)b * C + c0);
-            bool nz = false;
-#pragma unroll
-            for (int c = 0; c < CPL; c++) { g[c] = gv.v[c]; nz = nz || (g[c] != 0.0f); }
-            live = nz;  // per lane: a lane whose own channels carry an exactly-zero gradient has nothing to add
-        }
-        // This lane's NJ corners, chosen by ABSOLUTE PARITY of the vertex coordinates: lane class xl owns the vertex whose first
-        // coordinate has parity xl, slot s owns the parities (s bit d-1) of the remaining coordinates.  A vertex shared by
-        // neighbouring cells therefore sits in the same lane class and the same slot for every point that touches it: consecutive
-        // samples of a ray that share a VERTEX (not only a cell) form a run of equal addresses in one slot and are merged below,
-        // and vertices of different points that share a cache line are issued by the same instruction (one request).
-        const uint32_t xl = xb;  // lane class bit
-        float v[NJ][CPL];
         uint32_t addr[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            uint32_t pg[D];
-            const uint32_t bit0 = (xl ^ cell[0]) & 1u;
-            pg[0] = cell[0] + bit0;
-            float w = live ? (bit0 ? frac[0] : 1.0f - frac[0]) : 0.0f;
-#pragma unroll
-            for (int d = 1; d < D; d++) {
-                const uint32_t bit = (((uint32_t)j >> (d - 1)) ^ cell[d]) & 1u;
-                pg[d] = cell[d] + bit;
-                w *= bit ? frac[d] : (1.0f - frac[d]);
-            }
-            addr[j] = indexer(pg);
-#pragma unroll
-            for (int c = 0; c < CPL; c++) v[j][c] = w * g[c];
-        }
+        float v[NJ][CPL];
         bool issue[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) issue[j] = live;
-        if (MERGE) {
-            // (every shuffle is executed by all lanes: no short-circuit in front of a cross-lane read)
-            const int prev_live = __shfl_up((int)live, LPP, 64);
-#pragma unroll
-            for (int j = 0; j < NJ; j++) {
-                // same destination as the previous point slot?  (equal table address: equal vertex, or a hash collision -- either way
-                // the contributions go to the same place)
-                const uint32_t prev_addr = __shfl_up(addr[j], LPP, 64);
-                const bool same = live & (pl > 0) & (prev_live != 0) & (prev_addr == addr[j]);
-                if (__any(same)) {
-                    bool reached = !same;  // the scan of this lane has reached the head of its run
-#pragma unroll
-                    for (int o = 1; o < PTS; o <<= 1) {
-                        const int r_o = __shfl_up((int)reached, LPP * o, 64);
-                        const bool take = !reached && pl >= o;
-#pragma unroll
-                        for (int c = 0; c < CPL; c++) {
-                            const float t = __shfl_up(v[j][c], LPP * o, 64);
-                            if (take) v[j][c] += t;
-                        }
-                        if (take) reached = r_o != 0;
-                    }
-                    const int next_same = __shfl_down((int)same, LPP, 64);
-                    issue[j] = live && (pl == PTS - 1 || !next_same);  // the last lane of a run holds the run total
-                }
-            }
-        }
+        BwdSample<T, D, C> smp;
+        smp.load(inputs, glevel, b, b < b_end, c0);
+        corner_runs<T, D, C, MERGE>(smp, scale, align_corners, interp, indexer, im, pl, xb, addr, v, issue);
 #pragma unroll
         for (int j = 0; j < NJ; j++)
             if (issue[j]) scatter_add<T, CPL>(gtable + (size_t)addr[j] * C + c0, v[j], 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, BINNED levels (fp16 tables with C = 2: the instant-ngp configuration) -- no memory-side atomics at all.
+//
+// A global atomic is a fabric operation on this chip (~20 G requests/s, above); a fine hashed level needs ~4 of them per sample
+// and nothing merges them.  LDS is no faster for FLOAT atomics (ds_add_f32 / ds_pk_add_f16: 0.33 lanes/clk/CU, serialised),
+// but INTEGER LDS atomics run at ~7 lanes/clk/CU (tools/lds_atomic_probe.hip).  And every contribution is an fp16 number, i.e. an
+// integer multiple of 2^-24 below 2^16: a 64-bit fixed-point accumulator holds the EXACT sum of any number of them.  So:
+//   pass 1 (k_grid_backward_bin): the same corner/weight/run-merge arithmetic, but each issued contribution becomes an 8-byte
+//       record {table index, fp16x2 value}.  A workgroup counting-sorts the <= 4096 records of its 512 samples by table SLICE
+//       (4096 entries) in LDS and streams them, sorted, into ITS OWN chunk of the workspace (fully coalesced, no reservation, no
+//       overflow), plus one descriptor {begin, count} per slice;
+//   pass 2 (k_grid_backward_accumulate): one workgroup per (level, slice) walks the descriptors of all chunks, adds the matching
+//       runs into a 64 KiB int64 LDS accumulator with ds_add_u64, rounds each sum ONCE and adds it to the gradient table with plain
+//       loads/stores (it owns the slice).
+// The result is the exact sum rounded once -- more accurate than the reference's fp16 atomics and bit-reproducible run to run
+// (integer addition commutes); non-finite contributions poison their entry with NaN (the loss scaler skips the step either way).
+// ------------------------------------------------------------------------------------------------
+constexpr int BIN_THREADS = 512;
+constexpr int BIN_ITERS = 2;                                   // wave-steps per workgroup
+constexpr int BIN_PPB = BIN_ITERS * (BIN_THREADS / 64) * 32;   // samples per workgroup (2 lanes per sample)
+constexpr int BIN_SLICE_BITS = 12;                             // 4096 table entries per slice / bin
+constexpr int BIN_SLICE = 1 << BIN_SLICE_BITS;
+constexpr int BIN_MAX_BINS = BIN_THREADS;                      // one thread per bin in the layout step
+constexpr int ACC_THREADS = 1024;
+
+struct BinPlan {
+    uint8_t level[NGP_MAX_LEVELS];       // binned levels (blockIdx.y indexes these arrays)
+    uint16_t n_bins[NGP_MAX_LEVELS];
+    uint32_t desc_base[NGP_MAX_LEVELS];  // first descriptor of the level; descriptors are [bin][chunk]
+    uint32_t n_chunks;                   // workgroups of pass 1 per level = chunks per level
+};
+
+__device__ __forceinline__ uint32_t pack_half2(float a, float b) {
+    const half2_t h = {(half_t)a, (half_t)b};
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ void atomic_add_packed(half_t* p, uint32_t packed) {
+    (void)__builtin_amdgcn_flat_atomic_fadd_v2f16(reinterpret_cast<half2_t*>(p), __builtin_bit_cast(half2_t, packed));
+}
+
+template <int D>
+__global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restrict__ inputs,
+                                                                   const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid,
+                                                                   uint32_t B, GridLevels lv, uint32_t gridtype, bool align_corners,
+                                                                   uint32_t interp, InputMap im, BinPlan plan,
+                                                                   uint32_t* __restrict__ descriptors, uint2* __restrict__ records) {
+    using T = half_t;
+    constexpr int C = 2;
+    constexpr int NJ = 1 << (D - 1);
+    constexpr int CPL = 2, LPP = 2, PTS = 32;
+    constexpr int WAVES = BIN_THREADS / 64;
+    constexpr int MAX_REC = BIN_PPB * 2 * NJ;  // records per workgroup = slots per chunk
+    __shared__ __attribute__((aligned(16))) uint2 staging[MAX_REC];
+    __shared__ uint32_t hist[BIN_MAX_BINS];    // records per bin
+    __shared__ uint32_t loff[BIN_MAX_BINS];    // exclusive offsets of the bins in the sorted order
+    __shared__ uint32_t wsum[WAVES];
+
+    const uint32_t li = blockIdx.y;
+    const uint32_t level = plan.level[li];
+    const uint32_t n_bins = plan.n_bins[li];
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float scale = lv.scale[level];
+    LevelIndexer<D> indexer;
+    indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
+    half_t* __restrict__ gtable = grad_grid + (size_t)off0 * C;
+    const half_t* __restrict__ glevel = grad + (size_t)level * B * C;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int pl = lane / LPP;
+    const uint32_t xb = (uint32_t)lane & 1u;
+    const uint32_t b_begin = blockIdx.x * BIN_PPB;
+    const uint32_t b_end = min(B, b_begin + BIN_PPB);
+    // the plan was made from the caller's HOST copy of the offsets; if the device offsets describe a larger level, stay in bounds
+    // (those records take the atomic)
+    const bool plan_ok = hashmap_size <= (n_bins << BIN_SLICE_BITS);
+
+    BwdSample<T, D, C> smp[BIN_ITERS];  // every global load of the workgroup is in flight before the first use
+#pragma unroll
+    for (int it = 0; it < BIN_ITERS; it++) {
+        const uint32_t b = b_begin + (uint32_t)(it * WAVES + wid) * PTS + pl;
+        smp[it].load(inputs, glevel, b, b < b_end, 0);
+    }
+    hist[tid] = 0u;  // BIN_MAX_BINS == BIN_THREADS
+    __syncthreads();
+
+    uint32_t raddr[BIN_ITERS * NJ], rval[BIN_ITERS * NJ], rrank[BIN_ITERS * NJ];
+#pragma unroll
+    for (int it = 0; it < BIN_ITERS; it++) {
+        uint32_t addr[NJ];
+        float v[NJ][CPL];
+        bool issue[NJ];
+        corner_runs<T, D, C, 2>(smp[it], scale, align_corners, interp, indexer, im, pl, xb, addr, v, issue);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const uint32_t packed = pack_half2(v[j][0], v[j][1]);
+            const bool rec = issue[j] && (packed & 0x7fff7fffu) != 0u;  // (+-0, +-0) adds nothing
+            raddr[it * NJ + j] = addr[j];
+            rval[it * NJ + j] = packed;
+            if (rec && !plan_ok) atomic_add_packed(gtable + (size_t)addr[j] * C, packed);
+            rrank[it * NJ + j] = (rec && plan_ok) ? atomicAdd(&hist[addr[j] >> BIN_SLICE_BITS], 1u) : 0xffffffffu;
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the bin counts -> layout of the sorted chunk; one descriptor per bin
+        const uint32_t cnt = hist[tid];
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        uint32_t before = 0u;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) before += (w < wid) ? wsum[w] : 0u;
+        const uint32_t begin = before + incl - cnt;
+        loff[tid] = begin;
+        if ((uint32_t)tid < n_bins)
+            descriptors[plan.desc_base[li] + (size_t)tid * plan.n_chunks + blockIdx.x] = begin | (cnt << 16);  // begin < 4096, cnt <= 4096
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < BIN_ITERS * NJ; r++)
+        if (rrank[r] != 0xffffffffu) staging[loff[raddr[r] >> BIN_SLICE_BITS] + rrank[r]] = make_uint2(raddr[r], rval[r]);
+    __syncthreads();
+    uint32_t total = 0u;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) total += wsum[w];
+    // 16 bytes per lane (two records): 8-byte global accesses run at 0.5-0.7x the 16-byte rate on this chip (MI355X_MICROARCH.md)
+    uint4* __restrict__ chunk = reinterpret_cast<uint4*>(records + ((size_t)li * plan.n_chunks + blockIdx.x) * MAX_REC);
+    const uint4* staging2 = reinterpret_cast<const uint4*>(staging);
+    for (uint32_t r = tid; 2u * r < total; r += BIN_THREADS) chunk[r] = staging2[r];  // an odd tail writes one unused slot of the chunk
+}
+
+// fp16 bit pattern (finite) -> signed multiple of 2^-24
+__device__ __forceinline__ long long half_bits_to_fixed(uint32_t h) {
+    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    const unsigned long long mag = e ? ((unsigned long long)(1024u + m) << (e - 1u)) : (unsigned long long)m;
+    return (h & 0x8000u) ? -(long long)mag : (long long)mag;
+}
+
+template <int D>
+__global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_grid_backward_accumulate(const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid,
+                                                                          BinPlan plan, const uint32_t* __restrict__ descriptors,
+                                                                          const uint2* __restrict__ records) {
+    constexpr int MAX_REC = BIN_PPB * (1 << D);
+    extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_smem);                                // [BIN_SLICE][2]
+    uint32_t* poison = reinterpret_cast<uint32_t*>(acc_smem + sizeof(unsigned long long) * 2 * BIN_SLICE);  // [BIN_SLICE / 16], 2 bits per entry
+    const uint32_t li = blockIdx.y, bin = blockIdx.x;
+    if (bin >= plan.n_bins[li]) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * BIN_SLICE; i += ACC_THREADS) acc[i] = 0ull;
+    if (tid < BIN_SLICE / 16) poison[tid] = 0u;
+    __syncthreads();
+    const uint32_t n_chunks = plan.n_chunks;
+    const uint32_t* __restrict__ desc = descriptors + plan.desc_base[li] + (size_t)bin * n_chunks;
+    const uint2* __restrict__ level_records = records + (size_t)li * n_chunks * MAX_REC;
+    // A group of 16 lanes walks one run (the records of one chunk that fall into this slice: ~32 on a hashed level) at a time, two
+    // records = 16 bytes per lane (8-byte global accesses run at 0.5-0.7x the 16-byte rate).  Memory latency is the other cost, so a
+    // group fetches the descriptors of its next 16 runs with ONE load (a lane each), then issues the loads of RUNS_AHEAD runs back to
+    // back before it touches the accumulator.
+    constexpr int GROUP = 16, GROUPS = ACC_THREADS / GROUP, RUNS_AHEAD = 4;
+    const int grp = tid / GROUP, gl = tid % GROUP, lane = tid & 63, group_base = lane & ~(GROUP - 1);
+    auto add_record = [&](const uint32_t key, const uint32_t val) {
+        const uint32_t idx = key & (BIN_SLICE - 1u);
+        const uint32_t lo = val & 0xffffu, hi = val >> 16;
+        if ((lo & 0x7c00u) == 0x7c00u) atomicOr(&poison[idx >> 4], 1u << ((idx & 15u) * 2u));
+        else if (lo & 0x7fffu) __hip_atomic_fetch_add(&acc[2 * idx], (unsigned long long)half_bits_to_fixed(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((hi & 0x7c00u) == 0x7c00u) atomicOr(&poison[idx >> 4], 2u << ((idx & 15u) * 2u));
+        else if (hi & 0x7fffu) __hip_atomic_fetch_add(&acc[2 * idx + 1], (unsigned long long)half_bits_to_fixed(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(level_records);  // 2 words per record
+    auto load2 = [&](uint32_t first_record) {  // records first_record, first_record + 1 (the chunk has an even number of slots)
+        uint4 q;
+        __builtin_memcpy(&q, words + 2u * first_record, sizeof(q));  // 8-byte aligned: global_load_dwordx4 takes it
+        return q;
+    };
+    // every workgroup of a level walks the same chunks: start each one somewhere else, or they all hammer the same 32 KiB (the same
+    // few memory channels) at the same time
+    const uint32_t rot = (bin * 97u) % n_chunks;
+    auto chunk_of = [&](uint32_t i) { const uint32_t k = i + rot; return k >= n_chunks ? k - n_chunks : k; };
+    for (uint32_t k0 = grp; k0 < n_chunks; k0 += GROUPS * GROUP) {  // this group's runs k0 + GROUPS * i, i = 0..15 (before rotation)
+        const uint32_t my_k = k0 + (uint32_t)gl * GROUPS;
+        const uint32_t my_desc = my_k < n_chunks ? desc[chunk_of(my_k)] : 0u;
+#pragma unroll 1
+        for (int i0 = 0; i0 < GROUP; i0 += RUNS_AHEAD) {
+            if (k0 + (uint32_t)i0 * GROUPS >= n_chunks) break;
+            uint32_t d[RUNS_AHEAD];
+            uint4 rec[RUNS_AHEAD];
+#pragma unroll
+            for (int a = 0; a < RUNS_AHEAD; a++) {
+                d[a] = __shfl(my_desc, group_base + i0 + a, 64);
+                const uint32_t k = chunk_of(k0 + (uint32_t)(i0 + a) * GROUPS);
+                const uint32_t begin = d[a] & 0xffffu, cnt = d[a] >> 16;
+                rec[a] = 2u * gl < cnt ? load2(k * (uint32_t)MAX_REC + begin + 2u * gl) : make_uint4(0u, 0u, 0u, 0u);  // 32-bit index: < 2^28
+            }
+#pragma unroll
+            for (int a = 0; a < RUNS_AHEAD; a++) {
+                const uint32_t k = chunk_of(k0 + (uint32_t)(i0 + a) * GROUPS);
+                const uint32_t begin = d[a] & 0xffffu, cnt = d[a] >> 16;
+                if (2u * gl < cnt) add_record(rec[a].x, rec[a].y);
+                if (2u * gl + 1u < cnt) add_record(rec[a].z, rec[a].w);
+                for (uint32_t i = 2u * gl + 2u * GROUP; i < cnt; i += 2u * GROUP) {  // runs longer than 32 records: rare on hashed levels
+                    const uint4 q = load2(k * (uint32_t)MAX_REC + begin + i);
+                    add_record(q.x, q.y);
+                    if (i + 1u < cnt) add_record(q.z, q.w);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t level = plan.level[li];
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    half2_t* __restrict__ gtable = reinterpret_cast<half2_t*>(grad_grid + (size_t)off0 * 2);
+    for (uint32_t i = tid; i < (uint32_t)BIN_SLICE; i += ACC_THREADS) {
+        const uint32_t e = bin * BIN_SLICE + i;
+        if (e >= hashmap_size) break;
+        const long long s0 = (long long)acc[2 * i], s1 = (long long)acc[2 * i + 1];
+        const uint32_t bad = (poison[i >> 4] >> ((i & 15u) * 2u)) & 3u;
+        if (s0 == 0 && s1 == 0 && !bad) continue;
+        const half2_t old = gtable[e];
+        const float nan = __builtin_nanf("");
+        half2_t nu;
+        nu.x = (half_t)((float)old.x + ((bad & 1u) ? nan : (float)s0 * 0x1p-24f));
+        nu.y = (half_t)((float)old.y + ((bad & 2u) ? nan : (float)s1 * 0x1p-24f));
+        gtable[e] = nu;
     }
 }
 
@@ -676,23 +996,108 @@ static int grid_backward_variant() {  // NGP_GRID_BWD=nomerge disables the run m
     return mode;
 }
 
+// ---- host-side plan of a backward call: which levels go through the bins, and where their chunks live in the workspace ----
+struct BackwardPlan {
+    LevelList atomic_levels;
+    uint32_t n_atomic = 0;
+    BinPlan bins;
+    uint32_t n_binned = 0, total_desc = 0, max_bins = 0;
+    uint64_t total_records = 0;
+    size_t desc_bytes() const { return ((size_t)total_desc * sizeof(uint32_t) + 255) & ~(size_t)255; }
+    size_t workspace_bytes() const { return n_binned ? desc_bytes() + (size_t)total_records * sizeof(uint2) : 0; }
+};
+
+constexpr uint32_t BIN_MIN_SAMPLES = 16384;       // below this the launch overheads of the two extra kernels win
+constexpr uint32_t BIN_MAX_SAMPLES = 1u << 24;
+
+static int bin_first_level() {  // NGP_GRID_BWD_BIN_FROM=<level>: first level that may be binned (benchmarks / experiments); 99 = never
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("NGP_GRID_BWD_BIN_FROM");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
+}
+
+// Levels that are binned by default: HASHED ones (their records spread uniformly over the slices, and consecutive samples rarely share
+// a vertex, so the run merge of the atomic path has little to offer).  Dense levels keep the atomic path: consecutive samples merge.
+static void plan_backward(BackwardPlan& p, const int32_t* offsets_host, const GridLevels& lv, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                          int dtype, uint32_t gridtype, bool align_corners, bool have_workspace) {
+    const bool eligible = have_workspace && offsets_host && dtype == NGP_F16 && C == 2 && (D == 2 || D == 3) && B >= BIN_MIN_SAMPLES &&
+                          B <= BIN_MAX_SAMPLES;
+    const int first = bin_first_level();
+    p.bins.n_chunks = cdiv(B, (uint32_t)BIN_PPB);
+    for (uint32_t l = 0; l < L; l++) {
+        const uint32_t size = eligible ? (uint32_t)(offsets_host[l + 1] - offsets_host[l]) : 0u;
+        const uint32_t n_bins = (size + BIN_SLICE - 1) >> BIN_SLICE_BITS;
+        double dense = 1.0;
+        for (uint32_t d = 0; d < D; d++) dense *= (double)(align_corners ? lv.res[l] : lv.res[l] + 1u);
+        const bool hashed = gridtype == 0u && dense > (double)size;
+        const bool binned = eligible && n_bins >= 1 && n_bins <= (uint32_t)BIN_MAX_BINS && (first >= 0 ? (int)l >= first : hashed);
+        if (!binned) {
+            p.atomic_levels.level[p.n_atomic++] = (uint8_t)l;
+            continue;
+        }
+        const uint32_t i = p.n_binned++;
+        p.bins.level[i] = (uint8_t)l;
+        p.bins.n_bins[i] = (uint16_t)n_bins;
+        p.bins.desc_base[i] = p.total_desc;
+        p.total_desc += n_bins * p.bins.n_chunks;
+        p.total_records += (uint64_t)p.bins.n_chunks * BIN_PPB * (1u << D);
+        p.max_bins = n_bins > p.max_bins ? n_bins : p.max_bins;
+    }
+}
+
+template <int D>
+static int launch_backward_bins(const void* grad, const float* inputs, const int32_t* offsets, void* grad_emb, uint32_t B,
+                                const GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, InputMap im, const BackwardPlan& p,
+                                void* workspace, hipStream_t st) {
+    constexpr size_t acc_smem = sizeof(unsigned long long) * 2 * BIN_SLICE + sizeof(uint32_t) * (BIN_SLICE / 16);
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_accumulate<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)acc_smem) != hipSuccess) {
+            set_error("grid_encode_backward: hipFuncSetAttribute(LDS size) failed");
+            return NGP_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    uint32_t* descriptors = reinterpret_cast<uint32_t*>(workspace);
+    uint2* records = reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(workspace) + p.desc_bytes());
+    hipLaunchKernelGGL((k_grid_backward_bin<D>), dim3(p.bins.n_chunks, p.n_binned), dim3(BIN_THREADS), 0, st, (const half_t*)grad, inputs,
+                       offsets, (half_t*)grad_emb, B, lv, gridtype, ac, interp, im, p.bins, descriptors, records);
+    int rc = check_launch("grid_encode_backward(bin)");
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_grid_backward_accumulate<D>), dim3(p.max_bins, p.n_binned), dim3(ACC_THREADS), acc_smem, st, offsets,
+                       (half_t*)grad_emb, p.bins, (const uint32_t*)descriptors, (const uint2*)records);
+    return check_launch("grid_encode_backward(accumulate)");
+}
+
 template <typename T, int D, int C>
 static int launch_backward(const void* grad, const float* inputs, const int32_t* offsets, void* grad_emb, uint32_t B,
                            uint32_t L, const GridLevels& lv, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
-                           bool ac, uint32_t interp, InputMap im, hipStream_t st) {
+                           bool ac, uint32_t interp, InputMap im, const BackwardPlan& plan, void* workspace, hipStream_t st) {
     int rc = NGP_OK;
-    // one block covers `ppb` consecutive points of one level; >= ~4 blocks per CU over all levels fills the chip
-    uint32_t ppb = 2048;
-    while (ppb > 128 && (uint64_t)cdiv(B, ppb) * L < 2048) ppb >>= 1;
-    dim3 grid(cdiv(B, ppb), L, 1);
-    if (grid_backward_variant() == 1)
-        hipLaunchKernelGGL((k_grid_backward<T, D, C, false>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
-                           (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb, im);
-    else
-        hipLaunchKernelGGL((k_grid_backward<T, D, C, true>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
-                           (T*)grad_emb, B, L, lv, gridtype, ac, interp, ppb, im);
-    rc = check_launch("grid_encode_backward");
-    if (rc) return rc;
+    if (plan.n_atomic) {
+        // one block covers `ppb` consecutive points of one level; >= ~4 blocks per CU over all levels fills the chip
+        uint32_t ppb = 2048;
+        while (ppb > 128 && (uint64_t)cdiv(B, ppb) * plan.n_atomic < 2048) ppb >>= 1;
+        dim3 grid(cdiv(B, ppb), plan.n_atomic, 1);
+        if (grid_backward_variant() == 1)
+            hipLaunchKernelGGL((k_grid_backward<T, D, C, 0>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
+                               (T*)grad_emb, B, plan.atomic_levels, lv, gridtype, ac, interp, ppb, im);
+        else
+            hipLaunchKernelGGL((k_grid_backward<T, D, C, 1>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
+                               (T*)grad_emb, B, plan.atomic_levels, lv, gridtype, ac, interp, ppb, im);
+        rc = check_launch("grid_encode_backward");
+        if (rc) return rc;
+    }
+    if (plan.n_binned) {
+        if constexpr (sizeof(T) == 2 && C == 2 && (D == 2 || D == 3)) {
+            rc = launch_backward_bins<D>(grad, inputs, offsets, grad_emb, B, lv, gridtype, ac, interp, im, plan, workspace, st);
+            if (rc) return rc;
+        }
+    }
     if (dy_dx && grad_inputs) {
         hipLaunchKernelGGL((k_grid_input_backward<T>), dim3(cdiv(B * D, 256)), dim3(256), 0, st, (const T*)grad,
                            (const T*)dy_dx, (T*)grad_inputs, B, L, (uint32_t)D, (uint32_t)C);
@@ -796,10 +1201,21 @@ extern "C" int ngp_grid_encode_forward(const float* inputs, const void* embeddin
                                       dtype, 0.0f, stream);
 }
 
-extern "C" int ngp_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+extern "C" size_t ngp_grid_backward_workspace_bytes(const int32_t* offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                                    uint32_t H, uint32_t gridtype, int align_corners, int dtype) {
+    if (!offsets_host || L < 1 || L > NGP_MAX_LEVELS || D < 2 || D > 5) return 0;
+    GridLevels lv;
+    fill_levels(lv, L, S, H);
+    BackwardPlan plan;
+    plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0, true);
+    return plan.workspace_bytes();
+}
+
+extern "C" int ngp_grid_encode_backward_ws(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                            void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                            uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
-                                           uint32_t interp, int dtype, float bound, ngp_stream_t stream) {
+                                           uint32_t interp, int dtype, float bound, const int32_t* offsets_host, void* workspace,
+                                           size_t workspace_bytes, ngp_stream_t stream) {
     (void)embeddings;
     NGP_REQUIRE(!(bound > 0.0f && dy_dx), NGP_ERR_INVALID, "grid_encode_backward: the fused input mapping does not provide grad_inputs");
     const InputMap im = make_input_map(bound);
@@ -809,15 +1225,28 @@ extern "C" int ngp_grid_encode_backward_ex(const void* grad, const float* inputs
     NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: NULL tensor");
     GridLevels lv;
     fill_levels(lv, L, S, H);
+    BackwardPlan plan;
+    plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0, workspace != nullptr);
+    NGP_REQUIRE(plan.workspace_bytes() <= workspace_bytes, NGP_ERR_INVALID,
+                "grid_encode_backward: workspace of %zu bytes, ngp_grid_backward_workspace_bytes() asks for %zu", workspace_bytes,
+                plan.workspace_bytes());
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
     if (dtype == NGP_F16) {
-        NGP_DISPATCH_DC(launch_backward, half_t, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, im, st)
+        NGP_DISPATCH_DC(launch_backward, half_t, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, im, plan, workspace, st)
     } else {
-        NGP_DISPATCH_DC(launch_backward, float, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, im, st)
+        NGP_DISPATCH_DC(launch_backward, float, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, im, plan, workspace, st)
     }
     set_error("grid_encode_backward: unsupported (D=%u, C=%u)", D, C);
     return NGP_ERR_INVALID;
+}
+
+extern "C" int ngp_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                           void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                           uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                                           uint32_t interp, int dtype, float bound, ngp_stream_t stream) {
+    return ngp_grid_encode_backward_ws(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
+                                       align_corners, interp, dtype, bound, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int ngp_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,

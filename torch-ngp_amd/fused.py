@@ -17,6 +17,8 @@ Eligibility (checked by the caller, `NeRFNetwork._fused_ok`): CUDA fp32 inputs u
 D = 3 and C = 2, SH degree 4, 64-wide MLPs with 15 geometry features, and a sample count that is a multiple of 128 (the
 marchers pad to 128, raymarching.py:200-203).  Everything else takes the module-by-module path, which stays the reference.
 """
+import ctypes
+
 import numpy as np
 import torch
 from torch.autograd import Function
@@ -100,11 +102,18 @@ class _fused_ngp(Function):
         scratch_s = scratch_c[:nl_sigma]
         _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
                                               0, 6, 1, scratch_s.data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(), _PLANAR_IN | _PLANAR_DX, st))
-        _check(capi.lib.ngp_grid_encode_backward_ex(g_enc.data_ptr(), x.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
-                                                     None, None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
+        _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st)
         if deposited:
             return None, None, None, None, None, None, None, None
         return None, None, g_emb, g_ws, g_wc, None, None, None
+
+
+def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st):
+    """hash-grid scatter of the level-major fp16 gradient; large batches take the binned atomic-free path (needs scratch memory)"""
+    arr, ws, nbytes = capi.grid_backward_workspace(offsets, M, 3, 2, L, S, H, gridtype, align, capi.NGP_F16)
+    _check(capi.lib.ngp_grid_encode_backward_ws(g_enc.data_ptr(), x.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
+                                                 None, None, gridtype, align, interp, capi.NGP_F16, float(bound),
+                                                 None if arr is None else ctypes.cast(arr, ctypes.c_void_p), capi.ptr(ws), nbytes, st))
 
 
 def _half_weights(embeddings, w_sigma, w_color, bufs):
@@ -252,8 +261,7 @@ def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g
     _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
                                           0, 6, 1, scratch[:nl_sigma].data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
                                           _PLANAR_IN | _PLANAR_DX, st))
-    _check(capi.lib.ngp_grid_encode_backward_ex(g_enc.data_ptr(), xyzs.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
-                                                 None, None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
+    _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st)
 
 
 class _fused_render_train(Function):

@@ -35,9 +35,13 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, 
     capi.dense(grad, 'grad')
     capi.dense(grad_embeddings, 'grad_embeddings')
     code = capi.float_code(grad, 'grad')
-    capi.check(capi.lib.ngp_grid_encode_backward(
+    # large fp16 batches: the binned, atomic-free scatter needs scratch memory (include/ngp_hip.h, ngp_grid_encode_backward_ws); the
+    # reference signature has no workspace argument, so it is allocated here
+    arr, ws, nbytes = capi.grid_backward_workspace(offsets, B, D, C, L, S, H, gridtype, align_corners, code)
+    capi.check(capi.lib.ngp_grid_encode_backward_ws(
         capi.ptr(grad), capi.ptr(inputs), capi.ptr(embeddings), capi.ptr(offsets), capi.ptr(grad_embeddings), B, D, C, L,
-        float(S), H, capi.ptr(dy_dx), capi.ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, code, capi.stream()))
+        float(S), H, capi.ptr(dy_dx), capi.ptr(grad_inputs), gridtype, int(bool(align_corners)), interp, code, 0.0,
+        None if arr is None else capi.ctypes.cast(arr, capi.ctypes.c_void_p), capi.ptr(ws), nbytes, capi.stream()))
 
 
 def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners):

@@ -485,18 +485,18 @@ struct BwdSample {
     }
 };
 
-// DPP row shifts (VALU, no LDS traffic): lane i of each 16-lane row reads lane i -/+ N of the SAME row; lanes without a source keep `old`
+// DPP row shifts (VALU, no LDS traffic): lane i of each 16-lane row reads lane i -/+ N of the SAME row; a lane without a source reads 0
 template <int N>
-__device__ __forceinline__ uint32_t row_shr(uint32_t old, uint32_t src) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x110 + N, 0xF, 0xF, false);
+__device__ __forceinline__ uint32_t row_shr(uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x110 + N, 0xF, 0xF, true);
 }
 template <int N>
-__device__ __forceinline__ uint32_t row_shl(uint32_t old, uint32_t src) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x100 + N, 0xF, 0xF, false);
+__device__ __forceinline__ uint32_t row_shl(uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x100 + N, 0xF, 0xF, true);
 }
 template <int N>
-__device__ __forceinline__ float row_shr_f(float old, float src) {
-    return __builtin_bit_cast(float, row_shr<N>(__builtin_bit_cast(uint32_t, old), __builtin_bit_cast(uint32_t, src)));
+__device__ __forceinline__ float row_shr_f(float src) {
+    return __builtin_bit_cast(float, row_shr<N>(__builtin_bit_cast(uint32_t, src)));
 }
 
 // MERGE: 0 = every sample issues its own contribution; 1 = runs of equal table address over the whole wave (cross-lane reads through
@@ -547,29 +547,28 @@ __device__ __forceinline__ void corner_runs(const BwdSample<T, D, C>& smp, float
     for (int j = 0; j < NJ; j++) issue[j] = live;
     if constexpr (MERGE == 2) {
         static_assert(MERGE != 2 || LPP == 2, "the row-local merge is written for two lanes per sample");
-        const uint32_t prev_live = row_shr<2>(0u, (uint32_t)live);
+        const uint32_t prev_live = row_shr<2>((uint32_t)live);
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const uint32_t prev_addr = row_shr<2>(0xffffffffu, addr[j]);  // first sample of a row: no predecessor, the run starts here
-            const bool same = live & (prev_live != 0u) & (prev_addr == addr[j]);
-            if (__any(same)) {
-                uint32_t reached = same ? 0u : 1u;
+            const uint32_t prev_addr1 = row_shr<2>(addr[j] + 1u);  // first sample of a row reads 0: no predecessor, the run starts here
+            const bool same = live & (prev_live != 0u) & (prev_addr1 == addr[j] + 1u);
+            // worth a scan only when a fair share of the wave continues a run (fine levels: almost never)
+            if (__popcll(__ballot(same)) >= 12) {
+                uint32_t open = same ? 1u : 0u;  // the scan of this lane has not reached the head of its run yet
                 // segmented inclusive scan over the 8 samples of the row, distances 1, 2, 4 samples
-#define NGP_ROW_SCAN_STEP(N)                                                   \
-                {                                                                  \
-                    const uint32_t r_o = row_shr<N>(1u, reached);                 \
-                    float t[CPL];                                                  \
-                    _Pragma("unroll") for (int c = 0; c < CPL; c++) t[c] = row_shr_f<N>(0.0f, v[j][c]); \
-                    if (!reached) {                                                \
-                        _Pragma("unroll") for (int c = 0; c < CPL; c++) v[j][c] += t[c];               \
-                        reached = r_o;                                             \
-                    }                                                              \
+#define NGP_ROW_SCAN_STEP(N)                                                                                  \
+                {                                                                                                 \
+                    const uint32_t o_n = row_shr<N>(open);                                                       \
+                    float t[CPL];                                                                                 \
+                    _Pragma("unroll") for (int c = 0; c < CPL; c++) t[c] = row_shr_f<N>(v[j][c]);               \
+                    _Pragma("unroll") for (int c = 0; c < CPL; c++) v[j][c] += open ? t[c] : 0.0f;              \
+                    open = open ? o_n : 0u;                                                                       \
                 }
                 NGP_ROW_SCAN_STEP(2)
                 NGP_ROW_SCAN_STEP(4)
                 NGP_ROW_SCAN_STEP(8)
 #undef NGP_ROW_SCAN_STEP
-                const uint32_t next_same = row_shl<2>(0u, (uint32_t)same);
+                const uint32_t next_same = row_shl<2>((uint32_t)same);
                 issue[j] = live && !next_same;  // the last lane of a run holds the run total
             }
         }
@@ -603,14 +602,14 @@ __device__ __forceinline__ void corner_runs(const BwdSample<T, D, C>& smp, float
     }
 }
 
-template <typename T, int D, int C, int MERGE>
-__global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
-                                                               const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
-                                                               uint32_t B, LevelList ll, GridLevels lv, uint32_t gridtype,
-                                                               bool align_corners, uint32_t interp, uint32_t points_per_block, InputMap im) {
+// the atomic path of one workgroup: `points_per_block` consecutive samples (from block_x * points_per_block) of one level
+template <typename T, int D, int C, int MERGE, int THREADS>
+__device__ __forceinline__ void backward_atomic_block(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                      const int32_t* __restrict__ offsets, T* __restrict__ grad_grid, uint32_t B,
+                                                      uint32_t level, const GridLevels& lv, uint32_t gridtype, bool align_corners,
+                                                      uint32_t interp, uint32_t points_per_block, InputMap im, uint32_t block_x) {
     constexpr int NJ = 1 << (D - 1);  // corners per lane (all combinations of the coordinates 1..D-1)
     constexpr int CPL = BwdLanes<T, C>::CPL, CL = BwdLanes<T, C>::CL, LPP = BwdLanes<T, C>::LPP, PTS = BwdLanes<T, C>::PTS;
-    const uint32_t level = ll.level[blockIdx.y];
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
     const float scale = lv.scale[level];
@@ -623,10 +622,10 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
     const int pl = lane / LPP;                        // point slot inside the wave
     const uint32_t xb = (uint32_t)(lane / CL) & 1u;   // which first-coordinate corner class this lane owns
     const int c0 = (lane % CL) * CPL;                 // first channel this lane owns
-    const uint32_t b_begin = blockIdx.x * points_per_block;
+    const uint32_t b_begin = block_x * points_per_block;
     const uint32_t b_end = min(B, b_begin + points_per_block);
 
-    for (uint32_t base = b_begin + wid * PTS; base < b_end; base += (BWD_THREADS / 64) * PTS) {
+    for (uint32_t base = b_begin + wid * PTS; base < b_end; base += (THREADS / 64) * PTS) {
         const uint32_t b = base + pl;
         uint32_t addr[NJ];
         float v[NJ][CPL];
@@ -638,6 +637,15 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
         for (int j = 0; j < NJ; j++)
             if (issue[j]) scatter_add<T, CPL>(gtable + (size_t)addr[j] * C + c0, v[j], 1.0f);
     }
+}
+
+template <typename T, int D, int C, int MERGE>
+__global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                               const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                               uint32_t B, LevelList ll, GridLevels lv, uint32_t gridtype,
+                                                               bool align_corners, uint32_t interp, uint32_t points_per_block, InputMap im) {
+    backward_atomic_block<T, D, C, MERGE, BWD_THREADS>(grad, inputs, offsets, grad_grid, B, ll.level[blockIdx.y], lv, gridtype, align_corners,
+                                                       interp, points_per_block, im, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -662,7 +670,7 @@ constexpr int BIN_ITERS = 2;                                   // wave-steps per
 constexpr int BIN_PPB = BIN_ITERS * (BIN_THREADS / 64) * 32;   // samples per workgroup (2 lanes per sample)
 constexpr int BIN_SLICE_BITS = 12;                             // 4096 table entries per slice / bin
 constexpr int BIN_SLICE = 1 << BIN_SLICE_BITS;
-constexpr int BIN_MAX_BINS = BIN_THREADS;                      // one thread per bin in the layout step
+constexpr int BIN_MAX_BINS = 512;                              // one thread per bin in the layout step
 constexpr int ACC_THREADS = 1024;
 
 struct BinPlan {
@@ -680,24 +688,49 @@ __device__ __forceinline__ void atomic_add_packed(half_t* p, uint32_t packed) {
     (void)__builtin_amdgcn_flat_atomic_fadd_v2f16(reinterpret_cast<half2_t*>(p), __builtin_bit_cast(half2_t, packed));
 }
 
+// Pass 1 and the atomic levels share ONE launch: the record sort is VALU-bound, the atomic levels wait on the LDS crossbar (run merge)
+// and on the fabric, so workgroups of the two kinds are interleaved (evenly, by a Bresenham split of the block index) and overlap on
+// every CU instead of running back to back.
+struct AtomicPart {
+    LevelList levels;
+    uint32_t n_blocks;          // workgroups of the atomic kind in this launch (0: none)
+    uint32_t blocks_per_level;  // = cdiv(B, points_per_block)
+    uint32_t points_per_block;
+};
+
 template <int D>
 __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restrict__ inputs,
                                                                    const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid,
                                                                    uint32_t B, GridLevels lv, uint32_t gridtype, bool align_corners,
                                                                    uint32_t interp, InputMap im, BinPlan plan,
-                                                                   uint32_t* __restrict__ descriptors, uint2* __restrict__ records) {
+                                                                   uint32_t* __restrict__ descriptors, uint2* __restrict__ records,
+                                                                   AtomicPart ap) {
     using T = half_t;
+    uint32_t bin_block = blockIdx.x;
+    if (ap.n_blocks) {
+        const uint64_t total = gridDim.x;
+        const uint32_t a0 = (uint32_t)(((uint64_t)blockIdx.x * ap.n_blocks) / total);
+        const uint32_t a1 = (uint32_t)((((uint64_t)blockIdx.x + 1u) * ap.n_blocks) / total);
+        if (a1 > a0) {  // this workgroup is the a0-th of the atomic kind
+            backward_atomic_block<half_t, D, 2, 1, BIN_THREADS>(grad, inputs, offsets, grad_grid, B, ap.levels.level[a0 / ap.blocks_per_level], lv,
+                                                                gridtype, align_corners, interp, ap.points_per_block, im,
+                                                                a0 % ap.blocks_per_level);
+            return;
+        }
+        bin_block = blockIdx.x - a0;
+    }
+    const uint32_t li = bin_block / plan.n_chunks, chunk_x = bin_block % plan.n_chunks;
     constexpr int C = 2;
     constexpr int NJ = 1 << (D - 1);
     constexpr int CPL = 2, LPP = 2, PTS = 32;
     constexpr int WAVES = BIN_THREADS / 64;
     constexpr int MAX_REC = BIN_PPB * 2 * NJ;  // records per workgroup = slots per chunk
-    __shared__ __attribute__((aligned(16))) uint2 staging[MAX_REC];
-    __shared__ uint32_t hist[BIN_MAX_BINS];    // records per bin
-    __shared__ uint32_t loff[BIN_MAX_BINS];    // exclusive offsets of the bins in the sorted order
-    __shared__ uint32_t wsum[WAVES];
+    extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
+    uint2* staging = reinterpret_cast<uint2*>(bin_smem);                              // [MAX_REC]
+    uint32_t* hist = reinterpret_cast<uint32_t*>(bin_smem + sizeof(uint2) * MAX_REC);  // [BIN_MAX_BINS] records per bin
+    uint32_t* loff = hist + BIN_MAX_BINS;                                             // [BIN_MAX_BINS] exclusive offsets in the sorted order
+    uint32_t* wsum = loff + BIN_MAX_BINS;                                             // [WAVES]
 
-    const uint32_t li = blockIdx.y;
     const uint32_t level = plan.level[li];
     const uint32_t n_bins = plan.n_bins[li];
     const uint32_t off0 = (uint32_t)offsets[level];
@@ -710,7 +743,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int pl = lane / LPP;
     const uint32_t xb = (uint32_t)lane & 1u;
-    const uint32_t b_begin = blockIdx.x * BIN_PPB;
+    const uint32_t b_begin = chunk_x * BIN_PPB;
     const uint32_t b_end = min(B, b_begin + BIN_PPB);
     // the plan was made from the caller's HOST copy of the offsets; if the device offsets describe a larger level, stay in bounds
     // (those records take the atomic)
@@ -722,7 +755,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
         const uint32_t b = b_begin + (uint32_t)(it * WAVES + wid) * PTS + pl;
         smp[it].load(inputs, glevel, b, b < b_end, 0);
     }
-    hist[tid] = 0u;  // BIN_MAX_BINS == BIN_THREADS
+    if (tid < BIN_MAX_BINS) hist[tid] = 0u;
     __syncthreads();
 
     uint32_t raddr[BIN_ITERS * NJ], rval[BIN_ITERS * NJ], rrank[BIN_ITERS * NJ];
@@ -744,7 +777,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
     }
     __syncthreads();
     {   // exclusive scan of the bin counts -> layout of the sorted chunk; one descriptor per bin
-        const uint32_t cnt = hist[tid];
+        const uint32_t cnt = tid < BIN_MAX_BINS ? hist[tid] : 0u;
         uint32_t incl = cnt;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -757,9 +790,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
 #pragma unroll
         for (int w = 0; w < WAVES; w++) before += (w < wid) ? wsum[w] : 0u;
         const uint32_t begin = before + incl - cnt;
-        loff[tid] = begin;
+        if (tid < BIN_MAX_BINS) loff[tid] = begin;
         if ((uint32_t)tid < n_bins)
-            descriptors[plan.desc_base[li] + (size_t)tid * plan.n_chunks + blockIdx.x] = begin | (cnt << 16);  // begin < 4096, cnt <= 4096
+            descriptors[plan.desc_base[li] + (size_t)tid * plan.n_chunks + chunk_x] = begin | (cnt << 16);  // both <= 4096
     }
     __syncthreads();
 #pragma unroll
@@ -770,7 +803,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
 #pragma unroll
     for (int w = 0; w < WAVES; w++) total += wsum[w];
     // 16 bytes per lane (two records): 8-byte global accesses run at 0.5-0.7x the 16-byte rate on this chip (MI355X_MICROARCH.md)
-    uint4* __restrict__ chunk = reinterpret_cast<uint4*>(records + ((size_t)li * plan.n_chunks + blockIdx.x) * MAX_REC);
+    uint4* __restrict__ chunk = reinterpret_cast<uint4*>(records + ((size_t)li * plan.n_chunks + chunk_x) * MAX_REC);
     const uint4* staging2 = reinterpret_cast<const uint4*>(staging);
     for (uint32_t r = tid; 2u * r < total; r += BIN_THREADS) chunk[r] = staging2[r];  // an odd tail writes one unused slot of the chunk
 }
@@ -800,54 +833,65 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     const uint32_t* __restrict__ desc = descriptors + plan.desc_base[li] + (size_t)bin * n_chunks;
     const uint2* __restrict__ level_records = records + (size_t)li * n_chunks * MAX_REC;
     // A group of 16 lanes walks one run (the records of one chunk that fall into this slice: ~32 on a hashed level) at a time, two
-    // records = 16 bytes per lane (8-byte global accesses run at 0.5-0.7x the 16-byte rate).  Memory latency is the other cost, so a
-    // group fetches the descriptors of its next 16 runs with ONE load (a lane each), then issues the loads of RUNS_AHEAD runs back to
-    // back before it touches the accumulator.
+    // records = 16 bytes per lane (8-byte global accesses run at 0.5-0.7x the 16-byte rate); the rest of a longer run follows in a
+    // second pass.  The kernel is bound by the bytes it pulls (measured: fetching 64 records per run instead of 32 costs +40 %), so
+    // nothing is fetched speculatively.  A group fetches the descriptors of its next 16 runs with ONE load (a lane each), then issues
+    // the loads of RUNS_AHEAD runs back to back -- unconditionally, at clamped addresses -- before it touches the accumulator.
     constexpr int GROUP = 16, GROUPS = ACC_THREADS / GROUP, RUNS_AHEAD = 4;
     const int grp = tid / GROUP, gl = tid % GROUP, lane = tid & 63, group_base = lane & ~(GROUP - 1);
+    // (this kernel is bound by its VALU work per record, so the usual case is kept short: fp16 -> fp32 -> * 2^24 -> int32 is exact
+    // for |value| < 128, one sign extension makes it the 64-bit addend; larger and non-finite values take the bit-pattern path)
+    auto add_channel = [&](unsigned long long* slot, const uint32_t idx, const uint32_t ch, const half_t h) {
+        const float scaled = (float)h * 0x1p24f;  // exact: 11 significant bits
+        if (__builtin_fabsf(scaled) < 0x1p31f) {
+            const int32_t q = (int32_t)scaled;
+            if (q != 0) __hip_atomic_fetch_add(slot, (unsigned long long)(long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            const uint32_t bits = __builtin_bit_cast(uint16_t, h);
+            if ((bits & 0x7c00u) == 0x7c00u) atomicOr(&poison[idx >> 4], (1u + ch) << ((idx & 15u) * 2u));
+            else __hip_atomic_fetch_add(slot, (unsigned long long)half_bits_to_fixed(bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
     auto add_record = [&](const uint32_t key, const uint32_t val) {
         const uint32_t idx = key & (BIN_SLICE - 1u);
-        const uint32_t lo = val & 0xffffu, hi = val >> 16;
-        if ((lo & 0x7c00u) == 0x7c00u) atomicOr(&poison[idx >> 4], 1u << ((idx & 15u) * 2u));
-        else if (lo & 0x7fffu) __hip_atomic_fetch_add(&acc[2 * idx], (unsigned long long)half_bits_to_fixed(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((hi & 0x7c00u) == 0x7c00u) atomicOr(&poison[idx >> 4], 2u << ((idx & 15u) * 2u));
-        else if (hi & 0x7fffu) __hip_atomic_fetch_add(&acc[2 * idx + 1], (unsigned long long)half_bits_to_fixed(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const half2_t hv = __builtin_bit_cast(half2_t, val);
+        add_channel(&acc[2 * idx], idx, 0u, hv.x);
+        add_channel(&acc[2 * idx + 1], idx, 1u, hv.y);
     };
     const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(level_records);  // 2 words per record
-    auto load2 = [&](uint32_t first_record) {  // records first_record, first_record + 1 (the chunk has an even number of slots)
+    auto load2 = [&](uint32_t first_record) {  // records first_record, first_record + 1
         uint4 q;
         __builtin_memcpy(&q, words + 2u * first_record, sizeof(q));  // 8-byte aligned: global_load_dwordx4 takes it
         return q;
     };
-    // every workgroup of a level walks the same chunks: start each one somewhere else, or they all hammer the same 32 KiB (the same
-    // few memory channels) at the same time
+    // every workgroup of a level walks the same chunks: start each one somewhere else
     const uint32_t rot = (bin * 97u) % n_chunks;
     auto chunk_of = [&](uint32_t i) { const uint32_t k = i + rot; return k >= n_chunks ? k - n_chunks : k; };
-    for (uint32_t k0 = grp; k0 < n_chunks; k0 += GROUPS * GROUP) {  // this group's runs k0 + GROUPS * i, i = 0..15 (before rotation)
+    for (uint32_t k0 = grp; k0 < n_chunks; k0 += GROUPS * GROUP) {  // this group's runs k0 + GROUPS * i, i = 0..GROUP-1 (before rotation)
         const uint32_t my_k = k0 + (uint32_t)gl * GROUPS;
-        const uint32_t my_desc = my_k < n_chunks ? desc[chunk_of(my_k)] : 0u;
+        const uint32_t my_desc = desc[chunk_of(my_k < n_chunks ? my_k : k0)];  // (lanes past the end re-read a valid descriptor, unused)
 #pragma unroll 1
         for (int i0 = 0; i0 < GROUP; i0 += RUNS_AHEAD) {
             if (k0 + (uint32_t)i0 * GROUPS >= n_chunks) break;
-            uint32_t d[RUNS_AHEAD];
-            uint4 rec[RUNS_AHEAD];
+            uint32_t base[RUNS_AHEAD], cnt[RUNS_AHEAD];
+            uint4 ra[RUNS_AHEAD];
 #pragma unroll
             for (int a = 0; a < RUNS_AHEAD; a++) {
-                d[a] = __shfl(my_desc, group_base + i0 + a, 64);
-                const uint32_t k = chunk_of(k0 + (uint32_t)(i0 + a) * GROUPS);
-                const uint32_t begin = d[a] & 0xffffu, cnt = d[a] >> 16;
-                rec[a] = 2u * gl < cnt ? load2(k * (uint32_t)MAX_REC + begin + 2u * gl) : make_uint4(0u, 0u, 0u, 0u);  // 32-bit index: < 2^28
+                const uint32_t i = k0 + (uint32_t)(i0 + a) * GROUPS;
+                const uint32_t d = __shfl(my_desc, group_base + i0 + a, 64);
+                const uint32_t k = chunk_of(i < n_chunks ? i : k0);
+                cnt[a] = i < n_chunks ? d >> 16 : 0u;
+                base[a] = k * (uint32_t)MAX_REC + (cnt[a] ? (d & 0xffffu) : 0u);  // 32-bit record index: < 2^28
+                ra[a] = load2(base[a] + (2u * gl < cnt[a] ? 2u * gl : 0u));
             }
 #pragma unroll
             for (int a = 0; a < RUNS_AHEAD; a++) {
-                const uint32_t k = chunk_of(k0 + (uint32_t)(i0 + a) * GROUPS);
-                const uint32_t begin = d[a] & 0xffffu, cnt = d[a] >> 16;
-                if (2u * gl < cnt) add_record(rec[a].x, rec[a].y);
-                if (2u * gl + 1u < cnt) add_record(rec[a].z, rec[a].w);
-                for (uint32_t i = 2u * gl + 2u * GROUP; i < cnt; i += 2u * GROUP) {  // runs longer than 32 records: rare on hashed levels
-                    const uint4 q = load2(k * (uint32_t)MAX_REC + begin + i);
+                if (2u * gl < cnt[a]) add_record(ra[a].x, ra[a].y);
+                if (2u * gl + 1u < cnt[a]) add_record(ra[a].z, ra[a].w);
+                for (uint32_t i = 2u * GROUP + 2u * gl; i < cnt[a]; i += 2u * GROUP) {  // the part of the run beyond 32 records
+                    const uint4 q = load2(base[a] + i);
                     add_record(q.x, q.y);
-                    if (i + 1u < cnt) add_record(q.z, q.w);
+                    if (i + 1u < cnt[a]) add_record(q.z, q.w);
                 }
             }
         }
@@ -991,7 +1035,7 @@ static int grid_backward_variant() {  // NGP_GRID_BWD=nomerge disables the run m
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("NGP_GRID_BWD");
-        mode = (e && e[0] == 'n') ? 1 : 0;
+        mode = (e && e[0] == 'n') ? 1 : (e && e[0] == 'r') ? 2 : 0;
     }
     return mode;
 }
@@ -1004,7 +1048,8 @@ struct BackwardPlan {
     uint32_t n_binned = 0, total_desc = 0, max_bins = 0;
     uint64_t total_records = 0;
     size_t desc_bytes() const { return ((size_t)total_desc * sizeof(uint32_t) + 255) & ~(size_t)255; }
-    size_t workspace_bytes() const { return n_binned ? desc_bytes() + (size_t)total_records * sizeof(uint2) : 0; }
+    // (+64: the 16-byte load of a one-record run at the very end of the last chunk reads 8 bytes past it)
+    size_t workspace_bytes() const { return n_binned ? desc_bytes() + (size_t)total_records * sizeof(uint2) + 64 : 0; }
 };
 
 constexpr uint32_t BIN_MIN_SAMPLES = 16384;       // below this the launch overheads of the two extra kernels win
@@ -1051,12 +1096,15 @@ static void plan_backward(BackwardPlan& p, const int32_t* offsets_host, const Gr
 template <int D>
 static int launch_backward_bins(const void* grad, const float* inputs, const int32_t* offsets, void* grad_emb, uint32_t B,
                                 const GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, InputMap im, const BackwardPlan& p,
-                                void* workspace, hipStream_t st) {
+                                void* workspace, bool with_atomic_levels, hipStream_t st) {
     constexpr size_t acc_smem = sizeof(unsigned long long) * 2 * BIN_SLICE + sizeof(uint32_t) * (BIN_SLICE / 16);
+    constexpr size_t bin_smem = sizeof(uint2) * BIN_PPB * (1 << D) + sizeof(uint32_t) * (2 * BIN_MAX_BINS + BIN_THREADS / 64);
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_accumulate<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)acc_smem) != hipSuccess) {
+                                (int)acc_smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_bin<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bin_smem) != hipSuccess) {
             set_error("grid_encode_backward: hipFuncSetAttribute(LDS size) failed");
             return NGP_ERR_LAUNCH;
         }
@@ -1064,8 +1112,14 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     }
     uint32_t* descriptors = reinterpret_cast<uint32_t*>(workspace);
     uint2* records = reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(workspace) + p.desc_bytes());
-    hipLaunchKernelGGL((k_grid_backward_bin<D>), dim3(p.bins.n_chunks, p.n_binned), dim3(BIN_THREADS), 0, st, (const half_t*)grad, inputs,
-                       offsets, (half_t*)grad_emb, B, lv, gridtype, ac, interp, im, p.bins, descriptors, records);
+    AtomicPart ap;
+    ap.levels = p.atomic_levels;
+    ap.points_per_block = 1024;
+    ap.blocks_per_level = cdiv(B, ap.points_per_block);
+    ap.n_blocks = with_atomic_levels ? ap.blocks_per_level * p.n_atomic : 0u;
+    const uint32_t blocks = p.bins.n_chunks * p.n_binned + ap.n_blocks;
+    hipLaunchKernelGGL((k_grid_backward_bin<D>), dim3(blocks), dim3(BIN_THREADS), bin_smem, st, (const half_t*)grad, inputs, offsets,
+                       (half_t*)grad_emb, B, lv, gridtype, ac, interp, im, p.bins, descriptors, records, ap);
     int rc = check_launch("grid_encode_backward(bin)");
     if (rc) return rc;
     hipLaunchKernelGGL((k_grid_backward_accumulate<D>), dim3(p.max_bins, p.n_binned), dim3(ACC_THREADS), acc_smem, st, offsets,
@@ -1078,11 +1132,23 @@ static int launch_backward(const void* grad, const float* inputs, const int32_t*
                            uint32_t L, const GridLevels& lv, const void* dy_dx, void* grad_inputs, uint32_t gridtype,
                            bool ac, uint32_t interp, InputMap im, const BackwardPlan& plan, void* workspace, hipStream_t st) {
     int rc = NGP_OK;
-    if (plan.n_atomic) {
+    constexpr bool can_bin = sizeof(T) == 2 && C == 2 && (D == 2 || D == 3);
+    // the atomic levels ride in the launch of the record sort when there is one (and the merge variant is the default one)
+    const bool mixed = can_bin && plan.n_binned > 0 && grid_backward_variant() == 0 && getenv("NGP_GRID_BWD_SEPARATE") == nullptr;
+    if (plan.n_atomic && !mixed) {
         // one block covers `ppb` consecutive points of one level; >= ~4 blocks per CU over all levels fills the chip
         uint32_t ppb = 2048;
         while (ppb > 128 && (uint64_t)cdiv(B, ppb) * plan.n_atomic < 2048) ppb >>= 1;
         dim3 grid(cdiv(B, ppb), plan.n_atomic, 1);
+        if constexpr (BwdLanes<T, C>::LPP == 2) {
+            if (grid_backward_variant() == 2) {
+                hipLaunchKernelGGL((k_grid_backward<T, D, C, 2>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
+                                   (T*)grad_emb, B, plan.atomic_levels, lv, gridtype, ac, interp, ppb, im);
+                rc = check_launch("grid_encode_backward");
+                if (rc) return rc;
+                goto atomic_done;
+            }
+        }
         if (grid_backward_variant() == 1)
             hipLaunchKernelGGL((k_grid_backward<T, D, C, 0>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
                                (T*)grad_emb, B, plan.atomic_levels, lv, gridtype, ac, interp, ppb, im);
@@ -1092,9 +1158,11 @@ static int launch_backward(const void* grad, const float* inputs, const int32_t*
         rc = check_launch("grid_encode_backward");
         if (rc) return rc;
     }
+atomic_done:
     if (plan.n_binned) {
-        if constexpr (sizeof(T) == 2 && C == 2 && (D == 2 || D == 3)) {
-            rc = launch_backward_bins<D>(grad, inputs, offsets, grad_emb, B, lv, gridtype, ac, interp, im, plan, workspace, st);
+        if constexpr (can_bin) {
+            rc = launch_backward_bins<D>(grad, inputs, offsets, grad_emb, B, lv, gridtype, ac, interp, im, plan, workspace,
+                                         mixed && plan.n_atomic > 0, st);
             if (rc) return rc;
         }
     }

@@ -193,8 +193,8 @@ def main():
         o, d, gt = sc.training_batch(args.rays, seed=1000 * rank + k)
         pool.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
     total_samples = torch.zeros((), dtype=torch.int64, device=dev)
-    count_log = torch.zeros(args.steps + 1, 2, dtype=torch.int32, device=dev)
-    caps = []
+    count_log = torch.zeros(args.steps // 16 + 2, 16, 2, dtype=torch.int32, device=dev)  # snapshots of the model's 16-slot counter ring
+    caps, slots = [], []
     opt_kwargs = dict(staged=False, bg_color=1, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
 
     def keep_scene(m):
@@ -220,11 +220,14 @@ def main():
             loss = stepper.step(rays_o, rays_d, gt)
             cap = stepper.capacity if stepper.capacity is not None else args.rays * 1024
         if count:
-            # log this step's sample count (one 8-byte device copy); the clamp to the buffer capacity and the sum happen after the
-            # timed region.  Samples that were marched AND evaluated: rays that do not fit the estimated buffer are dropped whole by
-            # march_rays_train (raymarching.cu:416), so at most `cap` samples are processed in a step
-            count_log[len(caps)].copy_(model.step_counter[(model.local_step - 1) % 16], non_blocking=True)
+            # log the sample counts: the model keeps the last 16 in its counter ring (renderer.py:352), so one 128-byte device copy every
+            # 16 steps is enough; the clamp to the buffer capacity and the sum happen after the timed region.  Samples that were marched
+            # AND evaluated: rays that do not fit the estimated buffer are dropped whole by march_rays_train (raymarching.cu:416), so at
+            # most `cap` samples are processed in a step
             caps.append(cap)
+            slots.append((model.local_step - 1) % 16)
+            if len(caps) % 16 == 0:
+                count_log[len(caps) // 16 - 1].copy_(model.step_counter, non_blocking=True)
         return loss
 
     timers = KernelTimers(capi)
@@ -253,7 +256,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     final_loss = float(loss.item())
-    marched = count_log[:len(caps), 0].to(torch.int64)
+    if len(caps) % 16:  # the ring still holds the steps since the last snapshot
+        count_log[len(caps) // 16].copy_(model.step_counter)
+    blocks = torch.arange(len(caps), device=dev) // 16
+    marched = count_log[blocks, torch.tensor(slots, dtype=torch.int64, device=dev), 0].to(torch.int64)
     total_samples.add_(torch.minimum(marched, torch.tensor(caps, dtype=torch.int64, device=dev)).sum())
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -274,7 +274,11 @@ int ngp_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t* rays_ali
 /* composite_rays_train with NeRFRenderer.run_cuda's epilogue fused (renderer.py:316-318):
  *   image_out = image + (1 - weights_sum) * bg,  depth_out = clamp(depth - nears, 0) / (fars - nears)
  * bg_mode 0: off (= the reference op), 1: scalar background bg_scalar, 2: per-ray background bg [N,3].
- * The backward takes the gradient of image_out (and optionally of weights_sum, may be NULL when bg_mode != 0). */
+ * The backward takes the gradient of image_out (and optionally of weights_sum, may be NULL when bg_mode != 0).
+ * rows_used (backward, may be NULL): device scalar = number of sample rows the marcher handed out (first word of the
+ * march_rays_train workspace).  When given, grad_sigmas / grad_rgbs may arrive uninitialised: the kernel zeroes every row it does not
+ * write a gradient to (rows behind a ray's early termination, rows >= *rows_used); when NULL the caller pre-zeroes them (the
+ * reference contract). */
 int ngp_composite_rays_train_forward_ex(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
                                         uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth, float* image,
                                         int bg_mode, float bg_scalar, const float* bg, const float* nears, const float* fars,
@@ -283,7 +287,7 @@ int ngp_composite_rays_train_backward_ex(const float* grad_weights_sum, const fl
                                          const float* rgbs, const float* deltas, const int32_t* rays,
                                          const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                          float T_thresh, float* grad_sigmas, float* grad_rgbs, int bg_mode, float bg_scalar,
-                                         const float* bg, ngp_stream_t stream);
+                                         const float* bg, const uint32_t* rows_used, ngp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * freqencoder       (reference: freqencoder/src/freqencoder.h:6-10, bindings.cpp:5-8) -- SURVEY.md 8(f).3, fp32 only.

@@ -166,31 +166,49 @@ __device__ __forceinline__ int mip_exponent(float mx, float Cm1) {
 __device__ __forceinline__ float step_dt(const MarchParams& p, float t) { return clampf(t * p.dt_gamma, p.dt_min, p.dt_max); }
 
 // Evaluate the occupancy grid at parameter t.  Returns true when the voxel is occupied; otherwise tt
-// receives the parameter of the far face of the voxel (raymarching.cu:359-400).
-__device__ __forceinline__ bool probe(const MarchParams& p, const Ray& r, float t, float& x, float& y, float& z, float& dt,
-                                      float& tt) {
-    x = clampf(__builtin_fmaf(t, r.dx, r.ox), -p.bound, p.bound);
-    y = clampf(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
-    z = clampf(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
-    dt = step_dt(p, t);
-    const float mx = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+// receives the parameter of the far face of the voxel (raymarching.cu:359-400).  Split in two so that a caller can keep the
+// bitfield read of the NEXT batch of terms in flight while it finishes the current one.
+struct ProbeGeom {
+    float x, y, z, dt, mip_bound;
+    int nx, ny, nz;
+    uint32_t index;  // bit index in the occupancy bitfield
+};
+
+__device__ __forceinline__ ProbeGeom probe_geom(const MarchParams& p, const Ray& r, float t) {
+    ProbeGeom g;
+    g.x = clampf(__builtin_fmaf(t, r.dx, r.ox), -p.bound, p.bound);
+    g.y = clampf(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
+    g.z = clampf(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
+    g.dt = step_dt(p, t);
+    const float mx = fmaxf(fabsf(g.x), fmaxf(fabsf(g.y), fabsf(g.z)));
     const int lp = mip_exponent(mx, p.Cm1);
-    const int ld = mip_exponent((dt * p.Hf) * 0.5f, p.Cm1);
+    const int ld = mip_exponent((g.dt * p.Hf) * 0.5f, p.Cm1);
     const int level = lp > ld ? lp : ld;
-    const float mip_bound = fminf(scalbnf(1.0f, level), p.bound);
-    const float mip_rbound = 1.0f / mip_bound;
-    const int nx = (int)clampf((0.5f * __builtin_fmaf(x, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
-    const int ny = (int)clampf((0.5f * __builtin_fmaf(y, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
-    const int nz = (int)clampf((0.5f * __builtin_fmaf(z, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
-    const uint32_t index = (uint32_t)((float)level * p.H3f + (float)morton3D_1((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-    const bool occ = (p.grid[index >> 3] & (1u << (index & 7u))) != 0;
+    g.mip_bound = fminf(scalbnf(1.0f, level), p.bound);
+    const float mip_rbound = 1.0f / g.mip_bound;
+    g.nx = (int)clampf((0.5f * __builtin_fmaf(g.x, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
+    g.ny = (int)clampf((0.5f * __builtin_fmaf(g.y, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
+    g.nz = (int)clampf((0.5f * __builtin_fmaf(g.z, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
+    g.index = (uint32_t)((float)level * p.H3f + (float)morton3D_1((uint32_t)g.nx, (uint32_t)g.ny, (uint32_t)g.nz));
+    return g;
+}
+
+__device__ __forceinline__ bool probe_resolve(const MarchParams& p, const Ray& r, float t, const ProbeGeom& g, uint32_t byte, float& tt) {
+    const bool occ = (byte & (1u << (g.index & 7u))) != 0;
     if (!occ) {
-        const float tx = __builtin_fmaf(((float)nx + 0.5f + 0.5f * copysignf(1.0f, r.dx)) * p.rH * 2.0f - 1.0f, mip_bound, -x) * r.rdx;
-        const float ty = __builtin_fmaf(((float)ny + 0.5f + 0.5f * copysignf(1.0f, r.dy)) * p.rH * 2.0f - 1.0f, mip_bound, -y) * r.rdy;
-        const float tz = __builtin_fmaf(((float)nz + 0.5f + 0.5f * copysignf(1.0f, r.dz)) * p.rH * 2.0f - 1.0f, mip_bound, -z) * r.rdz;
+        const float tx = __builtin_fmaf(((float)g.nx + 0.5f + 0.5f * copysignf(1.0f, r.dx)) * p.rH * 2.0f - 1.0f, g.mip_bound, -g.x) * r.rdx;
+        const float ty = __builtin_fmaf(((float)g.ny + 0.5f + 0.5f * copysignf(1.0f, r.dy)) * p.rH * 2.0f - 1.0f, g.mip_bound, -g.y) * r.rdy;
+        const float tz = __builtin_fmaf(((float)g.nz + 0.5f + 0.5f * copysignf(1.0f, r.dz)) * p.rH * 2.0f - 1.0f, g.mip_bound, -g.z) * r.rdz;
         tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     }
     return occ;
+}
+
+__device__ __forceinline__ bool probe(const MarchParams& p, const Ray& r, float t, float& x, float& y, float& z, float& dt,
+                                      float& tt) {
+    const ProbeGeom g = probe_geom(p, r, t);
+    x = g.x; y = g.y; z = g.z; dt = g.dt;
+    return probe_resolve(p, r, t, g, p.grid[g.index >> 3], tt);
 }
 
 // advance in whole steps to the far face of an empty voxel (raymarching.cu:396-399).  The extra
@@ -246,6 +264,40 @@ __device__ __forceinline__ float readlane_f(float v, uint32_t l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)l));
 }
 
+// The 64 terms t_base, t_base (+) dt, ... of one window (lane j keeps term j) and the base of the next window.
+// With a constant step the fp32 recurrence has a closed form inside one binade: every term is a multiple of the binade's ulp u, so
+// each step adds the SAME increment  inc = fl(t + dt) - t  (dt rounded to a multiple of u, to nearest), unless dt sits exactly half
+// way between two multiples (round-to-even would alternate).  So when all 65 terms stay in the binade of t_base and there is no
+// tie, term j = t_base + j * inc EXACTLY (j * inc < 2^23 u is exact, the sum is a multiple of u inside the binade) -- bit-identical to
+// the 64 dependent additions, without the dependent chain.  Otherwise (binade crossing: a handful of windows per ray; dt_gamma != 0)
+// the recurrence is evaluated as written.
+template <bool CONST_DT>
+__device__ __forceinline__ void window_terms(const MarchParams& p, float t_base, float dt_const, uint32_t lane, float& mine,
+                                             float& t_next_base) {
+    if (CONST_DT) {
+        const float t1 = t_base + dt_const;
+        const float inc = t1 - t_base;                    // exact (Sterbenz)
+        const float err = dt_const - inc;                 // exact: the rounding error of the first step
+        const float t_end = __builtin_fmaf(64.0f, inc, t_base);
+        const uint32_t e0 = __builtin_bit_cast(uint32_t, t_base) >> 23, e1 = __builtin_bit_cast(uint32_t, t_end) >> 23;
+        const float half_ulp = __builtin_bit_cast(float, (e0 > 24u ? e0 - 24u : 0u) << 23);  // u / 2 of the binade (0: give up)
+        const bool closed = inc > 0.0f && e0 == e1 && e0 > 24u && e0 < 255u && fabsf(err) != half_ulp;
+        if (__builtin_amdgcn_readfirstlane((int)closed)) {  // wave-uniform by construction
+            mine = __builtin_fmaf((float)lane, inc, t_base);
+            t_next_base = t_end;
+            return;
+        }
+    }
+    float t = t_base;
+    mine = t_base;
+#pragma unroll
+    for (uint32_t j = 1; j < 64; j++) {
+        t += CONST_DT ? dt_const : step_dt(p, t);
+        mine = (lane == j) ? t : mine;
+    }
+    t_next_base = t + (CONST_DT ? dt_const : step_dt(p, t));
+}
+
 template <bool WRITE, bool CONST_DT>
 __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                                     const uint8_t* __restrict__ grid, float bound, float dt_gamma,
@@ -283,13 +335,9 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
         if (nw <= MARCH_MASK_WINDOWS) {
             const uint64_t* my_masks = masks + (size_t)n * MARCH_MASK_WINDOWS;
             for (; window < nw; window++) {
-                float t = t_base, mine = t_base;
-#pragma unroll
-                for (uint32_t j = 1; j < 64; j++) {
-                    t += CONST_DT ? dt_const : step_dt(p, t);
-                    mine = (lane == j) ? t : mine;
-                }
-                t_base = t + (CONST_DT ? dt_const : step_dt(p, t));
+                float mine, t_next;
+                window_terms<CONST_DT>(p, t_base, dt_const, lane, mine, t_next);
+                t_base = t_next;
                 const uint64_t emit = my_masks[window];
                 if (emit == 0ull) continue;
                 const float x = clampf(__builtin_fmaf(mine, r.dx, r.ox), -p.bound, p.bound);
@@ -320,21 +368,34 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
     float carry = -INFINITY;  // the walk enters a window at its first term that is not < carry
     bool done = !(t_base < far);
 
-    while (!done) {
-        // ---- 1. the window's 64 terms (lane j keeps t_{base+j}) ----
-        float t = t_base, mine = t_base;
-#pragma unroll
-        for (uint32_t j = 1; j < 64; j++) {
-            t += CONST_DT ? dt_const : step_dt(p, t);
-            mine = (lane == j) ? t : mine;
-        }
-        const float t_next_base = t + (CONST_DT ? dt_const : step_dt(p, t));
+    // The windows of a ray are a dependent chain (carry, step budget), and each one needs a bitfield read: software-pipelined -- the
+    // terms of window w+1 do not depend on the walk of window w, so their positions are computed and their reads issued before the
+    // walk of window w starts.
+    float mine_n = 0.0f, t_after_n = t_base;
+    ProbeGeom g_n = {};
+    uint32_t byte_n = 0u;
+    bool valid_n = false;
+    auto issue_window = [&](float base) {
+        window_terms<CONST_DT>(p, base, dt_const, lane, mine_n, t_after_n);
+        valid_n = mine_n < far;
+        g_n = probe_geom(p, r, valid_n ? mine_n : near);
+        byte_n = p.grid[g_n.index >> 3];  // unconditional (a valid address for every lane): nothing waits on it here
+    };
+    if (!done) issue_window(t_base);
 
-        // ---- 2. probe all terms that lie in front of `far` ----
-        const bool valid = mine < far;
+    while (!done) {
+        // ---- 1. + 2. this window's terms and probes were issued one iteration ago; start the next window's ----
+        const float mine = mine_n;
+        const float t_next_base = t_after_n;
+        const bool valid = valid_n;
+        const ProbeGeom g = g_n;
+        const uint32_t byte = byte_n;
+        if (__builtin_amdgcn_readfirstlane((int)(t_next_base < far))) issue_window(t_next_base);
+        else valid_n = false;  // a further window (entered when all 64 terms were in front of `far`) has nothing to probe
         bool occ = false;
-        float x = 0.0f, y = 0.0f, z = 0.0f, dt = 0.0f, tt = -INFINITY;
-        if (valid) occ = probe(p, r, mine, x, y, z, dt, tt);
+        float tt = -INFINITY;
+        const float x = g.x, y = g.y, z = g.z, dt = g.dt;
+        if (valid) occ = probe_resolve(p, r, mine, g, byte, tt);
         const uint64_t validmask = __ballot(valid);
         const uint64_t occmask = __ballot(valid && occ);
         const uint64_t entrymask = __ballot(!(mine < carry));
@@ -610,8 +671,21 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_bwd(const flo
                                                                        const float* __restrict__ deltas, const int32_t* __restrict__ rays,
                                                                        const float* __restrict__ weights_sum, const float* __restrict__ image,
                                                                        uint32_t M, uint32_t N, float T_thresh, float* __restrict__ grad_sigmas,
-                                                                       float* __restrict__ grad_rgbs, Finish fin) {
+                                                                       float* __restrict__ grad_rgbs, Finish fin,
+                                                                       const uint32_t* __restrict__ rows_used, uint32_t ray_blocks) {
     const int lane = threadIdx.x & 63;
+    // rows_used != NULL: the outputs arrive UNINITIALISED and every row the compositing does not reach is zeroed here -- the rows of
+    // a ray behind its early termination (below) and the rows >= *rows_used that no ray owns (the workgroups after the ray ones)
+    if (blockIdx.x >= ray_blocks) {
+        const uint32_t first = min(rows_used[0], M);
+        const uint32_t stride = (gridDim.x - ray_blocks) * CT_WAVES * 64;
+        for (uint32_t o = first + (blockIdx.x - ray_blocks) * CT_WAVES * 64 + threadIdx.x; o < M; o += stride) {
+            grad_sigmas[o] = 0.0f;
+            grad_rgbs[(size_t)o * 3] = 0.0f; grad_rgbs[(size_t)o * 3 + 1] = 0.0f; grad_rgbs[(size_t)o * 3 + 2] = 0.0f;
+        }
+        return;
+    }
+    const bool zero_fill = rows_used != nullptr;
     const uint32_t n = blockIdx.x * CT_WAVES + (threadIdx.x >> 6);
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num = (uint32_t)rays[n * 3 + 2];
@@ -653,10 +727,22 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_bwd(const flo
             grad_rgbs[(size_t)o * 3 + 2] = gi2 * w;
             grad_sigmas[o] = d0 * (gi0 * (T_after * cr - (rf - ra)) + gi1 * (T_after * cg - (gf - ga)) +
                                    gi2 * (T_after * cb - (bf - ba)) + gw * (1.0f - wsf));
+        } else if (zero_fill && valid) {
+            const uint32_t o = offset + s;
+            grad_rgbs[(size_t)o * 3] = 0.0f; grad_rgbs[(size_t)o * 3 + 1] = 0.0f; grad_rgbs[(size_t)o * 3 + 2] = 0.0f;
+            grad_sigmas[o] = 0.0f;
         }
         T = T * __shfl(pin, 63, 64);
         rc = __shfl(ra, 63, 64); gc = __shfl(ga, 63, 64); bc = __shfl(ba, 63, 64);
-        if (T < T_thresh) break;
+        if (T < T_thresh) {
+            if (zero_fill)
+                for (uint32_t z = s0 + 64 + lane; z < num; z += 64) {
+                    const uint32_t o = offset + z;
+                    grad_rgbs[(size_t)o * 3] = 0.0f; grad_rgbs[(size_t)o * 3 + 1] = 0.0f; grad_rgbs[(size_t)o * 3 + 2] = 0.0f;
+                    grad_sigmas[o] = 0.0f;
+                }
+            break;
+        }
     }
 }
 
@@ -870,7 +956,7 @@ extern "C" int ngp_composite_rays_train_backward_ex(const float* grad_weights_su
                                                     const float* rgbs, const float* deltas, const int32_t* rays,
                                                     const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                                     float T_thresh, float* grad_sigmas, float* grad_rgbs, int bg_mode, float bg_scalar,
-                                                    const float* bg, ngp_stream_t stream) {
+                                                    const float* bg, const uint32_t* rows_used, ngp_stream_t stream) {
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs, NGP_ERR_INVALID,
                 "composite_rays_train_backward: NULL tensor");
@@ -879,8 +965,11 @@ extern "C" int ngp_composite_rays_train_backward_ex(const float* grad_weights_su
     int rc = make_finish("composite_rays_train_backward", bg_mode, bg_scalar, bg, nullptr, nullptr, nullptr, nullptr, false, &fin);
     if (rc) return rc;
     if (N == 0) return NGP_OK;
-    hipLaunchKernelGGL(k_composite_train_bwd, dim3(cdiv(N, CT_WAVES)), dim3(CT_WAVES * 64), 0, as_stream(stream), grad_weights_sum,
-                       grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, fin);
+    const uint32_t ray_blocks = cdiv(N, CT_WAVES);
+    const uint32_t tail_blocks = rows_used ? 32u : 0u;
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(ray_blocks + tail_blocks), dim3(CT_WAVES * 64), 0, as_stream(stream), grad_weights_sum,
+                       grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, fin, rows_used,
+                       ray_blocks);
     return check_launch("composite_rays_train_backward");
 }
 
@@ -890,7 +979,7 @@ extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, 
                                                  float T_thresh, float* grad_sigmas, float* grad_rgbs, ngp_stream_t stream) {
     NGP_REQUIRE(grad_weights_sum || N == 0, NGP_ERR_INVALID, "composite_rays_train_backward: NULL tensor");
     return ngp_composite_rays_train_backward_ex(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
-                                                grad_sigmas, grad_rgbs, 0, 0.0f, nullptr, stream);
+                                                grad_sigmas, grad_rgbs, 0, 0.0f, nullptr, nullptr, stream);
 }
 
 extern "C" int ngp_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t, const float* rays_o,

@@ -227,27 +227,27 @@ def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfie
                                                         float(T_thresh), weights_sum.data_ptr(), depth_raw.data_ptr(), image_raw.data_ptr(),
                                                         bg_mode, float(bg_scalar), capi.ptr(bg), nears.data_ptr(), fars.data_ptr(),
                                                         image.data_ptr(), depth.data_ptr(), st))
-    saved = (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg)
+    saved = (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, ws)
     return image, depth, weights_sum, saved
 
 
 def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g_wc):
     """the backward launches: grad_image [N,3] fp32 (and optionally grad_ws [N]) -> gradients accumulated into g_emb (scatter-add, must
     hold the running sum / zeros) and written to g_ws / g_wc (fp16, flat)"""
-    (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg) = saved
+    (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, march_ws) = saved
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
     (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
     M, N = xyzs.shape[0], rays.shape[0]
     dev = xyzs.device
     st = capi.stream()
     half = dict(device=dev, dtype=torch.half)
-    g_sigma = torch.zeros(M, device=dev)
-    g_rgb = torch.zeros(M, 3, device=dev)
+    g_sigma = torch.empty(M, device=dev)  # rows without a gradient are zeroed by the compositor (rows_used = first word of the march workspace)
+    g_rgb = torch.empty(M, 3, device=dev)
     bg_mode = 2 if bg is not None else 1
     _check(capi.lib.ngp_composite_rays_train_backward_ex(capi.ptr(grad_ws), grad_image.data_ptr(), sigma.data_ptr(), rgb.data_ptr(),
                                                          deltas.data_ptr(), rays.data_ptr(), weights_sum.data_ptr(), image_raw.data_ptr(),
                                                          M, N, float(T_thresh), g_sigma.data_ptr(), g_rgb.data_ptr(), bg_mode,
-                                                         float(bg_scalar), capi.ptr(bg), st))
+                                                         float(bg_scalar), capi.ptr(bg), march_ws.data_ptr(), st))
     g_out16 = torch.empty(M, 16, **half)
     _check(capi.lib.ngp_pipeline_rgb_backward(g_rgb.data_ptr(), rgb.data_ptr(), g_out16.data_ptr(), M, st))
     g_color_in = torch.empty(M, 32, **half)
@@ -279,7 +279,7 @@ class _fused_render_train(Function):
     def backward(ctx, grad_image, grad_depth, grad_ws):
         saved = ctx.saved_tensors
         dev = saved[0].device
-        N = saved[12].shape[0]
+        N = saved[12].shape[0]  # rays
         grad_image = torch.zeros(N, 3, device=dev) if grad_image is None else grad_image.contiguous().float()
         grad_ws = None if grad_ws is None else grad_ws.contiguous().float()
         g_emb, g_ws, g_wc, deposited = _grad_targets(ctx.bufs, ctx.n_emb, saved[3], saved[4], dev)

@@ -183,9 +183,9 @@ class GraphedTrainStep:
                 loss = self._eager(rays_o, rays_d, target)
                 self.global_step += 1
                 return loss
-        self.rays_o.copy_(rays_o.view_as(self.rays_o), non_blocking=True)
-        self.rays_d.copy_(rays_d.view_as(self.rays_d), non_blocking=True)
-        self.target.copy_(target, non_blocking=True)
+        # the batch into the static input buffers: ONE multi-tensor copy kernel (three separate copies cost ~5 us each plus the gaps)
+        torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
+                             non_blocking=True)
         self.graphs[0].replay()
         if len(self.graphs) == 2:
             self.averager.all_reduce()

@@ -110,3 +110,33 @@ def test_ops_fail_loudly_without_a_gpu():
     import raymarching
     with pytest.raises((RuntimeError, AssertionError)):
         raymarching.near_far_from_aabb(torch.rand(4, 3), torch.rand(4, 3), torch.tensor([-1., -1, -1, 1, 1, 1]), 0.2)
+
+
+def test_grid_backward_workspace_plan_is_host_only():
+    """ngp_grid_backward_workspace_bytes plans the atomic-free scatter on the host: which levels are sorted (the hashed ones of an fp16
+    C = 2 table, large batches only) and how much scratch they need (64 B per sample and sorted level + descriptors)."""
+    import _ngp_capi as capi
+    import oracle
+    offs, pls = oracle.grid_offsets(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048)
+    S = float(np.log2(pls))
+    arr = (ctypes.c_int32 * len(offs))(*[int(v) for v in offs])
+    ptr = ctypes.cast(arr, ctypes.c_void_p)
+    ws = lambda B, D=3, C=2, dtype=capi.NGP_F16, gridtype=0: int(capi.lib.ngp_grid_backward_workspace_bytes(ptr, B, D, C, 16, S, 16, gridtype, 0, dtype))
+    n_hashed = int((np.diff(offs) == (1 << 19)).sum())
+    assert n_hashed == 11
+    B = 1 << 18
+    chunks = B // 512
+    records = n_hashed * chunks * 512 * 8 * 8                       # 8 corners x 8 bytes per sample and level
+    descriptors = n_hashed * 128 * chunks * 4                       # one word per (4096-entry slice, chunk)
+    assert ws(B) == ((descriptors + 255) // 256) * 256 + records + 64
+    assert ws(1 << 12) == 0                                         # small batch: atomic path
+    assert ws(B, dtype=capi.NGP_F32) == 0 and ws(B, C=4) == 0 and ws(B, D=4) == 0
+    assert ws(B, gridtype=1) == 0                                   # tiled grids have no hashed level
+    assert ws(2 * B) > ws(B)
+    assert int(capi.lib.ngp_grid_backward_workspace_bytes(None, B, 3, 2, 16, S, 16, 0, 0, capi.NGP_F16)) == 0
+    # host copy of the offsets used by the Python wrappers: cached on the tensor, refreshed when it changes
+    t = torch.from_numpy(offs.astype(np.int32))
+    a1 = capi.host_offsets(t)
+    assert list(a1) == [int(v) for v in offs] and capi.host_offsets(t) is a1
+    t[1] += 8
+    assert list(capi.host_offsets(t))[1] == int(offs[1]) + 8

@@ -113,8 +113,8 @@ def test_ops_fail_loudly_without_a_gpu():
 
 
 def test_grid_backward_workspace_plan_is_host_only():
-    """ngp_grid_backward_workspace_bytes plans the atomic-free scatter on the host: which levels are sorted (the hashed ones of an fp16
-    C = 2 table, large batches only) and how much scratch they need (64 B per sample and sorted level + descriptors)."""
+    """ngp_grid_backward_workspace_bytes plans the atomic-free scatter on the host: which calls are eligible (fp16 C = 2 tables, D <= 3,
+    large batches) and how much scratch they need (64 B per sample and level + one descriptor word per (slice, chunk))."""
     import _ngp_capi as capi
     import oracle
     offs, pls = oracle.grid_offsets(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048)
@@ -122,16 +122,15 @@ def test_grid_backward_workspace_plan_is_host_only():
     arr = (ctypes.c_int32 * len(offs))(*[int(v) for v in offs])
     ptr = ctypes.cast(arr, ctypes.c_void_p)
     ws = lambda B, D=3, C=2, dtype=capi.NGP_F16, gridtype=0: int(capi.lib.ngp_grid_backward_workspace_bytes(ptr, B, D, C, 16, S, 16, gridtype, 0, dtype))
-    n_hashed = int((np.diff(offs) == (1 << 19)).sum())
-    assert n_hashed == 11
+    n_levels = 16                                                   # 11 hashed levels (128 slices of 4096 entries) + 5 dense ones (128 round-robin bins)
     B = 1 << 18
     chunks = B // 512
-    records = n_hashed * chunks * 512 * 8 * 8                       # 8 corners x 8 bytes per sample and level
-    descriptors = n_hashed * 128 * chunks * 4                       # one word per (4096-entry slice, chunk)
+    records = n_levels * chunks * 512 * 8 * 8                       # 8 corners x 8 bytes per sample and level
+    descriptors = n_levels * 128 * chunks * 4                       # one word per (slice, chunk)
     assert ws(B) == ((descriptors + 255) // 256) * 256 + records + 64
     assert ws(1 << 12) == 0                                         # small batch: atomic path
     assert ws(B, dtype=capi.NGP_F32) == 0 and ws(B, C=4) == 0 and ws(B, D=4) == 0
-    assert ws(B, gridtype=1) == 0                                   # tiled grids have no hashed level
+    assert ws(B, gridtype=1) > 0                                    # tiled grids: every level dense -> round-robin bins
     assert ws(2 * B) > ws(B)
     assert int(capi.lib.ngp_grid_backward_workspace_bytes(None, B, 3, 2, 16, S, 16, 0, 0, capi.NGP_F16)) == 0
     # host copy of the offsets used by the Python wrappers: cached on the tensor, refreshed when it changes

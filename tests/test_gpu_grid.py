@@ -268,9 +268,7 @@ def test_backward_binned_matches_oracle_and_is_reproducible():
     ge1, nbytes = _backward_ws(g, x, offs, S, True)
     assert nbytes > 0, 'this batch must take the binned path'
     ge2, _ = _backward_ws(g, x, offs, S, True)
-    sizes = np.diff(offs)
-    first_binned = int(np.argmax(sizes == (1 << 19)))  # smaller levels keep the (order-dependent) fp16 atomics
-    assert torch.equal(ge1[int(offs[first_binned]):], ge2[int(offs[first_binned]):]), 'integer accumulation: bit-reproducible'
+    assert torch.equal(ge1, ge2), 'integer accumulation on every level: bit-reproducible'
     got = ge1.float().cpu().numpy().astype(np.float64)
     ref, _ = oracle.grid_backward(g, x, offs, int(offs[-1]), 2, S, 16)
     assert np.all(got[ref == 0] == 0)
@@ -291,8 +289,8 @@ def test_backward_binned_accumulates_poisons_and_survives_bin_overflow():
     offs, pls = oracle.grid_offsets(**LEGO)
     S = float(np.log2(pls))
     B = 1 << 14
-    # eight far-apart cells in rotation: no run merge, and every record of a level lands in the same few slices -> those bins exceed
-    # their capacity (mean * 1.25 + 512) and the excess records take the atomic fallback
+    # eight far-apart cells in rotation: no run merge, and every record of a level lands in the same few slices (the most skewed
+    # distribution there is: per-workgroup chunks have no capacity to overflow)
     cells = rng.uniform(0.1, 0.9, (8, 3)).astype(np.float32)
     x = cells[np.arange(B) % 8]
     g = oracle.round_fp16(rng.uniform(0.5, 1.0, size=(16, B, 2)).astype(np.float32) * 2.0 ** -9)
@@ -301,9 +299,7 @@ def test_backward_binned_accumulates_poisons_and_survives_bin_overflow():
     got = ge.float().cpu().numpy().astype(np.float64)
     ref, _ = oracle.grid_backward(g, x, offs, int(offs[-1]), 2, S, 16)
     assert np.all(got[ref == 0] == 0)
-    lo = int(offs[int(np.argmax(np.diff(offs) == (1 << 19)))])  # the binned levels (the small ones are plain fp16 atomics: 2048 adds
-    np.testing.assert_allclose(got[lo:], ref[lo:], rtol=1e-2, atol=1e-3)  # of ~1e-3 into one fp16 entry stagnate, as in the reference)
-    np.testing.assert_allclose(got[:lo], ref[:lo], rtol=0.25, atol=1e-2)
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-4)  # exact sums, one rounding (fp16 atomics would stagnate on the 2048-fold sums)
     # += semantics: untouched entries keep their value, touched ones add to it
     xr = rng.uniform(0, 1, (B, 3)).astype(np.float32)
     g1 = oracle.round_fp16(rng.normal(size=(16, B, 2)).astype(np.float32) * 0.05)

@@ -494,6 +494,15 @@ template <int N>
 __device__ __forceinline__ uint32_t row_shl(uint32_t src) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x100 + N, 0xF, 0xF, true);
 }
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t src) {  // lane i reads lane i-1 across the whole wave; lane 0 reads 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t src) {  // lane i reads lane i+1; lane 63 reads 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x130, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t row_bcast15(uint32_t src) {  // every lane of rows 1..3 reads lane 15 of the row below (row 0: unused)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x142, 0xE, 0xF, false);
+}
 template <int N>
 __device__ __forceinline__ float row_shr_f(float src) {
     return __builtin_bit_cast(float, row_shr<N>(__builtin_bit_cast(uint32_t, src)));
@@ -545,30 +554,59 @@ __device__ __forceinline__ void corner_runs(const BwdSample<T, D, C>& smp, float
     }
 #pragma unroll
     for (int j = 0; j < NJ; j++) issue[j] = live;
-    if constexpr (MERGE == 2) {
-        static_assert(MERGE != 2 || LPP == 2, "the row-local merge is written for two lanes per sample");
-        const uint32_t prev_live = row_shr<2>((uint32_t)live);
+    if constexpr (MERGE == 2 || MERGE == 3) {
+        // Segmented scan with DPP only (VALU; no LDS crossbar).  MERGE == 2: runs inside a 16-lane row (8 samples).  MERGE == 3: runs
+        // over the whole wave -- the links to the neighbouring sample cross rows with wave_shr/shl:1 (twice: two lanes per sample), the
+        // scan runs inside the rows, and the rows are then chained by three carry rounds (row_bcast:15 hands the last sample of a row
+        // to the next row; the class-0 lane first moves into lane 15 with row_shr:1).
+        static_assert((MERGE != 2 && MERGE != 3) || LPP == 2, "the DPP merges are written for two lanes per sample");
+        auto prev2 = [](uint32_t x) {  // value of the lane two below (0 for a sample without predecessor)
+            if constexpr (MERGE == 2) return row_shr<2>(x);
+            else return wave_shr1(wave_shr1(x));
+        };
+        auto next2 = [](uint32_t x) {
+            if constexpr (MERGE == 2) return row_shl<2>(x);
+            else return wave_shl1(wave_shl1(x));
+        };
+        const uint32_t prev_live = prev2((uint32_t)live);
+        const uint32_t row = (uint32_t)(threadIdx.x & 63) >> 4;
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-            const uint32_t prev_addr1 = row_shr<2>(addr[j] + 1u);  // first sample of a row reads 0: no predecessor, the run starts here
+            const uint32_t prev_addr1 = prev2(addr[j] + 1u);
             const bool same = live & (prev_live != 0u) & (prev_addr1 == addr[j] + 1u);
-            // worth a scan only when a fair share of the wave continues a run (fine levels: almost never)
-            if (__popcll(__ballot(same)) >= 12) {
-                uint32_t open = same ? 1u : 0u;  // the scan of this lane has not reached the head of its run yet
-                // segmented inclusive scan over the 8 samples of the row, distances 1, 2, 4 samples
+            // the record sort merges only when a fair share of the wave continues a run (fine levels: almost never);
+            // in front of a fabric atomic every merged lane pays
+            if (__popcll(__ballot(same)) >= (MERGE == 2 ? 12 : 1)) {
+                uint32_t closed = same ? 0u : 1u;  // the scan of this lane has reached the head of its run
+                // inside the row, distances 1, 2, 4 samples; a lane without a source reads 0: adds nothing and stays open
 #define NGP_ROW_SCAN_STEP(N)                                                                                  \
                 {                                                                                                 \
-                    const uint32_t o_n = row_shr<N>(open);                                                       \
+                    const uint32_t c_n = row_shr<N>(closed);                                                     \
                     float t[CPL];                                                                                 \
                     _Pragma("unroll") for (int c = 0; c < CPL; c++) t[c] = row_shr_f<N>(v[j][c]);               \
-                    _Pragma("unroll") for (int c = 0; c < CPL; c++) v[j][c] += open ? t[c] : 0.0f;              \
-                    open = open ? o_n : 0u;                                                                       \
+                    _Pragma("unroll") for (int c = 0; c < CPL; c++) v[j][c] += closed ? 0.0f : t[c];            \
+                    closed = closed ? 1u : c_n;                                                                   \
                 }
                 NGP_ROW_SCAN_STEP(2)
                 NGP_ROW_SCAN_STEP(4)
                 NGP_ROW_SCAN_STEP(8)
 #undef NGP_ROW_SCAN_STEP
-                const uint32_t next_same = row_shl<2>((uint32_t)same);
+                if constexpr (MERGE == 3) {
+#pragma unroll
+                    for (uint32_t r = 1; r < 4; r++) {  // carry of row r-1 (its last sample, already carrying its own) into row r
+                        const uint32_t c1 = row_bcast15(closed), c0 = row_bcast15(row_shr<1>(closed));
+                        const uint32_t cc = xb ? c1 : c0;
+                        const bool take = (row == r) && !closed;
+#pragma unroll
+                        for (int c = 0; c < CPL; c++) {
+                            const float t1 = __builtin_bit_cast(float, row_bcast15(__builtin_bit_cast(uint32_t, v[j][c])));
+                            const float t0 = __builtin_bit_cast(float, row_bcast15(row_shr<1>(__builtin_bit_cast(uint32_t, v[j][c]))));
+                            v[j][c] += take ? (xb ? t1 : t0) : 0.0f;
+                        }
+                        closed = take ? cc : closed;
+                    }
+                }
+                const uint32_t next_same = next2((uint32_t)same);
                 issue[j] = live && !next_same;  // the last lane of a run holds the run total
             }
         }
@@ -672,10 +710,15 @@ constexpr int BIN_SLICE_BITS = 12;                             // 4096 table ent
 constexpr int BIN_SLICE = 1 << BIN_SLICE_BITS;
 constexpr int BIN_MAX_BINS = 512;                              // one thread per bin in the layout step
 constexpr int ACC_THREADS = 1024;
+// Dense levels: samples cluster where the scene is, so contiguous slices would be very unevenly loaded (and a 4913-entry level would
+// have two of them).  Their entries are dealt round-robin to BIN_DENSE_BINS workgroups instead: bin = index mod 128, slot = index / 128.
+constexpr int BIN_DENSE_BITS = 7;
+constexpr int BIN_DENSE_BINS = 1 << BIN_DENSE_BITS;
 
 struct BinPlan {
     uint8_t level[NGP_MAX_LEVELS];       // binned levels (blockIdx.y indexes these arrays)
     uint16_t n_bins[NGP_MAX_LEVELS];
+    uint8_t interleaved[NGP_MAX_LEVELS];  // 0: bin = index >> 12 (contiguous slices); 1: bin = index & 127 (dense levels, see below)
     uint32_t desc_base[NGP_MAX_LEVELS];  // first descriptor of the level; descriptors are [bin][chunk]
     uint32_t n_chunks;                   // workgroups of pass 1 per level = chunks per level
 };
@@ -698,7 +741,7 @@ struct AtomicPart {
     uint32_t points_per_block;
 };
 
-template <int D>
+template <int D, int AMERGE /* run merge of the atomic workgroups: 3 = DPP over the wave, 1 = ds_bpermute */>
 __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restrict__ inputs,
                                                                    const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid,
                                                                    uint32_t B, GridLevels lv, uint32_t gridtype, bool align_corners,
@@ -712,7 +755,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
         const uint32_t a0 = (uint32_t)(((uint64_t)blockIdx.x * ap.n_blocks) / total);
         const uint32_t a1 = (uint32_t)((((uint64_t)blockIdx.x + 1u) * ap.n_blocks) / total);
         if (a1 > a0) {  // this workgroup is the a0-th of the atomic kind
-            backward_atomic_block<half_t, D, 2, 1, BIN_THREADS>(grad, inputs, offsets, grad_grid, B, ap.levels.level[a0 / ap.blocks_per_level], lv,
+            backward_atomic_block<half_t, D, 2, AMERGE, BIN_THREADS>(grad, inputs, offsets, grad_grid, B, ap.levels.level[a0 / ap.blocks_per_level], lv,
                                                                 gridtype, align_corners, interp, ap.points_per_block, im,
                                                                 a0 % ap.blocks_per_level);
             return;
@@ -748,6 +791,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
     // the plan was made from the caller's HOST copy of the offsets; if the device offsets describe a larger level, stay in bounds
     // (those records take the atomic)
     const bool plan_ok = hashmap_size <= (n_bins << BIN_SLICE_BITS);
+    const bool interleaved = plan.interleaved[li] != 0;
+    auto bin_of = [&](uint32_t a) { return interleaved ? (a & (uint32_t)(BIN_DENSE_BINS - 1)) : (a >> BIN_SLICE_BITS); };
 
     BwdSample<T, D, C> smp[BIN_ITERS];  // every global load of the workgroup is in flight before the first use
 #pragma unroll
@@ -772,7 +817,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
             raddr[it * NJ + j] = addr[j];
             rval[it * NJ + j] = packed;
             if (rec && !plan_ok) atomic_add_packed(gtable + (size_t)addr[j] * C, packed);
-            rrank[it * NJ + j] = (rec && plan_ok) ? atomicAdd(&hist[addr[j] >> BIN_SLICE_BITS], 1u) : 0xffffffffu;
+            rrank[it * NJ + j] = (rec && plan_ok) ? atomicAdd(&hist[bin_of(addr[j])], 1u) : 0xffffffffu;
         }
     }
     __syncthreads();
@@ -797,7 +842,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < BIN_ITERS * NJ; r++)
-        if (rrank[r] != 0xffffffffu) staging[loff[raddr[r] >> BIN_SLICE_BITS] + rrank[r]] = make_uint2(raddr[r], rval[r]);
+        if (rrank[r] != 0xffffffffu) staging[loff[bin_of(raddr[r])] + rrank[r]] = make_uint2(raddr[r], rval[r]);
     __syncthreads();
     uint32_t total = 0u;
 #pragma unroll
@@ -852,8 +897,9 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
             else __hip_atomic_fetch_add(slot, (unsigned long long)half_bits_to_fixed(bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
+    const bool interleaved = plan.interleaved[li] != 0;
     auto add_record = [&](const uint32_t key, const uint32_t val) {
-        const uint32_t idx = key & (BIN_SLICE - 1u);
+        const uint32_t idx = interleaved ? (key >> BIN_DENSE_BITS) : (key & (BIN_SLICE - 1u));
         const half2_t hv = __builtin_bit_cast(half2_t, val);
         add_channel(&acc[2 * idx], idx, 0u, hv.x);
         add_channel(&acc[2 * idx + 1], idx, 1u, hv.y);
@@ -902,7 +948,7 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
     half2_t* __restrict__ gtable = reinterpret_cast<half2_t*>(grad_grid + (size_t)off0 * 2);
     for (uint32_t i = tid; i < (uint32_t)BIN_SLICE; i += ACC_THREADS) {
-        const uint32_t e = bin * BIN_SLICE + i;
+        const uint32_t e = interleaved ? (i << BIN_DENSE_BITS) + bin : bin * BIN_SLICE + i;
         if (e >= hashmap_size) break;
         const long long s0 = (long long)acc[2 * i], s1 = (long long)acc[2 * i + 1];
         const uint32_t bad = (poison[i >> 4] >> ((i & 15u) * 2u)) & 3u;
@@ -1035,7 +1081,7 @@ static int grid_backward_variant() {  // NGP_GRID_BWD=nomerge disables the run m
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("NGP_GRID_BWD");
-        mode = (e && e[0] == 'n') ? 1 : (e && e[0] == 'r') ? 2 : 0;
+        mode = (e && e[0] == 'n') ? 1 : (e && e[0] == 'r') ? 2 : (e && e[0] == 'b') ? 3 : 0;  // none / row / bpermute-wave / default
     }
     return mode;
 }
@@ -1064,8 +1110,7 @@ static int bin_first_level() {  // NGP_GRID_BWD_BIN_FROM=<level>: first level th
     return v;
 }
 
-// Levels that are binned by default: HASHED ones (their records spread uniformly over the slices, and consecutive samples rarely share
-// a vertex, so the run merge of the atomic path has little to offer).  Dense levels keep the atomic path: consecutive samples merge.
+// Every level of an eligible call is binned: hashed levels in contiguous slices, dense levels in round-robin bins.
 static void plan_backward(BackwardPlan& p, const int32_t* offsets_host, const GridLevels& lv, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                           int dtype, uint32_t gridtype, bool align_corners, bool have_workspace) {
     const bool eligible = have_workspace && offsets_host && dtype == NGP_F16 && C == 2 && (D == 2 || D == 3) && B >= BIN_MIN_SAMPLES &&
@@ -1074,11 +1119,13 @@ static void plan_backward(BackwardPlan& p, const int32_t* offsets_host, const Gr
     p.bins.n_chunks = cdiv(B, (uint32_t)BIN_PPB);
     for (uint32_t l = 0; l < L; l++) {
         const uint32_t size = eligible ? (uint32_t)(offsets_host[l + 1] - offsets_host[l]) : 0u;
-        const uint32_t n_bins = (size + BIN_SLICE - 1) >> BIN_SLICE_BITS;
         double dense = 1.0;
         for (uint32_t d = 0; d < D; d++) dense *= (double)(align_corners ? lv.res[l] : lv.res[l] + 1u);
         const bool hashed = gridtype == 0u && dense > (double)size;
-        const bool binned = eligible && n_bins >= 1 && n_bins <= (uint32_t)BIN_MAX_BINS && (first >= 0 ? (int)l >= first : hashed);
+        // hashed levels: contiguous 4096-entry slices (records spread evenly by construction); dense levels: 128 round-robin bins
+        const bool interleave = !hashed && size <= (uint32_t)BIN_DENSE_BINS * BIN_SLICE;
+        const uint32_t n_bins = interleave ? (uint32_t)BIN_DENSE_BINS : (size + BIN_SLICE - 1) >> BIN_SLICE_BITS;
+        const bool binned = eligible && size >= 1 && n_bins <= (uint32_t)BIN_MAX_BINS && (first >= 0 ? (int)l >= first : (hashed || interleave));
         if (!binned) {
             p.atomic_levels.level[p.n_atomic++] = (uint8_t)l;
             continue;
@@ -1086,6 +1133,7 @@ static void plan_backward(BackwardPlan& p, const int32_t* offsets_host, const Gr
         const uint32_t i = p.n_binned++;
         p.bins.level[i] = (uint8_t)l;
         p.bins.n_bins[i] = (uint16_t)n_bins;
+        p.bins.interleaved[i] = interleave ? 1 : 0;
         p.bins.desc_base[i] = p.total_desc;
         p.total_desc += n_bins * p.bins.n_chunks;
         p.total_records += (uint64_t)p.bins.n_chunks * BIN_PPB * (1u << D);
@@ -1093,7 +1141,7 @@ static void plan_backward(BackwardPlan& p, const int32_t* offsets_host, const Gr
     }
 }
 
-template <int D>
+template <int D, int AMERGE>
 static int launch_backward_bins(const void* grad, const float* inputs, const int32_t* offsets, void* grad_emb, uint32_t B,
                                 const GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, InputMap im, const BackwardPlan& p,
                                 void* workspace, bool with_atomic_levels, hipStream_t st) {
@@ -1103,7 +1151,7 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_accumulate<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)acc_smem) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_bin<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_bin<D, AMERGE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)bin_smem) != hipSuccess) {
             set_error("grid_encode_backward: hipFuncSetAttribute(LDS size) failed");
             return NGP_ERR_LAUNCH;
@@ -1118,7 +1166,7 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     ap.blocks_per_level = cdiv(B, ap.points_per_block);
     ap.n_blocks = with_atomic_levels ? ap.blocks_per_level * p.n_atomic : 0u;
     const uint32_t blocks = p.bins.n_chunks * p.n_binned + ap.n_blocks;
-    hipLaunchKernelGGL((k_grid_backward_bin<D>), dim3(blocks), dim3(BIN_THREADS), bin_smem, st, (const half_t*)grad, inputs, offsets,
+    hipLaunchKernelGGL((k_grid_backward_bin<D, AMERGE>), dim3(blocks), dim3(BIN_THREADS), bin_smem, st, (const half_t*)grad, inputs, offsets,
                        (half_t*)grad_emb, B, lv, gridtype, ac, interp, im, p.bins, descriptors, records, ap);
     int rc = check_launch("grid_encode_backward(bin)");
     if (rc) return rc;
@@ -1134,22 +1182,27 @@ static int launch_backward(const void* grad, const float* inputs, const int32_t*
     int rc = NGP_OK;
     constexpr bool can_bin = sizeof(T) == 2 && C == 2 && (D == 2 || D == 3);
     // the atomic levels ride in the launch of the record sort when there is one (and the merge variant is the default one)
-    const bool mixed = can_bin && plan.n_binned > 0 && grid_backward_variant() == 0 && getenv("NGP_GRID_BWD_SEPARATE") == nullptr;
+    const int variant = grid_backward_variant();
+    const bool mixed = can_bin && plan.n_binned > 0 && (variant == 0 || variant == 3) && getenv("NGP_GRID_BWD_SEPARATE") == nullptr;
     if (plan.n_atomic && !mixed) {
         // one block covers `ppb` consecutive points of one level; >= ~4 blocks per CU over all levels fills the chip
         uint32_t ppb = 2048;
         while (ppb > 128 && (uint64_t)cdiv(B, ppb) * plan.n_atomic < 2048) ppb >>= 1;
         dim3 grid(cdiv(B, ppb), plan.n_atomic, 1);
-        if constexpr (BwdLanes<T, C>::LPP == 2) {
-            if (grid_backward_variant() == 2) {
-                hipLaunchKernelGGL((k_grid_backward<T, D, C, 2>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
-                                   (T*)grad_emb, B, plan.atomic_levels, lv, gridtype, ac, interp, ppb, im);
+        if constexpr (BwdLanes<T, C>::LPP == 2) {  // two lanes per sample: the run merge is pure DPP (default: over the whole wave)
+            if (variant == 2 || variant == 0) {
+                if (variant == 2)
+                    hipLaunchKernelGGL((k_grid_backward<T, D, C, 2>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
+                                       (T*)grad_emb, B, plan.atomic_levels, lv, gridtype, ac, interp, ppb, im);
+                else
+                    hipLaunchKernelGGL((k_grid_backward<T, D, C, 3>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
+                                       (T*)grad_emb, B, plan.atomic_levels, lv, gridtype, ac, interp, ppb, im);
                 rc = check_launch("grid_encode_backward");
                 if (rc) return rc;
                 goto atomic_done;
             }
         }
-        if (grid_backward_variant() == 1)
+        if (variant == 1)
             hipLaunchKernelGGL((k_grid_backward<T, D, C, 0>), grid, dim3(BWD_THREADS), 0, st, (const T*)grad, inputs, offsets,
                                (T*)grad_emb, B, plan.atomic_levels, lv, gridtype, ac, interp, ppb, im);
         else
@@ -1161,8 +1214,10 @@ static int launch_backward(const void* grad, const float* inputs, const int32_t*
 atomic_done:
     if (plan.n_binned) {
         if constexpr (can_bin) {
-            rc = launch_backward_bins<D>(grad, inputs, offsets, grad_emb, B, lv, gridtype, ac, interp, im, plan, workspace,
-                                         mixed && plan.n_atomic > 0, st);
+            rc = variant == 3 ? launch_backward_bins<D, 1>(grad, inputs, offsets, grad_emb, B, lv, gridtype, ac, interp, im, plan, workspace,
+                                                           mixed && plan.n_atomic > 0, st)
+                              : launch_backward_bins<D, 3>(grad, inputs, offsets, grad_emb, B, lv, gridtype, ac, interp, im, plan, workspace,
+                                                           mixed && plan.n_atomic > 0, st);
             if (rc) return rc;
         }
     }

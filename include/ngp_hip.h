@@ -118,6 +118,10 @@ int ngp_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, ngp_stream
 int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, ngp_stream_t stream);
 /* replaces packbits (raymarching.cu:292-300): N = number of output bytes, grid has 8*N floats */
 int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, ngp_stream_t stream);
+/* extension: the threshold is min(density_thresh, *thresh_cap) with thresh_cap a DEVICE scalar (may be NULL) -- the occupancy refresh
+ * packs against min(mean_density, density_thresh) (renderer.py:527-529) without reading the mean back to the host */
+int ngp_packbits_ex(const float* grid, uint32_t N, float density_thresh, const float* thresh_cap, uint8_t* bitfield,
+                    ngp_stream_t stream);
 
 /* replaces march_rays_train (raymarching.cu:482-490).
  * Sample slots are handed out by a deterministic prefix sum in ray order (rays[n] = (n, offset_n,

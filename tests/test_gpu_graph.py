@@ -175,7 +175,45 @@ def test_graph_replay_direct_and_autograd_modes_agree():
             counts.append(int(model.step_counter[(model.local_step - 1) % 16, 0].item()))
         assert st.n_captures >= 1 and st.capture_error is None
         assert st.used_direct == direct
+        assert st.update_capture_error is None and len(st.update_graphs) >= 1, 'the occupancy refresh replays from its own graph'
+
         runs[direct] = (losses, counts)
     assert runs[True][1] == runs[False][1]
     np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=8e-2, atol=2e-3)
     assert runs[True][0][-1] < runs[True][0][0]
+
+
+def test_sync_free_occupancy_refresh():
+    """model.refresh_occupancy (the device part of update_extra_state) needs no host read-back: the bitfield it packs equals packbits
+    against min(mean_density, density_thresh), the partial sweep touches a quarter of the cells at random plus draws from the
+    occupied ones only, and the lazily read mean_density equals the mean of the clamped grid."""
+    import raymarching
+    dev = torch.device('cuda')
+    model, _ = _make_ngp(dev)
+    grid0 = torch.from_numpy(sc.occupancy_density()).to(dev)
+    for full in (True, False):
+        model.density_grid.copy_(grid0)
+        model.iter_density = 0 if full else 20
+        model.local_step = 0
+        with torch.autocast('cuda', dtype=torch.float16):
+            model.update_extra_state()
+        g = model.density_grid
+        assert torch.isfinite(g).all()
+        mean = float(g.clamp(min=0).mean())
+        assert abs(model.mean_density - mean) <= 1e-6 * max(1.0, mean)
+        ref_bits = oracle.packbits(g.cpu().numpy(), min(mean, model.density_thresh))
+        assert np.array_equal(model.density_bitfield.cpu().numpy(), ref_bits)
+        changed = (g != grid0)
+        if full:
+            assert changed.float().mean() > 0.9
+        else:
+            # a quarter of all cells at random (with replacement) + as many draws among the occupied ones
+            frac = changed.float().mean().item()
+            assert 0.15 < frac < 0.6
+            occ0 = grid0 > 0
+            assert changed[occ0].float().mean() > changed[~occ0].float().mean() + 0.2
+    cap = torch.tensor([0.5], device=dev)
+    a = raymarching.packbits_capped(grid0, 10.0, cap, torch.empty_like(model.density_bitfield))
+    b = raymarching.packbits(grid0, 0.5, torch.empty_like(model.density_bitfield))
+    c = raymarching.packbits_capped(grid0, 0.25, cap, torch.empty_like(model.density_bitfield))
+    assert torch.equal(a, b) and torch.equal(c, raymarching.packbits(grid0, 0.25, torch.empty_like(model.density_bitfield)))

@@ -47,6 +47,7 @@ _SIGNATURES = {
     'ngp_morton3D': [_vp, _u32, _vp, _vp],
     'ngp_morton3D_invert': [_vp, _u32, _vp, _vp],
     'ngp_packbits': [_vp, _u32, _f32, _vp, _vp],
+    'ngp_packbits_ex': [_vp, _u32, _f32, _vp, _vp, _vp],
     'ngp_march_rays_train': [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_composite_rays_train_forward': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp],
     'ngp_composite_rays_train_backward': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp],

@@ -104,9 +104,11 @@ __global__ void k_morton3D_invert(const int32_t* __restrict__ indices, uint32_t 
 
 // raymarching.cu:268-289.  One lane packs one byte from two 16-byte loads (the grid is a pure stream:
 // 4.125 B per cell).
-__global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield) {
+__global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thresh, const float* __restrict__ thresh_cap,
+                           uint8_t* __restrict__ bitfield) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    if (thresh_cap) thresh = fminf(thresh, thresh_cap[0]);  // min(mean_density, density_thresh) with the mean still on the device
     const float4_t a = *reinterpret_cast<const float4_t*>(grid + (size_t)n * 8);
     const float4_t b = *reinterpret_cast<const float4_t*>(grid + (size_t)n * 8 + 4);
     uint32_t bits = 0;
@@ -855,12 +857,17 @@ extern "C" int ngp_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* 
     return check_launch("morton3D_invert");
 }
 
-extern "C" int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, ngp_stream_t stream) {
+extern "C" int ngp_packbits_ex(const float* grid, uint32_t N, float density_thresh, const float* thresh_cap, uint8_t* bitfield,
+                               ngp_stream_t stream) {
     if (N == 0) return NGP_OK;
     NGP_REQUIRE(grid && bitfield, NGP_ERR_INVALID, "packbits: NULL tensor");
     NGP_REQUIRE((reinterpret_cast<uintptr_t>(grid) & 15) == 0, NGP_ERR_INVALID, "packbits: grid must be 16-byte aligned");
-    RM_LAUNCH_1D(k_packbits, N, as_stream(stream), grid, N, density_thresh, bitfield);
+    RM_LAUNCH_1D(k_packbits, N, as_stream(stream), grid, N, density_thresh, thresh_cap, bitfield);
     return check_launch("packbits");
+}
+
+extern "C" int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, ngp_stream_t stream) {
+    return ngp_packbits_ex(grid, N, density_thresh, nullptr, bitfield, stream);
 }
 
 // workspace: [0] fit_end, [1] pad, [2 .. 2+N) windows per ray, then N x MARCH_MASK_WINDOWS 64-bit emit masks

@@ -53,6 +53,9 @@ class GraphedTrainStep:
         self.n_captures = 0
         self.capture_error = None
         self.used_direct = False
+        self.graph_updates = True   # replay the occupancy refresh from a HIP graph as well (see _update_extra_state)
+        self.update_graphs = {}     # {full sweep?: (graph, device mean density)}
+        self.update_capture_error = None
         self.capacity = None  # sample capacity of the step that ran last (None while eager/worst-case)
         # autograd-free iteration (fused.fused_train_iteration): needs the default loss, an optimizer that owns its loss scale and
         # deposits gradients (optim.NGPAdam), and a model/render configuration the fused training render accepts
@@ -140,6 +143,40 @@ class GraphedTrainStep:
             self.graphs = (g1, g2)
         self.n_captures += 1
 
+    def _update_extra_state(self):
+        """the occupancy refresh at the Trainer's cadence.  Its device part (model.refresh_occupancy: ~50 small launches around one
+        big density evaluation, no host synchronisation) is replayed from a HIP graph of its own once training runs from graphs -- issued
+        eagerly it leaves the GPU idle for about half of its 1.2 ms; the host part (sample-count estimate) stays eager."""
+        m = self.model
+        refresh = getattr(m, 'refresh_occupancy', None)
+        if refresh is None or not getattr(m, 'cuda_ray', False):
+            with torch.autocast('cuda', dtype=self.autocast_dtype):
+                m.update_extra_state()
+            return
+        full = m.iter_density < 16
+        use_graph = self.graph_updates and self.graphs is not None and self.update_capture_error is None
+        if use_graph and full not in self.update_graphs:
+            try:
+                import gc
+                gc.collect()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.graphs[0].pool()):
+                    with torch.autocast('cuda', dtype=self.autocast_dtype):
+                        mean = refresh(full=full)
+                self.update_graphs[full] = (g, mean)
+            except Exception as e:  # noqa: BLE001 -- keep refreshing eagerly; the caller can inspect .update_capture_error
+                self.update_capture_error = repr(e)
+                torch.cuda.synchronize()
+                use_graph = False
+        if use_graph:
+            g, mean = self.update_graphs[full]
+            g.replay()
+        else:
+            with torch.autocast('cuda', dtype=self.autocast_dtype):
+                mean = refresh(full=full)
+        m.finish_update(mean)
+
     def _eager(self, rays_o, rays_d, target):
         self.optimizer.zero_grad(set_to_none=True)
         with torch.autocast('cuda', dtype=self.autocast_dtype):
@@ -158,8 +195,7 @@ class GraphedTrainStep:
         """one training iteration on rays_o/rays_d [1,N,3], target [N,3]; returns the (device) loss of this step"""
         m = self.model
         if self.global_step % self.update_interval == 0:
-            with torch.autocast('cuda', dtype=self.autocast_dtype):
-                m.update_extra_state()
+            self._update_extra_state()
             if self.after_update is not None:
                 self.after_update(m)
         cap = self._capacity()

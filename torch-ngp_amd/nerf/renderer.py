@@ -43,7 +43,7 @@ class NeRFRenderer(nn.Module):
             self.register_buffer('density_grid', torch.zeros(self.cascade, cells))
             self.register_buffer('density_bitfield', torch.zeros(self.cascade * cells // 8, dtype=torch.uint8))
             self.register_buffer('step_counter', torch.zeros(16, 2, dtype=torch.int32))
-            self.mean_density = 0
+            self._mean_density, self._mean_density_dev = 0.0, None
             self.iter_density = 0
             self.mean_count = 0
             self.local_step = 0
@@ -223,14 +223,29 @@ class NeRFRenderer(nn.Module):
                             count[cas, cell_ids] += seen.sum(0).reshape(-1)
         self.density_grid[count == 0] = -1
 
+    @property
+    def mean_density(self):
+        """mean of the clamped density grid (renderer.py:527); kept on the device by the refresh and read back only when asked for"""
+        if self._mean_density_dev is not None:
+            self._mean_density = float(self._mean_density_dev.item())
+            self._mean_density_dev = None
+        return self._mean_density
+
+    @mean_density.setter
+    def mean_density(self, value):
+        self._mean_density, self._mean_density_dev = float(value), None
+
     @torch.no_grad()
-    def update_extra_state(self, decay=0.95, S=128):
-        """refresh the density grid / bitfield and the sample-count estimate (renderer.py:444-538)"""
-        if not self.cuda_ray:
-            return
+    def refresh_occupancy(self, decay=0.95, S=128, full=None):
+        """the device part of update_extra_state (renderer.py:444-529): re-evaluate the density on the grid cells, EMA-max update,
+        bitfield.  No host synchronisation anywhere (so it can be captured in a HIP graph, graph.GraphedTrainStep does): the
+        `torch.nonzero` + random choice of the reference's partial sweep is replaced by an equivalent draw (uniform over the occupied
+        cells, with replacement) through a prefix sum and a binary search, and the bitfield is packed against
+        min(mean_density, density_thresh) with the mean still on the device (ngp_packbits_ex)."""
         dev = self.density_bitfield.device
         fresh = -torch.ones_like(self.density_grid)
-        if self.iter_density < 16:  # full sweep
+        full = (self.iter_density < 16) if full is None else full
+        if full:  # full sweep
             axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
             for xs in axis:
                 for ys in axis:
@@ -245,8 +260,10 @@ class NeRFRenderer(nn.Module):
             for cas in range(self.cascade):
                 rand_coords = torch.randint(0, self.grid_size, (n, 3), device=dev)
                 rand_ids = raymarching.morton3D(rand_coords).long()
-                occ_ids = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                occ_ids = occ_ids[torch.randint(0, occ_ids.shape[0], [n], dtype=torch.long, device=dev)]
+                # occ_ids = nonzero(grid > 0)[randint(0, count, n)] without knowing `count` on the host
+                occupied = torch.cumsum(self.density_grid[cas] > 0, 0, dtype=torch.int32)
+                pick = (torch.rand(n, device=dev) * occupied[-1]).to(torch.int32).clamp_(max=occupied[-1] - 1).clamp_(min=0)
+                occ_ids = torch.searchsorted(occupied, pick + 1).clamp_(max=occupied.shape[0] - 1)
                 occ_coords = raymarching.morton3D_invert(occ_ids)
                 cell_ids = torch.cat([rand_ids, occ_ids], 0)
                 coords = torch.cat([rand_coords, occ_coords], 0)
@@ -256,14 +273,25 @@ class NeRFRenderer(nn.Module):
         # gather/scatter (and its host synchronisation) is needed: identical values
         both = (self.density_grid >= 0) & (fresh >= 0)
         self.density_grid.copy_(torch.where(both, torch.maximum(self.density_grid * decay, fresh), self.density_grid))
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        mean = torch.mean(self.density_grid.clamp(min=0))
+        raymarching.packbits_capped(self.density_grid, self.density_thresh, mean, self.density_bitfield)
+        return mean
+
+    def finish_update(self, mean):
+        """the host part of update_extra_state: bookkeeping and the sample-count estimate (one read-back, renderer.py:531-538)"""
+        self._mean_density_dev = mean.detach().reshape(())
         self.iter_density += 1
-        self.density_bitfield = raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh),
-                                                     self.density_bitfield)
         used = min(16, self.local_step)
         if used > 0:
             self.mean_count = int(self.step_counter[:used, 0].sum().item() / used)
         self.local_step = 0
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        """refresh the density grid / bitfield and the sample-count estimate (renderer.py:444-538)"""
+        if not self.cuda_ray:
+            return
+        self.finish_update(self.refresh_occupancy(decay, S))
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         if not self.cuda_ray:

@@ -52,6 +52,11 @@ def packbits(grid, N, density_thresh, bitfield):
     capi.check(capi.lib.ngp_packbits(capi.ptr(grid), N, float(density_thresh), capi.ptr(bitfield), capi.stream()))
 
 
+def packbits_capped(grid, N, density_thresh, thresh_cap, bitfield):
+    """extension: threshold = min(density_thresh, thresh_cap[0]) with thresh_cap a device scalar (include/ngp_hip.h, ngp_packbits_ex)"""
+    capi.check(capi.lib.ngp_packbits_ex(capi.ptr(grid), N, float(density_thresh), capi.ptr(thresh_cap), capi.ptr(bitfield), capi.stream()))
+
+
 def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
                      counter, noises):
     for t, n in ((rays_o, 'rays_o'), (rays_d, 'rays_d'), (nears, 'nears'), (fars, 'fars'), (xyzs, 'xyzs'), (dirs, 'dirs'),
@@ -132,7 +137,7 @@ def compact_rays(rays_alive, n_alive, out_alive, out_count):
 
 _backend = types.SimpleNamespace(
     near_far_from_aabb=near_far_from_aabb, sph_from_ray=sph_from_ray, morton3D=morton3D, morton3D_invert=morton3D_invert,
-    packbits=packbits, march_rays_train=march_rays_train, composite_rays_train_forward=composite_rays_train_forward,
+    packbits=packbits, packbits_capped=packbits_capped, march_rays_train=march_rays_train, composite_rays_train_forward=composite_rays_train_forward,
     composite_rays_train_backward=composite_rays_train_backward, march_rays=march_rays, march_rays_ex=march_rays_ex,
     composite_rays=composite_rays,
     compact_rays=compact_rays)

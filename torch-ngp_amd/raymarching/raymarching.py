@@ -14,7 +14,7 @@ from torch.amp import custom_bwd, custom_fwd
 
 from .backend import _backend
 
-__all__ = ['near_far_from_aabb', 'sph_from_ray', 'morton3D', 'morton3D_invert', 'packbits', 'march_rays_train',
+__all__ = ['near_far_from_aabb', 'sph_from_ray', 'morton3D', 'morton3D_invert', 'packbits', 'packbits_capped', 'march_rays_train',
            'composite_rays_train', 'march_rays', 'composite_rays', 'compact_rays']
 
 _f32_fwd = custom_fwd(device_type='cuda', cast_inputs=torch.float32)
@@ -106,6 +106,16 @@ class _packbits(Function):
 
 
 packbits = _packbits.apply
+
+
+def packbits_capped(grid, thresh, thresh_cap, bitfield):
+    """extension (not in the reference): packbits against min(thresh, thresh_cap) where thresh_cap is a 0-dim / 1-element float32
+    DEVICE tensor -- the occupancy refresh uses the mean density as the cap without reading it back (no host synchronisation, so the
+    refresh can be captured in a HIP graph).  Writes `bitfield` in place and returns it."""
+    grid = grid.contiguous()
+    n_bytes = grid.shape[0] * grid.shape[1] // 8
+    _backend.packbits_capped(grid, n_bytes, float(thresh), thresh_cap.reshape(1).float().contiguous(), bitfield)
+    return bitfield
 
 
 # ----------------------------------------------------------------------------------------------

@@ -84,6 +84,30 @@ def test_forward_inference_backward(din, hid, nl, B):
     assert torch.equal(gw2, gw) and dummy.item() == 0
 
 
+@pytest.mark.parametrize('din,hid,nl', [(64, 64, 4), (32, 64, 3)])
+def test_backward_many_tiles_per_wave(din, hid, nl):
+    """2^17 samples = 4096 tiles of 32 on ~1024 resident waves: every wave walks several tiles, so the operand prefetch is exercised
+    in both of its forms (two stage buffers per wave; a single one when the 64-input 4-layer weight image leaves no room for two)."""
+    B = 1 << 17
+    rng = np.random.default_rng(77 + din + nl)
+    n_params = hid * (din + hid * (nl - 1) + 16)
+    w = oracle.round_fp16(rng.uniform(-1, 1, n_params) * np.sqrt(3 / hid))
+    x = oracle.round_fp16(rng.uniform(-1, 1, (B, din)))
+    out, fb, xt, wt = _run_forward(x, w, din, hid, nl)
+    ref, rfb = oracle.ffmlp_forward(x, w, din, 16, hid, nl)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+    g = oracle.round_fp16(rng.normal(size=(B, 16)) * 0.1)
+    gi = torch.zeros(B, din, device='cuda', dtype=torch.half)
+    gw = torch.zeros(n_params, device='cuda', dtype=torch.half)
+    bb = torch.zeros(nl, B, hid, device='cuda', dtype=torch.half)
+    _be().ffmlp_backward(cu16(g), xt, wt, fb, B, din, 16, hid, nl, 0, 6, True, bb, gi, gw)
+    rgx, rgw = oracle.ffmlp_backward(g, x, w, rfb, din, 16, hid, nl)
+    _close_except_relu_flips(gi.float().cpu().numpy(), rgx, 4e-3)
+    gwn = gw.float().cpu().numpy()
+    assert np.isfinite(gwn).all()
+    assert np.linalg.norm(gwn - rgw) / np.linalg.norm(rgw) < 2e-3
+
+
 def test_backward_is_deterministic():
     rng = np.random.default_rng(0)
     din, hid, nl, B = 32, 64, 2, 1 << 17

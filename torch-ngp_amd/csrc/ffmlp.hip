@@ -435,7 +435,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
                                                                const half_t* __restrict__ weights, const half_t* __restrict__ forward_buffer,
                                                                uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
                                                                bool with_dx, half_t* __restrict__ grad_inputs, float* __restrict__ slabs,
-                                                               half_t* __restrict__ grad_weights_direct, bool in_planar, bool dx_planar, uint32_t pf_depth) {
+                                                               half_t* __restrict__ grad_weights_direct, bool in_planar, bool dx_planar, uint32_t pf_depth, uint32_t diag) {
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img = reinterpret_cast<half8_t*>(smem);
@@ -484,12 +484,13 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
     for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += tile_step) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's operands have landed in buffer `cur`
         const unsigned char* tb = pf_base + (size_t)cur * tile_frags * 1024;
-        if (pf_depth > 1) {
+        if (pf_depth > 1 && diag != 1u) {  // (diag: timing experiments of tools/bench_kernels.py -- 1 = no loads after the first tile, 2 = loads only)
             cur ^= 1u;
             if (tile + tile_step < n_tiles)
                 prefetch_tile<WIDTH>(pf_base + (size_t)cur * tile_frags * 1024, tile + tile_step, grad, fb, inputs, num_layers, layer_stride,
                                      rows, in_dim, in_planar, lane, n, h);
         }
+        if (diag == 2u) continue;
         const half8_t* tfrag = reinterpret_cast<const half8_t*>(tb) + lane;
         // ---- output layer -------------------------------------------------------------------
         const half8_t dy = tfrag[0];
@@ -584,6 +585,12 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
                     }
                 }
             }
+        }
+        if (pf_depth == 1 && tile + tile_step < n_tiles) {
+            // single buffer (the weight image + two stages per wave do not fit 160 KiB): the next tile can only be requested once
+            // this one has been consumed -- no overlap, but every tile is loaded
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            prefetch_tile<WIDTH>(pf_base, tile + tile_step, grad, fb, inputs, num_layers, layer_stride, rows, in_dim, in_planar, lane, n, h);
         }
     }
 
@@ -721,6 +728,7 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
     const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
     // weight image + per-wave tile buffers (double-buffered when both fit the 160 KiB LDS of a CU)
     const size_t tile_bytes = (size_t)(1 + num_layers * NKB + in_dim / 16) * 1024;
+    static const uint32_t diag = getenv("NGP_FF_BWD_DIAG") ? (uint32_t)atoi(getenv("NGP_FF_BWD_DIAG")) : 0u;
     uint32_t pf_depth = 2;
     if ((size_t)nfrag * 1024 + 2 * FF_WAVES * tile_bytes > 160 * 1024) pf_depth = 1;
     size_t lds = (size_t)nfrag * 1024 + (size_t)pf_depth * FF_WAVES * tile_bytes;
@@ -741,12 +749,12 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
     if (blocks <= 1) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
                            (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)nullptr,
-                           (half_t*)grad_weights, in_planar, dx_planar, pf_depth);
+                           (half_t*)grad_weights, in_planar, dx_planar, pf_depth, diag);
         return check_launch("ffmlp_backward");
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
                        (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)backward_buffer,
-                       (half_t*)nullptr, in_planar, dx_planar, pf_depth);
+                       (half_t*)nullptr, in_planar, dx_planar, pf_depth, diag);
     int rc = check_launch("ffmlp_backward");
     if (rc) return rc;
     hipLaunchKernelGGL(k_ffmlp_reduce_slabs, dim3(cdiv(n_params, RS_PARAMS)), dim3(RS_PARAMS * RS_GROUPS), 0, st, (const float*)backward_buffer, blocks, n_params,

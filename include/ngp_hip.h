@@ -259,6 +259,13 @@ int ngp_pipeline_mid_backward(const float* grad_sigma, const void* h16, const vo
 int ngp_pipeline_mse_loss(const float* image, const float* target, uint32_t n, const float* loss_scale, float* loss,
                           float* grad_image, ngp_stream_t stream);
 
+/* Data path: the arithmetic of get_rays (nerf/utils.py:53-137).  poses [B,4,4] row-major camera-to-world; pixel
+ * indices inds [B,N] int64 (inds_batch_stride = N) or [N] shared by every pose (inds_batch_stride = 0) or NULL (pixel n = n: a full
+ * H x W frame with N = H * W); pixel p is (column p % W, row p / W), sampled at its centre.  rays_o, rays_d [B,N,3] fp32:
+ * rays_d = normalize(((col + 0.5 - cx) / fx, (row + 0.5 - cy) / fy, 1)) . R^T,  rays_o = camera position. */
+int ngp_rays_from_pixels(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t W, const int64_t* inds,
+                         uint32_t inds_batch_stride, uint32_t N, float* rays_o, float* rays_d, ngp_stream_t stream);
+
 /* march_rays_train with two conveniences for the fused renderer: the counter may be reset in-kernel and the sample rows no ray
  * writes are zeroed in-kernel (the reference contract keeps both with the caller: counter.zero_(), torch.zeros buffers). */
 #define NGP_MARCH_RESET_COUNTER 1u

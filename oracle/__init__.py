@@ -394,3 +394,26 @@ def freq_backward(grad, outputs, input_dim, degree):
         c = slice(D + 2 * f * D + D, D + 2 * f * D + 2 * D)
         r += (2.0 ** f) * (g[:, s] * o[:, c] - g[:, c] * o[:, s])
     return r
+
+
+def get_rays(poses, intrinsics, W, inds=None, n_pixels=None):
+    """nerf/utils.py:53-137, the arithmetic part in fp32: poses [B,4,4] cam2world, intrinsics (fx, fy, cx, cy), pixel indices [B,N] or
+    [N] (None: all n_pixels pixels in order) -> rays_o, rays_d [B,N,3].  Pixel p = (column p % W, row p // W), sampled at its centre."""
+    poses = np.asarray(poses, np.float32)
+    B = poses.shape[0]
+    fx, fy, cx, cy = (np.float32(v) for v in intrinsics)
+    if inds is None:
+        inds = np.arange(n_pixels, dtype=np.int64)
+    inds = np.asarray(inds, np.int64)
+    if inds.ndim == 1:
+        inds = np.broadcast_to(inds, (B, inds.shape[0]))
+    i = (inds % W).astype(np.float32) + np.float32(0.5)
+    j = (inds // W).astype(np.float32) + np.float32(0.5)
+    xs = (i - cx) / fx
+    ys = (j - cy) / fy
+    length = np.sqrt((xs * xs + ys * ys) + np.float32(1.0))
+    d = np.stack([xs / length, ys / length, np.float32(1.0) / length], -1).astype(np.float32)   # [B,N,3]
+    R = poses[:, :3, :3]
+    rays_d = ((d[..., 0:1] * R[:, None, :, 0] + d[..., 1:2] * R[:, None, :, 1]) + d[..., 2:3] * R[:, None, :, 2]).astype(np.float32)
+    rays_o = np.broadcast_to(poses[:, None, :3, 3], rays_d.shape).astype(np.float32)
+    return rays_o, rays_d

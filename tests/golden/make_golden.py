@@ -11,6 +11,7 @@ What can be executed from the reference without CUDA (everything else on the hot
   5. nerf/renderer.py:125-253         NeRFRenderer.run  (cumprod compositing; near/far stubbed
                                       by the oracle because the reference's is CUDA-only) -> composite_ref.npz
   6. encoding.py:5-42                 FreqEncoder (pure torch sin/cos positional encoding)    -> freq_ref.npz
+  7. nerf/utils.py:53-137             get_rays (pixel draw + pinhole rays; CPU tensors)         -> get_rays_ref.npz
 Nothing is copied from the reference into this repository: the classes are exec'd from the files
 where they lie.
 
@@ -181,6 +182,45 @@ def gen_composite():
     print('composite_ref.npz')
 
 
+def gen_get_rays():
+    # nerf/utils.py imports a dozen packages that are not in this image (imageio, cv2, tensorboardX, ...); none of them is touched by
+    # get_rays, so they are stubbed until the import goes through.  get_rays itself runs unmodified, from the file where it lies.
+    import importlib
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for name in ('nerf', 'nerf.utils', 'nerf.renderer', 'raymarching', 'trimesh'):
+        sys.modules.pop(name, None)
+    for _ in range(64):
+        try:
+            mod = importlib.import_module('nerf.utils')
+            break
+        except ModuleNotFoundError as e:
+            stub = types.ModuleType(e.name)
+            stub.__path__ = []
+            stub.__getattr__ = lambda attr: types.ModuleType(attr) if not attr.startswith('__') else (_ for _ in ()).throw(AttributeError(attr))
+            sys.modules[e.name] = stub
+    torch.manual_seed(11)
+    B, H, W = 3, 37, 53
+    ang = torch.tensor([0.3, -1.1, 2.0])
+    poses = torch.eye(4).repeat(B, 1, 1)
+    for b in range(B):
+        c, s_ = torch.cos(ang[b]), torch.sin(ang[b])
+        Ry = torch.tensor([[c, 0, s_], [0, 1, 0], [-s_, 0, c]])
+        Rx = torch.tensor([[1, 0, 0], [0, c, -s_], [0, s_, c]])
+        poses[b, :3, :3] = Ry @ Rx
+        poses[b, :3, 3] = torch.tensor([0.5 * b - 0.4, 0.2, 2.0 - 0.7 * b])
+    intr = np.array([41.5, 39.25, 26.1, 18.7], np.float32)
+    some = mod.get_rays(poses, intr, H, W, N=257)
+    full = mod.get_rays(poses, intr, H, W, N=-1)
+    err = torch.rand(B, 128 * 128)
+    guided = mod.get_rays(poses, intr, H, W, N=64, error_map=err)
+    np.savez_compressed(os.path.join(HERE, 'get_rays_ref.npz'), poses=poses.numpy(), intrinsics=intr, H=H, W=W,
+                        inds=some['inds'].numpy(), rays_o=some['rays_o'].numpy(), rays_d=some['rays_d'].numpy(),
+                        full_rays_o=full['rays_o'].numpy(), full_rays_d=full['rays_d'].numpy(),
+                        guided_inds=guided['inds'].numpy(), guided_rays_d=guided['rays_d'].numpy())
+    print('get_rays_ref.npz')
+
+
 def gen_freq():
     # encoding.py:5-42 -- the reference's pure-torch FreqEncoder (the algorithm freqencoder.cu:30-94 accelerates): float64 run with
     # autograd gradients, for D = 3 (deg 4 and 10) and D = 2 (deg 6)
@@ -209,9 +249,14 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'freq':
         gen_freq()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'get_rays':
+        sys.path.insert(0, REF)
+        gen_get_rays()
+        sys.exit(0)
     gen_sh()
     gen_mlp()
     gen_offsets()
     gen_trunc_exp()
     gen_composite()
     gen_freq()
+    gen_get_rays()

@@ -70,6 +70,7 @@ _SIGNATURES = {
     'ngp_pipeline_rgb_backward': [_vp, _vp, _vp, _u32, _vp],
     'ngp_pipeline_mid_backward': [_vp, _vp, _vp, _vp, _u32, _f32, _vp],
     'ngp_pipeline_mse_loss': [_vp, _vp, _u32, _vp, _vp, _vp, _vp],
+    'ngp_rays_from_pixels': [_vp, _u32, _f32, _f32, _f32, _f32, _u32, _vp, _u32, _u32, _vp, _vp, _vp],
     'ngp_march_rays_train_ex': [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     'ngp_composite_rays_train_forward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_composite_rays_train_backward_ex': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _i32, _f32, _vp, _vp, _vp],

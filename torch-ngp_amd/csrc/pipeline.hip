@@ -123,6 +123,31 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_mse_loss(const float* __restri
     }
 }
 
+// nerf/utils.py:53-137 (get_rays), the arithmetic part: pixel index -> camera-space direction through the pinhole intrinsics ->
+// normalise -> rotate by the camera-to-world pose; the ray origin is the camera position.  Pixel p of a W-wide image sits at
+// (column p % W + 0.5, row p / W + 0.5) (the reference's transposed meshgrid, flattened row-major).  One lane per ray.
+__global__ __launch_bounds__(PL_THREADS) void k_rays_from_pixels(const float* __restrict__ poses, uint32_t B, float fx, float fy, float cx,
+                                                                 float cy, uint32_t W, const long long* __restrict__ inds,
+                                                                 uint32_t inds_batch_stride, uint32_t N, float* __restrict__ rays_o,
+                                                                 float* __restrict__ rays_d) {
+    const uint32_t t = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (t >= B * N) return;
+    const uint32_t b = t / N, n = t - b * N;
+    const long long pix = inds ? inds[(size_t)b * inds_batch_stride + n] : (long long)n;
+    const float i = (float)(uint32_t)(pix % W) + 0.5f, j = (float)(uint32_t)(pix / W) + 0.5f;
+    const float xs = (i - cx) / fx, ys = (j - cy) / fy;
+    const float len = sqrtf((xs * xs + ys * ys) + 1.0f);
+    const float dx = xs / len, dy = ys / len, dz = 1.0f / len;
+    const float* P = poses + (size_t)b * 16;  // row-major 4x4, rotation in the upper-left 3x3, position in the last column
+    float* o = rays_o + (size_t)t * 3;
+    float* d = rays_d + (size_t)t * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        d[k] = (dx * P[4 * k] + dy * P[4 * k + 1]) + dz * P[4 * k + 2];
+        o[k] = P[4 * k + 3];
+    }
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -166,4 +191,15 @@ extern "C" int ngp_pipeline_mse_loss(const float* image, const float* target, ui
     NGP_REQUIRE(n > 0, NGP_ERR_INVALID, "pipeline_mse_loss: empty batch (the mean of no values is undefined)");
     hipLaunchKernelGGL(k_mse_loss, dim3(1), dim3(LOSS_THREADS), 0, as_stream(stream), image, target, n, loss_scale, loss, grad_image);
     return check_launch("pipeline_mse_loss");
+}
+
+extern "C" int ngp_rays_from_pixels(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t W, const int64_t* inds,
+                                    uint32_t inds_batch_stride, uint32_t N, float* rays_o, float* rays_d, ngp_stream_t stream) {
+    if (B == 0 || N == 0) return NGP_OK;
+    NGP_REQUIRE(poses && rays_o && rays_d, NGP_ERR_INVALID, "rays_from_pixels: NULL tensor");
+    NGP_REQUIRE(W > 0 && fx != 0.0f && fy != 0.0f, NGP_ERR_INVALID, "rays_from_pixels: W, fx and fy must be non-zero");
+    NGP_REQUIRE((uint64_t)B * N <= 0xffffffffull, NGP_ERR_INVALID, "rays_from_pixels: B * N must fit 32 bits");
+    hipLaunchKernelGGL(k_rays_from_pixels, dim3(cdiv(B * N, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), poses, B, fx, fy, cx, cy, W,
+                       (const long long*)inds, inds_batch_stride, N, rays_o, rays_d);
+    return check_launch("rays_from_pixels");
 }

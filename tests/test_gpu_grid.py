@@ -319,3 +319,35 @@ def test_backward_binned_accumulates_poisons_and_survives_bin_overflow():
     assert 1 <= bad.sum() <= 8
     assert np.isfinite(lvl[:, 1]).all()
     assert np.isfinite(ge2[:int(offs[15])].float().cpu().numpy()).all()
+
+
+@pytest.mark.parametrize('D,gridtype,align,interp', [(2, 0, False, 0), (2, 1, True, 1), (3, 1, False, 0), (3, 0, True, 0), (3, 0, False, 1), (3, 1, True, 1)])
+def test_backward_binned_all_index_modes(D, gridtype, align, interp):
+    """the atomic-free path over the index modes of gridencoder.cu:66-84 / :146-159: 2-D and 3-D inputs, hash and tiled grids (dense,
+    round-robin binned and hashed, contiguous-sliced levels in one table), align_corners, smoothstep; with dL/dx in the same call"""
+    rng = np.random.default_rng(100 * D + 10 * gridtype + 2 * int(align) + interp)
+    offs, pls = oracle.grid_offsets(input_dim=D, num_levels=8, level_dim=2, per_level_scale=1.9, base_resolution=8, log2_hashmap_size=15,
+                                    align_corners=align)
+    S = float(np.log2(pls))
+    L, B, C = 8, 1 << 15, 2
+    x = _points(B, D, rng)
+    g = oracle.round_fp16(rng.normal(size=(L, B, C)).astype(np.float32) * 0.1)
+    emb = oracle.round_fp16(rng.uniform(-1, 1, (int(offs[-1]), C)).astype(np.float32))
+    _, dy = _run_forward(x, emb, offs, S, 8, torch.float16, calc_grad=True, gridtype=gridtype, align=align, interp=interp)
+    dyt = torch.from_numpy(dy).cuda().half()
+    ge = torch.zeros(int(offs[-1]), C, device='cuda', dtype=torch.half)
+    gi = torch.zeros(B, D, device='cuda', dtype=torch.half)
+    _backend().grid_encode_backward(torch.from_numpy(g).cuda().half(), torch.from_numpy(x).cuda(), torch.from_numpy(emb).cuda().half(),
+                                    torch.from_numpy(offs).cuda(), ge, B, D, C, L, S, 8, dyt, gi, gridtype, align, interp)
+    ref_e, ref_i = oracle.grid_backward(g, x, offs, int(offs[-1]), C, S, 8, dy_dx=dyt.float().cpu().numpy(), gridtype=gridtype,
+                                        align_corners=align, interp=interp)
+    got = ge.float().cpu().numpy().astype(np.float64)
+    assert np.all(got[ref_e == 0] == 0)
+    # exact sums rounded once to fp16: half an ulp of the result (2^-11 relative) plus the rounding of each contribution
+    np.testing.assert_allclose(got, ref_e, rtol=1.5e-3, atol=1e-3 * np.abs(ref_e).max())
+    assert np.linalg.norm(got - ref_e) / np.linalg.norm(ref_e) < 6e-4
+    np.testing.assert_allclose(gi.float().cpu().numpy(), ref_i, rtol=2e-2, atol=0.2)
+    import ctypes
+    import _ngp_capi as capi
+    arr = (ctypes.c_int32 * len(offs))(*[int(v) for v in offs])
+    assert capi.lib.ngp_grid_backward_workspace_bytes(ctypes.cast(arr, ctypes.c_void_p), B, D, C, L, S, 8, gridtype, int(align), capi.NGP_F16) > 0

@@ -105,7 +105,7 @@ __device__ void build_forward_image(half8_t* img, const half_t* __restrict__ w, 
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     const uint32_t in_kb = in_dim / 16;
     const uint32_t nfrag = fwd_frag_count<WIDTH>(in_dim, num_layers);
-    for (uint32_t e = threadIdx.x; e < nfrag * 64; e += FF_THREADS) {
+    for (uint32_t e = threadIdx.x; e < nfrag * 64; e += blockDim.x) {
         const uint32_t frag = e >> 6, lane = e & 63;
         const int i = lane & 31, h = lane >> 5;
         half8_t v;
@@ -265,7 +265,7 @@ __device__ void build_backward_image(half8_t* img, const half_t* __restrict__ w,
     const uint32_t nfrag = bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx);
     const half_t* w_hid = w + (size_t)WIDTH * in_dim;
     const half_t* w_out = w_hid + (size_t)(num_layers - 1) * WIDTH * WIDTH;
-    for (uint32_t e = threadIdx.x; e < nfrag * 64; e += FF_THREADS) {
+    for (uint32_t e = threadIdx.x; e < nfrag * 64; e += blockDim.x) {
         const uint32_t frag = e >> 6, lane = e & 63;
         const int i = lane & 31, h = lane >> 5;
         half8_t v;
@@ -639,6 +639,276 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, PAIRED variant (networks with 2 or 3 layers: the instant-ngp ones).
+//
+// What bounds the single-wave kernel above is not memory but its own instruction stream: with every weight-gradient accumulator
+// of the network in one wave's registers (> 256), only one wave fits a SIMD -- nothing to interleave with -- and the compiler puts
+// every MFMA destination into accumulation registers, so each result that VALU code consumes costs 16 register copies (a quarter of
+// the kernel's instructions).  Here two sibling waves share one stream of tiles and SPLIT the accumulators:
+//   role 0 (waves 0..3): dW of the output layer and of the top hidden matmul -- needs the dgrad chain only down to there;
+//   role 1 (waves 4..7): the full dgrad chain, dW of the remaining hidden matmul (3-layer nets) and of the input layer, dL/dx.
+// Each role fits the 256-register budget of two waves per SIMD: MFMA results land in ordinary vector registers (no copies), and the
+// two waves of a SIMD hide each other's MFMA / LDS latencies.  The duplicated part of the dgrad chain is ~10 MFMAs per tile.
+// Role 0 issues the global->LDS DMA of the pair's tile buffers; one workgroup barrier per tile hands the landed tile to role 1 and
+// frees the other buffer for the next prefetch.  The four pairs of a workgroup share the weight image.
+// ------------------------------------------------------------------------------------------------
+constexpr int FP_PAIRS = 4;
+constexpr int FP_THREADS = 2 * FP_PAIRS * 64;
+
+template <int WIDTH, int IN_JB, int NHM /* 1 or 2 */, bool RELU>
+__global__ __launch_bounds__(FP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
+                             const half_t* __restrict__ forward_buffer, uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
+                             bool with_dx, half_t* __restrict__ grad_inputs, float* __restrict__ slabs,
+                             half_t* __restrict__ grad_weights_direct, bool in_planar, bool dx_planar, uint32_t pf_depth) {
+    static_assert(NHM == 1 || NHM == 2, "the paired backward covers 2- and 3-layer networks");
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8_t* img = reinterpret_cast<half8_t*>(smem);
+    const uint32_t nfrag = bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx);
+    build_backward_image<WIDTH>(img, weights, in_dim, num_layers, with_dx);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int pair = wid & (FP_PAIRS - 1), role = wid / FP_PAIRS;
+    const Selectors sel = make_selectors(n, h);
+    __syncthreads();
+
+    const uint32_t in_kb = in_dim / 16;
+    const half8_t* img_out = img + lane;
+    const half8_t* img_hid = img_out + (size_t)NIB * 64;
+    const half8_t* img_in = img_hid + (size_t)(num_layers - 1) * NIB * NKB * 64;
+    const size_t layer_stride = (size_t)n_tiles * NKB * 64;
+    const half8_t* fb = reinterpret_cast<const half8_t*>(forward_buffer);
+    const size_t rows = (size_t)n_tiles * FF_TILE;
+    const uint32_t tile_frags = 1 + num_layers * NKB + in_dim / 16;
+    unsigned char* pf_base = smem + (size_t)nfrag * 1024 + (size_t)pair * pf_depth * tile_frags * 1024;
+    const uint32_t base_step = gridDim.x * FP_PAIRS;
+    uint32_t cur = 0;
+    auto prefetch = [&](uint32_t buffer, uint32_t tile) {
+        prefetch_tile<WIDTH>(pf_base + (size_t)buffer * tile_frags * 1024, tile, grad, fb, inputs, num_layers, layer_stride, rows, in_dim, in_planar,
+                             lane, n, h);
+    };
+    if (role == 0 && blockIdx.x * FP_PAIRS + pair < n_tiles) prefetch(0, blockIdx.x * FP_PAIRS + pair);
+    // per tile round: the landed tile is handed over (barrier), the other buffer is refilled; returns the tile's buffer
+    auto next_tile_buffer = [&](uint32_t base) -> const unsigned char* {
+        if (role == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned char* tb = pf_base + (size_t)cur * tile_frags * 1024;
+        if (pf_depth > 1) {
+            cur ^= 1u;
+            if (role == 0 && base + base_step + pair < n_tiles) prefetch(cur, base + base_step + pair);
+        }
+        return tb;
+    };
+    auto end_of_round = [&](uint32_t base) {  // single buffer: refill only after both roles are done with it
+        if (pf_depth == 1) {
+            __syncthreads();
+            if (role == 0 && base + base_step + pair < n_tiles) prefetch(0, base + base_step + pair);
+        }
+    };
+    float* red = reinterpret_cast<float*>(smem);
+    const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
+    auto flush = [&](const float16_t& a, uint32_t base, uint32_t ld, int ib, int jb, uint32_t rws, uint32_t cols) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t o = (uint32_t)acc_row(ib, h, r), i = 32 * jb + n;
+            if (o < rws && i < cols) red[base + o * ld + i] += a[r];
+        }
+    };
+    auto begin_reduction = [&]() {
+        __syncthreads();  // every wave is done with the weight image and the stages
+        for (uint32_t i = threadIdx.x; i < n_params; i += FP_THREADS) red[i] = 0.0f;
+        __syncthreads();
+    };
+    const uint32_t base_out = WIDTH * in_dim + (num_layers - 1) * WIDTH * WIDTH;
+    const uint32_t base_top = WIDTH * in_dim + (num_layers - 2) * WIDTH * WIDTH;  // hidden matmul into the last hidden layer
+
+    if (role == 0) {
+        // ---- dW_out and dW of the top hidden matmul ----
+        float16_t gw_out[NIB], gw_top[NIB][NIB];
+#pragma unroll
+        for (int jb = 0; jb < NIB; jb++) gw_out[jb] = zero16();
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+            for (int jb = 0; jb < NIB; jb++) gw_top[ib][jb] = zero16();
+        for (uint32_t base = blockIdx.x * FP_PAIRS; base < n_tiles; base += base_step) {
+            const unsigned char* tb = next_tile_buffer(base);
+            if (base + pair < n_tiles) {
+                const half8_t* tfrag = reinterpret_cast<const half8_t*>(tb) + lane;
+                const half8_t dy = tfrag[0];
+                half8_t a_top[NKB], a_below[NKB];
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) a_top[kb] = tfrag[(1 + NHM * NKB + kb) * 64];
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) a_below[kb] = tfrag[(1 + (NHM - 1) * NKB + kb) * 64];
+                half8_t aT[NIB][2], zT[NIB][2];
+                transpose_hidden<WIDTH>(a_top, sel, aT);
+                {
+                    half8_t yT[2];
+                    pack_transposed(mfma(dy, sel.out, zero16()), yT);
+#pragma unroll
+                    for (int g = 0; g < 2; g++)
+#pragma unroll
+                        for (int jb = 0; jb < NIB; jb++) gw_out[jb] = mfma(yT[g], aT[jb][g], gw_out[jb]);
+                }
+                float16_t acc[NIB];
+#pragma unroll
+                for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(img_out[ib * 64], dy, zero16());
+                half8_t dz[NKB];
+                activation_transfer<WIDTH, RELU>(act, acc, a_top, dz);
+                transpose_hidden<WIDTH>(dz, sel, zT);
+                transpose_hidden<WIDTH>(a_below, sel, aT);
+#pragma unroll
+                for (int g = 0; g < 2; g++)
+#pragma unroll
+                    for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+                        for (int jb = 0; jb < NIB; jb++) gw_top[ib][jb] = mfma(zT[ib][g], aT[jb][g], gw_top[ib][jb]);
+            }
+            end_of_round(base);
+        }
+        begin_reduction();
+        for (int turn = 0; turn < 2 * FP_PAIRS; turn++) {
+            if (wid == turn) {
+#pragma unroll
+                for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+                    for (int jb = 0; jb < NIB; jb++) flush(gw_top[ib][jb], base_top, WIDTH, ib, jb, WIDTH, WIDTH);
+#pragma unroll
+                for (int jb = 0; jb < NIB; jb++) flush(gw_out[jb], base_out, WIDTH, 0, jb, 16, WIDTH);
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- the full dgrad chain, dW of the lower hidden matmul (3-layer nets) and of the input layer, dL/dx ----
+        float16_t gw_in[NIB][IN_JB], gw_low[NHM == 2 ? NIB : 1][NHM == 2 ? NIB : 1];
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+            for (int jb = 0; jb < IN_JB; jb++) gw_in[ib][jb] = zero16();
+        if constexpr (NHM == 2) {
+#pragma unroll
+            for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+                for (int jb = 0; jb < NIB; jb++) gw_low[ib][jb] = zero16();
+        }
+        for (uint32_t base = blockIdx.x * FP_PAIRS; base < n_tiles; base += base_step) {
+            const unsigned char* tb = next_tile_buffer(base);
+            const uint32_t tile = base + pair;
+            if (tile < n_tiles) {
+                const half8_t* tfrag = reinterpret_cast<const half8_t*>(tb) + lane;
+                const half8_t dy = tfrag[0];
+                half8_t a_prev[NKB];
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) a_prev[kb] = tfrag[(1 + NHM * NKB + kb) * 64];
+                float16_t acc[NIB];
+#pragma unroll
+                for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(img_out[ib * 64], dy, zero16());
+                half8_t dz[NKB];
+                half8_t aT[NIB][2], zT[NIB][2];
+                // top hidden matmul: dgrad only (its dW belongs to role 0)
+                activation_transfer<WIDTH, RELU>(act, acc, a_prev, dz);
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) a_prev[kb] = tfrag[(1 + (NHM - 1) * NKB + kb) * 64];
+#pragma unroll
+                for (int ib = 0; ib < NIB; ib++) {
+                    acc[ib] = zero16();
+#pragma unroll
+                    for (int kb = 0; kb < NKB; kb++) acc[ib] = mfma(img_hid[(ib * NKB + kb) * 64], dz[kb], acc[ib]);
+                }
+                if constexpr (NHM == 2) {  // lower hidden matmul: dW and dgrad
+                    activation_transfer<WIDTH, RELU>(act, acc, a_prev, dz);
+#pragma unroll
+                    for (int kb = 0; kb < NKB; kb++) a_prev[kb] = tfrag[(1 + kb) * 64];
+                    transpose_hidden<WIDTH>(dz, sel, zT);
+                    transpose_hidden<WIDTH>(a_prev, sel, aT);
+#pragma unroll
+                    for (int g = 0; g < 2; g++)
+#pragma unroll
+                        for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+                            for (int jb = 0; jb < NIB; jb++) gw_low[ib][jb] = mfma(zT[ib][g], aT[jb][g], gw_low[ib][jb]);
+                    const half8_t* wl = img_hid + (size_t)NIB * NKB * 64;
+#pragma unroll
+                    for (int ib = 0; ib < NIB; ib++) {
+                        acc[ib] = zero16();
+#pragma unroll
+                        for (int kb = 0; kb < NKB; kb++) acc[ib] = mfma(wl[(ib * NKB + kb) * 64], dz[kb], acc[ib]);
+                    }
+                }
+                // input layer
+                activation_transfer<WIDTH, RELU>(act, acc, a_prev, dz);
+                transpose_hidden<WIDTH>(dz, sel, zT);
+#pragma unroll
+                for (int jb = 0; jb < IN_JB; jb++) {
+                    float16_t t = zero16();
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const uint32_t kb = 2 * jb + e;
+                        if (kb < in_kb) t = mfma(tile_x(tb + (size_t)(1 + num_layers * NKB) * 1024, kb, in_planar, lane), sel.nat[e], t);
+                    }
+                    half8_t xT[2];
+                    pack_transposed(t, xT);
+#pragma unroll
+                    for (int g = 0; g < 2; g++)
+#pragma unroll
+                        for (int ib = 0; ib < NIB; ib++) gw_in[ib][jb] = mfma(zT[ib][g], xT[g], gw_in[ib][jb]);
+                }
+                if (with_dx) {
+#pragma unroll
+                    for (int ib = 0; ib < IN_JB; ib++) {
+                        float16_t dx = zero16();
+#pragma unroll
+                        for (int kb = 0; kb < NKB; kb++) dx = mfma(img_in[(ib * NKB + kb) * 64], dz[kb], dx);
+                        const size_t srow = (size_t)tile * FF_TILE + n;
+                        half_t* grow = grad_inputs + srow * in_dim;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t f0 = 32 * ib + 8 * q + 4 * h;
+                            if (f0 < in_dim) {
+                                if (dx_planar) {
+                                    const half2_t lo = {(half_t)dx[4 * q], (half_t)dx[4 * q + 1]}, hi = {(half_t)dx[4 * q + 2], (half_t)dx[4 * q + 3]};
+                                    *reinterpret_cast<half2_t*>(grad_inputs + ((size_t)(f0 / 2) * rows + srow) * 2) = lo;
+                                    *reinterpret_cast<half2_t*>(grad_inputs + ((size_t)(f0 / 2 + 1) * rows + srow) * 2) = hi;
+                                } else {
+                                    half4_t v = {(half_t)dx[4 * q], (half_t)dx[4 * q + 1], (half_t)dx[4 * q + 2], (half_t)dx[4 * q + 3]};
+                                    *reinterpret_cast<half4_t*>(grow + f0) = v;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            end_of_round(base);
+        }
+        begin_reduction();
+        for (int turn = 0; turn < 2 * FP_PAIRS; turn++) {
+            if (wid == turn) {
+#pragma unroll
+                for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+                    for (int jb = 0; jb < IN_JB; jb++) flush(gw_in[ib][jb], 0, in_dim, ib, jb, WIDTH, in_dim);
+                if constexpr (NHM == 2) {
+                    const uint32_t base_low = WIDTH * in_dim;  // hidden matmul into hidden layer 1
+#pragma unroll
+                    for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+                        for (int jb = 0; jb < NIB; jb++) flush(gw_low[ib][jb], base_low, WIDTH, ib, jb, WIDTH, WIDTH);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (grad_weights_direct) {
+        for (uint32_t i = threadIdx.x; i < n_params; i += FP_THREADS) grad_weights_direct[i] = (half_t)red[i];
+    } else {
+        float* slab = slabs + (size_t)blockIdx.x * n_params;
+        for (uint32_t i = threadIdx.x; i < n_params; i += FP_THREADS) slab[i] = red[i];
+    }
+}
+
 // sum the per-workgroup slabs in a fixed order and round once to fp16.
 // One workgroup = 64 consecutive parameters x 16 slab groups: thread (g, i) adds slabs g, g+16, g+32, ... of parameter i
 // (coalesced 256-byte rows), the 16 partial sums are combined in LDS in ascending g -- a fixed summation tree, so the
@@ -734,11 +1004,6 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
     size_t lds = (size_t)nfrag * 1024 + (size_t)pf_depth * FF_WAVES * tile_bytes;
     if (lds < (size_t)n_params * 4) lds = (size_t)n_params * 4;
     NGP_REQUIRE(lds <= 160 * 1024, NGP_ERR_INVALID, "ffmlp_backward: LDS need (%zu B) exceeds 160 KiB", lds);
-    auto kern = k_ffmlp_backward<WIDTH, IN_JB, NHM, RELU>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp_backward: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-    }
     // one fp32 slab per workgroup lives in the caller's backward_buffer ([num_layers, B, hidden] fp16)
     const size_t buf_bytes = (size_t)num_layers * B * WIDTH * sizeof(half_t);
     uint32_t blocks = (uint32_t)device_info().cus;
@@ -746,6 +1011,32 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
     if (blocks > need) blocks = need;
     const size_t fit = buf_bytes / ((size_t)n_params * 4);
     if (blocks > fit) blocks = (uint32_t)fit;
+    if constexpr (NHM == 1 || NHM == 2) {
+        // 2- and 3-layer networks: two sibling waves per tile stream split the weight-gradient accumulators (see the kernel)
+        static const bool single = getenv("NGP_FF_BWD_SINGLE") != nullptr;
+        if (!single && diag == 0u) {
+            auto pk = k_ffmlp_backward_paired<WIDTH, IN_JB, NHM, RELU>;
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp_backward: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+            }
+            const bool direct = blocks <= 1;
+            hipLaunchKernelGGL(pk, dim3(direct ? 1 : blocks), dim3(FP_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs,
+                               (const half_t*)weights, (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs,
+                               direct ? (float*)nullptr : (float*)backward_buffer, direct ? (half_t*)grad_weights : (half_t*)nullptr, in_planar,
+                               dx_planar, pf_depth);
+            int rc = check_launch("ffmlp_backward");
+            if (rc || direct) return rc;
+            hipLaunchKernelGGL(k_ffmlp_reduce_slabs, dim3(cdiv(n_params, RS_PARAMS)), dim3(RS_PARAMS * RS_GROUPS), 0, st,
+                               (const float*)backward_buffer, blocks, n_params, (half_t*)grad_weights);
+            return check_launch("ffmlp_backward(reduce)");
+        }
+    }
+    auto kern = k_ffmlp_backward<WIDTH, IN_JB, NHM, RELU>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp_backward: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }
     if (blocks <= 1) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
                            (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)nullptr,

@@ -100,43 +100,67 @@ __device__ __forceinline__ uint32_t fwd_frag_count(uint32_t in_dim, uint32_t num
 }
 
 // Fill the forward image.  weights: flat fp16 as in ffmlp.cu:631-634.
+// Every workgroup pays for this before its first tile, so the loop is organised around memory latency: the sources of IMG_BATCH
+// fragments per thread are worked out first, ALL their loads are issued (unconditionally, at clamped addresses), and only then is
+// anything stored -- one round trip to L2 per batch instead of one per fragment (measured: ~12 us of fixed cost per launch before).
+constexpr int IMG_BATCH = 8;
+
+// where the two 8-byte halves of fragment element e come from (nullptr: zeros)
 template <int WIDTH>
-__device__ void build_forward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers) {
+__device__ __forceinline__ void forward_fragment_source(uint32_t e, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers,
+                                                        const half_t*& lo, const half_t*& hi) {
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     const uint32_t in_kb = in_dim / 16;
-    const uint32_t nfrag = fwd_frag_count<WIDTH>(in_dim, num_layers);
-    for (uint32_t e = threadIdx.x; e < nfrag * 64; e += blockDim.x) {
-        const uint32_t frag = e >> 6, lane = e & 63;
-        const int i = lane & 31, h = lane >> 5;
-        half8_t v;
-        uint32_t f = frag;
-        if (f < NIB * in_kb) {  // input layer: natural k order, slot (kb,h,j) = input feature 16kb + 8h + j
-            const uint32_t ib = f / in_kb, kb = f % in_kb;
-            v = *reinterpret_cast<const half8_t*>(w + (size_t)(32 * ib + i) * in_dim + 16 * kb + 8 * h);
-        } else {
-            f -= NIB * in_kb;
-            const half_t* base = w + (size_t)WIDTH * in_dim;
-            if (f < (num_layers - 1) * NIB * NKB) {  // hidden layer
-                const uint32_t l = f / (NIB * NKB), rem = f % (NIB * NKB);
-                const uint32_t ib = rem / NKB, kb = rem % NKB;
-                const half_t* row = base + (size_t)l * WIDTH * WIDTH + (size_t)(32 * ib + i) * WIDTH;
-                const half4_t lo = *reinterpret_cast<const half4_t*>(row + 16 * kb + 4 * h);
-                const half4_t hi = *reinterpret_cast<const half4_t*>(row + 16 * kb + 8 + 4 * h);
-                v = half8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-            } else {  // output layer: 16 real rows, rows 16..31 of the block are zero
-                const uint32_t kb = f - (num_layers - 1) * NIB * NKB;
-                const half_t* row = base + (size_t)(num_layers - 1) * WIDTH * WIDTH + (size_t)i * WIDTH;
-                if (i < 16) {
-                    const half4_t lo = *reinterpret_cast<const half4_t*>(row + 16 * kb + 4 * h);
-                    const half4_t hi = *reinterpret_cast<const half4_t*>(row + 16 * kb + 8 + 4 * h);
-                    v = half8_t{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                } else {
+    const uint32_t frag = e >> 6, lane = e & 63;
+    const int i = lane & 31, h = lane >> 5;
+    uint32_t f = frag;
+    if (f < NIB * in_kb) {  // input layer: natural k order, slot (kb,h,j) = input feature 16kb + 8h + j
+        const uint32_t ib = f / in_kb, kb = f % in_kb;
+        lo = w + (size_t)(32 * ib + i) * in_dim + 16 * kb + 8 * h;
+        hi = lo + 4;
+        return;
+    }
+    f -= NIB * in_kb;
+    const half_t* base = w + (size_t)WIDTH * in_dim;
+    if (f < (num_layers - 1) * NIB * NKB) {  // hidden layer
+        const uint32_t l = f / (NIB * NKB), rem = f % (NIB * NKB);
+        const uint32_t ib = rem / NKB, kb = rem % NKB;
+        const half_t* row = base + (size_t)l * WIDTH * WIDTH + (size_t)(32 * ib + i) * WIDTH;
+        lo = row + 16 * kb + 4 * h;
+        hi = lo + 8;
+        return;
+    }
+    // output layer: 16 real rows, rows 16..31 of the block are zero
+    const uint32_t kb = f - (num_layers - 1) * NIB * NKB;
+    const half_t* row = base + (size_t)(num_layers - 1) * WIDTH * WIDTH + (size_t)i * WIDTH;
+    lo = i < 16 ? row + 16 * kb + 4 * h : nullptr;
+    hi = i < 16 ? lo + 8 : nullptr;
+}
+
+template <int WIDTH>
+__device__ void build_forward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers) {
+    const uint32_t total = fwd_frag_count<WIDTH>(in_dim, num_layers) * 64;
+    for (uint32_t e0 = threadIdx.x; e0 < total; e0 += IMG_BATCH * blockDim.x) {
+        half4_t lo[IMG_BATCH], hi[IMG_BATCH];
+        bool real[IMG_BATCH];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = (half_t)0.0f;
-                }
+        for (int b = 0; b < IMG_BATCH; b++) {
+            const uint32_t e = e0 + b * blockDim.x;
+            const half_t *pl = nullptr, *ph = nullptr;
+            if (e < total) forward_fragment_source<WIDTH>(e, w, in_dim, num_layers, pl, ph);
+            real[b] = pl != nullptr;
+            lo[b] = *reinterpret_cast<const half4_t*>(pl ? pl : w);
+            hi[b] = *reinterpret_cast<const half4_t*>(ph ? ph : w);
+        }
+#pragma unroll
+        for (int b = 0; b < IMG_BATCH; b++) {
+            const uint32_t e = e0 + b * blockDim.x;
+            if (e < total) {
+                const half4_t z = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+                const half4_t l4 = real[b] ? lo[b] : z, h4 = real[b] ? hi[b] : z;
+                img[e] = half8_t{l4.x, l4.y, l4.z, l4.w, h4.x, h4.y, h4.z, h4.w};
             }
         }
-        img[e] = v;
     }
 }
 
@@ -171,11 +195,12 @@ __device__ __forceinline__ half8_t load_features8(const half_t* __restrict__ inp
 // ------------------------------------------------------------------------------------------------
 // forward / inference
 // ------------------------------------------------------------------------------------------------
-template <int WIDTH, bool TRAIN>
-__global__ __launch_bounds__(FF_THREADS) void k_ffmlp_forward(const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
+template <int WIDTH, bool TRAIN, bool PLAIN /* ReLU hidden layers, no output activation: the only case FFMLP produces (ffmlp.py:107) */>
+__global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ffmlp_forward(const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
                                                               half_t* __restrict__ forward_buffer, half_t* __restrict__ outputs,
                                                               uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
-                                                              uint32_t out_act, bool in_planar) {
+                                                              uint32_t out_act, bool in_planar, uint32_t diag) {
+    // (diag: timing experiments of tools/bench_kernels.py -- bit 0: no activation/output stores, bit 1: no input loads)
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img = reinterpret_cast<half8_t*>(smem);
@@ -197,14 +222,14 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_forward(const half_t* __re
 #pragma unroll
         for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
         for (uint32_t kb = 0; kb < in_kb; kb++) {
-            const half8_t x = load_features8(inputs, in_planar, rows, srow, in_dim, 16 * kb + 8 * h);
+            const half8_t x = (diag & 2u) ? img_l0[kb * 64] : load_features8(inputs, in_planar, rows, srow, in_dim, 16 * kb + 8 * h);
 #pragma unroll
             for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(img_l0[(ib * in_kb + kb) * 64], x, acc[ib]);
         }
         half8_t hid[NKB];
         for (uint32_t l = 0;; l++) {
             // activation of hidden layer l (fp32), then round to fp16 operand fragments
-            if (act == ACT_RELU) {
+            if (PLAIN || act == ACT_RELU) {
 #pragma unroll
                 for (int ib = 0; ib < NIB; ib++)
 #pragma unroll
@@ -216,7 +241,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_forward(const half_t* __re
                     for (int r = 0; r < 16; r++) acc[ib][r] = act_forward(act, acc[ib][r]);
             }
             pack_hidden<WIDTH>(acc, hid);
-            if (TRAIN) {
+            if (TRAIN && !(diag & 1u)) {
                 half8_t* dst = reinterpret_cast<half8_t*>(forward_buffer) + l * layer_stride + (size_t)tile * NKB * 64 + lane;
 #pragma unroll
                 for (int kb = 0; kb < NKB; kb++) dst[kb * 64] = hid[kb];
@@ -237,12 +262,14 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_forward(const half_t* __re
         half4_t lo, hi;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            lo[c] = (half_t)act_forward(out_act, o[c]);      // out features 4h + c
-            hi[c] = (half_t)act_forward(out_act, o[4 + c]);  // out features 8 + 4h + c
+            lo[c] = (half_t)(PLAIN ? o[c] : act_forward(out_act, o[c]));          // out features 4h + c
+            hi[c] = (half_t)(PLAIN ? o[4 + c] : act_forward(out_act, o[4 + c]));  // out features 8 + 4h + c
         }
         half_t* orow = outputs + ((size_t)tile * FF_TILE + n) * 16 + 4 * h;
-        *reinterpret_cast<half4_t*>(orow) = lo;
-        *reinterpret_cast<half4_t*>(orow + 8) = hi;
+        if (!(diag & 1u) || tile == 0) {
+            *reinterpret_cast<half4_t*>(orow) = lo;
+            *reinterpret_cast<half4_t*>(orow + 8) = hi;
+        }
     }
 }
 
@@ -259,36 +286,71 @@ __device__ __forceinline__ uint32_t bwd_frag_count(uint32_t in_dim, uint32_t num
     return NIB + (num_layers - 1) * NIB * NKB + (with_dx ? ((in_dim + 31) / 32) * NKB : 0);
 }
 
+// element j of fragment element e is read from src + row_of(j) * stride (rows 0..3 then 8..11 in slot order, 0..7 for the output
+// block); src == nullptr: zeros
 template <int WIDTH>
-__device__ void build_backward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers, bool with_dx) {
+__device__ __forceinline__ void backward_fragment_source(uint32_t e, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers,
+                                                         const half_t*& src, uint32_t& stride, bool& slot_order) {
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
-    const uint32_t nfrag = bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx);
     const half_t* w_hid = w + (size_t)WIDTH * in_dim;
     const half_t* w_out = w_hid + (size_t)(num_layers - 1) * WIDTH * WIDTH;
-    for (uint32_t e = threadIdx.x; e < nfrag * 64; e += blockDim.x) {
-        const uint32_t frag = e >> 6, lane = e & 63;
-        const int i = lane & 31, h = lane >> 5;
-        half8_t v;
-        uint32_t f = frag;
-        if (f < NIB) {
-            const int feat = 32 * f + i;
+    const uint32_t frag = e >> 6, lane = e & 63;
+    const int i = lane & 31, h = lane >> 5;
+    uint32_t f = frag;
+    if (f < NIB) {  // W_out^T: rows 8h + j
+        src = w_out + (size_t)(8 * h) * WIDTH + (32 * f + i);
+        stride = WIDTH;
+        slot_order = false;
+    } else if ((f -= NIB) < (num_layers - 1) * NIB * NKB) {
+        const uint32_t li = f / (NIB * NKB), rem = f % (NIB * NKB);  // li = 0 -> layer NL-1
+        const uint32_t ib = rem / NKB, kb = rem % NKB;
+        const half_t* wl = w_hid + (size_t)(num_layers - 2 - li) * WIDTH * WIDTH;
+        src = wl + (size_t)slot_feature(kb, h, 0) * WIDTH + (32 * ib + i);
+        stride = WIDTH;
+        slot_order = true;
+    } else {
+        f -= (num_layers - 1) * NIB * NKB;
+        const uint32_t ib = f / NKB, kb = f % NKB;
+        const uint32_t col = 32 * ib + i;
+        src = col < in_dim ? w + (size_t)slot_feature(kb, h, 0) * in_dim + col : nullptr;
+        stride = in_dim;
+        slot_order = true;
+    }
+}
+
+template <int WIDTH>
+__device__ void build_backward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers, bool with_dx) {
+    constexpr int BATCH = 3;  // x 8 two-byte gathers per fragment element, all in flight before the first store
+    const uint32_t total = bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx) * 64;
+    for (uint32_t e0 = threadIdx.x; e0 < total; e0 += BATCH * blockDim.x) {
+        half_t v[BATCH][8];
+        bool real[BATCH];
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = w_out[(size_t)(8 * h + j) * WIDTH + feat];
-        } else if ((f -= NIB) < (num_layers - 1) * NIB * NKB) {
-            const uint32_t li = f / (NIB * NKB), rem = f % (NIB * NKB);  // li = 0 -> layer NL-1
-            const uint32_t ib = rem / NKB, kb = rem % NKB;
-            const half_t* wl = w_hid + (size_t)(num_layers - 2 - li) * WIDTH * WIDTH;
-            const int col = 32 * ib + i;
+        for (int b = 0; b < BATCH; b++) {
+            const uint32_t e = e0 + b * blockDim.x;
+            const half_t* src = nullptr;
+            uint32_t stride = 0;
+            bool slot_order = false;
+            if (e < total) backward_fragment_source<WIDTH>(e, w, in_dim, num_layers, src, stride, slot_order);
+            real[b] = src != nullptr;
+            const half_t* p = src ? src : w;
+            const uint32_t st = src ? stride : 0u;
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = wl[(size_t)slot_feature(kb, h, j) * WIDTH + col];
-        } else {
-            f -= (num_layers - 1) * NIB * NKB;
-            const uint32_t ib = f / NKB, kb = f % NKB;
-            const uint32_t col = 32 * ib + i;
-#pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = col < in_dim ? w[(size_t)slot_feature(kb, h, j) * in_dim + col] : (half_t)0.0f;
+            for (int j = 0; j < 8; j++) {
+                const uint32_t row = slot_order ? (uint32_t)((j & 3) + 8 * (j >> 2)) : (uint32_t)j;  // slot_feature(kb,h,j) - slot_feature(kb,h,0)
+                v[b][j] = p[(size_t)row * st];
+            }
         }
-        img[e] = v;
+#pragma unroll
+        for (int b = 0; b < BATCH; b++) {
+            const uint32_t e = e0 + b * blockDim.x;
+            if (e < total) {
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = real[b] ? v[b][j] : (half_t)0.0f;
+                img[e] = o;
+            }
+        }
     }
 }
 
@@ -973,17 +1035,21 @@ static int launch_forward(const void* inputs, const void* weights, uint32_t B, u
     const uint32_t nfrag = NIB * (in_dim / 16) + (num_layers - 1) * NIB * NKB + NKB;
     const size_t lds = (size_t)nfrag * 1024;
     NGP_REQUIRE(lds <= 160 * 1024, NGP_ERR_INVALID, "ffmlp: weights (%zu B) exceed the 160 KiB LDS of a CU", lds);
-    auto kern = k_ffmlp_forward<WIDTH, TRAIN>;
+    // the specialisation without the other activations' code is a fifth of the size (instruction fetch at kernel start matters for a
+    // 25 us kernel)
+    const bool plain = act == ACT_RELU && out_act == ACT_NONE;
+    auto kern = plain ? k_ffmlp_forward<WIDTH, TRAIN, true> : k_ffmlp_forward<WIDTH, TRAIN, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
     }
+    static const uint32_t diag = getenv("NGP_FF_FWD_DIAG") ? (uint32_t)atoi(getenv("NGP_FF_FWD_DIAG")) : 0u;
     const uint32_t per_cu = (uint32_t)((160 * 1024) / (lds + 1024));
     uint32_t blocks = (uint32_t)device_info().cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     const uint32_t need = cdiv(n_tiles, FF_WAVES);
     if (blocks > need) blocks = need;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)inputs, (const half_t*)weights, (half_t*)fwd,
-                       (half_t*)outputs, n_tiles, in_dim, num_layers, act, out_act, (flags & NGP_FF_INPUT_PLANAR) != 0);
+                       (half_t*)outputs, n_tiles, in_dim, num_layers, act, out_act, (flags & NGP_FF_INPUT_PLANAR) != 0, diag);
     return check_launch(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
 }
 

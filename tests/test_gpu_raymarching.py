@@ -124,6 +124,50 @@ def test_march_rays_train_bit_exact(bound, cascade, dt_gamma, perturb, N):
     assert not xyzs[total:total + 4096].any()
 
 
+def test_march_rays_train_seeded_noise_matches_explicit_noise():
+    """NGP_MARCH_NOISE_FROM_SEED: the per-ray start offsets drawn in-kernel from (ray index, a device word) give exactly the samples
+    of the explicit-noise call fed with the same draws (restated here in numpy), lie in [0, 1), and change with the seed."""
+    import _ngp_capi as capi
+    N, bound = 2048, 1.0
+    bits = _scene(1.0, 1)
+    o, d = _random_rays(N, 9, radius=3.2, spread=0.6)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+
+    def draws(seed):
+        n = np.arange(N, dtype=np.uint64)
+        x = ((n * 0x9E3779B9) & 0xFFFFFFFF) ^ ((seed * 0x85EBCA6B + 0x27D4EB2F) & 0xFFFFFFFF)
+        x ^= x >> 16; x = (x * 0x7FEB352D) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846CA68B) & 0xFFFFFFFF; x ^= x >> 16
+        return ((x >> 8).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+
+    totals = []
+    for seed in (np.float32(7.0).view(np.uint32).item(), 123456789):
+        noises = draws(seed)
+        assert noises.min() >= 0.0 and noises.max() < 1.0 and 0.4 < noises.mean() < 0.6
+        ref = oracle.march_rays_train(o, d, bound, bits, 1, 128, nears, fars, noises, dt_gamma=0.0)
+        total = int(ref[4][0])
+        M = total + 512
+        xyzs = torch.empty(M, 3, device='cuda'); dirs = torch.empty(M, 3, device='cuda'); deltas = torch.empty(M, 2, device='cuda')
+        rays = torch.empty(N, 3, dtype=torch.int32, device='cuda'); counter = torch.full((2,), 99, dtype=torch.int32, device='cuda')
+        seed_t = torch.tensor([seed], dtype=torch.int64, device='cuda').to(torch.int32) if seed < 2 ** 31 else None
+        if seed_t is None:
+            seed_t = torch.from_numpy(np.array([seed], np.uint32).view(np.int32)).cuda()
+        ws = torch.empty(capi.lib.ngp_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device='cuda')
+        flags = capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL | capi.NGP_MARCH_NOISE_FROM_SEED
+        to, td, tb, tn, tf = cu(o), cu(d), cu(bits), cu(nears), cu(fars)  # (kept alive: only raw pointers cross the C ABI)
+        capi.check(capi.lib.ngp_march_rays_train_ex(to.data_ptr(), td.data_ptr(), tb.data_ptr(), bound, 0.0, 1024, N, 1, 128, M,
+                                                    tn.data_ptr(), tf.data_ptr(), xyzs.data_ptr(), dirs.data_ptr(),
+                                                    deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(), seed_t.data_ptr(), ws.data_ptr(),
+                                                    flags, capi.stream()))
+        torch.cuda.synchronize()
+        assert counter.cpu().numpy().tolist() == ref[4].tolist()
+        assert np.array_equal(rays.cpu().numpy(), ref[3])
+        assert np.array_equal(xyzs[:total].cpu().numpy(), ref[0][:total])
+        assert np.array_equal(deltas[:total].cpu().numpy(), ref[2][:total])
+        totals.append(total)
+    assert not np.array_equal(draws(1), draws(2))
+
+
 def test_march_rays_train_wrapper_semantics():
     bits = _scene(1.0, 1)
     o, d = _random_rays(4096, 6)

@@ -300,6 +300,15 @@ __device__ __forceinline__ void window_terms(const MarchParams& p, float t_base,
     t_next_base = t + (CONST_DT ? dt_const : step_dt(p, t));
 }
 
+// NGP_MARCH_NOISE_FROM_SEED: the per-ray start offset in [0, 1) without a noise tensor -- a counter-based draw from (ray index, seed),
+// the seed read from device memory (any word that changes from step to step, e.g. the optimizer's step count), so that a captured
+// graph needs neither torch's generator bookkeeping (two fill launches per replay) nor a separate rand kernel.
+__device__ __forceinline__ float seeded_noise(uint32_t n, uint32_t seed) {
+    uint32_t x = (n * 0x9E3779B9u) ^ (seed * 0x85EBCA6Bu + 0x27D4EB2Fu);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return (float)(x >> 8) * 0x1p-24f;
+}
+
 template <bool WRITE, bool CONST_DT>
 __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                                     const uint8_t* __restrict__ grid, float bound, float dt_gamma,
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
                                                                     float* __restrict__ xyzs, float* __restrict__ dirs,
                                                                     float* __restrict__ deltas, int32_t* __restrict__ rays,
                                                                     const float* __restrict__ noises, uint32_t* __restrict__ n_windows,
-                                                                    uint64_t* __restrict__ masks) {
+                                                                    uint64_t* __restrict__ masks, bool noise_from_seed) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n = blockIdx.x * MW_WAVES + wid;  // wave-uniform
@@ -326,7 +335,8 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
         if (limit == 0 || offset + limit > M) return;  // raymarching.cu:405-416: recorded, nothing written
     }
     uint32_t num_steps = 0;
-    float t_base = __builtin_fmaf(step_dt(p, near), noises[n], near);
+    const float noise = noise_from_seed ? seeded_noise(n, reinterpret_cast<const uint32_t*>(noises)[0]) : noises[n];
+    float t_base = __builtin_fmaf(step_dt(p, near), noise, near);
     float last_t = t_base;
     uint32_t window = 0;
 
@@ -897,7 +907,7 @@ extern "C" int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d,
     const bool const_dt = dt_gamma == 0.0f;
 #define MARCH_WAVE(WRITE, CDT)                                                                                                     \
     hipLaunchKernelGGL((k_march_train_wave<WRITE, CDT>), grid, block, 0, st, rays_o, rays_d, grid_bits, bound, dt_gamma, max_steps, N, C, H, \
-                       M, nears, fars, xyzs, dirs, deltas, rays, noises, ws_windows, ws_masks)
+                       M, nears, fars, xyzs, dirs, deltas, rays, noises, ws_windows, ws_masks, (flags & NGP_MARCH_NOISE_FROM_SEED) != 0)
     const uint8_t* grid_bits = grid_in;
     uint32_t* ws_windows = ws + 2;                                                               // [N]
     uint64_t* ws_masks = reinterpret_cast<uint64_t*>(ws + 2 + ((N + 1u) & ~1u));                 // [N][MARCH_MASK_WINDOWS], 8-byte aligned

@@ -174,7 +174,7 @@ def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
 # 14 launches forward, 11 backward; same arithmetic and rounding points as the module-by-module path (tests/test_gpu_pipeline.py).
 # Only used when the sample buffer is sized from the running `mean_count` estimate (no host read-back).
 # ------------------------------------------------------------------------------------------------------------------
-def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfield, aabb, counter, cfg, rcfg):
+def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfield, aabb, counter, cfg, rcfg, noise_seed=None):
     """-> (image, depth, weights_sum, saved): the forward launches of the fused training render on the current stream"""
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
     (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
@@ -192,12 +192,17 @@ def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfie
     dirs = torch.empty(M, 3, **f32)
     deltas = torch.empty(M, 2, **f32)
     rays = torch.empty(N, 3, device=dev, dtype=torch.int32)
-    noises = torch.rand(N, **f32) if perturb else torch.zeros(N, **f32)
+    march_flags = capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL
+    if perturb and noise_seed is not None:
+        # start offsets drawn in-kernel from (ray index, *noise_seed): no rand launch, no generator bookkeeping in a captured graph
+        noises, march_flags = noise_seed, march_flags | capi.NGP_MARCH_NOISE_FROM_SEED
+    else:
+        noises = torch.rand(N, **f32) if perturb else torch.zeros(N, **f32)
     ws = torch.empty(capi.lib.ngp_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device=dev)
     _check(capi.lib.ngp_march_rays_train_ex(rays_o.data_ptr(), rays_d.data_ptr(), bitfield.data_ptr(), float(bound), float(dt_gamma),
                                             max_steps, N, cascade, grid_size, M, nears.data_ptr(), fars.data_ptr(), xyzs.data_ptr(),
                                             dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(), noises.data_ptr(),
-                                            ws.data_ptr(), capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL, st))
+                                            ws.data_ptr(), march_flags, st))
     # ---- network ----
     enc = torch.empty(L, M, 2, **half)
     _check(capi.lib.ngp_grid_encode_forward_ex(xyzs.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
@@ -313,12 +318,14 @@ def _render_cfg(model, capacity, bg_color, perturb, dt_gamma, max_steps, T_thres
 
 @torch.no_grad()
 def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity, loss_scale, bg_color=1, perturb=False, dt_gamma=0,
-                          max_steps=1024, T_thresh=1e-4):
+                          max_steps=1024, T_thresh=1e-4, noise_seed=None):
     """One training iteration's forward + MSE loss + backward WITHOUT autograd: the launches of `_fused_render_train` forward, the
     Trainer's loss (nerf/utils.py:516,557) and its scaled gradient in one kernel, then the backward launches, depositing the gradients
     into the optimizer's fp16 buffers (optim.NGPAdam with deposit=True must manage the three parameter tensors).  28 launches instead
     of 45: autograd's bookkeeping kernels (ones/zeros fills, the loss-scale multiplies, the mse forward/backward/mean kernels) vanish.
-    rays_o/rays_d [N,3] fp32, target [N,3] fp32, loss_scale: device scalar (NGPAdam.scalars[0:1]) or None.
+    rays_o/rays_d [N,3] fp32, target [N,3] fp32, loss_scale: device scalar (NGPAdam.scalars[0:1]) or None.  noise_seed: optional
+    4-byte device word that changes from step to step (NGPAdam's step count); with perturb=True the marcher then draws the per-ray start
+    offsets itself (NGP_MARCH_NOISE_FROM_SEED) instead of reading a torch.rand tensor.
     -> (loss [1] fp32, image [N,3], depth [N], weights_sum [N]); same arithmetic as model.render + mse_loss + scaled backward
     (tests/test_gpu_graph.py)."""
     cfg = network_cfg(model.encoder, model.sigma_net, model.color_net, model.bound, True)
@@ -332,7 +339,7 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     if target.shape[0] != rays_o.shape[0] or target.dtype != torch.float32:
         raise RuntimeError('fused_train_iteration: target must be [N,3] float32')
     image, depth, weights_sum, saved = _render_train_forward(rays_o, rays_d, bufs[0], bufs[1], bufs[2], bg_t, model.encoder.offsets,
-                                                             model.density_bitfield, box, counter, cfg, rcfg)
+                                                             model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
     loss = torch.empty(1, device=rays_o.device, dtype=torch.float32)
     grad_image = torch.empty_like(image)
     _check(capi.lib.ngp_pipeline_mse_loss(image.data_ptr(), target.data_ptr(), image.numel(), capi.ptr(loss_scale), loss.data_ptr(),

@@ -90,7 +90,7 @@ class GraphedTrainStep:
             loss, _, _, _ = fused_train_iteration(m, self.rays_o, self.rays_d, self.target, m.aabb_train, self.counter[0],
                                                   self.captured_capacity, self.optimizer.scalars[0:1], 1 if bg is None else bg,
                                                   kw.get('perturb', False), kw.get('dt_gamma', 0), kw.get('max_steps', 1024),
-                                                  kw.get('T_thresh', 1e-4))
+                                                  kw.get('T_thresh', 1e-4), noise_seed=self.optimizer.scalars[3:4])
             self.used_direct = True
             return loss[0]
         self.used_direct = False

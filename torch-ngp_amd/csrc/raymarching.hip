@@ -182,10 +182,13 @@ __device__ __forceinline__ ProbeGeom probe_geom(const MarchParams& p, const Ray&
     g.y = clampf(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
     g.z = clampf(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
     g.dt = step_dt(p, t);
-    const float mx = fmaxf(fabsf(g.x), fmaxf(fabsf(g.y), fabsf(g.z)));
-    const int lp = mip_exponent(mx, p.Cm1);
-    const int ld = mip_exponent((g.dt * p.Hf) * 0.5f, p.Cm1);
-    const int level = lp > ld ? lp : ld;
+    int level = 0;  // a single cascade: both mip exponents clamp to 0 (min(C - 1, .) in raymarching.cu:367-369), skip the frexp work
+    if (p.Cm1 > 0.0f) {
+        const float mx = fmaxf(fabsf(g.x), fmaxf(fabsf(g.y), fabsf(g.z)));
+        const int lp = mip_exponent(mx, p.Cm1);
+        const int ld = mip_exponent((g.dt * p.Hf) * 0.5f, p.Cm1);
+        level = lp > ld ? lp : ld;
+    }
     g.mip_bound = fminf(scalbnf(1.0f, level), p.bound);
     const float mip_rbound = 1.0f / g.mip_bound;
     g.nx = (int)clampf((0.5f * __builtin_fmaf(g.x, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
@@ -275,7 +278,7 @@ __device__ __forceinline__ float readlane_f(float v, uint32_t l) {
 // the recurrence is evaluated as written.
 template <bool CONST_DT>
 __device__ __forceinline__ void window_terms(const MarchParams& p, float t_base, float dt_const, uint32_t lane, float& mine,
-                                             float& t_next_base) {
+                                             float& t_next_base, float& inc_out, bool& closed_out) {
     if (CONST_DT) {
         const float t1 = t_base + dt_const;
         const float inc = t1 - t_base;                    // exact (Sterbenz)
@@ -287,9 +290,13 @@ __device__ __forceinline__ void window_terms(const MarchParams& p, float t_base,
         if (__builtin_amdgcn_readfirstlane((int)closed)) {  // wave-uniform by construction
             mine = __builtin_fmaf((float)lane, inc, t_base);
             t_next_base = t_end;
+            inc_out = inc;
+            closed_out = true;
             return;
         }
     }
+    inc_out = 0.0f;
+    closed_out = false;
     float t = t_base;
     mine = t_base;
 #pragma unroll
@@ -347,8 +354,9 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
         if (nw <= MARCH_MASK_WINDOWS) {
             const uint64_t* my_masks = masks + (size_t)n * MARCH_MASK_WINDOWS;
             for (; window < nw; window++) {
-                float mine, t_next;
-                window_terms<CONST_DT>(p, t_base, dt_const, lane, mine, t_next);
+                float mine, t_next, inc_unused;
+                bool closed_unused;
+                window_terms<CONST_DT>(p, t_base, dt_const, lane, mine, t_next, inc_unused, closed_unused);
                 t_base = t_next;
                 const uint64_t emit = my_masks[window];
                 if (emit == 0ull) continue;
@@ -383,12 +391,14 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
     // The windows of a ray are a dependent chain (carry, step budget), and each one needs a bitfield read: software-pipelined -- the
     // terms of window w+1 do not depend on the walk of window w, so their positions are computed and their reads issued before the
     // walk of window w starts.
-    float mine_n = 0.0f, t_after_n = t_base;
+    float mine_n = 0.0f, t_after_n = t_base, base_n = t_base, inc_n = 0.0f;
+    bool closed_n = false;
     ProbeGeom g_n = {};
     uint32_t byte_n = 0u;
     bool valid_n = false;
     auto issue_window = [&](float base) {
-        window_terms<CONST_DT>(p, base, dt_const, lane, mine_n, t_after_n);
+        base_n = base;
+        window_terms<CONST_DT>(p, base, dt_const, lane, mine_n, t_after_n, inc_n, closed_n);
         valid_n = mine_n < far;
         g_n = probe_geom(p, r, valid_n ? mine_n : near);
         byte_n = p.grid[g_n.index >> 3];  // unconditional (a valid address for every lane): nothing waits on it here
@@ -399,6 +409,8 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
         // ---- 1. + 2. this window's terms and probes were issued one iteration ago; start the next window's ----
         const float mine = mine_n;
         const float t_next_base = t_after_n;
+        const float win_base = base_n, win_inc = inc_n;
+        const bool win_closed = closed_n;
         const bool valid = valid_n;
         const ProbeGeom g = g_n;
         const uint32_t byte = byte_n;
@@ -419,12 +431,27 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
             // landing index of "do t += dt(t) while (t < tt)" started at this lane: first j > lane with !(t_j < tt)
             const float target = (valid && !occ) ? tt : -INFINITY;
             uint32_t land = lane + 1u;
+            if (CONST_DT && win_closed) {
+                // closed-form window: term q = win_base + q * win_inc exactly, so the landing index is ceil((target - base) / inc) up
+                // to the rounding of that quotient -- start one below the estimate and confirm against the exact terms (the
+                // estimate is off by less than one, so two confirmations reach the first q with !(t_q < target))
+                const float est = fminf(fmaxf(ceilf((target - win_base) / win_inc) - 1.0f, 0.0f), 64.0f);  // (-inf target -> 0)
+                const uint32_t q0 = (uint32_t)est;
+                land = q0 > land ? q0 : land;
 #pragma unroll
-            for (uint32_t s = 32; s >= 1; s >>= 1) {
-                const uint32_t q = land + s - 1u;
-                const float tq = __shfl(mine, (int)(q & 63u), 64);
-                const bool adv = (q < 64u) && (tq < target);
-                land = adv ? land + s : land;
+                for (int k = 0; k < 2; k++) {
+                    const float tq = __builtin_fmaf((float)land, win_inc, win_base);
+                    land = (land < 64u && tq < target) ? land + 1u : land;
+                }
+                land = land < 64u ? land : 64u;
+            } else {
+#pragma unroll
+                for (uint32_t s = 32; s >= 1; s >>= 1) {
+                    const uint32_t q = land + s - 1u;
+                    const float tq = __shfl(mine, (int)(q & 63u), 64);
+                    const bool adv = (q < 64u) && (tq < target);
+                    land = adv ? land + s : land;
+                }
             }
             carry = -INFINITY;
             // ---- 3. the sequential walk over wave-uniform scalars ----

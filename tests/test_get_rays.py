@@ -27,6 +27,26 @@ def test_oracle_get_rays_matches_reference_fixture():
     assert np.allclose(np.linalg.norm(d, axis=-1), 1.0, atol=1e-6)
 
 
+def test_pixel_draw_modes_on_cpu():
+    """which pixels get_rays draws is plain torch (the reference's three modes): runs without a GPU"""
+    from nerf.utils import _draw_pixels
+    torch.manual_seed(3)
+    H, W, B = 40, 56, 2
+    inds, coarse = _draw_pixels(B, H, W, 500, None, 1, 'cpu')
+    assert coarse is None and inds.shape == (500,) and 0 <= int(inds.min()) and int(inds.max()) < H * W
+    inds, coarse = _draw_pixels(B, H, W, 4 * 16 + 3, None, 4, 'cpu')
+    assert coarse is None and inds.shape == (64,)
+    r, c = (inds // W).view(4, 4, 4), (inds % W).view(4, 4, 4)
+    assert torch.equal(r - r[:, :1, :1], torch.arange(4).view(1, 4, 1).expand(4, 4, 4))
+    assert torch.equal(c - c[:, :1, :1], torch.arange(4).view(1, 1, 4).expand(4, 4, 4))
+    err = torch.zeros(B, 128 * 128)
+    err[:, 64 * 128 + 64] = 1.0
+    err[:, 3] = 1.0
+    inds, coarse = _draw_pixels(B, H, W, 2, err, 1, 'cpu')
+    assert inds.shape == (B, 2) and set(coarse.flatten().tolist()) == {64 * 128 + 64, 3}
+    assert int(inds.max()) < H * W and int(inds.min()) >= 0
+
+
 @pytest.mark.gpu
 def test_kernel_matches_oracle_and_fixture():
     import _ngp_capi as capi

@@ -911,25 +911,28 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     // the loads of RUNS_AHEAD runs back to back -- unconditionally, at clamped addresses -- before it touches the accumulator.
     constexpr int GROUP = 16, GROUPS = ACC_THREADS / GROUP, RUNS_AHEAD = 4;
     const int grp = tid / GROUP, gl = tid % GROUP, lane = tid & 63, group_base = lane & ~(GROUP - 1);
-    // (this kernel is bound by its VALU work per record, so the usual case is kept short: fp16 -> fp32 -> * 2^24 -> int32 is exact
-    // for |value| < 128, one sign extension makes it the 64-bit addend; larger and non-finite values take the bit-pattern path)
-    auto add_channel = [&](unsigned long long* slot, const uint32_t idx, const uint32_t ch, const half_t h) {
-        const float scaled = (float)h * 0x1p24f;  // exact: 11 significant bits
-        if (__builtin_fabsf(scaled) < 0x1p31f) {
-            const int32_t q = (int32_t)scaled;
-            if (q != 0) __hip_atomic_fetch_add(slot, (unsigned long long)(long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            const uint32_t bits = __builtin_bit_cast(uint16_t, h);
-            if ((bits & 0x7c00u) == 0x7c00u) atomicOr(&poison[idx >> 4], (1u + ch) << ((idx & 15u) * 2u));
-            else __hip_atomic_fetch_add(slot, (unsigned long long)half_bits_to_fixed(bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
+    // (this kernel is bound by its VALU work per record, so the usual case is straight-line code: fp16 -> fp32 -> * 2^24 -> int32 is
+    // exact for |value| < 128, one sign extension makes it the 64-bit addend, both channels are added unconditionally (a zero addend
+    // is harmless); values >= 128 and non-finite ones are rare and handled behind ONE branch per record)
     const bool interleaved = plan.interleaved[li] != 0;
     auto add_record = [&](const uint32_t key, const uint32_t val) {
         const uint32_t idx = interleaved ? (key >> BIN_DENSE_BITS) : (key & (BIN_SLICE - 1u));
         const half2_t hv = __builtin_bit_cast(half2_t, val);
-        add_channel(&acc[2 * idx], idx, 0u, hv.x);
-        add_channel(&acc[2 * idx + 1], idx, 1u, hv.y);
+        const float s0 = (float)hv.x * 0x1p24f, s1 = (float)hv.y * 0x1p24f;  // exact: 11 significant bits
+        const bool ok0 = __builtin_fabsf(s0) < 0x1p31f, ok1 = __builtin_fabsf(s1) < 0x1p31f;  // false for large values, inf and NaN
+        const int32_t q0 = (int32_t)(ok0 ? s0 : 0.0f), q1 = (int32_t)(ok1 ? s1 : 0.0f);
+        __hip_atomic_fetch_add(&acc[2 * idx], (unsigned long long)(long long)q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[2 * idx + 1], (unsigned long long)(long long)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!(ok0 && ok1)) {
+            const uint32_t bits[2] = {val & 0xffffu, val >> 16};
+            const bool ok[2] = {ok0, ok1};
+#pragma unroll
+            for (uint32_t ch = 0; ch < 2; ch++) {
+                if (ok[ch]) continue;
+                if ((bits[ch] & 0x7c00u) == 0x7c00u) atomicOr(&poison[idx >> 4], (1u + ch) << ((idx & 15u) * 2u));
+                else __hip_atomic_fetch_add(&acc[2 * idx + ch], (unsigned long long)half_bits_to_fixed(bits[ch]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
     };
     const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(level_records);  // 2 words per record
     auto load2 = [&](uint32_t first_record) {  // records first_record, first_record + 1

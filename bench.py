@@ -18,7 +18,17 @@ roofline: `roofline` = the dominant kernel (grid_encode_backward, 1100 B per poi
           (grid fwd/bwd, ffmlp fwd/bwd with their MFMA fraction).  HIP graphs cannot carry timing events, so after the
           timed region the same iteration is run eagerly for a few steps with HIP-event pairs around the named kernels on
           the launch stream; algorithmic bytes per SURVEY.md 8(d); `traffic` from the committed rocprofv3 --pmc passes.
-cpu_baseline: the CPU oracle's full training step (forward+backward, one host thread) on the same workload.
+          `traffic` is NOT measured in this run (PMC needs rocprofv3 around the process): it is the per-launch HBM byte count of the
+          committed counter pass named in `traffic_source`.
+steady state: every HIP graph the timed region replays (the training iteration and the occupancy refresh) is captured AND replayed
+          at least once during the untimed setup (33 iterations: the reference's 16 worst-case-sized steps, the first estimate, one
+          full refresh period from graphs); `captures_in_timed_region` reports graph captures that happened between t0 and t1 (0).
+dropin_path: the same workload through the pure drop-in surface only -- module-by-module network (`model.fused = False`), eager
+          launches, torch.optim.Adam + GradScaler (what the reference's unchanged network_ff.py / renderer.py / Trainer execute) --
+          timed the same way on a shorter run (N = 1 only).
+cpu_baseline: the reference's pure-PyTorch path (NeRFRenderer.run, nn.Linear MLPs, fp32, device='cpu', restated in
+          oracle/torch_cpu.py because the reference's own encoders are CUDA-only) on all host cores; `scalar_port` = the scalar-C
+          oracle's cuda_ray-shaped step on one thread.
 """
 import argparse
 import json
@@ -108,16 +118,178 @@ class KernelTimers:
 
 
 def load_pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json, produced by
-    tools/pmc_traffic.py on the same workload); None when the file is absent."""
+    """(HBM bytes per launch, file name) from the newest committed rocprofv3 --pmc pass (profiles/*_pmc_traffic.json, produced by
+    tools/pmc_traffic.py on the same workload); (None, None) when the file is absent.  NOT a measurement of this run."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
     if not files:
-        return None
+        return None, None
     try:
-        return json.load(open(files[-1]))['per_launch']
+        return json.load(open(files[-1]))['per_launch'], os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
+
+
+SETUP_ITERATIONS = 33  # 16 worst-case-sized eager steps + the first estimate-sized one (graph capture) + one refresh period from graphs
+
+
+class TrainingRun:
+    """one configuration of the training workload (model + optimizer + stepper + resident batches) and its timing protocol"""
+
+    def __init__(self, args, dev, world, rank, fused, graph, torch_optim, autograd):
+        import raymarching
+        import synthetic_scene as sc
+        import ddp
+        from nerf.network_ff import NeRFNetwork
+        from ddp import GradientAverager
+        from graph import GraphedTrainStep, mse_loss
+        self.args, self.dev, self.world, self.rank, self.use_graph, self.torch_optim = args, dev, world, rank, graph, torch_optim
+        torch.manual_seed(0)  # identical parameters on every rank (FFMLP reseeds to 42 itself)
+        model = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
+        model.train()
+        model.fused = fused
+        occ = torch.from_numpy(sc.occupancy_density()).to(dev)
+        model.density_grid.copy_(occ)
+        model.density_bitfield = raymarching.packbits(model.density_grid, 10.0, model.density_bitfield)
+        fixed_bits = model.density_bitfield.clone()
+        model.iter_density = 16          # steady state: partial occupancy refreshes (renderer.py:488-514)
+        model.mean_density = float(occ.clamp(min=0).mean())
+        if torch_optim:
+            # the reference's pair (main_nerf.py:132, nerf/utils.py:393): torch Adam (fused, capturable) + GradScaler
+            optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
+            scaler = torch.amp.GradScaler('cuda')
+            averager = GradientAverager(model, world) if world > 1 else None
+        else:
+            # same update rule and scale dynamics in one fused device-side step (torch-ngp_amd/optim.py)
+            from optim import NGPAdam
+            optimizer = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, world_size=world)
+            scaler = None
+            averager = optimizer if world > 1 else None
+        # a pool of pre-generated batches resident in HBM (one camera each, 4096 random pixels)
+        self.n_pool = 16
+        self.pool = []
+        for k in range(self.n_pool):
+            o, d, gt = sc.training_batch(args.rays, seed=1000 * rank + k)
+            self.pool.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
+        self.opt_kwargs = dict(staged=False, bg_color=1, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+
+        def keep_scene(m):
+            # N > 1: the occupancy exchange of the data-parallel path (element-wise MAX of the grid + re-pack + common sample estimate)
+            if world > 1:
+                ddp.sync_occupancy(m)
+            # the synthetic scene keeps its analytic occupancy: the refresh work is done, its result is discarded
+            m.density_grid.copy_(occ)
+            m.density_bitfield.copy_(fixed_bits)
+        self.keep_scene = keep_scene
+        self.model, self.optimizer = model, optimizer
+        self.stepper = GraphedTrainStep(model, optimizer, scaler, args.rays, self.opt_kwargs, loss_fn=mse_loss, averager=averager,
+                                        after_update=keep_scene, direct=not autograd)
+        self.step_no = 0
+        self.caps, self.slots = [], []
+        self.count_log = None
+
+    def train_step(self, count=True):
+        stepper, model, args = self.stepper, self.model, self.args
+        rays_o, rays_d, gt = self.pool[self.step_no % self.n_pool]
+        self.step_no += 1
+        if not self.use_graph:
+            # eager path: same cadence, no capture
+            if stepper.global_step % 16 == 0:
+                with torch.autocast('cuda', dtype=torch.float16):
+                    model.update_extra_state()
+                self.keep_scene(model)
+            mc = model.mean_count
+            cap = mc + (128 - mc % 128) if mc > 0 else args.rays * 1024
+            loss = stepper._eager(rays_o, rays_d, gt)
+            stepper.global_step += 1
+        else:
+            loss = stepper.step(rays_o, rays_d, gt)
+            cap = stepper.capacity if stepper.capacity is not None else args.rays * 1024
+        if count:
+            # log the sample counts: the model keeps the last 16 in its counter ring (renderer.py:352), so one 128-byte device copy every
+            # 16 steps is enough; the clamp to the buffer capacity and the sum happen after the timed region.  Samples that were marched
+            # AND evaluated: rays that do not fit the estimated buffer are dropped whole by march_rays_train (raymarching.cu:416), so at
+            # most `cap` samples are processed in a step
+            self.caps.append(cap)
+            self.slots.append((model.local_step - 1) % 16)
+            if len(self.caps) % 16 == 0:
+                self.count_log[len(self.caps) // 16 - 1].copy_(model.step_counter, non_blocking=True)
+        return loss
+
+    def setup(self, warmup):
+        """untimed, not part of --warmup: bring the run to the steady state of a running training.  The first 16 iterations size the
+        sample buffer for the worst case and read the count back (raymarching.py:223-231); after the first update_extra_state the
+        running estimate `mean_count` exists, the iteration is sync-free and (graph mode) is captured; every graph a later step replays
+        is captured here and replayed at least once before the timed region starts."""
+        for _ in range(17):
+            self.train_step(count=False)
+        if self.use_graph:
+            self.stepper.precapture()
+        while self.step_no < SETUP_ITERATIONS:
+            self.train_step(count=False)
+        for _ in range(warmup):
+            self.train_step(count=False)
+
+    def timed(self, steps):
+        dev, world, model = self.dev, self.world, self.model
+        self.count_log = torch.zeros(steps // 16 + 2, 16, 2, dtype=torch.int32, device=dev)  # snapshots of the model's 16-slot counter ring
+        self.caps, self.slots = [], []
+        captures0 = self.stepper.captures
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = self.train_step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        captures = self.stepper.captures - captures0
+        final_loss = float(loss.item())
+        caps, slots = self.caps, self.slots
+        if len(caps) % 16:  # the ring still holds the steps since the last snapshot
+            self.count_log[len(caps) // 16].copy_(model.step_counter)
+        blocks = torch.arange(len(caps), device=dev) // 16
+        marched = self.count_log[blocks, torch.tensor(slots, dtype=torch.int64, device=dev), 0].to(torch.int64)
+        total = torch.minimum(marched, torch.tensor(caps, dtype=torch.int64, device=dev)).sum()
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        return {'elapsed': float(el.item()), 'samples': int(total.item()), 'final_loss': final_loss, 'captures': int(captures)}
+
+    def execution(self):
+        st = self.stepper
+        if not self.use_graph:
+            return 'eager'
+        if st.capture_error is not None:
+            return f'eager (graph capture failed: {st.capture_error[:120]})'
+        return f'hip-graph replay ({st.n_captures} iteration + {st.n_update_captures} refresh capture(s), all before the timed region)'
+
+
+def cpu_baselines(args):
+    """rank 0, N = 1: (a) the reference's pure-PyTorch device='cpu' path on all host cores, (b) the scalar-C oracle on one thread"""
+    import oracle
+    import synthetic_scene as sc
+    from oracle.pipeline import time_cpu_baseline
+    from oracle.torch_cpu import time_reference_cpu_path
+    half = max(2.0, args.cpu_seconds / 2)
+    r = time_reference_cpu_path(n_rays=args.rays, min_seconds=half)
+    cpu = {'value': round(r['samples_per_s'], 1), 'unit': 'samples/s', 'cores': r['threads'], 'kind': 'port',
+           'host_cores_available': os.cpu_count(), 'ms_per_step': round(r['median_step_s'] * 1e3, 1),
+           'sample': f"{r['steps']} timed training step(s) (median; {r['warmup']} warm-up) of the reference's pure-PyTorch path "
+                     f"(NeRFRenderer.run num_steps={r['num_steps']} upsample_steps=0, hashgrid + nn.Linear MLPs, fp32, Adam) restated in "
+                     f"oracle/torch_cpu.py, {args.rays} rays x {r['num_steps']} = {r['samples_per_step']} samples per step, "
+                     f"torch.set_num_threads({r['threads']})"}
+    bits = oracle.packbits(sc.occupancy_density(), 10.0)
+    q = time_cpu_baseline(bits, n_rays=args.rays, min_seconds=half, max_steps_timed=4)
+    cpu['scalar_port'] = {'value': round(q['samples_per_s'], 1), 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
+                          'sample': f"{q['steps']} full oracle training step(s) of the cuda_ray-shaped workload (forward+backward, no optimiser) "
+                                    f"of {args.rays} rays = {q['samples']} samples in {q['seconds']:.1f} s, one host thread"}
+    return cpu
 
 
 def main():
@@ -133,8 +305,10 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--torch-optim', action='store_true', help='torch.optim.Adam(fused) + GradScaler instead of optim.NGPAdam')
     ap.add_argument('--no-render', action='store_true', help='skip the 800x800 inference-frame timing')
+    ap.add_argument('--no-dropin', action='store_true', help='skip the second, drop-in-surface-only measurement')
+    ap.add_argument('--dropin-steps', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=10.0)
+    ap.add_argument('--cpu-seconds', type=float, default=24.0)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -157,126 +331,24 @@ def main():
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     import _ngp_capi as capi
-    import raymarching
     import synthetic_scene as sc
-    from nerf.network_ff import NeRFNetwork
-    from ddp import GradientAverager
-    from graph import GraphedTrainStep, mse_loss
-
-    torch.manual_seed(0)  # identical parameters on every rank (FFMLP reseeds to 42 itself)
-    model = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
-    model.train()
-    model.fused = not args.no_fused
-    occ = torch.from_numpy(sc.occupancy_density()).to(dev)
-    model.density_grid.copy_(occ)
-    model.density_bitfield = raymarching.packbits(model.density_grid, 10.0, model.density_bitfield)
-    fixed_bits = model.density_bitfield.clone()
-    model.iter_density = 16          # steady state: partial occupancy refreshes (renderer.py:488-514)
-    model.mean_density = float(occ.clamp(min=0).mean())
-
-    if args.torch_optim:
-        # the reference's pair (main_nerf.py:132, nerf/utils.py:393): torch Adam (fused, capturable) + GradScaler
-        optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
-        scaler = torch.amp.GradScaler('cuda')
-        averager = GradientAverager(model, world) if world > 1 else None
-    else:
-        # same update rule and scale dynamics in one fused device-side step (torch-ngp_amd/optim.py)
-        from optim import NGPAdam
-        optimizer = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, world_size=world)
-        scaler = None
-        averager = optimizer if world > 1 else None
-
-    # a pool of pre-generated batches resident in HBM (one camera each, 4096 random pixels)
-    n_pool = 16
-    pool = []
-    for k in range(n_pool):
-        o, d, gt = sc.training_batch(args.rays, seed=1000 * rank + k)
-        pool.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
-    total_samples = torch.zeros((), dtype=torch.int64, device=dev)
-    count_log = torch.zeros(args.steps // 16 + 2, 16, 2, dtype=torch.int32, device=dev)  # snapshots of the model's 16-slot counter ring
-    caps, slots = [], []
-    opt_kwargs = dict(staged=False, bg_color=1, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
-
-    def keep_scene(m):
-        # the synthetic scene keeps its analytic occupancy: the refresh work is done, its result is discarded
-        m.density_grid.copy_(occ)
-        m.density_bitfield.copy_(fixed_bits)
-
-    stepper = GraphedTrainStep(model, optimizer, scaler, args.rays, opt_kwargs, loss_fn=mse_loss, averager=averager,
-                               after_update=keep_scene, direct=not args.autograd)
-    def train_step(i, count=True):
-        rays_o, rays_d, gt = pool[i % n_pool]
-        if args.no_graph:
-            # eager path: same cadence, no capture
-            if stepper.global_step % 16 == 0:
-                with torch.autocast('cuda', dtype=torch.float16):
-                    model.update_extra_state()
-                keep_scene(model)
-            mc = model.mean_count
-            cap = mc + (128 - mc % 128) if mc > 0 else args.rays * 1024
-            loss = stepper._eager(rays_o, rays_d, gt)
-            stepper.global_step += 1
-        else:
-            loss = stepper.step(rays_o, rays_d, gt)
-            cap = stepper.capacity if stepper.capacity is not None else args.rays * 1024
-        if count:
-            # log the sample counts: the model keeps the last 16 in its counter ring (renderer.py:352), so one 128-byte device copy every
-            # 16 steps is enough; the clamp to the buffer capacity and the sum happen after the timed region.  Samples that were marched
-            # AND evaluated: rays that do not fit the estimated buffer are dropped whole by march_rays_train (raymarching.cu:416), so at
-            # most `cap` samples are processed in a step
-            caps.append(cap)
-            slots.append((model.local_step - 1) % 16)
-            if len(caps) % 16 == 0:
-                count_log[len(caps) // 16 - 1].copy_(model.step_counter, non_blocking=True)
-        return loss
-
     timers = KernelTimers(capi)
 
-    # setup (untimed, not part of --warmup): bring the model to the steady state of a running training -- the first 16
-    # iterations size the sample buffer for the worst case and read the count back (raymarching.py:223-231); after the
-    # first update_extra_state the running estimate `mean_count` exists and the iteration is sync-free.
-    step_no = 0
-    for _ in range(17):
-        train_step(step_no, count=False)
-        step_no += 1
-    for _ in range(args.warmup):
-        train_step(step_no, count=False)
-        step_no += 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step(step_no)
-        step_no += 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    final_loss = float(loss.item())
-    if len(caps) % 16:  # the ring still holds the steps since the last snapshot
-        count_log[len(caps) // 16].copy_(model.step_counter)
-    blocks = torch.arange(len(caps), device=dev) // 16
-    marched = count_log[blocks, torch.tensor(slots, dtype=torch.int64, device=dev), 0].to(torch.int64)
-    total_samples.add_(torch.minimum(marched, torch.tensor(caps, dtype=torch.int64, device=dev)).sum())
-
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(total_samples, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    samples = int(total_samples.item())
+    run = TrainingRun(args, dev, world, rank, fused=not args.no_fused, graph=not args.no_graph, torch_optim=args.torch_optim,
+                      autograd=args.autograd)
+    run.setup(args.warmup)
+    res = run.timed(args.steps)
+    elapsed, samples = res['elapsed'], res['samples']
+    model, stepper = run.model, run.stepper
 
     # roofline pass (untimed): HIP graphs cannot carry timing events, so the same iteration is run eagerly for a few steps
     # with HIP-event pairs around the named kernels, on the stream they are launched on, same batches, same state.
-    roofs = []
+    roofs, traffic_source = [], None
     if rank == 0 and not args.no_roofline:
         stepper.averager = None  # rank-0 only: no collectives in this pass
         timers.enabled = True
         for k in range(min(16, max(4, args.steps))):
-            rays_o, rays_d, gt = pool[(step_no + k) % n_pool]
+            rays_o, rays_d, gt = run.pool[(run.step_no + k) % run.n_pool]
             saved = (model.mean_count, model.local_step)
             if stepper.captured_capacity:
                 model.mean_count = stepper.captured_capacity - 128
@@ -284,7 +356,11 @@ def main():
             model.mean_count, model.local_step = saved
         torch.cuda.synchronize()
         timers.enabled = False
-        roofs = timers.summary(load_pmc_traffic())
+        traffic, traffic_source = load_pmc_traffic()
+        roofs = timers.summary(traffic)
+        for r in roofs:
+            r['traffic_source'] = (f'{traffic_source} (committed rocprofv3 --pmc pass of the same workload; not measured in this run)'
+                                   if r['traffic'] is not None else None)
 
     render = None
     if rank == 0 and not args.no_render:
@@ -311,6 +387,19 @@ def main():
         model.density_scale = 1
         model.train()
 
+    dropin = None
+    if rank == 0 and world == 1 and not args.no_dropin and not (args.no_fused and args.no_graph and args.torch_optim):
+        # the pure drop-in surface: what the reference's unchanged network_ff.py / renderer.py / Trainer would execute on this library
+        d_run = TrainingRun(args, dev, 1, 0, fused=False, graph=False, torch_optim=True, autograd=True)
+        d_run.setup(min(args.warmup, 8))
+        d_res = d_run.timed(args.dropin_steps)
+        dropin = {'value': round(d_res['samples'] / d_res['elapsed'], 1), 'unit': 'samples/s', 'steps': args.dropin_steps,
+                  'ms_per_step': round(d_res['elapsed'] / args.dropin_steps * 1e3, 4),
+                  'samples_per_step': round(d_res['samples'] / args.dropin_steps, 1),
+                  'execution': 'eager launches, module-by-module network (model.fused = False), torch.optim.Adam(fused) + GradScaler',
+                  'final_loss': d_res['final_loss']}
+        del d_run
+
     if rank == 0:
         roof = None
         for r in roofs:
@@ -319,15 +408,8 @@ def main():
         if roof is None and roofs:
             roof = roofs[0]  # the dominant one by total time
         cpu = None
-        if not args.no_cpu_baseline:
-            import oracle
-            from oracle.pipeline import time_cpu_baseline
-            bits = oracle.packbits(sc.occupancy_density(), 10.0)
-            r = time_cpu_baseline(bits, n_rays=args.rays, min_seconds=args.cpu_seconds, max_steps_timed=4)
-            cpu = {'value': round(r['samples_per_s'], 1), 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
-                   'host_cores_available': os.cpu_count(),
-                   'sample': f"{r['steps']} full oracle training step(s) (forward+backward, no optimiser) of {args.rays} rays = "
-                             f"{r['samples']} samples in {r['seconds']:.1f} s, one host thread"}
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baselines(args)
         line = {
             'metric': 'training samples/s (rays x steps), lego-shaped synthetic, fp16 autocast, full step incl. Adam',
             'value': round(samples / elapsed, 1), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -337,11 +419,12 @@ def main():
                                    'FFMLP 64x2 / 64x3), bound=1, 128^3 occupancy grid, dt_gamma=0, max_steps=1024',
                        'rays_per_gpu_per_step': args.rays, 'samples_per_step_per_gpu': round(samples / args.steps / world, 1),
                        'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}',
-                       'execution': 'eager' if args.no_graph else (f'hip-graph replay ({stepper.n_captures} capture(s))' if stepper.capture_error is None
-                                                                   else f'eager (graph capture failed: {stepper.capture_error[:120]})'),
-                       'autograd_free_iteration': bool(stepper.used_direct), 'fused_pipeline': bool(model.fused), 'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
-                       'final_loss': final_loss},
-            'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'render_800x800_ms': render,
+                       'execution': run.execution(), 'setup_iterations_untimed': SETUP_ITERATIONS,
+                       'captures_in_timed_region': res['captures'],
+                       'autograd_free_iteration': bool(stepper.used_direct), 'fused_pipeline': bool(model.fused),
+                       'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
+                       'final_loss': res['final_loss']},
+            'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'dropin_path': dropin, 'render_800x800_ms': render,
         }
         print(json.dumps(line))
     if world > 1:

@@ -319,13 +319,32 @@ int ngp_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
  * grad_is_half[k] (the buffer grid_encode_backward / ffmlp_backward wrote) else fp32, and is ZEROED by the call; params_fp16[k]
  * (optional, may be NULL per tensor or as a whole) receives the fp16 copy of the updated weights.
  * state = device float[8]: {loss scale, growth tracker, found_inf, Adam step count, lr multiplier, -, -, -}; no host sync.
- * grad_mult: extra factor on the gradients (1 / world_size after a SUM all-reduce).  A step over more than 8 tensors is several
- * calls: pass growth_interval < 0 on all but the last (the scale / step-count commit then runs once); NOTE the non-finite check of a
- * later call cannot undo the update of an earlier one, so put the tensors most likely to overflow (the hash table) first. */
+ * grad_mult: extra factor on the gradients (1 / world_size after a SUM all-reduce).  A step over more than 8 tensors uses
+ * ngp_optim_adam_step_ex below (phases), which keeps "a non-finite gradient anywhere skips the whole step" across calls; for
+ * compatibility growth_interval < 0 here still means "CHECK + UPDATE of this chunk, no COMMIT". */
 int ngp_optim_adam_step(int count, const uint64_t* n, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
                         void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
                         float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
                         float* state, ngp_stream_t stream);
+
+/* The same step in phases, for parameter sets of more than 8 tensors and for the data-parallel sharded update: CHECK sweeps the
+ * gradients of this call's tensors into found_inf, UPDATE applies Adam (or skips) to them, COMMIT updates the loss scale and the step
+ * count once (count may be 0 for a COMMIT-only call).  A caller with several chunks issues CHECK for every chunk, then UPDATE for every
+ * chunk, then COMMIT -- a non-finite gradient anywhere then skips the step everywhere, as GradScaler.step does.
+ * ema / ema_one_minus_decay (optional: NULL / 0): exponential moving average of the parameters in the same sweep,
+ * ema[k] -= ema_one_minus_decay * (ema[k] - params[k]) on the updated parameters -- torch_ema's ExponentialMovingAverage.update()
+ * (the reference Trainer's `ema`, nerf/utils.py:388-391,760-761,891-892); the caller computes the effective decay
+ * min(decay, (1 + num_updates) / (10 + num_updates)). */
+#define NGP_OPT_PHASE_CHECK 1u
+#define NGP_OPT_PHASE_UPDATE 2u
+#define NGP_OPT_PHASE_COMMIT 4u
+int ngp_optim_adam_step_ex(int count, const uint64_t* n, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                           void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
+                           float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
+                           float* state, float* const* ema, float ema_one_minus_decay, uint32_t phases, ngp_stream_t stream);
+/* torch_ema's update() on its own (the Trainer calls it once per epoch): ema[k] -= one_minus_decay * (ema[k] - params[k]), up to 8
+ * tensors per call */
+int ngp_optim_ema_update(int count, const uint64_t* n, float* const* params, float* const* ema, float one_minus_decay, ngp_stream_t stream);
 
 #ifdef __cplusplus
 }

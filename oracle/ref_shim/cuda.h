@@ -1,0 +1,2 @@
+/* stand-in for <cuda.h> on the host, see ngp_cuda_on_host.h (TEST INFRASTRUCTURE) */
+#include "ngp_cuda_on_host.h"

@@ -79,3 +79,68 @@ def test_reference_wrappers_bind_to_our_backend(pkg, mod, backend_names):
     src = open(os.path.join(REF, pkg, f'{mod}.py')).read()
     used = set(__import__('re').findall(r'_backend\.([a-zA-Z0-9_]+)\(', src))
     assert used and used <= set(backend_names)
+
+
+_HEADERS = {'gridencoder': 'gridencoder/src/gridencoder.h', 'shencoder': 'shencoder/src/shencoder.h',
+            'raymarching': 'raymarching/src/raymarching.h', 'ffmlp': 'ffmlp/src/ffmlp.h'}
+_WRAPPERS = {'gridencoder': 'grid', 'shencoder': 'sphere_harmonics', 'raymarching': 'raymarching', 'ffmlp': 'ffmlp'}
+
+
+def _header_signatures(pkg):
+    """{callable: [argument names in order]} parsed from the reference's C++ header (e.g. raymarching/src/raymarching.h:7-18)"""
+    import re
+    txt = re.sub(r'//.*', '', open(os.path.join(REF, _HEADERS[pkg])).read())
+    sigs = {}
+    for m in re.finditer(r'void\s+(\w+)\s*\(([^;]*?)\)\s*;', txt, re.S):
+        sigs[m.group(1)] = [a.strip().split()[-1].lstrip('&*').rstrip('_') for a in m.group(2).split(',') if a.strip()]
+    return sigs
+
+
+@pytest.mark.parametrize('pkg', sorted(_HEADERS))
+def test_backend_signatures_match_reference_headers(pkg):
+    """every callable of the reference's pybind module exists in our `_backend` with the SAME number of positional parameters, in the
+    SAME order and under the same names as the C++ declaration (gridencoder.h:12-15, shencoder.h:9-10, raymarching.h:7-18, ffmlp.h:8-14)"""
+    import inspect
+    ours = importlib.import_module(f'{pkg}.backend')._backend
+    sigs = _header_signatures(pkg)
+    assert sigs
+    for name, ref_args in sigs.items():
+        params = inspect.signature(getattr(ours, name)).parameters
+        assert all(p.kind == p.POSITIONAL_OR_KEYWORD and p.default is p.empty for p in params.values()), name
+        assert list(params) == ref_args, (name, list(params), ref_args)
+
+
+@pytest.mark.parametrize('pkg', sorted(_WRAPPERS))
+def test_reference_wrapper_call_sites_fit_our_backend(pkg):
+    """parse every `_backend.<fn>(...)` call in the reference's unchanged Python wrapper with `ast`: purely positional, argument COUNT
+    equal to our callable's, and wherever the wrapper passes a plain variable its name agrees with our parameter name at that position
+    (catches a transposed pair such as (nears, fars) or (xyzs, dirs) that a name-only check would miss)"""
+    import ast
+    import inspect
+    ours = importlib.import_module(f'{pkg}.backend')._backend
+    tree = ast.parse(open(os.path.join(REF, pkg, f'{_WRAPPERS[pkg]}.py')).read())
+    calls = [n for n in ast.walk(tree) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute)
+             and isinstance(n.func.value, ast.Name) and n.func.value.id == '_backend']
+    assert calls
+    # names the wrappers use for the same tensor under a different local name (reference file:line in the comment)
+    alias = {'density_bitfield': 'grid',       # raymarching.py:217,342: the bitfield is the kernels' `grid`
+             'density_grid': 'grid',           # raymarching.py:150 (packbits)
+             'step_counter': 'counter',        # raymarching.py:217
+             'thresh': 'density_thresh',       # raymarching.py:150
+             'grad_outputs': 'grad', 'grad': 'grad',  # ffmlp.py:62, grid.py:84
+             'T_thresh': 'T_thresh', 'ctx.dims': None, 'weight': 'weight'}
+    for call in calls:
+        fn = call.func.attr
+        params = list(inspect.signature(getattr(ours, fn)).parameters)
+        assert not call.keywords, (fn, 'keyword arguments in a reference call site')
+        assert not any(isinstance(a, ast.Starred) for a in call.args), fn
+        assert len(call.args) == len(params), (fn, len(call.args), len(params), call.lineno)
+        for pos, (arg, param) in enumerate(zip(call.args, params)):
+            if not isinstance(arg, ast.Name):
+                continue
+            name = alias.get(arg.id, arg.id)
+            if name is None:
+                continue
+            # single-letter dimension variables (B, D, C, L, S, H, N, M) and exact tensor names must sit at the same position
+            if name in params:
+                assert name == param, (fn, call.lineno, pos, arg.id, param)

@@ -1,0 +1,130 @@
+"""GPU: the non-`--ff` model family on the MI355X kernels -- `nerf.network.NeRFNetwork` (nn.Linear stacks, optional background head,
+the reference's nerf/network.py) through `NeRFRenderer.run` (the plain sampler, nerf/renderer.py:125-253) and through the cuda_ray
+renderer with a background model (BASELINE config 5's branch: sph_from_ray -> 2-D hash grid -> bg_net, renderer.py:271-273).
+
+Checker 1: tests/golden/run_ref.npz -- the REFERENCE'S OWN network.py + renderer.run executed unchanged on CPU (make_golden.py gen_run).
+Checker 2: oracle/torch_cpu.py, the pure-torch restatement (live, more configurations).  fp32 model: tolerance 1e-3 of the output range
+(hash-grid fractions differ by ~2^-24 * resolution between a fused and an unfused pos = x * scale + 0.5)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synthetic_scene as sc
+
+pytestmark = pytest.mark.gpu
+
+
+def _product_model(z, tag, cuda_ray=False):
+    from gridencoder import GridEncoder
+    from nerf.network import NeRFNetwork
+    bound, bg_radius = float(z[f'{tag}_cfg'][0]), float(z[f'{tag}_cfg'][1])
+    bound = int(bound) if bound == int(bound) else bound
+    m = NeRFNetwork(bound=bound, cuda_ray=cuda_ray, bg_radius=bg_radius, min_near=0.2, density_scale=1)
+    # the fixture was made with 2^10-entry tables (small file); everything else is the constructor's
+    m.encoder = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=10, desired_resolution=2048 * bound)
+    if bg_radius > 0:
+        m.encoder_bg = GridEncoder(input_dim=2, num_levels=4, level_dim=2, base_resolution=16, log2_hashmap_size=10, desired_resolution=2048)
+    sd = {k[len(tag) + 4:]: torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith(f'{tag}_sd_')}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(('offsets' in k or 'aabb' in k or 'density' in k or 'step_counter' in k) for k in missing), (missing, unexpected)
+    return m.cuda(), bound, bg_radius
+
+
+@pytest.mark.parametrize('tag', ['plain', 'bg'])
+def test_run_matches_the_reference_executed_on_cpu(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'run_ref.npz'))
+    m, bound, bg_radius = _product_model(z, tag)
+    o, d = torch.from_numpy(z[f'{tag}_rays_o'])[None].cuda(), torch.from_numpy(z[f'{tag}_rays_d'])[None].cuda()
+    m.train()
+    res = m.run(o, d, num_steps=48, upsample_steps=0, bg_color=None, perturb=False)
+    ((res['image'] ** 2).sum() + res['depth'].sum()).backward()
+    np.testing.assert_allclose(res['image'][0].detach().cpu().numpy(), z[f'{tag}_train_image'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(res['depth'][0].detach().cpu().numpy(), z[f'{tag}_train_depth'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(res['weights_sum'].detach().cpu().numpy(), z[f'{tag}_train_ws'], rtol=0, atol=1e-3)
+    for name, got in (('grad_sigma0', m.sigma_net[0].weight.grad), ('grad_color2', m.color_net[2].weight.grad)):
+        want = z[f'{tag}_{name}']
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-3 * np.abs(want).max())
+    assert abs(float(m.encoder.embeddings.grad.norm()) / float(z[f'{tag}_grad_emb_norm']) - 1) < 2e-3
+    if bg_radius > 0:
+        want = z[f'{tag}_grad_bg0']
+        np.testing.assert_allclose(m.bg_net[0].weight.grad.cpu().numpy(), want, rtol=0, atol=2e-3 * np.abs(want).max())
+        assert m.encoder_bg.embeddings.grad.abs().sum() > 0
+    # eval: importance resampling with the deterministic inverse-CDF draw, staged in two ray batches
+    m.eval()
+    with torch.no_grad():
+        res = m.render(o, d, staged=True, max_ray_batch=48, num_steps=32, upsample_steps=24, bg_color=None, perturb=False)
+    np.testing.assert_allclose(res['image'][0].cpu().numpy(), z[f'{tag}_eval_image'], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(res['depth'][0].cpu().numpy(), z[f'{tag}_eval_depth'], rtol=0, atol=2e-3)
+
+
+def test_run_under_fp16_autocast_and_perturbation_statistics():
+    """the same model under the Trainer's fp16 autocast (fp16 tables, fp16 Linear layers): within fp16 tolerance of the fp32 run;
+    perturb=True jitters every sample inside its own stratum (renderer.py:150-154)"""
+    from nerf.network import NeRFNetwork
+    torch.manual_seed(3)
+    m = NeRFNetwork(bound=1, cuda_ray=False).cuda().train()
+    with torch.no_grad():
+        m.encoder.embeddings.uniform_(-0.3, 0.3)
+    o, d, _ = sc.training_batch(256, seed=4)
+    o, d = torch.from_numpy(o)[None].cuda(), torch.from_numpy(d)[None].cuda()
+    with torch.no_grad():
+        a = m.run(o, d, num_steps=64, upsample_steps=0, perturb=False)
+        with torch.autocast('cuda', dtype=torch.float16):
+            b = m.run(o, d, num_steps=64, upsample_steps=0, perturb=False)
+        torch.manual_seed(1)
+        c = m.run(o, d, num_steps=64, upsample_steps=16, perturb=True)
+    assert (a['image'].float() - b['image'].float()).abs().max() < 2e-2
+    assert torch.isfinite(c['image']).all() and c['image'].shape == (1, 256, 3) and c['depth'].min() >= 0 and c['depth'].max() <= 1
+
+
+def test_cuda_ray_training_step_with_background_model_vs_oracle():
+    """BASELINE config 5's model branch: bound = 8 (4 cascades, dt_gamma = 1/128), nn.Linear network, background head fed by
+    sph_from_ray, through run_cuda under fp16 autocast.  Sample counts bit-exact vs the oracle marcher; image vs an oracle composition of
+    the same network evaluated in fp32 on the fp16-rounded parameters (torch_cpu restatement of the encoders), 1e-3 of the range... the
+    fp16 Linear layers (rocBLAS) bound it to ~4e-3"""
+    from nerf.network import NeRFNetwork
+    from oracle import torch_cpu as tc
+    import raymarching
+    torch.manual_seed(11)
+    bound, cascade, bg_radius = 8, 4, 32.0
+    m = NeRFNetwork(bound=bound, cuda_ray=True, bg_radius=bg_radius, min_near=0.2, density_thresh=10).cuda().train()
+    with torch.no_grad():
+        m.encoder.embeddings.uniform_(-0.3, 0.3)
+        m.encoder_bg.embeddings.uniform_(-0.5, 0.5)
+    grid = sc.occupancy_density(bound=float(bound), cascade=cascade)
+    grid = np.maximum(grid, np.where(np.random.default_rng(5).uniform(size=grid.shape) < 0.02, 30.0, 0.0).astype(np.float32))
+    m.density_grid.copy_(torch.from_numpy(grid))
+    m.density_bitfield = raymarching.packbits(m.density_grid, 10.0, m.density_bitfield)
+    bits = oracle.packbits(grid, 10.0)
+    assert np.array_equal(m.density_bitfield.cpu().numpy(), bits)
+    N = 512
+    o, d, gt = sc.training_batch(N, seed=8)
+    o = o * np.float32(2.0)
+    ot, dt_ = torch.from_numpy(o)[None].cuda(), torch.from_numpy(d)[None].cuda()
+    with torch.autocast('cuda', dtype=torch.float16):
+        out = m.render(ot, dt_, staged=False, bg_color=None, perturb=False, force_all_rays=True, dt_gamma=1 / 128, max_steps=1024)
+        loss = ((out['image'][0] - torch.from_numpy(gt).cuda()) ** 2).mean()
+    loss.backward()
+    for p in (m.encoder.embeddings, m.encoder_bg.embeddings, m.bg_net[0].weight, m.sigma_net[0].weight):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
+    # oracle side
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    xyzs, dirs, deltas, rays, counter = oracle.march_rays_train(o, d, float(bound), bits, cascade, 128, nears, fars, np.zeros(N, np.float32),
+                                                                dt_gamma=1 / 128)
+    assert m.step_counter[0].cpu().numpy().tolist() == counter.tolist()
+    mm = int(counter[0])
+    ref = tc.TorchNeRF(bound=bound, bg_radius=bg_radius)
+    sd = {k: v.detach().cpu().half().float() for k, v in m.state_dict().items() if 'embeddings' in k or 'weight' in k}
+    ref.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        sigma, rgb = ref(torch.from_numpy(xyzs[:mm]), torch.from_numpy(dirs[:mm]))
+        bgc = ref.background(tc.sph_from_ray(torch.from_numpy(o), torch.from_numpy(d), bg_radius), torch.from_numpy(d)).numpy()
+    ws, dep, img = oracle.composite_rays_train_forward(sigma.numpy(), rgb.numpy(), deltas[:mm], rays)
+    want = img + (1 - ws)[:, None] * bgc
+    got = out['image'][0].detach().float().cpu().numpy()
+    assert np.abs(got - want).max() < 5e-3, np.abs(got - want).max()
+    np.testing.assert_allclose(out['weights_sum'].detach().cpu().numpy(), ws, rtol=0, atol=5e-3)

@@ -21,7 +21,8 @@ LIB_PATH = os.path.join(_HERE, 'libngp_hip.so')
 NGP_F32, NGP_F16 = 0, 1
 NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR = 1, 2
 NGP_MARCH_RESET_COUNTER, NGP_MARCH_ZERO_TAIL, NGP_MARCH_NOISE_FROM_SEED = 1, 2, 4
-ABI_VERSION = 3
+NGP_OPT_PHASE_CHECK, NGP_OPT_PHASE_UPDATE, NGP_OPT_PHASE_COMMIT = 1, 2, 4
+ABI_VERSION = 4
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -75,6 +76,8 @@ _SIGNATURES = {
     'ngp_composite_rays_train_forward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_composite_rays_train_backward_ex': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _i32, _f32, _vp, _vp, _vp],
     'ngp_optim_adam_step': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
+    'ngp_optim_adam_step_ex': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _u32, _vp],
+    'ngp_optim_ema_update': [_i32, _vp, _vp, _vp, _f32, _vp],
     'ngp_allocate_splitk': [_sz],
     'ngp_free_splitk': [],
 }

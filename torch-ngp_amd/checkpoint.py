@@ -58,6 +58,10 @@ def load_checkpoint(checkpoint, model, optimizer=None, scaler=None, lr_scheduler
         _load_optimizer(optimizer, ck['optimizer'], ck.get('scaler'))
     if lr_scheduler is not None and 'lr_scheduler' in ck:
         lr_scheduler.load_state_dict(ck['lr_scheduler'])
+    elif optimizer is not None and 'lr_scheduler' in ck and getattr(optimizer, '_lr_lambda', None) is not None:
+        # optim.NGPAdam is not a torch Optimizer (LambdaLR cannot wrap it): its own step-based rule resumes at the saved step.  Without a
+        # rule the decayed rate itself was already restored from the optimizer state (load_torch_adam_state: lr / initial_lr)
+        optimizer.schedule_step(int(ck['lr_scheduler'].get('last_epoch', 0)))
     if scaler is not None and 'scaler' in ck:
         scaler.load_state_dict(ck['scaler'])
     return info

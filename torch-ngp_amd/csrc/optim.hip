@@ -11,7 +11,12 @@
 //                    Adam step counter, on device -- the whole step is free of host synchronisation and graph-capturable.
 // Update rule = PyTorch's Adam (amsgrad = False, weight_decay = 0, maximize = False), restated from its documented formula:
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
-// A step with a non-finite gradient anywhere is skipped as a whole (moments, weights and t untouched), as GradScaler.step does.
+// A step with a non-finite gradient anywhere is skipped as a whole (moments, weights and t untouched), as GradScaler.step does; with more
+// than 8 tensors the caller runs the phases separately (check every chunk, then update every chunk, then commit once) so that "as a
+// whole" holds across chunks.
+// Optional, in the same sweep: the exponential moving average of the parameters the reference Trainer keeps with torch_ema
+// (nerf/utils.py:388-391,760-761,891-892): shadow -= (1 - decay) * (shadow - param), computed on the UPDATED parameter -- one extra
+// fp32 read-modify-write stream instead of a separate pass over every parameter.
 #include "common.h"
 #include <math.h>
 
@@ -30,6 +35,7 @@ struct OptTensors {
     half_t* p16[OPT_MAX_TENSORS];   // optional fp16 shadow of the weights
     int g_is_half[OPT_MAX_TENSORS];
     float lr[OPT_MAX_TENSORS];
+    float* ema[OPT_MAX_TENSORS];    // optional EMA shadow (fp32), updated when ema_omd > 0
 };
 
 // state[0] = loss scale, state[1] = growth tracker, state[2] = found_inf (0/1), state[3] = Adam step count t, state[4] = lr multiplier
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_check_finite(OptTensors ts, flo
 }
 
 __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float* __restrict__ state, float beta1, float beta2, float eps,
-                                                      float grad_mult) {
+                                                      float grad_mult, float ema_omd) {
     const bool skip = state[2] != 0.0f;
     const float inv_scale = grad_mult / state[0];
     const float t = state[3] + 1.0f;  // this step's count (k_update_scale commits it)
@@ -71,6 +77,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
         float* __restrict__ m = ts.m[k];
         float* __restrict__ v = ts.v[k];
         half_t* __restrict__ p16 = ts.p16[k];
+        float* __restrict__ ema = ema_omd > 0.0f ? ts.ema[k] : nullptr;
         const bool gh = ts.g_is_half[k] != 0;
         half_t* g16 = reinterpret_cast<half_t*>(ts.g[k]);
         float* g32 = reinterpret_cast<float*>(ts.g[k]);
@@ -87,7 +94,15 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
                 g0 = x.x; g1 = x.y;
                 reinterpret_cast<float2_t*>(g32)[i] = float2_t{0.0f, 0.0f};
             }
-            if (skip) continue;
+            if (skip) {
+                if (ema) {  // the average moves towards the (unchanged) parameters as torch_ema's update() would
+                    const float2_t pp = reinterpret_cast<float2_t*>(p)[i];
+                    float2_t e = reinterpret_cast<float2_t*>(ema)[i];
+                    e.x -= ema_omd * (e.x - pp.x); e.y -= ema_omd * (e.y - pp.y);
+                    reinterpret_cast<float2_t*>(ema)[i] = e;
+                }
+                continue;
+            }
             g0 *= inv_scale; g1 *= inv_scale;
             float2_t pm = reinterpret_cast<float2_t*>(m)[i], pv = reinterpret_cast<float2_t*>(v)[i], pp = reinterpret_cast<float2_t*>(p)[i];
             pm.x = beta1 * pm.x + (1.0f - beta1) * g0; pm.y = beta1 * pm.y + (1.0f - beta1) * g1;
@@ -98,6 +113,11 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
             reinterpret_cast<float2_t*>(v)[i] = pv;
             reinterpret_cast<float2_t*>(p)[i] = pp;
             if (p16) reinterpret_cast<half2_t*>(p16)[i] = half2_t{(half_t)pp.x, (half_t)pp.y};
+            if (ema) {
+                float2_t e = reinterpret_cast<float2_t*>(ema)[i];
+                e.x -= ema_omd * (e.x - pp.x); e.y -= ema_omd * (e.y - pp.y);
+                reinterpret_cast<float2_t*>(ema)[i] = e;
+            }
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const uint64_t i = n - 1;
@@ -110,6 +130,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
                 m[i] = nm; v[i] = nv; p[i] = np_;
                 if (p16) p16[i] = (half_t)np_;
             }
+            if (ema) ema[i] -= ema_omd * (ema[i] - p[i]);
         }
     }
 }
@@ -135,43 +156,99 @@ __global__ void k_update_scale(float* __restrict__ state, float growth, float ba
     state[2] = 0.0f;
 }
 
+// torch_ema's update() on its own (the Trainer calls it once per epoch, not per step): shadow -= omd * (shadow - param)
+__global__ __launch_bounds__(OPT_THREADS) void k_ema(OptTensors ts, float omd) {
+    for (int k = 0; k < ts.count; k++) {
+        const uint64_t n = ts.n[k];
+        const float* __restrict__ p = ts.p[k];
+        float* __restrict__ e = ts.ema[k];
+        for (uint64_t i = (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * OPT_THREADS) e[i] -= omd * (e[i] - p[i]);
+    }
+}
+
 }  // namespace ngp
 
 using namespace ngp;
+
+static uint32_t opt_blocks(uint64_t total) {
+    uint32_t blocks = (uint32_t)cdiv64(total / 2 + 1, OPT_THREADS * 4);  // ~8 elements per lane
+    if (blocks > 2048u) blocks = 2048u;
+    if (blocks < 1u) blocks = 1u;
+    return blocks;
+}
+
+extern "C" int ngp_optim_adam_step_ex(int count, const uint64_t* n, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                                      void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
+                                      float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
+                                      float* state, float* const* ema, float ema_one_minus_decay, uint32_t phases, ngp_stream_t stream) {
+    NGP_REQUIRE(state, NGP_ERR_INVALID, "optim_adam_step: NULL state");
+    NGP_REQUIRE((phases & ~7u) == 0 && phases != 0, NGP_ERR_INVALID, "optim_adam_step: phases must be a non-empty subset of CHECK|UPDATE|COMMIT");
+    hipStream_t st = as_stream(stream);
+    if (phases & (NGP_OPT_PHASE_CHECK | NGP_OPT_PHASE_UPDATE)) {
+        NGP_REQUIRE(count >= 1 && count <= OPT_MAX_TENSORS, NGP_ERR_INVALID, "optim_adam_step: between 1 and %d tensors per call (got %d)",
+                    OPT_MAX_TENSORS, count);
+        NGP_REQUIRE(n && params && exp_avg && exp_avg_sq && grads && grad_is_half && lr, NGP_ERR_INVALID, "optim_adam_step: NULL argument");
+        NGP_REQUIRE(!(ema_one_minus_decay > 0.0f) || ema, NGP_ERR_INVALID, "optim_adam_step: EMA decay given without shadow tensors");
+        OptTensors ts;
+        ts.count = count;
+        uint64_t total = 0;
+        for (int k = 0; k < count; k++) {
+            NGP_REQUIRE(params[k] && exp_avg[k] && exp_avg_sq[k] && grads[k], NGP_ERR_INVALID, "optim_adam_step: NULL tensor %d", k);
+            ts.n[k] = n[k];
+            ts.p[k] = params[k];
+            ts.m[k] = exp_avg[k];
+            ts.v[k] = exp_avg_sq[k];
+            ts.g[k] = grads[k];
+            ts.p16[k] = params_fp16 ? reinterpret_cast<half_t*>(params_fp16[k]) : nullptr;
+            ts.g_is_half[k] = grad_is_half[k];
+            ts.lr[k] = lr[k];
+            ts.ema[k] = ema ? ema[k] : nullptr;
+            total += n[k];
+        }
+        const uint32_t blocks = opt_blocks(total);
+        if (phases & NGP_OPT_PHASE_CHECK) {
+            hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(OPT_THREADS), 0, st, ts, state);
+            const int rc = check_launch("optim_adam_step(check)");
+            if (rc) return rc;
+        }
+        if (phases & NGP_OPT_PHASE_UPDATE) {
+            hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(OPT_THREADS), 0, st, ts, (const float*)state, beta1, beta2, eps, grad_mult,
+                               ema_one_minus_decay > 0.0f ? ema_one_minus_decay : 0.0f);
+            const int rc = check_launch("optim_adam_step(adam)");
+            if (rc) return rc;
+        }
+    }
+    if (phases & NGP_OPT_PHASE_COMMIT) {
+        hipLaunchKernelGGL(k_update_scale, dim3(1), dim3(64), 0, st, state, growth_factor, backoff_factor, growth_interval);
+        return check_launch("optim_adam_step(scale)");
+    }
+    return NGP_OK;
+}
 
 extern "C" int ngp_optim_adam_step(int count, const uint64_t* n, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
                                    void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
                                    float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
                                    float* state, ngp_stream_t stream) {
-    NGP_REQUIRE(count >= 1 && count <= OPT_MAX_TENSORS, NGP_ERR_INVALID, "optim_adam_step: between 1 and %d tensors per call (got %d)",
+    const uint32_t phases = NGP_OPT_PHASE_CHECK | NGP_OPT_PHASE_UPDATE | (growth_interval < 0.0f ? 0u : NGP_OPT_PHASE_COMMIT);
+    return ngp_optim_adam_step_ex(count, n, params, exp_avg, exp_avg_sq, grads, params_fp16, grad_is_half, lr, beta1, beta2, eps, grad_mult,
+                                  growth_factor, backoff_factor, growth_interval, state, nullptr, 0.0f, phases, stream);
+}
+
+extern "C" int ngp_optim_ema_update(int count, const uint64_t* n, float* const* params, float* const* ema, float one_minus_decay,
+                                    ngp_stream_t stream) {
+    NGP_REQUIRE(count >= 1 && count <= OPT_MAX_TENSORS, NGP_ERR_INVALID, "optim_ema_update: between 1 and %d tensors per call (got %d)",
                 OPT_MAX_TENSORS, count);
-    NGP_REQUIRE(n && params && exp_avg && exp_avg_sq && grads && grad_is_half && lr && state, NGP_ERR_INVALID, "optim_adam_step: NULL argument");
-    OptTensors ts;
+    NGP_REQUIRE(n && params && ema, NGP_ERR_INVALID, "optim_ema_update: NULL argument");
+    OptTensors ts = {};
     ts.count = count;
     uint64_t total = 0;
     for (int k = 0; k < count; k++) {
-        NGP_REQUIRE(params[k] && exp_avg[k] && exp_avg_sq[k] && grads[k], NGP_ERR_INVALID, "optim_adam_step: NULL tensor %d", k);
+        NGP_REQUIRE(params[k] && ema[k], NGP_ERR_INVALID, "optim_ema_update: NULL tensor %d", k);
         ts.n[k] = n[k];
         ts.p[k] = params[k];
-        ts.m[k] = exp_avg[k];
-        ts.v[k] = exp_avg_sq[k];
-        ts.g[k] = grads[k];
-        ts.p16[k] = params_fp16 ? reinterpret_cast<half_t*>(params_fp16[k]) : nullptr;
-        ts.g_is_half[k] = grad_is_half[k];
-        ts.lr[k] = lr[k];
+        ts.ema[k] = ema[k];
         total += n[k];
     }
-    hipStream_t st = as_stream(stream);
-    uint32_t blocks = (uint32_t)cdiv64(total / 2 + 1, OPT_THREADS * 4);  // ~8 elements per lane
-    if (blocks > 2048u) blocks = 2048u;
-    if (blocks < 1u) blocks = 1u;
-    hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(OPT_THREADS), 0, st, ts, state);
-    int rc = check_launch("optim_adam_step(check)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(OPT_THREADS), 0, st, ts, (const float*)state, beta1, beta2, eps, grad_mult);
-    rc = check_launch("optim_adam_step(adam)");
-    if (rc) return rc;
-    if (growth_interval < 0.0f) return NGP_OK;  // more tensors follow in another call of the same step
-    hipLaunchKernelGGL(k_update_scale, dim3(1), dim3(64), 0, st, state, growth_factor, backoff_factor, growth_interval);
-    return check_launch("optim_adam_step(scale)");
+    hipLaunchKernelGGL(k_ema, dim3(opt_blocks(total)), dim3(OPT_THREADS), 0, as_stream(stream), ts, one_minus_decay);
+    return check_launch("optim_ema_update");
 }

@@ -21,6 +21,11 @@ class GradientAverager:
     def __init__(self, module, world_size=None):
         self.world = world_size if world_size is not None else dist.get_world_size()
         self.params = [p for p in module.parameters() if p.requires_grad]
+        if any(getattr(p, '_ngp_grad16', None) is not None for p in self.params):
+            # optim.NGPAdam(deposit=True) keeps these gradients in its own fp16 buffer and p.grad stays None: this averager would
+            # manufacture zero .grad tensors, the optimizer would step on them and the deposited gradient would never be consumed
+            raise RuntimeError('GradientAverager: the parameters are managed by optim.NGPAdam(deposit=True); use the optimizer\'s own '
+                               'all_reduce() (pass the optimizer as `averager`)')
         self.big = [p for p in self.params if p.numel() >= (1 << 20)]
         self.small = [p for p in self.params if p.numel() < (1 << 20)]
         self._flat = None
@@ -56,6 +61,13 @@ def broadcast_parameters(module, src=0):
     """make parameters and buffers identical on every rank (start of training / after loading a checkpoint)"""
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
+    # an optim.NGPAdam built before this call holds fp16 shadow copies of the OLD values, and a write through `.data` does not bump the
+    # autograd version counter the fused path watches: refresh them here so that every rank starts from the broadcast weights
+    for p in module.parameters():
+        sh = getattr(p, '_ngp_fp16', None)
+        if sh is not None:
+            sh.copy_(p.detach())
+            p._ngp_version = p._version
 
 
 @torch.no_grad()

@@ -15,7 +15,11 @@ and one graph launch.
 
 What stays eager, at the reference Trainer's cadence (nerf/utils.py:851-856): `update_extra_state` every 16 steps, which also
 refreshes `mean_count`.  The captured sample capacity is `mean_count` rounded up to a multiple of `capacity_quantum`
-(default 8192 samples, ~3 % of a lego-sized batch), so the graph is re-captured only when the estimate crosses a quantum.
+(default 8192 samples, ~3 % of a lego-sized batch) and is kept while the estimate stays inside [capacity - 2 quanta, capacity]
+(a larger buffer only drops fewer rays than the reference's `mean_count`-sized one), so the graph is re-captured only when the
+estimate grows past the captured buffer or falls well below it.  `precapture()` records every graph a steady-state run replays
+(the iteration and the occupancy refresh) up front, so that no one-time capture cost lands inside a measured or latency-critical
+stretch of steps.
 
 Requirements: a torch optimizer constructed with `capturable=True` (and preferably `fused=True`) plus a GradScaler, or
 `optim.NGPAdam` with `scaler=None` (it owns the loss scale; `averager` may then be the optimizer itself); the model has completed at least
@@ -32,11 +36,16 @@ def mse_loss(out, target):
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, scaler, n_rays, render_kwargs, loss_fn=mse_loss, averager=None, capacity_quantum=8192,
-                 update_interval=16, after_update=None, autocast_dtype=torch.float16, direct=True):
+                 update_interval=16, after_update=None, autocast_dtype=torch.float16, direct=True, capacity_slack=2):
         self.model, self.optimizer, self.scaler = model, optimizer, scaler
         self.loss_fn, self.averager = loss_fn, averager
+        if averager is not None and averager is not optimizer and getattr(optimizer, 'flat_grad16', None) is not None:
+            # a gradient-depositing optimizer keeps the table gradient in its own fp16 buffer (p.grad stays None): only its own
+            # all_reduce() sees it -- a foreign averager would average nothing and make the optimizer step on zeros
+            raise RuntimeError('GraphedTrainStep: with optim.NGPAdam(deposit=True) pass the optimizer itself as `averager`')
         self.render_kwargs = dict(render_kwargs)
         self.quantum = int(capacity_quantum)
+        self.slack = int(capacity_slack)  # quanta the estimate may fall below the captured capacity before a re-capture
         self.update_interval = int(update_interval)
         self.after_update = after_update
         self.autocast_dtype = autocast_dtype
@@ -55,6 +64,7 @@ class GraphedTrainStep:
         self.used_direct = False
         self.graph_updates = True   # replay the occupancy refresh from a HIP graph as well (see _update_extra_state)
         self.update_graphs = {}     # {full sweep?: (graph, device mean density)}
+        self.n_update_captures = 0
         self.update_capture_error = None
         self.capacity = None  # sample capacity of the step that ran last (None while eager/worst-case)
         # autograd-free iteration (fused.fused_train_iteration): needs the default loss, an optimizer that owns its loss scale and
@@ -67,6 +77,39 @@ class GraphedTrainStep:
         if mc <= 0:
             return None
         return ((mc + 128 + self.quantum - 1) // self.quantum) * self.quantum
+
+    def _fits(self, cap):
+        """the captured buffer still serves an estimate of `cap` samples (hysteresis: see the module docstring)"""
+        return (self.graphs is not None and self.captured_capacity is not None
+                and self.captured_capacity - self.slack * self.quantum <= cap <= self.captured_capacity)
+
+    @property
+    def captures(self):
+        """number of graph captures so far (training iteration + occupancy refresh); constant over a stretch of steps = pure replay"""
+        return self.n_captures + self.n_update_captures
+
+    def precapture(self, update_modes=None):
+        """capture, without executing anything, every graph the coming steps will replay: the training iteration (needs the
+        `mean_count` estimate, i.e. >= 16 eager steps and one update_extra_state) and the occupancy refresh in the given modes
+        (True = full sweep, False = partial; default: the mode the model is in now and, while it still does full sweeps, the partial
+        one that follows).  Returns the number of graphs captured.  Failures fall back to eager execution as in `step()`."""
+        before = self.captures
+        cap = self._capacity()
+        if cap is not None and self.capture_error is None and not self._fits(cap):
+            self.captured_capacity = cap
+            try:
+                self._capture()
+            except Exception as e:  # noqa: BLE001
+                self.capture_error = repr(e)
+                self.graphs = None
+                torch.cuda.synchronize()
+        m = self.model
+        if self.graphs is not None and self.graph_updates and getattr(m, 'refresh_occupancy', None) is not None and getattr(m, 'cuda_ray', False):
+            if update_modes is None:
+                update_modes = (True, False) if m.iter_density < 16 else (False,)
+            for full in update_modes:
+                self._capture_update(bool(full))
+        return self.captures - before
 
     def _direct_ok(self):
         m, kw = self.model, self.render_kwargs
@@ -143,6 +186,28 @@ class GraphedTrainStep:
             self.graphs = (g1, g2)
         self.n_captures += 1
 
+    def _capture_update(self, full):
+        """record model.refresh_occupancy(full) into a graph of its own (nothing executes); False when capture is not possible"""
+        if full in self.update_graphs:
+            return True
+        if self.update_capture_error is not None or self.graphs is None:
+            return False
+        try:
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.graphs[0].pool()):
+                with torch.autocast('cuda', dtype=self.autocast_dtype):
+                    mean = self.model.refresh_occupancy(full=full)
+            self.update_graphs[full] = (g, mean)
+            self.n_update_captures += 1
+            return True
+        except Exception as e:  # noqa: BLE001 -- keep refreshing eagerly; the caller can inspect .update_capture_error
+            self.update_capture_error = repr(e)
+            torch.cuda.synchronize()
+            return False
+
     def _update_extra_state(self):
         """the occupancy refresh at the Trainer's cadence.  Its device part (model.refresh_occupancy: ~50 small launches around one
         big density evaluation, no host synchronisation) is replayed from a HIP graph of its own once training runs from graphs -- issued
@@ -156,19 +221,7 @@ class GraphedTrainStep:
         full = m.iter_density < 16
         use_graph = self.graph_updates and self.graphs is not None and self.update_capture_error is None
         if use_graph and full not in self.update_graphs:
-            try:
-                import gc
-                gc.collect()
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.graphs[0].pool()):
-                    with torch.autocast('cuda', dtype=self.autocast_dtype):
-                        mean = refresh(full=full)
-                self.update_graphs[full] = (g, mean)
-            except Exception as e:  # noqa: BLE001 -- keep refreshing eagerly; the caller can inspect .update_capture_error
-                self.update_capture_error = repr(e)
-                torch.cuda.synchronize()
-                use_graph = False
+            use_graph = self._capture_update(full)
         if use_graph:
             g, mean = self.update_graphs[full]
             g.replay()
@@ -208,7 +261,7 @@ class GraphedTrainStep:
             loss = self._eager(rays_o, rays_d, target)
             self.global_step += 1
             return loss
-        if self.graphs is None or cap != self.captured_capacity:
+        if not self._fits(cap):
             self.captured_capacity = cap
             try:
                 self._capture()
@@ -219,6 +272,7 @@ class GraphedTrainStep:
                 loss = self._eager(rays_o, rays_d, target)
                 self.global_step += 1
                 return loss
+        self.capacity = self.captured_capacity
         # the batch into the static input buffers: ONE multi-tensor copy kernel (three separate copies cost ~5 us each plus the gaps)
         torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
                              non_blocking=True)

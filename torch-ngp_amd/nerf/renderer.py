@@ -1,8 +1,7 @@
-"""Occupancy-grid volume renderer: the `--cuda_ray` half of the reference's NeRFRenderer
-(nerf/renderer.py:61-574) -- same constructor, buffers (aabb_train, aabb_infer, density_grid,
-density_bitfield, step_counter: checkpoint compatible), `render`, `run_cuda`, `update_extra_state`,
-`mark_untrained_grid`, `reset_extra_state`.  The non-cuda_ray sampler (`run`, renderer.py:125-253) is not part
-of the hot path and is not provided.
+"""Volume renderer with the reference NeRFRenderer's surface (nerf/renderer.py:61-574): same constructor, buffers (aabb_train,
+aabb_infer, density_grid, density_bitfield, step_counter: checkpoint compatible), `render`, `run_cuda` (occupancy-grid ray
+marching, the hot path), `run` (the plain sampler of renderer.py:125-253: uniform + importance samples, cumprod compositing --
+BASELINE config 1's algorithm), `update_extra_state`, `mark_untrained_grid`, `reset_extra_state`.
 
 Semantics kept from the reference: training depth is measured from the perturbed start of the ray and then has
 `nears` subtracted again (renderer.py:317), inference depth is absolute; the 16-slot step_counter ring and
@@ -20,6 +19,36 @@ import raymarching
 
 def _meshgrid(*axes):
     return torch.meshgrid(*axes, indexing='ij')
+
+
+def sample_pdf(bins, weights, n_samples, det=False):
+    """inverse-transform sampling of the piecewise-constant pdf `weights` [B,T-1] over `bins` [B,T] -> [B,n_samples]
+    (the NeRF hierarchical sampler, renderer.py:12-46)"""
+    pdf = weights + 1e-5
+    pdf = pdf / pdf.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    if det:
+        u = torch.linspace(0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples, device=weights.device)
+        u = u.expand(*cdf.shape[:-1], n_samples)
+    else:
+        u = torch.rand(*cdf.shape[:-1], n_samples, device=weights.device)
+    u = u.contiguous()
+    hi = torch.searchsorted(cdf, u, right=True)
+    lo = (hi - 1).clamp(min=0)
+    hi = hi.clamp(max=cdf.shape[-1] - 1)
+    cdf_lo, cdf_hi = torch.gather(cdf, -1, lo), torch.gather(cdf, -1, hi)
+    bin_lo, bin_hi = torch.gather(bins, -1, lo), torch.gather(bins, -1, hi)
+    width = cdf_hi - cdf_lo
+    width = torch.where(width < 1e-5, torch.ones_like(width), width)
+    return bin_lo + (u - cdf_lo) / width * (bin_hi - bin_lo)
+
+
+def _alpha_weights(z_vals, sample_dist, sigma, density_scale):
+    """per-sample compositing weights of the plain sampler (renderer.py:181-186, 218-222)"""
+    deltas = torch.cat([z_vals[..., 1:] - z_vals[..., :-1], sample_dist * torch.ones_like(z_vals[..., :1])], -1)
+    alphas = 1 - torch.exp(-deltas * density_scale * sigma)
+    trans = torch.cumprod(torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], -1), -1)[..., :-1]
+    return deltas, alphas * trans
 
 
 class NeRFRenderer(nn.Module):
@@ -69,8 +98,51 @@ class NeRFRenderer(nn.Module):
         self.local_step = 0
 
     # -- rendering ------------------------------------------------------------------------------
-    def run(self, *args, **kwargs):
-        raise NotImplementedError("only the cuda_ray renderer is part of the MI355X hot-path build")
+    def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
+        """the plain (non-cuda_ray) sampler, renderer.py:125-253: `num_steps` uniform samples between the AABB hits, optionally
+        `upsample_steps` importance samples drawn from the coarse weights, density queried for every sample, colour only where the
+        weight exceeds 1e-4, cumprod compositing.  rays_o, rays_d [B,N,3] (B == 1) -> image [B,N,3], depth [B,N], weights_sum [N]"""
+        lead = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        n_rays, dev = rays_o.shape[0], rays_o.device
+        box = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, box, self.min_near)
+        nears, fars = nears.unsqueeze(-1), fars.unsqueeze(-1)
+        span = fars - nears
+        z_vals = nears + span * torch.linspace(0.0, 1.0, num_steps, device=dev).unsqueeze(0).expand(n_rays, num_steps)
+        sample_dist = span / num_steps
+        if perturb:
+            z_vals = z_vals + (torch.rand(z_vals.shape, device=dev) - 0.5) * sample_dist
+
+        def points(z):
+            p = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1)
+            return torch.min(torch.max(p, box[:3]), box[3:])
+
+        xyzs = points(z_vals)
+        dens = {k: v.view(n_rays, num_steps, -1) for k, v in self.density(xyzs.reshape(-1, 3)).items()}
+        if upsample_steps > 0:
+            with torch.no_grad():
+                deltas, weights = _alpha_weights(z_vals, sample_dist, dens['sigma'].squeeze(-1), self.density_scale)
+                mids = z_vals[..., :-1] + 0.5 * deltas[..., :-1]
+                new_z = sample_pdf(mids, weights[:, 1:-1], upsample_steps, det=not self.training).detach()
+                new_xyzs = points(new_z)
+            new_dens = {k: v.view(n_rays, upsample_steps, -1) for k, v in self.density(new_xyzs.reshape(-1, 3)).items()}
+            z_vals, order = torch.sort(torch.cat([z_vals, new_z], 1), dim=1)
+            xyzs = torch.cat([xyzs, new_xyzs], 1)
+            xyzs = torch.gather(xyzs, 1, order.unsqueeze(-1).expand_as(xyzs))
+            for k in dens:
+                both = torch.cat([dens[k], new_dens[k]], 1)
+                dens[k] = torch.gather(both, 1, order.unsqueeze(-1).expand_as(both))
+        _, weights = _alpha_weights(z_vals, sample_dist, dens['sigma'].squeeze(-1), self.density_scale)
+        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+        flat = {k: v.reshape(-1, v.shape[-1]) for k, v in dens.items()}
+        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=(weights > 1e-4).reshape(-1), **flat).view(n_rays, -1, 3)
+        weights_sum = weights.sum(-1)
+        depth = torch.sum(weights * ((z_vals - nears) / span).clamp(0, 1), -1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, -2)
+        image = image + (1 - weights_sum).unsqueeze(-1) * self._background(rays_o, rays_d, bg_color)
+        return {'depth': depth.view(*lead), 'image': image.view(*lead, 3), 'weights_sum': weights_sum}
 
     def _background(self, rays_o, rays_d, bg_color):
         if self.bg_radius > 0:
@@ -294,6 +366,18 @@ class NeRFRenderer(nn.Module):
         self.finish_update(self.refresh_occupancy(decay, S))
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
-        if not self.cuda_ray:
-            raise NotImplementedError("only the cuda_ray renderer is part of the MI355X hot-path build")
-        return self.run_cuda(rays_o, rays_d, **kwargs)  # never staged with cuda_ray (renderer.py:553-554)
+        """renderer.py:540-574: run_cuda with cuda_ray (never staged), else `run`, in ray batches of `max_ray_batch` when staged"""
+        if self.cuda_ray:
+            return self.run_cuda(rays_o, rays_d, **kwargs)
+        if not staged:
+            return self.run(rays_o, rays_d, **kwargs)
+        B, N = rays_o.shape[:2]
+        depth = torch.empty(B, N, device=rays_o.device)
+        image = torch.empty(B, N, 3, device=rays_o.device)
+        for b in range(B):
+            for head in range(0, N, max_ray_batch):
+                tail = min(head + max_ray_batch, N)
+                part = self.run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
+                depth[b:b + 1, head:tail] = part['depth']
+                image[b:b + 1, head:tail] = part['image']
+        return {'depth': depth, 'image': image}

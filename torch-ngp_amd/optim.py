@@ -44,6 +44,7 @@ class NGPAdam:
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
         self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), float(growth_interval)
         self.world_size = int(world_size)
+        self.check_mixed_gradients = False  # debugging aid: costs a device read-back per deposited parameter and step
         self.state = {}
         dev = None
         flat_params = [p for g in self.param_groups for p in g['params']]
@@ -82,6 +83,16 @@ class NGPAdam:
         """multiplies every group's lr (what the reference's LambdaLR does, main_nerf.py:137); a device write, valid under graph replay"""
         self.scalars[4:5].fill_(float(factor))
 
+    def set_lr_lambda(self, fn):
+        """`fn(step) -> factor`: the reference's LambdaLR rule (main_nerf.py:137: 0.1 ** min(step / iters, 1)); `schedule_step(step)`
+        evaluates it on the host and writes the device multiplier (valid under graph replay)"""
+        self._lr_lambda = fn
+
+    def schedule_step(self, step):
+        fn = getattr(self, '_lr_lambda', None)
+        if fn is not None:
+            self.set_lr_scale(fn(int(step)))
+
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
             for p in g['params']:
@@ -111,13 +122,17 @@ class NGPAdam:
             dist.all_reduce(self.flat_grad16)
 
     # -- the step ----------------------------------------------------------------------------------
-    @torch.no_grad()
-    def step(self):
+    def _entries(self):
+        """(param, state, gradient tensor, is_half, lr) of every parameter that received a gradient this iteration.  A parameter with
+        neither a `.grad` nor a deposit buffer is left alone, as torch.optim.Adam skips `grad is None` parameters."""
         entries = []
         for g in self.param_groups:
             for p in g['params']:
                 st = self.state[p]
                 if p.grad is not None:
+                    if 'grad16' in st and self._deposit_used(st):
+                        raise RuntimeError('NGPAdam: a parameter has BOTH an autograd .grad and a deposited fp16 gradient -- the fused path '
+                                           'and the module-by-module path were mixed within one step (or a foreign averager created .grad)')
                     grad, is_half = p.grad, 0
                     if not grad.is_contiguous() or grad.dtype != torch.float32:
                         raise RuntimeError('NGPAdam: p.grad must be a contiguous float32 tensor')
@@ -126,10 +141,28 @@ class NGPAdam:
                 else:
                     continue
                 entries.append((p, st, grad, is_half, g['lr']))
+        return entries
+
+    def _deposit_used(self, st):
+        # only checked on the eager path (never while capturing a graph: it reads the device)
+        if torch.cuda.is_current_stream_capturing() or not self.check_mixed_gradients:
+            return False
+        return bool(st['grad16'].ne(0).any().item())
+
+    @torch.no_grad()
+    def step(self, update_ema=None):
+        """one optimizer + loss-scaling step.  `update_ema`: an `NGPEma` whose moving average is advanced inside the same sweep (the
+        Trainer does that once per epoch, nerf/utils.py:760-761,891-892; call it with the last step of the epoch)"""
+        entries = self._entries()
         stream = capi.stream()
+        omd = 0.0
+        if update_ema is not None:
+            omd = update_ema.begin_update()
         keep = []
-        for i in range(0, len(entries), _MAX):
-            chunk = entries[i:i + _MAX]
+        chunks = [entries[i:i + _MAX] for i in range(0, len(entries), _MAX)]
+        CHECK, UPDATE, COMMIT = capi.NGP_OPT_PHASE_CHECK, capi.NGP_OPT_PHASE_UPDATE, capi.NGP_OPT_PHASE_COMMIT
+
+        def call(chunk, phases):
             k = len(chunk)
             n = (ctypes.c_uint64 * k)(*[e[0].numel() for e in chunk])
             ps = (ctypes.c_void_p * k)(*[e[0].data_ptr() for e in chunk])
@@ -139,15 +172,26 @@ class NGPAdam:
             p16 = (ctypes.c_void_p * k)(*[(e[1]['fp16'].data_ptr() if 'fp16' in e[1] else None) for e in chunk])
             gh = (ctypes.c_int * k)(*[e[3] for e in chunk])
             lrs = (ctypes.c_float * k)(*[e[4] for e in chunk])
-            keep.append((n, ps, ms, vs, gs, p16, gh, lrs))
-            last = i + _MAX >= len(entries)
-            # only the last chunk commits the scale / step counter (k_update_scale runs once per step)
-            capi.check(capi.lib.ngp_optim_adam_step(
-                k, ctypes.cast(n, ctypes.c_void_p), ctypes.cast(ps, ctypes.c_void_p), ctypes.cast(ms, ctypes.c_void_p),
-                ctypes.cast(vs, ctypes.c_void_p), ctypes.cast(gs, ctypes.c_void_p), ctypes.cast(p16, ctypes.c_void_p),
-                ctypes.cast(gh, ctypes.c_void_p), ctypes.cast(lrs, ctypes.c_void_p), self.betas[0], self.betas[1], self.eps,
-                1.0 / self.world_size, self.growth_factor, self.backoff_factor, self.growth_interval if last else -1.0,
-                self.scalars.data_ptr(), stream))
+            em = (ctypes.c_void_p * k)(*[update_ema.shadow_of(e[0]).data_ptr() for e in chunk]) if update_ema is not None else None
+            keep.append((n, ps, ms, vs, gs, p16, gh, lrs, em))
+            vp = ctypes.c_void_p
+            capi.check(capi.lib.ngp_optim_adam_step_ex(
+                k, ctypes.cast(n, vp), ctypes.cast(ps, vp), ctypes.cast(ms, vp), ctypes.cast(vs, vp), ctypes.cast(gs, vp),
+                ctypes.cast(p16, vp), ctypes.cast(gh, vp), ctypes.cast(lrs, vp), self.betas[0], self.betas[1], self.eps,
+                1.0 / self.world_size, self.growth_factor, self.backoff_factor, self.growth_interval, self.scalars.data_ptr(),
+                None if em is None else ctypes.cast(em, vp), float(omd), phases, stream))
+
+        if len(chunks) == 1:
+            call(chunks[0], CHECK | UPDATE | COMMIT)
+        else:
+            # "skipped as a whole": every chunk is swept for non-finite values BEFORE any chunk is updated (GradScaler.step semantics)
+            for c in chunks:
+                call(c, CHECK)
+            for c in chunks:
+                call(c, UPDATE)
+            capi.check(capi.lib.ngp_optim_adam_step_ex(0, None, None, None, None, None, None, None, None, self.betas[0], self.betas[1], self.eps,
+                                                       1.0, self.growth_factor, self.backoff_factor, self.growth_interval,
+                                                       self.scalars.data_ptr(), None, 0.0, COMMIT, stream))
         self._keep = keep
 
     # -- checkpointing -----------------------------------------------------------------------------
@@ -167,9 +211,21 @@ class NGPAdam:
             self.state[p]['exp_avg_sq'].copy_(st['exp_avg_sq'])
             step = max(step, float(st['step']))
         self.scalars[3:4].fill_(step)
+        # learning rate: the group keeps the scheduler-free base rate, the scheduler's current factor (LambdaLR writes lr =
+        # initial_lr * lambda(step), main_nerf.py:137) goes into the device-side multiplier -- a resumed run continues at the decayed rate
+        factors = []
         for g, tg in zip(self.param_groups, adam_sd['param_groups']):
-            g['lr'] = float(tg.get('initial_lr', tg['lr']))
-            # a scheduler's current factor is restored by the caller through set_lr_scale(tg['lr'] / tg['initial_lr'])
+            base = float(tg.get('initial_lr', tg['lr']))
+            g['lr'] = base
+            factors.append(float(tg['lr']) / base if base != 0.0 else 1.0)
+        if factors:
+            if max(factors) - min(factors) > 1e-6 * max(1.0, max(factors)):
+                # per-group schedules: fold each factor into its group's rate, keep the common multiplier at 1
+                for g, f in zip(self.param_groups, factors):
+                    g['lr'] *= f
+                self.set_lr_scale(1.0)
+            else:
+                self.set_lr_scale(factors[0])
         if scaler_sd:
             self.scalars[0:1].fill_(float(scaler_sd.get('scale', self.get_scale())))
             self.scalars[1:2].fill_(float(scaler_sd.get('_growth_tracker', 0)))
@@ -190,3 +246,85 @@ class NGPAdam:
         for g, lr in zip(self.param_groups, sd['lr']):
             g['lr'] = lr
         self.sync_shadows()
+
+
+class NGPEma:
+    """Exponential moving average of the parameters with torch_ema.ExponentialMovingAverage's surface and update rule (the reference
+    Trainer's `self.ema`, nerf/utils.py:388-391: update() once per epoch :760-761,891-892, store()/copy_to()/restore() around evaluation
+    :800-810,928-1011, state_dict() in checkpoints :1034-1035):
+
+        decay_t = min(decay, (1 + num_updates) / (10 + num_updates))          (use_num_updates=True, torch_ema's default)
+        shadow -= (1 - decay_t) * (shadow - param)
+
+    `update()` is one fused launch over all parameters (ngp_optim_ema_update); `NGPAdam.step(update_ema=ema)` folds it into the Adam
+    sweep instead.  copy_to()/restore() refresh the optimizer's fp16 shadow weights when given the optimizer."""
+
+    def __init__(self, parameters, decay, use_num_updates=True, optimizer=None):
+        if decay < 0.0 or decay > 1.0:
+            raise ValueError('Decay must be between 0 and 1')
+        self.params = [p for p in parameters if p.requires_grad]
+        self.decay = float(decay)
+        self.num_updates = 0 if use_num_updates else None
+        self.shadow_params = [p.detach().clone() for p in self.params]
+        self.collected_params = None
+        self.optimizer = optimizer
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+
+    def shadow_of(self, p):
+        return self.shadow_params[self._index[id(p)]]
+
+    def begin_update(self):
+        """advance the update counter and return this update's (1 - decay_t)"""
+        decay = self.decay
+        if self.num_updates is not None:
+            self.num_updates += 1
+            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        return 1.0 - decay
+
+    @torch.no_grad()
+    def update(self):
+        omd = self.begin_update()
+        stream = capi.stream()
+        keep = []
+        for i in range(0, len(self.params), _MAX):
+            ps, sh = self.params[i:i + _MAX], self.shadow_params[i:i + _MAX]
+            k = len(ps)
+            n = (ctypes.c_uint64 * k)(*[p.numel() for p in ps])
+            pp = (ctypes.c_void_p * k)(*[p.data_ptr() for p in ps])
+            ss = (ctypes.c_void_p * k)(*[t.data_ptr() for t in sh])
+            keep.append((n, pp, ss))
+            capi.check(capi.lib.ngp_optim_ema_update(k, ctypes.cast(n, ctypes.c_void_p), ctypes.cast(pp, ctypes.c_void_p),
+                                                     ctypes.cast(ss, ctypes.c_void_p), float(omd), stream))
+        self._keep = keep
+
+    @torch.no_grad()
+    def copy_to(self):
+        for s_, p in zip(self.shadow_params, self.params):
+            p.copy_(s_)  # bumps the version counter: stale fp16 shadows are detected by fused._resync_stale_shadows
+        if self.optimizer is not None:
+            self.optimizer.sync_shadows()
+
+    @torch.no_grad()
+    def store(self):
+        self.collected_params = [p.detach().clone() for p in self.params]
+
+    @torch.no_grad()
+    def restore(self):
+        if self.collected_params is None:
+            raise RuntimeError('This ExponentialMovingAverage has no `store()`ed weights to `restore()`')
+        for c, p in zip(self.collected_params, self.params):
+            p.copy_(c)
+        if self.optimizer is not None:
+            self.optimizer.sync_shadows()
+
+    def state_dict(self):
+        return {'decay': self.decay, 'num_updates': self.num_updates, 'shadow_params': self.shadow_params,
+                'collected_params': self.collected_params}
+
+    def load_state_dict(self, sd):
+        self.decay = float(sd['decay'])
+        self.num_updates = sd['num_updates']
+        for s_, t in zip(self.shadow_params, sd['shadow_params']):
+            s_.copy_(t)
+        cp = sd.get('collected_params')
+        self.collected_params = None if cp is None else [t.detach().clone().to(p.device) for t, p in zip(cp, self.params)]

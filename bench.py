@@ -162,7 +162,10 @@ class TrainingRun:
         else:
             # same update rule and scale dynamics in one fused device-side step (torch-ngp_amd/optim.py)
             from optim import NGPAdam
-            optimizer = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, world_size=world)
+            # N > 1: ZeRO-1-style sharded update (reduce-scatter -> Adam on 1/N -> all-gather of the fp16 shadows under the next march);
+            # --replicated-optim selects the all-reduce + full update on every rank instead
+            optimizer = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, world_size=world,
+                                shard=world > 1 and not args.replicated_optim)
             scaler = None
             averager = optimizer if world > 1 else None
         # a pool of pre-generated batches resident in HBM (one camera each, 4096 random pixels)
@@ -271,19 +274,38 @@ class TrainingRun:
 
 
 def cpu_baselines(args):
-    """rank 0, N = 1: (a) the reference's pure-PyTorch device='cpu' path on all host cores, (b) the scalar-C oracle on one thread"""
+    """rank 0, N = 1: (a) the reference's pure-PyTorch device='cpu' path on the host cores this container may use, (b) the scalar-C
+    oracle on one thread.  (a) runs in a subprocess with a hard timeout: an intra-op pool larger than the container's CPU quota can
+    stall for minutes, and nothing here may hold up the GPU numbers."""
+    import subprocess
     import oracle
     import synthetic_scene as sc
     from oracle.pipeline import time_cpu_baseline
-    from oracle.torch_cpu import time_reference_cpu_path
+    from oracle.torch_cpu import usable_cores
     half = max(2.0, args.cpu_seconds / 2)
-    r = time_reference_cpu_path(n_rays=args.rays, min_seconds=half)
-    cpu = {'value': round(r['samples_per_s'], 1), 'unit': 'samples/s', 'cores': r['threads'], 'kind': 'port',
-           'host_cores_available': os.cpu_count(), 'ms_per_step': round(r['median_step_s'] * 1e3, 1),
-           'sample': f"{r['steps']} timed training step(s) (median; {r['warmup']} warm-up) of the reference's pure-PyTorch path "
-                     f"(NeRFRenderer.run num_steps={r['num_steps']} upsample_steps=0, hashgrid + nn.Linear MLPs, fp32, Adam) restated in "
-                     f"oracle/torch_cpu.py, {args.rays} rays x {r['num_steps']} = {r['samples_per_step']} samples per step, "
-                     f"torch.set_num_threads({r['threads']})"}
+    cores = usable_cores()
+    cpu, tried = None, []
+    for threads in sorted({cores, min(cores, 64), min(cores, 16)}, reverse=True):
+        # glibc malloc tuned to keep the step's large temporaries mapped (otherwise page faults dominate: 3-9x slower, measured)
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='',
+                   MALLOC_TRIM_THRESHOLD_='34359738368', MALLOC_MMAP_MAX_='0', MALLOC_TOP_PAD_='1073741824')
+        try:
+            out = subprocess.run([sys.executable, '-m', 'oracle.torch_cpu', '1024', str(half), str(threads)], cwd=ROOT, env=env, capture_output=True,
+                                 text=True, timeout=6 * half + 45)
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001 -- timeout / crash: try fewer threads
+            tried.append(f'{threads} threads: {type(e).__name__}')
+            continue
+        cpu = {'value': round(r['samples_per_s'], 1), 'unit': 'samples/s', 'cores': r['threads'], 'kind': 'port',
+               'host_cores_available': os.cpu_count(), 'usable_cores': cores, 'ms_per_step': round(r['median_step_s'] * 1e3, 1),
+               'sample': f"{r['steps']} timed training step(s) (median; 1 warm-up) of the reference's pure-PyTorch path (NeRFRenderer.run "
+                         f"num_steps={r['num_steps']} upsample_steps=0, hashgrid + nn.Linear MLPs, fp32, Adam) restated in oracle/torch_cpu.py, "
+                         f"{r['n_rays']} rays x {r['num_steps']} = {r['samples_per_step']} samples per step, {r['threads']} intra-op threads "
+                         f"({cores} cores usable by this container of {os.cpu_count()} on the host; glibc malloc trim/mmap thresholds raised), {r['wall_s']:.0f} s wall"
+                         + (f"; gave up on: {tried}" if tried else '')}
+        break
+    if cpu is None:
+        cpu = {'value': None, 'unit': 'samples/s', 'cores': 0, 'kind': 'port', 'sample': f'pure-PyTorch path did not finish in time: {tried}'}
     bits = oracle.packbits(sc.occupancy_density(), 10.0)
     q = time_cpu_baseline(bits, n_rays=args.rays, min_seconds=half, max_steps_timed=4)
     cpu['scalar_port'] = {'value': round(q['samples_per_s'], 1), 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
@@ -304,11 +326,12 @@ def main():
     ap.add_argument('--no-fused', action='store_true', help='module-by-module network path (reference-style glue) instead of fused.py')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--torch-optim', action='store_true', help='torch.optim.Adam(fused) + GradScaler instead of optim.NGPAdam')
+    ap.add_argument('--replicated-optim', action='store_true', help='N > 1: all-reduce + full Adam on every rank instead of the sharded update')
     ap.add_argument('--no-render', action='store_true', help='skip the 800x800 inference-frame timing')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second, drop-in-surface-only measurement')
     ap.add_argument('--dropin-steps', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=24.0)
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -344,9 +367,9 @@ def main():
     # roofline pass (untimed): HIP graphs cannot carry timing events, so the same iteration is run eagerly for a few steps
     # with HIP-event pairs around the named kernels, on the stream they are launched on, same batches, same state.
     roofs, traffic_source = [], None
-    if rank == 0 and not args.no_roofline:
-        stepper.averager = None  # rank-0 only: no collectives in this pass
-        timers.enabled = True
+    if not args.no_roofline:
+        # every rank runs these iterations (the data-parallel exchange inside them is collective); only rank 0 times its kernels
+        timers.enabled = rank == 0
         for k in range(min(16, max(4, args.steps))):
             rays_o, rays_d, gt = run.pool[(run.step_no + k) % run.n_pool]
             saved = (model.mean_count, model.local_step)
@@ -356,11 +379,16 @@ def main():
             model.mean_count, model.local_step = saved
         torch.cuda.synchronize()
         timers.enabled = False
-        traffic, traffic_source = load_pmc_traffic()
-        roofs = timers.summary(traffic)
-        for r in roofs:
-            r['traffic_source'] = (f'{traffic_source} (committed rocprofv3 --pmc pass of the same workload; not measured in this run)'
-                                   if r['traffic'] is not None else None)
+        if rank == 0:
+            traffic, traffic_source = load_pmc_traffic()
+            roofs = timers.summary(traffic)
+            for r in roofs:
+                r['traffic_source'] = (f'{traffic_source} (committed rocprofv3 --pmc pass of the same workload; not measured in this run)'
+                                       if r['traffic'] is not None else None)
+    if world > 1 and getattr(run.optimizer, 'shard', False):
+        run.optimizer.wait_shadows()
+        run.optimizer.gather_master()  # collective: every rank's fp32 master weights complete again (rank 0 renders with them below)
+        torch.cuda.synchronize()
 
     render = None
     if rank == 0 and not args.no_render:
@@ -418,7 +446,7 @@ def main():
             'config': {'workload': 'nerf_synthetic/lego-shaped --fp16 --cuda_ray --ff training step (hashgrid L=16 F=2 T=2^19, SH deg 4, '
                                    'FFMLP 64x2 / 64x3), bound=1, 128^3 occupancy grid, dt_gamma=0, max_steps=1024',
                        'rays_per_gpu_per_step': args.rays, 'samples_per_step_per_gpu': round(samples / args.steps / world, 1),
-                       'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}',
+                       'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}' + ('' if world == 1 else (' (all-reduce, replicated Adam)' if (args.replicated_optim or args.torch_optim) else ' (reduce-scatter, sharded Adam, all-gather of fp16 shadows)')),
                        'execution': run.execution(), 'setup_iterations_untimed': SETUP_ITERATIONS,
                        'captures_in_timed_region': res['captures'],
                        'autograd_free_iteration': bool(stepper.used_direct), 'fused_pipeline': bool(model.fused),

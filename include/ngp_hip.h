@@ -163,9 +163,11 @@ int ngp_compact_rays(const int32_t* rays_alive, uint32_t n_alive, int32_t* out_a
  * ffmlp            (reference: ffmlp/src/ffmlp.h:8-14, bindings.cpp:5-11)
  * All tensors fp16.  weights: flat [hidden*in] + (num_layers-1) x [hidden*hidden] + [output_dim*hidden],
  * each matrix row-major [out,in].  B must be a multiple of 128 (the wrapper pads), hidden_dim in
- * {16,32,64,128,256} is accepted by the reference; this library implements hidden_dim 64 and 32/16/128
- * through the same tiled kernel -- unsupported shapes return NGP_ERR_INVALID.
- * input_dim % 16 == 0, output_dim == 16 (padded by the wrapper), num_layers >= 2.
+ * {16,32,64,128,256}, input_dim % 16 == 0, output_dim == 16 (padded by the wrapper), num_layers >= 2 -- the reference's own
+ * constraints (ffmlp.py:112-115, ffmlp.cu:543-556,653-658).  Register-resident kernels serve hidden_dim <= 128 forward and the
+ * instant-ngp shapes backward (hidden 32/64, <= 4 hidden layers, input_dim <= 64); every other shape runs the layered kernels
+ * (one matmul's weights in LDS at a time).  The only shapes refused (NGP_ERR_INVALID) are those whose single largest
+ * layer exceeds the LDS: hidden_dim * max(input_dim, hidden_dim) * 2 bytes > 152 KiB, i.e. input_dim > 304 with 256-wide layers.
  * activation ids: 0 ReLU, 1 Exp, 2 Sine, 3 Sigmoid, 4 Squareplus, 5 Softplus, 6 None (utils.h:29-37).
  * --------------------------------------------------------------------------------------------- */
 
@@ -174,7 +176,7 @@ int ngp_compact_rays(const int32_t* rays_alive, uint32_t n_alive, int32_t* out_a
 int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                       uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                       void* forward_buffer, void* outputs, ngp_stream_t stream);
-/* replaces ffmlp_inference (ffmlp.cu:673-709): inference_buffer [B,hidden] is accepted and left untouched */
+/* replaces ffmlp_inference (ffmlp.cu:673-709): inference_buffer [B,hidden] is scratch (used by the layered kernel only) */
 int ngp_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim,
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, void* inference_buffer, void* outputs, ngp_stream_t stream);
@@ -228,6 +230,8 @@ int ngp_grid_encode_backward_ws(const void* grad, const float* inputs, const voi
 /* flags of the ffmlp *_ex entry points */
 #define NGP_FF_INPUT_PLANAR 1u /* inputs are [input_dim/2][B][2] fp16 planes = the grid encoder's [L,B,C=2] output */
 #define NGP_FF_DX_PLANAR 2u    /* grad_inputs is written in that planar layout = what grid_encode_backward reads */
+#define NGP_FF_LAYERED 4u      /* testing: force the layered kernels on shapes the register-resident ones would serve */
+#define NGP_FF_SINGLE_WAVE 8u  /* testing: backward with one wave per tile stream instead of the paired kernel (2- and 3-layer nets) */
 int ngp_ffmlp_forward_ex(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                          uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                          void* forward_buffer, void* outputs, uint32_t flags, ngp_stream_t stream);
@@ -239,6 +243,15 @@ int ngp_ffmlp_backward_ex(const void* grad, const void* inputs, const void* weig
                           uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
                           uint32_t activation, uint32_t output_activation, int calc_grad_inputs, void* backward_buffer,
                           void* grad_inputs, void* grad_weights, uint32_t flags, ngp_stream_t stream);
+
+/* ffmlp_backward with a caller-provided workspace (ngp_ffmlp_backward_workspace_bytes(...) bytes; 0 for the shapes served by the
+ * register-resident kernels): the layered path splits the batch reduction of the weight gradients over sample chunks and keeps one fp32
+ * slab per chunk there.  workspace == NULL: one chunk (same results to fp32 summation order, less parallelism). */
+size_t ngp_ffmlp_backward_workspace_bytes(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers);
+int ngp_ffmlp_backward_ws(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
+                          uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                          uint32_t output_activation, int calc_grad_inputs, void* backward_buffer, void* grad_inputs, void* grad_weights,
+                          uint32_t flags, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
 
 /* network_ff.py:55-72 between the two MLPs: h16 [M,16] fp16 (sigma-net output), dirs [M_valid,3] fp32 ->
  * sigma [M] fp32 = exp(h[:,0]) (trunc_exp), color_in [M,32] fp16 = [SH deg 4 | h[:,1:16] | 0]; rows >= M_valid use dir = 0 */
@@ -283,6 +296,24 @@ int ngp_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t* rays_ali
                       const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                       const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                       const float* noises, uint32_t zero_rows, ngp_stream_t stream);
+
+/* On-device inference loop: march_rays / composite_rays / alive-list compaction of NeRFRenderer.run_cuda's eval
+ * branch (renderer.py:322-367) with the loop state on the DEVICE: state = int32[2] {n_alive, samples marched per ray so far}.  The host
+ * launches for an upper bound `alive_bound` of the alive count (the value it last read back) and may issue many iterations between
+ * read-backs; the kernels take the true count from `state`, derive n_step = max(min(n_total / n_alive, 8), 1) from it (renderer.py:349),
+ * and do nothing for lanes beyond it.  march: sample rows [n_alive * n_step, rows) are zero-filled (rows >= min(n_total, 8 * alive_bound)
+ * always suffices); noises may be NULL.  compact: writes the surviving ids in order to out_alive and the next iteration's state to
+ * out_state (count forced to 0 once max_steps samples were marched); workspace: ngp_compact_rays_workspace_bytes(alive_bound).
+ * Slot layout, n_step sequence and compaction order equal the host-driven loop's, so do the results. */
+int ngp_march_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, const int32_t* rays_alive, const float* rays_t,
+                       const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                       const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                       const float* noises, uint32_t rows, ngp_stream_t stream);
+int ngp_composite_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, float T_thresh, int32_t* rays_alive, float* rays_t,
+                           const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image,
+                           ngp_stream_t stream);
+int ngp_compact_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t max_steps, const int32_t* rays_alive,
+                         int32_t* out_alive, int32_t* out_state, void* workspace, ngp_stream_t stream);
 
 /* composite_rays_train with NeRFRenderer.run_cuda's epilogue fused (renderer.py:316-318):
  *   image_out = image + (1 - weights_sum) * bg,  depth_out = clamp(depth - nears, 0) / (fars - nears)

@@ -293,40 +293,65 @@ class TorchNeRF(nn.Module):
         return groups
 
 
-def time_reference_cpu_path(n_rays=4096, num_steps=512, min_seconds=10.0, warmup=1, min_timed=3, max_timed=9, bound=1, threads=None, seed=0):
-    """Time full training steps of the pure-PyTorch path (forward through `run`, MSE loss, backward, Adam) on the host cores.
-    The reference's config-1 settings: num_steps = 512 uniform samples per ray, upsample_steps = 0 (main_nerf.py:29-30), fp32,
-    Adam lr 1e-2 betas (0.9, 0.99) eps 1e-15 (main_nerf.py:132); lego-shaped synthetic rays (the same generator as the GPU run).
-    samples/s = n_rays * num_steps / median step time.  returns dict(samples_per_s, median_step_s, steps, warmup, threads, ...)"""
+def _train_step(model, opt, n_rays, num_steps, seed):
     import synthetic_scene as sc
-    threads = int(threads or os.cpu_count() or 1)
+    o, d, gt = sc.training_batch(n_rays, seed=seed)
+    o, d, gt = torch.from_numpy(o)[None], torch.from_numpy(d)[None], torch.from_numpy(gt)
+    t0 = time.perf_counter()
+    opt.zero_grad(set_to_none=True)
+    out = model.render(o, d, staged=False, num_steps=num_steps, upsample_steps=0, bg_color=1, perturb=True)
+    loss = F.mse_loss(out['image'][0], gt)
+    loss.backward()
+    opt.step()
+    return time.perf_counter() - t0, float(loss.item())
+
+
+def usable_cores():
+    """cores this process may actually run on: the scheduler affinity mask capped by the cgroup CPU quota (a container on a 256-core host
+    often owns far fewer; an OpenMP pool sized by os.cpu_count() then spins against itself)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else int(os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(math.ceil(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
+def time_reference_cpu_path(n_rays=1024, num_steps=512, min_seconds=10.0, threads=None, bound=1, seed=0):
+    """Time full training steps of the pure-PyTorch path (forward through `run`, MSE loss, backward, Adam) on `threads` host cores
+    (default: usable_cores()).  The reference's config-1 settings: num_steps = 512 uniform samples per ray, upsample_steps = 0
+    (main_nerf.py:29-30), fp32, Adam lr 1e-2 betas (0.9, 0.99) eps 1e-15 (main_nerf.py:132); lego-shaped synthetic rays (the same
+    generator as the GPU run).  1 warm-up step, then steps until `min_seconds` have passed (at least 3, at most 7); samples/s = n_rays *
+    num_steps / median step time.  bench.py runs this in a SUBPROCESS with a timeout (python -m oracle.torch_cpu)."""
+    t_begin = time.perf_counter()
+    threads = int(threads or usable_cores())
     prev = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
         torch.manual_seed(seed)
         model = TorchNeRF(bound=bound).train()
         opt = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
-        times = []
-        k = 0
-        t_begin = time.perf_counter()
+        warm = _train_step(model, opt, n_rays, num_steps, 500)[0]
+        times, loss, k = [], float('nan'), 0
         while True:
-            o, d, gt = sc.training_batch(n_rays, seed=500 + k)
-            o, d, gt = torch.from_numpy(o)[None], torch.from_numpy(d)[None], torch.from_numpy(gt)
-            t0 = time.perf_counter()
-            opt.zero_grad(set_to_none=True)
-            out = model.render(o, d, staged=False, num_steps=num_steps, upsample_steps=0, bg_color=1, perturb=True)
-            loss = F.mse_loss(out['image'][0], gt)
-            loss.backward()
-            opt.step()
-            dt = time.perf_counter() - t0
-            if k >= warmup:
-                times.append(dt)
+            dt, loss = _train_step(model, opt, n_rays, num_steps, 501 + k)
+            times.append(dt)
             k += 1
-            timed = len(times)
-            if timed >= max_timed or (timed >= min_timed and time.perf_counter() - t_begin >= min_seconds):
+            if k >= 7 or (k >= 3 and time.perf_counter() - t_begin >= min_seconds):
                 break
         med = float(np.median(times))
-        return dict(samples_per_s=n_rays * num_steps / med, median_step_s=med, steps=len(times), warmup=warmup, threads=threads,
-                    num_steps=num_steps, samples_per_step=n_rays * num_steps, final_loss=float(loss.item()))
+        return dict(samples_per_s=n_rays * num_steps / med, median_step_s=med, steps=len(times), warmup=1, threads=threads, n_rays=n_rays,
+                    num_steps=num_steps, samples_per_step=n_rays * num_steps, final_loss=loss, host_cores=int(os.cpu_count() or 1),
+                    usable_cores=usable_cores(), first_step_s=warm, wall_s=time.perf_counter() - t_begin)
     finally:
         torch.set_num_threads(prev)
+
+
+if __name__ == '__main__':  # python -m oracle.torch_cpu <n_rays> <min_seconds> <threads>   -> one JSON line
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    n_rays, min_seconds, threads = int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3])
+    print(json.dumps(time_reference_cpu_path(n_rays=n_rays, min_seconds=min_seconds, threads=threads)))

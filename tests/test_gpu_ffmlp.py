@@ -32,12 +32,12 @@ def _run_forward(x, w, din, hid, nl, act=0, out_act=6, train=True):
     return out, None, xt, wt
 
 
-def _close_except_relu_flips(got, ref, tol):
+def _close_except_relu_flips(got, ref, tol, bulk=0.995):
     """dL/dx goes through ReLU masks taken from fp16 activations: a pre-activation within rounding distance of 0 may be
     masked on one side and not on the other, which changes single entries by a whole weight column.  Require the bulk to
     agree element-wise and the tensor to agree in norm."""
     ok = np.abs(got - ref) <= tol * np.abs(ref) + tol * np.abs(ref).max()
-    assert ok.mean() > 0.995, ok.mean()
+    assert ok.mean() > bulk, ok.mean()
     row_err = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1).mean()
     assert (row_err < 2 * tol).mean() > 0.99 and np.median(row_err) < tol
 
@@ -69,7 +69,7 @@ def test_forward_inference_backward(din, hid, nl, B):
     _be().ffmlp_backward(gt, xt, wt, fb, B, din, 16, hid, nl, 0, 6, True, bb, gi, gw)
     rgx, rgw = oracle.ffmlp_backward(g, x, w, rfb, din, 16, hid, nl)
     gx = gi.float().cpu().numpy()
-    _close_except_relu_flips(gx, rgx, 4e-3)
+    _close_except_relu_flips(gx, rgx, 4e-3, bulk=0.995 if nl <= 4 else 0.98)  # every extra ReLU layer adds mask flips
     gwn = gw.float().cpu().numpy()
     # weight gradients are sums over the batch: relative to the gradient scale of each matrix
     assert np.isfinite(gwn).all()
@@ -82,6 +82,58 @@ def test_forward_inference_backward(din, hid, nl, B):
     bb.zero_()
     _be().ffmlp_backward(gt, xt, wt, fb, B, din, 16, hid, nl, 0, 6, False, bb, dummy, gw2)
     assert torch.equal(gw2, gw) and dummy.item() == 0
+
+
+# every hidden width the reference accepts (ffmlp.py:112: 16, 32, 64, 128, 256), deeper stacks than the register-resident backward
+# holds (> 4 hidden layers) and inputs wider than 64: the layered kernels
+CFGS_LAYERED = [(32, 16, 2), (16, 16, 3), (32, 128, 2), (64, 128, 3), (32, 256, 2), (48, 256, 3), (32, 64, 6), (96, 64, 2), (32, 32, 8),
+                (128, 128, 2), (32, 128, 5)]
+
+
+@pytest.mark.parametrize('din,hid,nl', CFGS_LAYERED)
+@pytest.mark.parametrize('B', [128, 4224])
+def test_all_reference_shapes_forward_inference_backward(din, hid, nl, B):
+    test_forward_inference_backward(din, hid, nl, B)
+
+
+def test_layered_kernels_agree_with_register_resident_ones():
+    """NGP_FF_LAYERED forces the matmul-by-matmul kernels on an instant-ngp shape: forward and dL/dx run the same MFMA sequence per output
+    (bit-identical), the weight gradients differ only in the order the tiles are summed"""
+    import _ngp_capi as capi
+    rng = np.random.default_rng(5)
+    for din, hid, nl in ((32, 64, 2), (32, 64, 3), (16, 32, 2)):
+        B = 8192
+        n_params = hid * (din + hid * (nl - 1) + 16)
+        xt = cu16(rng.uniform(-1, 1, (B, din)))
+        wt = cu16(rng.uniform(-1, 1, n_params) * np.sqrt(3 / hid))
+        gt = cu16(rng.normal(size=(B, 16)) * 0.1)
+        st = capi.stream()
+        res = []
+        for flags in (0, capi.NGP_FF_LAYERED):
+            out = torch.empty(B, 16, device='cuda', dtype=torch.half)
+            fb = torch.empty(nl, B, hid, device='cuda', dtype=torch.half)
+            capi.check(capi.lib.ngp_ffmlp_forward_ex(xt.data_ptr(), wt.data_ptr(), B, din, 16, hid, nl, 0, 6, fb.data_ptr(), out.data_ptr(), flags, st))
+            out_i = torch.empty(B, 16, device='cuda', dtype=torch.half)
+            scratch = torch.empty(B, hid, device='cuda', dtype=torch.half)
+            capi.check(capi.lib.ngp_ffmlp_inference_ex(xt.data_ptr(), wt.data_ptr(), B, din, 16, hid, nl, 0, 6, scratch.data_ptr(), out_i.data_ptr(),
+                                                       flags, st))
+            assert torch.equal(out, out_i)
+            gi = torch.zeros(B, din, device='cuda', dtype=torch.half)
+            gw = torch.zeros(n_params, device='cuda', dtype=torch.half)
+            bb = torch.zeros(nl, B, hid, device='cuda', dtype=torch.half)
+            nbytes = 64 * n_params * 4
+            ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+            capi.check(capi.lib.ngp_ffmlp_backward_ws(gt.data_ptr(), xt.data_ptr(), wt.data_ptr(), fb.data_ptr(), B, din, 16, hid, nl, 0, 6, 1,
+                                                      bb.data_ptr(), gi.data_ptr(), gw.data_ptr(), flags, ws.data_ptr(), nbytes, st))
+            gw_nows = torch.zeros_like(gw)
+            if flags:  # without a workspace: one chunk, direct store -- same sums up to fp32 order
+                capi.check(capi.lib.ngp_ffmlp_backward_ws(gt.data_ptr(), xt.data_ptr(), wt.data_ptr(), fb.data_ptr(), B, din, 16, hid, nl, 0, 6, 1,
+                                                          bb.data_ptr(), gi.data_ptr(), gw_nows.data_ptr(), flags, None, 0, st))
+            res.append((out.clone(), fb.clone(), gi.clone(), gw.float().cpu().numpy(), gw_nows.float().cpu().numpy()))
+        a, b = res
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        scale = np.abs(a[3]).max()
+        assert np.abs(a[3] - b[3]).max() <= 2e-3 * scale and np.abs(b[4] - b[3]).max() <= 2e-3 * scale
 
 
 @pytest.mark.parametrize('din,hid,nl', [(64, 64, 4), (32, 64, 3)])
@@ -207,6 +259,8 @@ def test_bad_shapes_raise():
     h = lambda *s: torch.zeros(*s, device='cuda', dtype=torch.half)
     with pytest.raises(RuntimeError, match='hidden_dim'):
         be.ffmlp_forward(h(128, 32), h(100000), 128, 32, 16, 48, 2, 0, 6, h(2, 128, 48), h(128, 16))
+    with pytest.raises(RuntimeError, match='LDS'):  # the only shapes refused: a single layer larger than the LDS of a CU
+        be.ffmlp_forward(h(128, 512), h(256 * (512 + 256 + 16)), 128, 512, 16, 256, 2, 0, 6, h(2, 128, 256), h(128, 16))
     with pytest.raises(RuntimeError, match='Half'):
         be.ffmlp_forward(torch.zeros(128, 32, device='cuda'), h(7168), 128, 32, 16, 64, 2, 0, 6, h(2, 128, 64), h(128, 16))
     with pytest.raises(RuntimeError, match='128'):

@@ -77,7 +77,10 @@ def test_run_under_fp16_autocast_and_perturbation_statistics():
         torch.manual_seed(1)
         c = m.run(o, d, num_steps=64, upsample_steps=16, perturb=True)
     assert (a['image'].float() - b['image'].float()).abs().max() < 2e-2
-    assert torch.isfinite(c['image']).all() and c['image'].shape == (1, 256, 3) and c['depth'].min() >= 0 and c['depth'].max() <= 1
+    # rays that miss the box have near = far = FLT_MAX: their depth is 0/0 in the reference as well (renderer.py:232)
+    hit = torch.isfinite(c['depth'])
+    assert torch.isfinite(c['image']).all() and c['image'].shape == (1, 256, 3) and hit.float().mean() > 0.5
+    assert c['depth'][hit].min() >= 0 and c['depth'][hit].max() <= 1
 
 
 def test_cuda_ray_training_step_with_background_model_vs_oracle():

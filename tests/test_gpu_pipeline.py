@@ -71,6 +71,29 @@ def test_render_eval_image_matches_oracle_loop():
     np.testing.assert_allclose(out['image'][0].float().cpu().numpy(), ref['image'], rtol=0, atol=4e-3)
 
 
+@pytest.mark.parametrize('density_scale,perturb', [(1.0, False), (40.0, False), (300.0, True)])
+def test_on_device_render_loop_equals_host_driven_loop(density_scale, perturb):
+    """the eval loop with its state on the device (one read-back per batch of iterations) against the reference's host-driven loop (one
+    per iteration, renderer.py:341-367): same slots, same n_step sequence, same compaction order -> the same image, bit for bit"""
+    model, orc, bits, dev = _setup(emb_scale=0.5)
+    rng = np.random.default_rng(3)
+    pose = sc.camera_pose(rng)
+    pix = rng.integers(0, sc.RES * sc.RES, 5000)
+    o, d = sc.rays_for_pixels(pose, pix)
+    ot, dt_ = torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev)
+    model.eval()
+    model.density_scale = density_scale
+    res = []
+    for on_device in (True, False):
+        model.device_loop = on_device
+        torch.manual_seed(5)
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+            out = model.render(ot, dt_, staged=True, bg_color=1, perturb=perturb, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+        res.append((out['image'].clone(), out['depth'].clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float(res[0][0].std()) > 0
+
+
 def test_update_extra_state_and_training_loop_run():
     model, orc, bits, dev = _setup(emb_scale=1e-4)
     model.train()

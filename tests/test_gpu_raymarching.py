@@ -291,3 +291,40 @@ def test_marcher_survives_degenerate_rays():
     out = _rm().march_rays_train(cu(o), cu(d), 1.0, cu(bits), 1, 128, cu(nears), cu(fars), counter, -1, False, 128, False, 0, 1024)
     torch.cuda.synchronize()
     assert counter[1].item() == 3
+
+
+def test_time_indexed_bitfields_dnerf_layout():
+    """D-NeRF keeps one occupancy grid per time slot -- density_grid [T, cascade, H^3], density_bitfield [T, cascade*H^3/8]
+    (dnerf/renderer.py:91-95) -- packs every slot in place with `packbits(density_grid[t], thresh, density_bitfield[t])` (:546-547) and
+    marches against the row of the frame's time stamp, `density_bitfield[t]` (:285,295,362).  The operators take such row views as they
+    are (in-place writes into the parent buffer, storage offsets honoured); one flat call over all T slots packs the same bytes."""
+    rm = _rm()
+    T, C = 4, 2
+    rng = np.random.default_rng(12)
+    grids = np.stack([np.maximum(sc.occupancy_density(bound=2.0, cascade=C), np.where(rng.uniform(size=(C, 128 ** 3)) < 0.01 * (t + 1), 30.0, 0.0))
+                      for t in range(T)]).astype(np.float32)
+    density_grid = cu(grids)
+    bitfield = torch.zeros(T, C * 128 ** 3 // 8, dtype=torch.uint8, device='cuda')
+    for t in range(T):
+        row = rm.packbits(density_grid[t], 10.0, bitfield[t])
+        assert row.data_ptr() == bitfield[t].data_ptr()
+        assert np.array_equal(bitfield[t].cpu().numpy(), oracle.packbits(grids[t], 10.0))
+    flat = torch.zeros_like(bitfield)
+    rm.packbits(density_grid.view(-1), 10.0, flat.view(-1))
+    assert torch.equal(flat, bitfield)
+    o, d = _random_rays(1024, 5, radius=3.0)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = rm.near_far_from_aabb(cu(o), cu(d), cu(aabb), 0.2)
+    counts = []
+    for t in range(T):
+        time_stamp = torch.tensor([[(t + 0.5) / T]], device='cuda')
+        slot = torch.floor(time_stamp[0][0] * T).clamp(min=0, max=T - 1).long()   # dnerf/renderer.py:285
+        counter = torch.zeros(2, dtype=torch.int32, device='cuda')
+        xyzs, dirs, deltas, rays = rm.march_rays_train(cu(o), cu(d), 2.0, bitfield[slot], C, 128, nears, fars, counter, 0, False, 128, True, 1 / 128, 1024)
+        ref = oracle.march_rays_train(o, d, 2.0, oracle.packbits(grids[t], 10.0), C, 128, nears.cpu().numpy(), fars.cpu().numpy(),
+                                      np.zeros(1024, np.float32), dt_gamma=1 / 128)
+        assert counter.cpu().numpy().tolist() == ref[4].tolist()
+        m = int(ref[4][0])
+        assert np.array_equal(xyzs[:m].cpu().numpy(), ref[0][:m]) and np.array_equal(rays.cpu().numpy(), ref[3])
+        counts.append(m)
+    assert len(set(counts)) == T  # every time slot really has its own occupancy

@@ -44,9 +44,10 @@ def test_marcher_bit_exact_vs_reference_kernel_vectors(golden_dir, tag):
     rays = torch.zeros(N, 3, dtype=torch.int32, device='cuda')
     counter = torch.zeros(2, dtype=torch.int32, device='cuda')
     ws = torch.empty(capi.lib.ngp_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device='cuda')
+    tz = cu(z[f'{tag}_noises'])
     capi.check(capi.lib.ngp_march_rays_train(o.data_ptr(), d.data_ptr(), bits.data_ptr(), bound, dt_gamma, 1024, N, cascade, 128, M, nears.data_ptr(),
                                              fars.data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(),
-                                             cu(z[f'{tag}_noises']).data_ptr(), ws.data_ptr(), capi.stream()))
+                                             tz.data_ptr(), ws.data_ptr(), capi.stream()))
     m = int(z[f'{tag}_counter'][0])
     assert counter.cpu().numpy().tolist() == z[f'{tag}_counter'].tolist()
     assert np.array_equal(rays.cpu().numpy(), z[f'{tag}_rays'])
@@ -144,9 +145,10 @@ def test_marcher_bit_exact_vs_live_reference_kernels_full_batch():
     rays = torch.zeros(N, 3, dtype=torch.int32, device='cuda')
     counter = torch.zeros(2, dtype=torch.int32, device='cuda')
     ws = torch.empty(capi.lib.ngp_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device='cuda')
-    capi.check(capi.lib.ngp_march_rays_train(cu(o).data_ptr(), cu(d).data_ptr(), bits.data_ptr(), 1.0, 0.0, 1024, N, 1, 128, M, cu(nears).data_ptr(),
-                                             cu(fars).data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(),
-                                             cu(noises).data_ptr(), ws.data_ptr(), capi.stream()))
+    to, td, tn, tf, tz = cu(o), cu(d), cu(nears), cu(fars), cu(noises)  # kept alive across the launch
+    capi.check(capi.lib.ngp_march_rays_train(to.data_ptr(), td.data_ptr(), bits.data_ptr(), 1.0, 0.0, 1024, N, 1, 128, M, tn.data_ptr(),
+                                             tf.data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(),
+                                             tz.data_ptr(), ws.data_ptr(), capi.stream()))
     m = int(rcnt[0])
     assert counter.cpu().numpy().tolist() == rcnt.tolist() and m > 200000
     assert np.array_equal(rays.cpu().numpy(), rrays)

@@ -91,16 +91,22 @@ def build_side(side):
     sys.modules['refnerf'] = ref_pkg
     _stub('refnerf.utils', custom_meshgrid=lambda *a: torch.meshgrid(*a, indexing='ij'))
     net = importlib.import_module('refnerf.network_ff')
-    for name in ('refnerf.network_ff', 'refnerf.renderer', 'gridencoder', 'shencoder', 'raymarching', 'ffmlp', 'encoding', 'activation'):
-        where[name] = getattr(sys.modules.get(name), '__file__', None)
-    if side == 'reference-all':
-        for name in ('gridencoder', 'ffmlp', 'raymarching', 'shencoder', 'encoding', 'activation'):
-            assert where[name].startswith(STAGE), (name, where[name])
-    else:
-        for name in ('gridencoder', 'ffmlp', 'raymarching', 'shencoder', 'encoding', 'activation'):
-            assert where[name].startswith(PKG), (name, where[name])
-    assert where['refnerf.network_ff'].startswith(STAGE) and where['refnerf.renderer'].startswith(STAGE)
+    assert net.__file__.startswith(STAGE) and sys.modules['refnerf.renderer'].__file__.startswith(STAGE)
     return net.NeRFNetwork, where
+
+
+def imported_from(side, where):
+    """after the model exists (the encoders are imported lazily by get_encoder): where every module of the path came from"""
+    for name in ('refnerf.network_ff', 'refnerf.renderer', 'nerf.network_ff', 'nerf.renderer', 'gridencoder', 'shencoder', 'raymarching', 'ffmlp',
+                 'encoding', 'activation'):
+        f = getattr(sys.modules.get(name), '__file__', None)
+        if f is not None:
+            where[name] = f
+    if side != 'mirror':
+        home = STAGE if side == 'reference-all' else PKG
+        for name in ('gridencoder', 'ffmlp', 'raymarching', 'shencoder', 'encoding', 'activation'):
+            assert where[name].startswith(home), (name, where[name])
+    return where
 
 
 def run_side(side, out_path, steps=20, n_rays=4096):
@@ -112,6 +118,7 @@ def run_side(side, out_path, steps=20, n_rays=4096):
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     model = Net(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
+    where = imported_from(side, where)
     if hasattr(model, 'fused'):
         model.fused = False  # the mirror's module-by-module path: the same call sequence as the reference's network_ff.forward
     # identical, seeded parameters on every side (FFMLP reseeds to 42 itself; the table gets values large enough to matter)
@@ -191,14 +198,26 @@ def compare(a_path, b_path, report_path=None):
             # (nerf/renderer.py refresh_occupancy): same distribution, different draws -- compared only between the reference sides
             rows.append({'key': k, 'check': 'skipped (mirror draws the refreshed cells differently)', 'ok': True})
             continue
-        exact = k.startswith(('counter_', 'bits_after', 'mean_count'))
+        if k.startswith(('grid_after', 'bits_after')):
+            # the refresh writes `tmp_grid[cas, indices] = sigmas` with REPEATED indices (random cells, drawn with replacement,
+            # renderer.py:488-520): which duplicate wins is not defined on a GPU, so two runs of the same code differ in those cells
+            same = float((x == y).mean())
+            rows.append({'key': k, 'check': 'fraction of identical cells (duplicate-index scatter is order-dependent)', 'value': 1.0 - same,
+                         'ok': same > 0.97})
+            ok = ok and same > 0.97
+            continue
+        exact = k.startswith(('counter_', 'mean_count'))
         if exact:
             good = bool(np.array_equal(x, y))
             rows.append({'key': k, 'check': 'bit-exact', 'ok': good})
         else:
             x64, y64 = x.astype(np.float64), y.astype(np.float64)
+            both_nan = np.isnan(x64) & np.isnan(y64)   # rays that miss the box: depth = 0/0 on every side (renderer.py:317)
+            x64, y64 = np.where(both_nan, 0.0, x64), np.where(both_nan, 0.0, y64)
             denom = max(np.abs(y64).max(), 1e-30)
             err = float(np.abs(x64 - y64).max() / denom)
+            if not np.isfinite(err):
+                err = float('inf')
             # both sides run the SAME kernels on the same inputs: identical up to the order of the atomic-free / atomic scatter;
             # 1e-3 of the tensor's range is the north-star's fp16 bar
             good = err <= 1e-3

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libngp_hip.so')
 
 NGP_F32, NGP_F16 = 0, 1
-NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR = 1, 2
+NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR, NGP_FF_LAYERED, NGP_FF_SINGLE_WAVE = 1, 2, 4, 8
 NGP_MARCH_RESET_COUNTER, NGP_MARCH_ZERO_TAIL, NGP_MARCH_NOISE_FROM_SEED = 1, 2, 4
 NGP_OPT_PHASE_CHECK, NGP_OPT_PHASE_UPDATE, NGP_OPT_PHASE_COMMIT = 1, 2, 4
 ABI_VERSION = 4
@@ -56,6 +56,9 @@ _SIGNATURES = {
     'ngp_march_rays_ex': [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     'ngp_composite_rays': [_u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_compact_rays': [_vp, _u32, _vp, _vp, _vp, _vp],
+    'ngp_march_rays_dev': [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    'ngp_composite_rays_dev': [_vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'ngp_compact_rays_dev': [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp],
     'ngp_ffmlp_forward': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     'ngp_ffmlp_inference': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     'ngp_ffmlp_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
@@ -66,6 +69,7 @@ _SIGNATURES = {
     'ngp_ffmlp_forward_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_inference_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_backward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp],
+    'ngp_ffmlp_backward_ws': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp, _sz, _vp],
     'ngp_pipeline_mid_forward': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp],
     'ngp_pipeline_rgb_forward': [_vp, _vp, _u32, _vp],
     'ngp_pipeline_rgb_backward': [_vp, _vp, _vp, _u32, _vp],
@@ -91,6 +95,8 @@ lib.ngp_abi_version.restype = ctypes.c_int
 lib.ngp_march_rays_train_workspace_bytes.argtypes = [_u32]
 lib.ngp_march_rays_train_workspace_bytes.restype = _sz
 lib.ngp_compact_rays_workspace_bytes.argtypes = [_u32]
+lib.ngp_ffmlp_backward_workspace_bytes.argtypes = [_u32, _u32, _u32, _u32]
+lib.ngp_ffmlp_backward_workspace_bytes.restype = _sz
 lib.ngp_grid_backward_workspace_bytes.argtypes = [_vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _i32]
 lib.ngp_grid_backward_workspace_bytes.restype = _sz
 lib.ngp_compact_rays_workspace_bytes.restype = _sz
@@ -100,7 +106,7 @@ if lib.ngp_abi_version() != ABI_VERSION:
 
 EXPORTED = sorted(list(_SIGNATURES) + ['ngp_last_error', 'ngp_target_arch', 'ngp_abi_version',
                                        'ngp_march_rays_train_workspace_bytes', 'ngp_compact_rays_workspace_bytes',
-                                       'ngp_grid_backward_workspace_bytes'])
+                                       'ngp_grid_backward_workspace_bytes', 'ngp_ffmlp_backward_workspace_bytes'])
 
 
 def check(rc):

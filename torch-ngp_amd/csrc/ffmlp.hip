@@ -90,8 +90,8 @@ __device__ __host__ __forceinline__ int acc_row(int ib, int h, int r) { return 3
 // ------------------------------------------------------------------------------------------------
 template <int WIDTH>
 struct Shape {
-    static constexpr int NIB = WIDTH / 32;  // 32-row output blocks of a hidden layer
-    static constexpr int NKB = WIDTH / 16;  // 16-wide k blocks of a hidden operand
+    static constexpr int NIB = (WIDTH + 31) / 32;  // 32-row output blocks of a hidden layer (WIDTH = 16: one block, rows 16..31 zero)
+    static constexpr int NKB = (WIDTH + 15) / 16;  // 16-wide k blocks of a hidden operand
 };
 
 template <int WIDTH>
@@ -116,6 +116,7 @@ __device__ __forceinline__ void forward_fragment_source(uint32_t e, const half_t
     uint32_t f = frag;
     if (f < NIB * in_kb) {  // input layer: natural k order, slot (kb,h,j) = input feature 16kb + 8h + j
         const uint32_t ib = f / in_kb, kb = f % in_kb;
+        if (32 * ib + i >= (uint32_t)WIDTH) { lo = hi = nullptr; return; }  // WIDTH = 16: rows 16..31 of the block are zero
         lo = w + (size_t)(32 * ib + i) * in_dim + 16 * kb + 8 * h;
         hi = lo + 4;
         return;
@@ -125,6 +126,7 @@ __device__ __forceinline__ void forward_fragment_source(uint32_t e, const half_t
     if (f < (num_layers - 1) * NIB * NKB) {  // hidden layer
         const uint32_t l = f / (NIB * NKB), rem = f % (NIB * NKB);
         const uint32_t ib = rem / NKB, kb = rem % NKB;
+        if (32 * ib + i >= (uint32_t)WIDTH) { lo = hi = nullptr; return; }
         const half_t* row = base + (size_t)l * WIDTH * WIDTH + (size_t)(32 * ib + i) * WIDTH;
         lo = row + 16 * kb + 4 * h;
         hi = lo + 8;
@@ -137,9 +139,13 @@ __device__ __forceinline__ void forward_fragment_source(uint32_t e, const half_t
     hi = i < 16 ? lo + 8 : nullptr;
 }
 
+// fragments [first_frag, first_frag + n_frags) of the image order land at img[0 ...] (default: the whole image)
 template <int WIDTH>
-__device__ void build_forward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers) {
-    const uint32_t total = fwd_frag_count<WIDTH>(in_dim, num_layers) * 64;
+__device__ void build_forward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers, uint32_t first_frag = 0,
+                                    uint32_t n_frags = 0xFFFFFFFFu) {
+    const uint32_t all = fwd_frag_count<WIDTH>(in_dim, num_layers);
+    const uint32_t total = (n_frags == 0xFFFFFFFFu ? all : n_frags) * 64;
+    const uint32_t shift = first_frag * 64;
     for (uint32_t e0 = threadIdx.x; e0 < total; e0 += IMG_BATCH * blockDim.x) {
         half4_t lo[IMG_BATCH], hi[IMG_BATCH];
         bool real[IMG_BATCH];
@@ -147,7 +153,7 @@ __device__ void build_forward_image(half8_t* img, const half_t* __restrict__ w, 
         for (int b = 0; b < IMG_BATCH; b++) {
             const uint32_t e = e0 + b * blockDim.x;
             const half_t *pl = nullptr, *ph = nullptr;
-            if (e < total) forward_fragment_source<WIDTH>(e, w, in_dim, num_layers, pl, ph);
+            if (e < total) forward_fragment_source<WIDTH>(e + shift, w, in_dim, num_layers, pl, ph);
             real[b] = pl != nullptr;
             lo[b] = *reinterpret_cast<const half4_t*>(pl ? pl : w);
             hi[b] = *reinterpret_cast<const half4_t*>(ph ? ph : w);
@@ -196,11 +202,14 @@ __device__ __forceinline__ half8_t load_features8(const half_t* __restrict__ inp
 // forward / inference
 // ------------------------------------------------------------------------------------------------
 template <int WIDTH, bool TRAIN, bool PLAIN /* ReLU hidden layers, no output activation: the only case FFMLP produces (ffmlp.py:107) */>
-__global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ffmlp_forward(const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
-                                                              half_t* __restrict__ forward_buffer, half_t* __restrict__ outputs,
-                                                              uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
-                                                              uint32_t out_act, bool in_planar, uint32_t diag) {
-    // (diag: timing experiments of tools/bench_kernels.py -- bit 0: no activation/output stores, bit 1: no input loads)
+__device__ __forceinline__ void ffmlp_forward_body(const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
+                                                   half_t* __restrict__ forward_buffer, half_t* __restrict__ outputs, uint32_t n_tiles,
+                                                   uint32_t in_dim, uint32_t num_layers, uint32_t act, uint32_t out_act, bool in_planar) {
+#ifdef NGP_FF_DIAG  // timing experiments of tools/bench_kernels.py (compile-time only) -- bit 0: no activation/output stores, bit 1: no input loads
+    const uint32_t diag = NGP_FF_DIAG;
+#else
+    constexpr uint32_t diag = 0u;
+#endif
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img = reinterpret_cast<half8_t*>(smem);
@@ -273,6 +282,21 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
 }
 
+// widths <= 64: four waves per SIMD without AGPR copies (<= 128 registers); 128-wide layers keep 64 accumulators + 32 operand registers
+// per lane and run two waves per SIMD
+template <int WIDTH, bool TRAIN, bool PLAIN>
+__global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ffmlp_forward(
+    const half_t* __restrict__ inputs, const half_t* __restrict__ weights, half_t* __restrict__ forward_buffer, half_t* __restrict__ outputs,
+    uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act, uint32_t out_act, bool in_planar) {
+    ffmlp_forward_body<WIDTH, TRAIN, PLAIN>(inputs, weights, forward_buffer, outputs, n_tiles, in_dim, num_layers, act, out_act, in_planar);
+}
+template <int WIDTH, bool TRAIN, bool PLAIN>
+__global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ffmlp_forward_wide(
+    const half_t* __restrict__ inputs, const half_t* __restrict__ weights, half_t* __restrict__ forward_buffer, half_t* __restrict__ outputs,
+    uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act, uint32_t out_act, bool in_planar) {
+    ffmlp_forward_body<WIDTH, TRAIN, PLAIN>(inputs, weights, forward_buffer, outputs, n_tiles, in_dim, num_layers, act, out_act, in_planar);
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -298,14 +322,14 @@ __device__ __forceinline__ void backward_fragment_source(uint32_t e, const half_
     const int i = lane & 31, h = lane >> 5;
     uint32_t f = frag;
     if (f < NIB) {  // W_out^T: rows 8h + j
-        src = w_out + (size_t)(8 * h) * WIDTH + (32 * f + i);
+        src = 32 * f + i < (uint32_t)WIDTH ? w_out + (size_t)(8 * h) * WIDTH + (32 * f + i) : nullptr;
         stride = WIDTH;
         slot_order = false;
     } else if ((f -= NIB) < (num_layers - 1) * NIB * NKB) {
         const uint32_t li = f / (NIB * NKB), rem = f % (NIB * NKB);  // li = 0 -> layer NL-1
         const uint32_t ib = rem / NKB, kb = rem % NKB;
         const half_t* wl = w_hid + (size_t)(num_layers - 2 - li) * WIDTH * WIDTH;
-        src = wl + (size_t)slot_feature(kb, h, 0) * WIDTH + (32 * ib + i);
+        src = 32 * ib + i < (uint32_t)WIDTH ? wl + (size_t)slot_feature(kb, h, 0) * WIDTH + (32 * ib + i) : nullptr;
         stride = WIDTH;
         slot_order = true;
     } else {
@@ -319,9 +343,11 @@ __device__ __forceinline__ void backward_fragment_source(uint32_t e, const half_
 }
 
 template <int WIDTH>
-__device__ void build_backward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers, bool with_dx) {
+__device__ void build_backward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers, bool with_dx,
+                                     uint32_t first_frag = 0, uint32_t n_frags = 0xFFFFFFFFu) {
     constexpr int BATCH = 3;  // x 8 two-byte gathers per fragment element, all in flight before the first store
-    const uint32_t total = bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx) * 64;
+    const uint32_t total = (n_frags == 0xFFFFFFFFu ? bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx) : n_frags) * 64;
+    const uint32_t shift = first_frag * 64;
     for (uint32_t e0 = threadIdx.x; e0 < total; e0 += BATCH * blockDim.x) {
         half_t v[BATCH][8];
         bool real[BATCH];
@@ -331,7 +357,7 @@ __device__ void build_backward_image(half8_t* img, const half_t* __restrict__ w,
             const half_t* src = nullptr;
             uint32_t stride = 0;
             bool slot_order = false;
-            if (e < total) backward_fragment_source<WIDTH>(e, w, in_dim, num_layers, src, stride, slot_order);
+            if (e < total) backward_fragment_source<WIDTH>(e + shift, w, in_dim, num_layers, src, stride, slot_order);
             real[b] = src != nullptr;
             const half_t* p = src ? src : w;
             const uint32_t st = src ? stride : 0u;
@@ -403,7 +429,7 @@ __device__ __forceinline__ void transpose_hidden(const half8_t (&v)[Shape<WIDTH>
 #pragma unroll
     for (int ib = 0; ib < Shape<WIDTH>::NIB; ib++) {
         float16_t t = mfma(v[2 * ib], sel.hid[0], zero16());
-        t = mfma(v[2 * ib + 1], sel.hid[1], t);
+        if constexpr (Shape<WIDTH>::NKB > 1) t = mfma(v[2 * ib + 1], sel.hid[1], t);
         pack_transposed(t, out[ib]);
     }
 }
@@ -497,7 +523,12 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
                                                                const half_t* __restrict__ weights, const half_t* __restrict__ forward_buffer,
                                                                uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
                                                                bool with_dx, half_t* __restrict__ grad_inputs, float* __restrict__ slabs,
-                                                               half_t* __restrict__ grad_weights_direct, bool in_planar, bool dx_planar, uint32_t pf_depth, uint32_t diag) {
+                                                               half_t* __restrict__ grad_weights_direct, bool in_planar, bool dx_planar, uint32_t pf_depth) {
+#ifdef NGP_FF_BWD_DIAG  // timing experiments (compile-time only): 1 = no loads after the first tile, 2 = loads only
+    constexpr uint32_t diag = NGP_FF_BWD_DIAG;
+#else
+    constexpr uint32_t diag = 0u;
+#endif
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img = reinterpret_cast<half8_t*>(smem);
@@ -546,7 +577,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
     for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += tile_step) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's operands have landed in buffer `cur`
         const unsigned char* tb = pf_base + (size_t)cur * tile_frags * 1024;
-        if (pf_depth > 1 && diag != 1u) {  // (diag: timing experiments of tools/bench_kernels.py -- 1 = no loads after the first tile, 2 = loads only)
+        if (pf_depth > 1 && diag != 1u) {
             cur ^= 1u;
             if (tile + tile_step < n_tiles)
                 prefetch_tile<WIDTH>(pf_base + (size_t)cur * tile_frags * 1024, tile + tile_step, grad, fb, inputs, num_layers, layer_stride,
@@ -971,6 +1002,279 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LAYERED kernels: every shape the reference's API accepts beyond the register-resident fast paths above -- hidden_dim 16 / 128 /
+// 256, more than 4 hidden layers, wide inputs (ffmlp.py:112-115, ffmlp.cu:543-556,653-658,830-835).
+// A 256-wide layer is 128 KiB of fp16 weights: only ONE matmul's fragment image fits the 160 KiB LDS.  So the loops are turned inside
+// out: a workgroup walks the network matmul by matmul, keeps that matmul's image in LDS, and pushes all of ITS tiles through it; the
+// activations between matmuls travel through the caller's buffers in the private fragment order (forward_buffer in training -- it
+// has to be written anyway --, the reference's inference_buffer [B, hidden] in place otherwise; backward_buffer holds the dZ of every
+// layer, exactly what the reference keeps there).  A wave re-reads only fragments it wrote itself, a __threadfence() between passes
+// orders them.  The weight gradients are their own kernel (k_ffmlp_wgrad): one workgroup per (matmul, 32-row block, 8 column
+// blocks, sample chunk), operands transposed on the matrix core as in the fast kernel, per-chunk fp32 slabs in a caller-provided
+// workspace summed in a fixed order (k_ffmlp_reduce_slabs) -- or, without a workspace, one chunk and a direct store.  Deterministic.
+// ------------------------------------------------------------------------------------------------
+template <int WIDTH>
+__device__ __forceinline__ void fwd_matmul_range(uint32_t m, uint32_t in_dim, uint32_t num_layers, uint32_t& first, uint32_t& count) {
+    constexpr uint32_t NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    const uint32_t in_kb = in_dim / 16;
+    if (m == 0) { first = 0; count = NIB * in_kb; }
+    else if (m < num_layers) { first = NIB * in_kb + (m - 1) * NIB * NKB; count = NIB * NKB; }
+    else { first = NIB * in_kb + (num_layers - 1) * NIB * NKB; count = NKB; }
+}
+
+template <int WIDTH, bool TRAIN>
+__global__ __launch_bounds__(FF_THREADS) void k_ffmlp_forward_layered(const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
+                                                                      half_t* __restrict__ buffer, half_t* __restrict__ outputs, uint32_t n_tiles,
+                                                                      uint32_t in_dim, uint32_t num_layers, uint32_t act, uint32_t out_act,
+                                                                      bool in_planar) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8_t* img = reinterpret_cast<half8_t*>(smem);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const uint32_t in_kb = in_dim / 16;
+    const size_t rows = (size_t)n_tiles * FF_TILE;
+    const size_t layer_stride = (size_t)n_tiles * NKB * 64;  // half8 units
+    half8_t* buf = reinterpret_cast<half8_t*>(buffer);
+    const half8_t* a = img + lane;
+    for (uint32_t m = 0; m <= num_layers; m++) {
+        uint32_t first, count;
+        fwd_matmul_range<WIDTH>(m, in_dim, num_layers, first, count);
+        __syncthreads();  // the previous matmul's readers are done with the image
+        build_forward_image<WIDTH>(img, weights, in_dim, num_layers, first, count);
+        __syncthreads();
+        for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += gridDim.x * FF_WAVES) {
+                const half8_t* src = buf + (TRAIN ? (size_t)(m ? m - 1 : 0) * layer_stride : 0) + (size_t)tile * NKB * 64 + lane;  // m >= 1 only
+            if (m == num_layers) {  // output layer: one 32-row block, rows 0..15 real
+                float16_t o = zero16();
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) o = mfma(a[kb * 64], src[kb * 64], o);
+                half4_t lo, hi;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    lo[c] = (half_t)act_forward(out_act, o[c]);
+                    hi[c] = (half_t)act_forward(out_act, o[4 + c]);
+                }
+                half_t* orow = outputs + ((size_t)tile * FF_TILE + n) * 16 + 4 * h;
+                *reinterpret_cast<half4_t*>(orow) = lo;
+                *reinterpret_cast<half4_t*>(orow + 8) = hi;
+                continue;
+            }
+            float16_t acc[NIB];
+#pragma unroll
+            for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
+            if (m == 0) {
+                const size_t srow = (size_t)tile * FF_TILE + n;
+                for (uint32_t kb = 0; kb < in_kb; kb++) {
+                    const half8_t x = load_features8(inputs, in_planar, rows, srow, in_dim, 16 * kb + 8 * h);
+#pragma unroll
+                    for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(a[(ib * in_kb + kb) * 64], x, acc[ib]);
+                }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) {
+                    const half8_t hk = src[kb * 64];
+#pragma unroll
+                    for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(a[(ib * NKB + kb) * 64], hk, acc[ib]);
+                }
+            }
+            half8_t* dst = buf + (TRAIN ? (size_t)m * layer_stride : 0) + (size_t)tile * NKB * 64 + lane;
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++) {
+                half8_t f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) f[j] = (half_t)act_forward(act, acc[kb >> 1][(kb & 1) * 8 + j]);
+                dst[kb * 64] = f;
+            }
+        }
+        __threadfence();
+    }
+}
+
+template <int WIDTH, bool RELU>
+__global__ __launch_bounds__(FF_THREADS) void k_ffmlp_dgrad_layered(const half_t* __restrict__ grad, const half_t* __restrict__ weights,
+                                                                    const half_t* __restrict__ forward_buffer, half_t* __restrict__ backward_buffer,
+                                                                    uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act, bool with_dx,
+                                                                    half_t* __restrict__ grad_inputs, bool dx_planar) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8_t* img = reinterpret_cast<half8_t*>(smem);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const size_t rows = (size_t)n_tiles * FF_TILE;
+    const size_t layer_stride = (size_t)n_tiles * NKB * 64;
+    const half8_t* fb = reinterpret_cast<const half8_t*>(forward_buffer);
+    half8_t* bb = reinterpret_cast<half8_t*>(backward_buffer);
+    const half8_t* a = img + lane;
+    const uint32_t in_jb = (in_dim + 31) / 32;
+    const uint32_t passes = num_layers + (with_dx ? 1u : 0u);
+    // pass 0: W_out^T . dY -> dZ of the top hidden layer; pass p (1..nl-1): W_h[nl-p]^T . dZ_{nl-p} -> dZ_{nl-1-p}; pass nl: W_in^T . dZ_0 -> dX
+    for (uint32_t p = 0; p < passes; p++) {
+        uint32_t first, count;
+        if (p == 0) { first = 0; count = NIB; }
+        else if (p < num_layers) { first = NIB + (p - 1) * NIB * NKB; count = NIB * NKB; }
+        else { first = NIB + (num_layers - 1) * NIB * NKB; count = in_jb * NKB; }
+        __syncthreads();
+        build_backward_image<WIDTH>(img, weights, in_dim, num_layers, with_dx, first, count);
+        __syncthreads();
+        for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += gridDim.x * FF_WAVES) {
+            const size_t srow = (size_t)tile * FF_TILE + n;
+            const half8_t* src = bb + (size_t)(p ? num_layers - p : 0) * layer_stride + (size_t)tile * NKB * 64 + lane;  // dZ of layer nl-p (p >= 1)
+            if (p == num_layers) {
+                for (uint32_t ib = 0; ib < in_jb; ib++) {
+                    float16_t dx = zero16();
+#pragma unroll
+                    for (int kb = 0; kb < NKB; kb++) dx = mfma(a[(ib * NKB + kb) * 64], src[kb * 64], dx);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t f0 = 32 * ib + 8 * q + 4 * h;
+                        if (f0 < in_dim) {
+                            if (dx_planar) {
+                                const half2_t lo = {(half_t)dx[4 * q], (half_t)dx[4 * q + 1]}, hi = {(half_t)dx[4 * q + 2], (half_t)dx[4 * q + 3]};
+                                *reinterpret_cast<half2_t*>(grad_inputs + ((size_t)(f0 / 2) * rows + srow) * 2) = lo;
+                                *reinterpret_cast<half2_t*>(grad_inputs + ((size_t)(f0 / 2 + 1) * rows + srow) * 2) = hi;
+                            } else {
+                                half4_t v = {(half_t)dx[4 * q], (half_t)dx[4 * q + 1], (half_t)dx[4 * q + 2], (half_t)dx[4 * q + 3]};
+                                *reinterpret_cast<half4_t*>(grad_inputs + srow * in_dim + f0) = v;
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
+            float16_t acc[NIB];
+            if (p == 0) {
+                const half8_t dy = *reinterpret_cast<const half8_t*>(grad + srow * 16 + 8 * h);
+#pragma unroll
+                for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(a[ib * 64], dy, zero16());
+            } else {
+#pragma unroll
+                for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
+#pragma unroll
+                for (int kb = 0; kb < NKB; kb++) {
+                    const half8_t d = src[kb * 64];
+#pragma unroll
+                    for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(a[(ib * NKB + kb) * 64], d, acc[ib]);
+                }
+            }
+            const uint32_t target = num_layers - 1 - p;
+            const half8_t* post = fb + (size_t)target * layer_stride + (size_t)tile * NKB * 64 + lane;
+            half8_t* dst = bb + (size_t)target * layer_stride + (size_t)tile * NKB * 64 + lane;
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++) {
+                const half8_t y = post[kb * 64];
+                half8_t dz;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float g = acc[kb >> 1][(kb & 1) * 8 + j];
+                    dz[j] = RELU ? ((float)y[j] > 0.0f ? (half_t)g : (half_t)0.0f) : (half_t)(g * act_backward_factor_slow(act, (float)y[j]));
+                }
+                dst[kb * 64] = dz;
+            }
+        }
+        __threadfence();
+    }
+}
+
+// weight gradients of the layered path.  job = (matmul m, 32-row block ib, group of WG_NJB column blocks); blockIdx.x = sample chunk.
+constexpr int WG_NJB = 8;
+__host__ __device__ inline uint32_t wgrad_jobs_of(uint32_t row_blocks, uint32_t col_blocks) { return row_blocks * ((col_blocks + WG_NJB - 1) / WG_NJB); }
+
+template <int WIDTH>
+__global__ __launch_bounds__(FF_THREADS) void k_ffmlp_wgrad(const half_t* __restrict__ grad, const half_t* __restrict__ inputs,
+                                                            const half_t* __restrict__ forward_buffer, const half_t* __restrict__ backward_buffer,
+                                                            uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, bool in_planar,
+                                                            uint32_t tiles_per_chunk, float* __restrict__ slabs,
+                                                            half_t* __restrict__ grad_weights_direct) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    __shared__ float red[32][WG_NJB * 32];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const Selectors sel = make_selectors(n, h);
+    const uint32_t in_kb = in_dim / 16, in_jb = (in_dim + 31) / 32;
+    // decode the job
+    uint32_t job = blockIdx.y, m = 0, row_blocks = NIB, col_blocks = in_jb;
+    for (;; m++) {
+        row_blocks = m == num_layers ? 1u : (uint32_t)NIB;
+        col_blocks = m == 0 ? in_jb : (uint32_t)NIB;
+        const uint32_t jobs = wgrad_jobs_of(row_blocks, col_blocks);
+        if (job < jobs) break;
+        job -= jobs;
+    }
+    const uint32_t groups = (col_blocks + WG_NJB - 1) / WG_NJB;
+    const uint32_t ib = job / groups, jg = job % groups;
+    const size_t rows = (size_t)n_tiles * FF_TILE;
+    const size_t layer_stride = (size_t)n_tiles * NKB * 64;
+    const half8_t* fb = reinterpret_cast<const half8_t*>(forward_buffer);
+    const half8_t* bb = reinterpret_cast<const half8_t*>(backward_buffer);
+
+    float16_t acc[WG_NJB];
+#pragma unroll
+    for (int j = 0; j < WG_NJB; j++) acc[j] = zero16();
+    const uint32_t t0 = blockIdx.x * tiles_per_chunk, t1 = t0 + tiles_per_chunk < n_tiles ? t0 + tiles_per_chunk : n_tiles;
+    for (uint32_t tile = t0 + wid; tile < t1; tile += FF_WAVES) {
+        const size_t srow = (size_t)tile * FF_TILE + n;
+        half8_t zT[2];
+        if (m == num_layers) {
+            const half8_t dy = *reinterpret_cast<const half8_t*>(grad + srow * 16 + 8 * h);
+            pack_transposed(mfma(dy, sel.out, zero16()), zT);
+        } else {
+            const half8_t* z = bb + (size_t)m * layer_stride + (size_t)tile * NKB * 64 + lane;
+            float16_t t = mfma(z[(2 * ib) * 64], sel.hid[0], zero16());
+            if (2 * ib + 1 < (uint32_t)NKB) t = mfma(z[(2 * ib + 1) * 64], sel.hid[1], t);
+            pack_transposed(t, zT);
+        }
+#pragma unroll
+        for (int j = 0; j < WG_NJB; j++) {
+            const uint32_t jb = jg * WG_NJB + j;
+            if (jb < col_blocks) {
+                float16_t t = zero16();
+                if (m == 0) {
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const uint32_t kb = 2 * jb + e;
+                        if (kb < in_kb) t = mfma(load_features8(inputs, in_planar, rows, srow, in_dim, 16 * kb + 8 * h), sel.nat[e], t);
+                    }
+                } else {
+                    const half8_t* av = fb + (size_t)(m - 1) * layer_stride + (size_t)tile * NKB * 64 + lane;
+                    t = mfma(av[(2 * jb) * 64], sel.hid[0], t);
+                    if (2 * jb + 1 < (uint32_t)NKB) t = mfma(av[(2 * jb + 1) * 64], sel.hid[1], t);
+                }
+                half8_t aT[2];
+                pack_transposed(t, aT);
+                acc[j] = mfma(zT[0], aT[0], acc[j]);
+                acc[j] = mfma(zT[1], aT[1], acc[j]);
+            }
+        }
+    }
+    // combine the four waves in a fixed order, then store this job's rectangle of the parameter vector
+    for (uint32_t i = threadIdx.x; i < 32 * WG_NJB * 32; i += FF_THREADS) (&red[0][0])[i] = 0.0f;
+    __syncthreads();
+    for (int turn = 0; turn < FF_WAVES; turn++) {
+        if (wid == turn) {
+#pragma unroll
+            for (int j = 0; j < WG_NJB; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[acc_row(0, h, r)][32 * j + n] += acc[j][r];
+        }
+        __syncthreads();
+    }
+    const uint32_t n_rows = m == num_layers ? 16u : (uint32_t)WIDTH, n_cols = m == 0 ? in_dim : (uint32_t)WIDTH;
+    const uint32_t base = m == 0 ? 0u : (uint32_t)WIDTH * in_dim + (m - 1) * (uint32_t)WIDTH * WIDTH;
+    const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
+    for (uint32_t i = threadIdx.x; i < 32 * WG_NJB * 32; i += FF_THREADS) {
+        const uint32_t r = i / (WG_NJB * 32), c = i % (WG_NJB * 32);
+        const uint32_t o = 32 * ib + r, col = jg * WG_NJB * 32 + c;
+        if (o < n_rows && col < n_cols) {
+            const uint32_t idx = base + o * n_cols + col;
+            if (grad_weights_direct) grad_weights_direct[idx] = (half_t)red[r][c];
+            else slabs[(size_t)blockIdx.x * n_params + idx] = red[r][c];
+        }
+    }
+}
+
 // sum the per-workgroup slabs in a fixed order and round once to fp16.
 // One workgroup = 64 consecutive parameters x 16 slab groups: thread (g, i) adds slabs g, g+16, g+32, ... of parameter i
 // (coalesced 256-byte rows), the 16 partial sums are combined in LDS in ascending g -- a fixed summation tree, so the
@@ -1018,8 +1322,9 @@ static DeviceInfo device_info() {
 }
 
 static int check_ff_args(const char* fn, uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t hidden, uint32_t num_layers) {
-    NGP_REQUIRE(hidden == 64 || hidden == 32, NGP_ERR_INVALID,
-                "%s: hidden_dim should in [16, 32, 64, 128, 256]; this build implements 32 and 64 (got %u)", fn, hidden);
+    // the reference's own checks (ffmlp.py:112-115, ffmlp.cu:543-556,653-658)
+    NGP_REQUIRE(hidden == 16 || hidden == 32 || hidden == 64 || hidden == 128 || hidden == 256, NGP_ERR_INVALID,
+                "%s: hidden_dim should in [16, 32, 64, 128, 256], but got %u", fn, hidden);
     NGP_REQUIRE(in_dim > 0 && in_dim % 16 == 0, NGP_ERR_INVALID, "%s: input_dim should be 16 * m (m > 0), but got %u", fn, in_dim);
     NGP_REQUIRE(out_dim == 16, NGP_ERR_INVALID, "%s: output_dim must be padded to 16 by the caller (got %u)", fn, out_dim);
     NGP_REQUIRE(num_layers >= 2, NGP_ERR_INVALID, "%s: num_layers should be larger than 2 (3 matmuls), but got %u", fn, num_layers);
@@ -1027,30 +1332,132 @@ static int check_ff_args(const char* fn, uint32_t B, uint32_t in_dim, uint32_t o
     return NGP_OK;
 }
 
+static int raise_lds(const void* kern, size_t lds, const char* what) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit: %s", what, hipGetErrorString(e));
+    }
+    return NGP_OK;
+}
+
+template <int WIDTH>
+static size_t forward_image_bytes(uint32_t in_dim, uint32_t num_layers) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    return (size_t)(NIB * (in_dim / 16) + (num_layers - 1) * NIB * NKB + NKB) * 1024;
+}
+
+// layered forward: one matmul image at a time (any width / depth whose single largest matmul fits the LDS)
+template <int WIDTH, bool TRAIN>
+static int launch_forward_layered(const void* inputs, const void* weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, uint32_t act,
+                                  uint32_t out_act, void* buffer, void* outputs, uint32_t flags, hipStream_t st) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    const uint32_t n_tiles = B / FF_TILE;
+    uint32_t frags = NIB * (in_dim / 16);
+    if (frags < (uint32_t)(NIB * NKB)) frags = NIB * NKB;
+    const size_t lds = (size_t)frags * 1024;
+    NGP_REQUIRE(lds <= 152 * 1024, NGP_ERR_INVALID, "ffmlp: one %u x %u layer (%zu B) exceeds the LDS of a CU", (unsigned)WIDTH, in_dim, lds);
+    NGP_REQUIRE(buffer, NGP_ERR_INVALID, "ffmlp: this network shape needs the %s the reference passes", TRAIN ? "forward_buffer" : "inference_buffer [B, hidden]");
+    auto kern = k_ffmlp_forward_layered<WIDTH, TRAIN>;
+    int rc = raise_lds(reinterpret_cast<const void*>(kern), lds, "ffmlp");
+    if (rc) return rc;
+    const uint32_t per_cu = (uint32_t)((160 * 1024) / (lds + 1024));
+    uint32_t blocks = (uint32_t)device_info().cus * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+    const uint32_t need = cdiv(n_tiles, FF_WAVES);
+    if (blocks > need) blocks = need;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)inputs, (const half_t*)weights, (half_t*)buffer,
+                       (half_t*)outputs, n_tiles, in_dim, num_layers, act, out_act, (flags & NGP_FF_INPUT_PLANAR) != 0);
+    return check_launch(TRAIN ? "ffmlp_forward(layered)" : "ffmlp_inference(layered)");
+}
+
 template <int WIDTH, bool TRAIN>
 static int launch_forward(const void* inputs, const void* weights, uint32_t B, uint32_t in_dim, uint32_t num_layers, uint32_t act,
                           uint32_t out_act, void* fwd, void* outputs, uint32_t flags, hipStream_t st) {
-    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     const uint32_t n_tiles = B / FF_TILE;
-    const uint32_t nfrag = NIB * (in_dim / 16) + (num_layers - 1) * NIB * NKB + NKB;
-    const size_t lds = (size_t)nfrag * 1024;
-    NGP_REQUIRE(lds <= 160 * 1024, NGP_ERR_INVALID, "ffmlp: weights (%zu B) exceed the 160 KiB LDS of a CU", lds);
+    const size_t lds = forward_image_bytes<WIDTH>(in_dim, num_layers);
+    // register-resident kernel: the whole network's fragment image in LDS (widths up to 128); everything else walks the network
+    // matmul by matmul (k_ffmlp_forward_layered)
+    if (WIDTH > 128 || lds > 152 * 1024 || (flags & NGP_FF_LAYERED))
+        return launch_forward_layered<WIDTH, TRAIN>(inputs, weights, B, in_dim, num_layers, act, out_act, fwd, outputs, flags, st);
     // the specialisation without the other activations' code is a fifth of the size (instruction fetch at kernel start matters for a
     // 25 us kernel)
     const bool plain = act == ACT_RELU && out_act == ACT_NONE;
-    auto kern = plain ? k_ffmlp_forward<WIDTH, TRAIN, true> : k_ffmlp_forward<WIDTH, TRAIN, false>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-    }
-    static const uint32_t diag = getenv("NGP_FF_FWD_DIAG") ? (uint32_t)atoi(getenv("NGP_FF_FWD_DIAG")) : 0u;
+    const void* kern;
+    if constexpr (WIDTH > 64) kern = plain ? reinterpret_cast<const void*>(k_ffmlp_forward_wide<WIDTH, TRAIN, true>)
+                                           : reinterpret_cast<const void*>(k_ffmlp_forward_wide<WIDTH, TRAIN, false>);
+    else kern = plain ? reinterpret_cast<const void*>(k_ffmlp_forward<WIDTH, TRAIN, true>) : reinterpret_cast<const void*>(k_ffmlp_forward<WIDTH, TRAIN, false>);
+    int rc = raise_lds(kern, lds, "ffmlp");
+    if (rc) return rc;
     const uint32_t per_cu = (uint32_t)((160 * 1024) / (lds + 1024));
     uint32_t blocks = (uint32_t)device_info().cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
     const uint32_t need = cdiv(n_tiles, FF_WAVES);
     if (blocks > need) blocks = need;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)inputs, (const half_t*)weights, (half_t*)fwd,
-                       (half_t*)outputs, n_tiles, in_dim, num_layers, act, out_act, (flags & NGP_FF_INPUT_PLANAR) != 0, diag);
+    const half_t* a0 = (const half_t*)inputs;
+    const half_t* a1 = (const half_t*)weights;
+    half_t* a2 = (half_t*)fwd;
+    half_t* a3 = (half_t*)outputs;
+    uint32_t a4 = n_tiles, a5 = in_dim, a6 = num_layers, a7 = act, a8 = out_act;
+    bool a9 = (flags & NGP_FF_INPUT_PLANAR) != 0;
+    void* args[] = {&a0, &a1, &a2, &a3, &a4, &a5, &a6, &a7, &a8, &a9};
+    hipError_t e = hipLaunchKernel(kern, dim3(blocks), dim3(FF_THREADS), args, lds, st);
+    NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp: kernel launch failed: %s", hipGetErrorString(e));
     return check_launch(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
+}
+
+// layered backward: dgrad chain (dZ of every layer into backward_buffer, dL/dx) + the weight-gradient kernel
+constexpr uint32_t WG_MAX_CHUNKS = 64;
+
+template <int WIDTH>
+static int launch_backward_layered(const void* grad, const void* inputs, const void* weights, const void* fwd, uint32_t B, uint32_t in_dim,
+                                   uint32_t num_layers, uint32_t act, bool with_dx, void* backward_buffer, void* grad_inputs,
+                                   void* grad_weights, uint32_t flags, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    const bool in_planar = (flags & NGP_FF_INPUT_PLANAR) != 0, dx_planar = (flags & NGP_FF_DX_PLANAR) != 0;
+    const uint32_t n_tiles = B / FF_TILE;
+    const uint32_t in_jb = (in_dim + 31) / 32;
+    uint32_t frags = NIB * NKB;
+    if (with_dx && frags < in_jb * NKB) frags = in_jb * NKB;
+    const size_t lds = (size_t)frags * 1024;
+    NGP_REQUIRE(lds <= 152 * 1024, NGP_ERR_INVALID, "ffmlp_backward: one %u x %u layer (%zu B) exceeds the LDS of a CU", (unsigned)WIDTH, in_dim, lds);
+    const void* dk = act == ACT_RELU ? reinterpret_cast<const void*>(k_ffmlp_dgrad_layered<WIDTH, true>)
+                                     : reinterpret_cast<const void*>(k_ffmlp_dgrad_layered<WIDTH, false>);
+    int rc = raise_lds(dk, lds, "ffmlp_backward");
+    if (rc) return rc;
+    const uint32_t per_cu = (uint32_t)((160 * 1024) / (lds + 1024));
+    uint32_t blocks = (uint32_t)device_info().cus * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+    const uint32_t need = cdiv(n_tiles, FF_WAVES);
+    if (blocks > need) blocks = need;
+    if (act == ACT_RELU)
+        hipLaunchKernelGGL((k_ffmlp_dgrad_layered<WIDTH, true>), dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)weights,
+                           (const half_t*)fwd, (half_t*)backward_buffer, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, dx_planar);
+    else
+        hipLaunchKernelGGL((k_ffmlp_dgrad_layered<WIDTH, false>), dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)weights,
+                           (const half_t*)fwd, (half_t*)backward_buffer, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, dx_planar);
+    rc = check_launch("ffmlp_backward(dgrad)");
+    if (rc) return rc;
+    // weight gradients
+    const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
+    const uint32_t jobs = wgrad_jobs_of(NIB, in_jb) + (num_layers - 1) * wgrad_jobs_of(NIB, NIB) + wgrad_jobs_of(1, NIB);
+    uint32_t chunks = 1;
+    if (workspace) {
+        chunks = (uint32_t)(workspace_bytes / ((size_t)n_params * 4));
+        const uint32_t want = cdiv((uint32_t)device_info().cus * 4u, jobs);  // ~4 workgroups per CU in flight
+        if (chunks > want) chunks = want;
+        if (chunks > WG_MAX_CHUNKS) chunks = WG_MAX_CHUNKS;
+        const uint32_t by_tiles = cdiv(n_tiles, 2 * FF_WAVES);               // at least two rounds of tiles per wave
+        if (chunks > by_tiles) chunks = by_tiles;
+        if (chunks < 1) chunks = 1;
+    }
+    const uint32_t tiles_per_chunk = cdiv(n_tiles, chunks);
+    chunks = cdiv(n_tiles, tiles_per_chunk);
+    const bool direct = chunks == 1;
+    hipLaunchKernelGGL(k_ffmlp_wgrad<WIDTH>, dim3(chunks, jobs), dim3(FF_THREADS), 0, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)fwd,
+                       (const half_t*)backward_buffer, n_tiles, in_dim, num_layers, in_planar, tiles_per_chunk, direct ? (float*)nullptr : (float*)workspace,
+                       direct ? (half_t*)grad_weights : (half_t*)nullptr);
+    rc = check_launch("ffmlp_backward(wgrad)");
+    if (rc || direct) return rc;
+    hipLaunchKernelGGL(k_ffmlp_reduce_slabs, dim3(cdiv(n_params, RS_PARAMS)), dim3(RS_PARAMS * RS_GROUPS), 0, st, (const float*)workspace, chunks,
+                       n_params, (half_t*)grad_weights);
+    return check_launch("ffmlp_backward(reduce)");
 }
 
 template <int WIDTH, int IN_JB, int NHM, bool RELU>
@@ -1064,7 +1471,6 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
     const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
     // weight image + per-wave tile buffers (double-buffered when both fit the 160 KiB LDS of a CU)
     const size_t tile_bytes = (size_t)(1 + num_layers * NKB + in_dim / 16) * 1024;
-    static const uint32_t diag = getenv("NGP_FF_BWD_DIAG") ? (uint32_t)atoi(getenv("NGP_FF_BWD_DIAG")) : 0u;
     uint32_t pf_depth = 2;
     if ((size_t)nfrag * 1024 + 2 * FF_WAVES * tile_bytes > 160 * 1024) pf_depth = 1;
     size_t lds = (size_t)nfrag * 1024 + (size_t)pf_depth * FF_WAVES * tile_bytes;
@@ -1079,8 +1485,7 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
     if (blocks > fit) blocks = (uint32_t)fit;
     if constexpr (NHM == 1 || NHM == 2) {
         // 2- and 3-layer networks: two sibling waves per tile stream split the weight-gradient accumulators (see the kernel)
-        static const bool single = getenv("NGP_FF_BWD_SINGLE") != nullptr;
-        if (!single && diag == 0u) {
+        if (!(flags & NGP_FF_SINGLE_WAVE)) {
             auto pk = k_ffmlp_backward_paired<WIDTH, IN_JB, NHM, RELU>;
             if (lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1106,12 +1511,12 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
     if (blocks <= 1) {
         hipLaunchKernelGGL(kern, dim3(1), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
                            (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)nullptr,
-                           (half_t*)grad_weights, in_planar, dx_planar, pf_depth, diag);
+                           (half_t*)grad_weights, in_planar, dx_planar, pf_depth);
         return check_launch("ffmlp_backward");
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs, (const half_t*)weights,
                        (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs, (float*)backward_buffer,
-                       (half_t*)nullptr, in_planar, dx_planar, pf_depth, diag);
+                       (half_t*)nullptr, in_planar, dx_planar, pf_depth);
     int rc = check_launch("ffmlp_backward");
     if (rc) return rc;
     hipLaunchKernelGGL(k_ffmlp_reduce_slabs, dim3(cdiv(n_params, RS_PARAMS)), dim3(RS_PARAMS * RS_GROUPS), 0, st, (const float*)backward_buffer, blocks, n_params,
@@ -1134,6 +1539,15 @@ static int launch_backward(const void* grad, const void* inputs, const void* wei
 
 using namespace ngp;
 
+#define FF_WIDTHS(CALL)                  \
+    switch (hidden_dim) {                \
+        case 16: return CALL(16);        \
+        case 32: return CALL(32);        \
+        case 64: return CALL(64);        \
+        case 128: return CALL(128);      \
+        default: return CALL(256);       \
+    }
+
 extern "C" int ngp_ffmlp_forward_ex(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                                     uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                                     void* forward_buffer, void* outputs, uint32_t flags, ngp_stream_t stream) {
@@ -1142,37 +1556,50 @@ extern "C" int ngp_ffmlp_forward_ex(const void* inputs, const void* weights, uin
     if (B == 0) return NGP_OK;
     NGP_REQUIRE(inputs && weights && forward_buffer && outputs, NGP_ERR_INVALID, "ffmlp_forward: NULL tensor");
     hipStream_t st = as_stream(stream);
-    if (hidden_dim == 64) return launch_forward<64, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, flags, st);
-    return launch_forward<32, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, flags, st);
+#define FF_FWD(W) launch_forward<W, true>(inputs, weights, B, input_dim, num_layers, activation, output_activation, forward_buffer, outputs, flags, st)
+    FF_WIDTHS(FF_FWD)
+#undef FF_FWD
 }
 
 extern "C" int ngp_ffmlp_inference_ex(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                                       uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                                       void* inference_buffer, void* outputs, uint32_t flags, ngp_stream_t stream) {
-    (void)inference_buffer;
+    // inference_buffer [B, hidden] (the reference's scratch, ffmlp.cu:673-709) is only touched by the layered kernel (256-wide layers
+    // and networks whose whole fragment image does not fit the LDS); the register-resident kernel leaves it alone and accepts NULL
     int rc = check_ff_args("ffmlp_inference", B, input_dim, output_dim, hidden_dim, num_layers);
     if (rc) return rc;
     if (B == 0) return NGP_OK;
     NGP_REQUIRE(inputs && weights && outputs, NGP_ERR_INVALID, "ffmlp_inference: NULL tensor");
     hipStream_t st = as_stream(stream);
-    if (hidden_dim == 64) return launch_forward<64, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, nullptr, outputs, flags, st);
-    return launch_forward<32, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, nullptr, outputs, flags, st);
+#define FF_INF(W) launch_forward<W, false>(inputs, weights, B, input_dim, num_layers, activation, output_activation, inference_buffer, outputs, flags, st)
+    FF_WIDTHS(FF_INF)
+#undef FF_INF
 }
 
-extern "C" int ngp_ffmlp_backward_ex(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
+extern "C" size_t ngp_ffmlp_backward_workspace_bytes(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {
+    const bool fast = (hidden_dim == 32 || hidden_dim == 64) && num_layers <= 4 && input_dim <= 64;
+    if (fast || B == 0) return 0;
+    return (size_t)WG_MAX_CHUNKS * ff_param_count(input_dim, hidden_dim, num_layers) * sizeof(float);
+}
+
+extern "C" int ngp_ffmlp_backward_ws(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
                                      uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                      uint32_t output_activation, int calc_grad_inputs, void* backward_buffer, void* grad_inputs,
-                                     void* grad_weights, uint32_t flags, ngp_stream_t stream) {
+                                     void* grad_weights, uint32_t flags, void* workspace, size_t workspace_bytes, ngp_stream_t stream) {
     (void)output_activation;  // the reference discards it as well (ffmlp.cu:780)
     int rc = check_ff_args("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers);
     if (rc) return rc;
-    NGP_REQUIRE(num_layers <= 4, NGP_ERR_INVALID, "ffmlp_backward: this build supports num_layers <= 4 (got %u)", num_layers);
-    NGP_REQUIRE(input_dim <= 64, NGP_ERR_INVALID, "ffmlp_backward: this build supports input_dim <= 64 (got %u)", input_dim);
     if (B == 0) return NGP_OK;
     NGP_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer && grad_weights, NGP_ERR_INVALID, "ffmlp_backward: NULL tensor");
     NGP_REQUIRE(!calc_grad_inputs || grad_inputs, NGP_ERR_INVALID, "ffmlp_backward: grad_inputs is NULL but calc_grad_inputs is set");
     hipStream_t st = as_stream(stream);
     const bool dx = calc_grad_inputs != 0;
+    const bool fast = (hidden_dim == 32 || hidden_dim == 64) && num_layers <= 4 && input_dim <= 64 && !(flags & NGP_FF_LAYERED);
+    if (!fast) {
+#define FF_LAY(W) launch_backward_layered<W>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, dx, backward_buffer, grad_inputs, grad_weights, flags, workspace, workspace_bytes, st)
+        FF_WIDTHS(FF_LAY)
+#undef FF_LAY
+    }
     const uint32_t in_jb = (input_dim + 31) / 32;
 #define FF_BWD(W, J, N) \
     return launch_backward<W, J, N>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, dx, backward_buffer, grad_inputs, grad_weights, flags, st)
@@ -1190,6 +1617,14 @@ extern "C" int ngp_ffmlp_backward_ex(const void* grad, const void* inputs, const
     FF_BWD_N(32, 2)
 #undef FF_BWD_N
 #undef FF_BWD
+}
+
+extern "C" int ngp_ffmlp_backward_ex(const void* grad, const void* inputs, const void* weights, const void* forward_buffer, uint32_t B,
+                                     uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
+                                     uint32_t output_activation, int calc_grad_inputs, void* backward_buffer, void* grad_inputs,
+                                     void* grad_weights, uint32_t flags, ngp_stream_t stream) {
+    return ngp_ffmlp_backward_ws(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                 output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, flags, nullptr, 0, stream);
 }
 
 extern "C" int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,

@@ -187,21 +187,23 @@ extern "C" int ngp_optim_adam_step_ex(int count, const uint64_t* n, float* const
     if (phases & (NGP_OPT_PHASE_CHECK | NGP_OPT_PHASE_UPDATE)) {
         NGP_REQUIRE(count >= 1 && count <= OPT_MAX_TENSORS, NGP_ERR_INVALID, "optim_adam_step: between 1 and %d tensors per call (got %d)",
                     OPT_MAX_TENSORS, count);
-        NGP_REQUIRE(n && params && exp_avg && exp_avg_sq && grads && grad_is_half && lr, NGP_ERR_INVALID, "optim_adam_step: NULL argument");
+        const bool upd = (phases & NGP_OPT_PHASE_UPDATE) != 0;
+        NGP_REQUIRE(n && grads && grad_is_half && (!upd || (params && exp_avg && exp_avg_sq && lr)), NGP_ERR_INVALID,
+                    "optim_adam_step: NULL argument");
         NGP_REQUIRE(!(ema_one_minus_decay > 0.0f) || ema, NGP_ERR_INVALID, "optim_adam_step: EMA decay given without shadow tensors");
         OptTensors ts;
         ts.count = count;
         uint64_t total = 0;
         for (int k = 0; k < count; k++) {
-            NGP_REQUIRE(params[k] && exp_avg[k] && exp_avg_sq[k] && grads[k], NGP_ERR_INVALID, "optim_adam_step: NULL tensor %d", k);
+            NGP_REQUIRE(grads[k] && (!upd || (params[k] && exp_avg[k] && exp_avg_sq[k])), NGP_ERR_INVALID, "optim_adam_step: NULL tensor %d", k);
             ts.n[k] = n[k];
-            ts.p[k] = params[k];
-            ts.m[k] = exp_avg[k];
-            ts.v[k] = exp_avg_sq[k];
+            ts.p[k] = upd ? params[k] : nullptr;   // a CHECK-only call needs the gradients alone
+            ts.m[k] = upd ? exp_avg[k] : nullptr;
+            ts.v[k] = upd ? exp_avg_sq[k] : nullptr;
             ts.g[k] = grads[k];
             ts.p16[k] = params_fp16 ? reinterpret_cast<half_t*>(params_fp16[k]) : nullptr;
             ts.g_is_half[k] = grad_is_half[k];
-            ts.lr[k] = lr[k];
+            ts.lr[k] = upd ? lr[k] : 0.0f;
             ts.ema[k] = ema ? ema[k] : nullptr;
             total += n[k];
         }

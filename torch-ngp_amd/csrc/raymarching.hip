@@ -559,6 +559,13 @@ __global__ __launch_bounds__(256) void k_march_train_zero_tail(float* __restrict
     }
 }
 
+// samples per ray and iteration of the inference loop (renderer.py:349: max(min(N // n_alive, 8), 1))
+__device__ __host__ __forceinline__ uint32_t loop_n_step(uint32_t n_total, uint32_t n_alive) {
+    if (n_alive == 0) return 1u;
+    const uint32_t q = n_total / n_alive;
+    return q > 8u ? 8u : (q < 1u ? 1u : q);
+}
+
 // raymarching.cu:701-805
 // zero_rows > 0: the kernel also zeroes every sample slot it does not fill (the unused tail of each ray's n_step slots and the
 // rows between n_alive * n_step and zero_rows), so the caller may pass uninitialised buffers (extension; the reference contract,
@@ -569,8 +576,13 @@ __global__ __launch_bounds__(RM_THREADS) void k_march_rays(uint32_t n_alive, uin
                                                            uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
                                                            const float* __restrict__ fars, float* __restrict__ xyzs,
                                                            float* __restrict__ dirs, float* __restrict__ deltas,
-                                                           const float* __restrict__ noises, uint32_t zero_rows) {
+                                                           const float* __restrict__ noises, uint32_t zero_rows,
+                                                           const int32_t* __restrict__ dev_state, uint32_t n_total) {
     const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+    if (dev_state) {  // on-device render loop: the alive count lives on the device, n_step follows the renderer's rule
+        n_alive = (uint32_t)dev_state[0];
+        n_step = loop_n_step(n_total, n_alive);
+    }
     if (zero_rows > 0) {  // padding rows behind the last ray's slots: at most `align` of them, spread over the first lanes
         for (uint32_t row = n_alive * n_step + n; row < zero_rows; row += gridDim.x * RM_THREADS) {
             xyzs[(size_t)row * 3] = 0.0f; xyzs[(size_t)row * 3 + 1] = 0.0f; xyzs[(size_t)row * 3 + 2] = 0.0f;
@@ -790,8 +802,12 @@ __global__ __launch_bounds__(RM_THREADS) void k_composite_rays(uint32_t n_alive,
                                                                float* __restrict__ rays_t, const float* __restrict__ sigmas,
                                                                const float* __restrict__ rgbs, const float* __restrict__ deltas,
                                                                float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                               float* __restrict__ image) {
+                                                               float* __restrict__ image, const int32_t* __restrict__ dev_state, uint32_t n_total) {
     const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+    if (dev_state) {
+        n_alive = (uint32_t)dev_state[0];
+        n_step = loop_n_step(n_total, n_alive);
+    }
     if (n >= n_alive) return;
     const uint32_t index = (uint32_t)rays_alive[n];
     const float* sg = sigmas + (size_t)n * n_step;
@@ -824,8 +840,10 @@ __global__ __launch_bounds__(RM_THREADS) void k_composite_rays(uint32_t n_alive,
 // order-preserving compaction of the alive list (extension; replaces a host-side boolean index)
 // workspace (uint32): per-block survivor counts
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RM_THREADS) void k_compact_count(const int32_t* __restrict__ rays_alive, uint32_t n_alive, uint32_t* __restrict__ ws) {
+__global__ __launch_bounds__(RM_THREADS) void k_compact_count(const int32_t* __restrict__ rays_alive, uint32_t n_alive, uint32_t* __restrict__ ws,
+                                                              const int32_t* __restrict__ dev_state) {
     __shared__ uint32_t lds4[RM_THREADS / 64];
+    if (dev_state) n_alive = (uint32_t)dev_state[0];
     const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
     const uint32_t keep = (n < n_alive && rays_alive[n] >= 0) ? 1u : 0u;
     const uint32_t tot = block_sum(keep, lds4);
@@ -833,9 +851,15 @@ __global__ __launch_bounds__(RM_THREADS) void k_compact_count(const int32_t* __r
 }
 __global__ __launch_bounds__(RM_THREADS) void k_compact_write(const int32_t* __restrict__ rays_alive, uint32_t n_alive,
                                                               int32_t* __restrict__ out_alive, int32_t* __restrict__ out_count,
-                                                              const uint32_t* __restrict__ ws) {
+                                                              const uint32_t* __restrict__ ws, const int32_t* __restrict__ dev_state,
+                                                              uint32_t n_total, uint32_t max_steps) {
     __shared__ uint32_t lds4[RM_THREADS / 64];
     __shared__ uint32_t wave_excl[RM_THREADS / 64];
+    uint32_t steps_done = 0;
+    if (dev_state) {  // out_count is the next iteration's state {n_alive, steps marched so far}
+        n_alive = (uint32_t)dev_state[0];
+        steps_done = (uint32_t)dev_state[1] + loop_n_step(n_total, n_alive);
+    }
     uint32_t part = 0;
     for (uint32_t j = threadIdx.x; j < blockIdx.x; j += RM_THREADS) part += ws[j];
     const uint32_t block_offset = block_sum(part, lds4);
@@ -855,7 +879,14 @@ __global__ __launch_bounds__(RM_THREADS) void k_compact_write(const int32_t* __r
         block_total += c;
     }
     if (keep) out_alive[block_offset + wbase + incl - 1] = id;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *out_count = (int32_t)(block_offset + block_total);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        if (dev_state) {  // the loop ends when no ray is alive or max_steps samples were marched (renderer.py:341-346)
+            out_count[0] = steps_done >= max_steps ? 0 : (int32_t)(block_offset + block_total);
+            out_count[1] = (int32_t)steps_done;
+        } else {
+            *out_count = (int32_t)(block_offset + block_total);
+        }
+    }
 }
 
 }  // namespace ngp
@@ -1039,7 +1070,7 @@ extern "C" int ngp_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_
     NGP_REQUIRE(zero_rows == 0 || zero_rows >= n_alive * n_step, NGP_ERR_INVALID, "march_rays: zero_rows is smaller than n_alive * n_step");
     const uint32_t lanes = n_alive > 0 ? n_alive : 1u;
     RM_LAUNCH_1D(k_march_rays, lanes, as_stream(stream), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
-                 max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, zero_rows);
+                 max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, zero_rows, (const int32_t*)nullptr, 0u);
     return check_launch("march_rays");
 }
 
@@ -1060,7 +1091,7 @@ extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thr
     NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, NGP_ERR_INVALID,
                 "composite_rays: NULL tensor");
     RM_LAUNCH_1D(k_composite_rays, n_alive, as_stream(stream), n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
-                 weights_sum, depth, image);
+                 weights_sum, depth, image, (const int32_t*)nullptr, 0u);
     return check_launch("composite_rays");
 }
 
@@ -1076,9 +1107,58 @@ extern "C" int ngp_compact_rays(const int32_t* rays_alive, uint32_t n_alive, int
         return NGP_OK;
     }
     uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
-    RM_LAUNCH_1D(k_compact_count, n_alive, st, rays_alive, n_alive, ws);
+    RM_LAUNCH_1D(k_compact_count, n_alive, st, rays_alive, n_alive, ws, (const int32_t*)nullptr);
     int rc = check_launch("compact_rays(count)");
     if (rc) return rc;
-    RM_LAUNCH_1D(k_compact_write, n_alive, st, rays_alive, n_alive, out_alive, out_count, (const uint32_t*)ws);
+    RM_LAUNCH_1D(k_compact_write, n_alive, st, rays_alive, n_alive, out_alive, out_count, (const uint32_t*)ws, (const int32_t*)nullptr, 0u, 0u);
     return check_launch("compact_rays(write)");
+}
+
+// ---------------------------------------------------------------------------------------------
+// On-device inference loop: march_rays / composite_rays / the alive-list compaction of NeRFRenderer.run_cuda's eval
+// branch (renderer.py:322-367) with the alive count, the per-iteration n_step = max(min(N // n_alive, 8), 1) and the marched-step total
+// kept in a device word pair `state` = {n_alive, steps marched}.  The host launches for an UPPER BOUND of the alive count
+// (`alive_bound`, the value it last read back) and may run many iterations between read-backs; every kernel takes the true count from
+// `state`, lanes and sample rows beyond it do nothing / are zero-filled up to `rows`.  Same slot layout, same n_step sequence and same
+// order-preserving compaction as the host-driven loop: identical results.
+// ---------------------------------------------------------------------------------------------
+extern "C" int ngp_march_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, const int32_t* rays_alive, const float* rays_t,
+                                  const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                  uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs,
+                                  float* deltas, const float* noises, uint32_t rows, ngp_stream_t stream) {
+    (void)nears;
+    int rc = check_march_args("march_rays", C, H, max_steps);
+    if (rc) return rc;
+    NGP_REQUIRE(state && rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas, NGP_ERR_INVALID, "march_rays: NULL tensor");
+    NGP_REQUIRE(rows > 0 && n_total > 0, NGP_ERR_INVALID, "march_rays_dev: rows and n_total must be positive");
+    const uint32_t lanes = alive_bound > 0 ? alive_bound : 1u;
+    RM_LAUNCH_1D(k_march_rays, lanes, as_stream(stream), alive_bound, 1u, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
+                 grid, fars, xyzs, dirs, deltas, noises, rows, state, n_total);
+    return check_launch("march_rays_dev");
+}
+
+extern "C" int ngp_composite_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, float T_thresh, int32_t* rays_alive,
+                                      float* rays_t, const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
+                                      float* depth, float* image, ngp_stream_t stream) {
+    if (alive_bound == 0) return NGP_OK;
+    NGP_REQUIRE(state && rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, NGP_ERR_INVALID,
+                "composite_rays: NULL tensor");
+    RM_LAUNCH_1D(k_composite_rays, alive_bound, as_stream(stream), alive_bound, 1u, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
+                 weights_sum, depth, image, state, n_total);
+    return check_launch("composite_rays_dev");
+}
+
+/* compaction + loop bookkeeping: out_alive / out_state {n_alive, steps marched} describe the next iteration; the count becomes 0 once
+ * max_steps samples per ray were marched */
+extern "C" int ngp_compact_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t max_steps, const int32_t* rays_alive,
+                                    int32_t* out_alive, int32_t* out_state, void* workspace, ngp_stream_t stream) {
+    NGP_REQUIRE(state && rays_alive && out_alive && out_state && workspace, NGP_ERR_INVALID, "compact_rays: NULL tensor");
+    hipStream_t st = as_stream(stream);
+    const uint32_t lanes = alive_bound > 0 ? alive_bound : 1u;
+    uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
+    RM_LAUNCH_1D(k_compact_count, lanes, st, rays_alive, alive_bound, ws, state);
+    int rc = check_launch("compact_rays_dev(count)");
+    if (rc) return rc;
+    RM_LAUNCH_1D(k_compact_write, lanes, st, rays_alive, alive_bound, out_alive, out_state, (const uint32_t*)ws, state, n_total, max_steps);
+    return check_launch("compact_rays_dev(write)");
 }

@@ -35,9 +35,14 @@ def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_d
     for t, n in ((grad, 'grad'), (inputs, 'inputs'), (weights, 'weights'), (forward_buffer, 'forward_buffer'),
                  (backward_buffer, 'backward_buffer'), (grad_inputs, 'grad_inputs'), (grad_weights, 'grad_weights')):
         _half(t, n)
-    capi.check(capi.lib.ngp_ffmlp_backward(capi.ptr(grad), capi.ptr(inputs), capi.ptr(weights), capi.ptr(forward_buffer), B, input_dim,
-                                           output_dim, hidden_dim, num_layers, activation, output_activation, int(bool(calc_grad_inputs)),
-                                           capi.ptr(backward_buffer), capi.ptr(grad_inputs), capi.ptr(grad_weights), capi.stream()))
+    # shapes outside the register-resident kernels (hidden 16/128/256, > 4 hidden layers, wide inputs) split the batch reduction of the
+    # weight gradients over sample chunks: that needs scratch the reference signature has no argument for, so it is allocated here
+    nbytes = int(capi.lib.ngp_ffmlp_backward_workspace_bytes(B, input_dim, hidden_dim, num_layers))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=grad.device) if nbytes else None
+    capi.check(capi.lib.ngp_ffmlp_backward_ws(capi.ptr(grad), capi.ptr(inputs), capi.ptr(weights), capi.ptr(forward_buffer), B, input_dim,
+                                              output_dim, hidden_dim, num_layers, activation, output_activation, int(bool(calc_grad_inputs)),
+                                              capi.ptr(backward_buffer), capi.ptr(grad_inputs), capi.ptr(grad_weights), 0, capi.ptr(ws), nbytes,
+                                              capi.stream()))
 
 
 def allocate_splitk(size):

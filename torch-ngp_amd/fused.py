@@ -176,6 +176,13 @@ def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
 # ------------------------------------------------------------------------------------------------------------------
 def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfield, aabb, counter, cfg, rcfg, noise_seed=None):
     """-> (image, depth, weights_sum, saved): the forward launches of the fused training render on the current stream"""
+    marched = _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, noise_seed)
+    return _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg)
+
+
+def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, noise_seed=None):
+    """the parameter-independent front of the iteration: near/far + march_rays_train.  Needs neither the table nor the MLP weights, so
+    in data-parallel training it overlaps the all-gather of the freshly updated fp16 shadows (optim.NGPAdam.gather_shadows)."""
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
     (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
     N = rays_o.shape[0]
@@ -183,7 +190,6 @@ def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfie
     dev = rays_o.device
     st = capi.stream()
     f32 = dict(device=dev, dtype=torch.float32)
-    half = dict(device=dev, dtype=torch.half)
     nears = torch.empty(N, **f32)
     fars = torch.empty(N, **f32)
     _check(capi.lib.ngp_near_far_from_aabb(rays_o.data_ptr(), rays_d.data_ptr(), aabb.data_ptr(), N, min_near, nears.data_ptr(),
@@ -203,6 +209,18 @@ def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfie
                                             max_steps, N, cascade, grid_size, M, nears.data_ptr(), fars.data_ptr(), xyzs.data_ptr(),
                                             dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(), noises.data_ptr(),
                                             ws.data_ptr(), march_flags, st))
+    return (xyzs, dirs, deltas, rays, nears, fars, ws)
+
+
+def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg):
+    (xyzs, dirs, deltas, rays, nears, fars, ws) = marched
+    (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
+    (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
+    N, M = rays.shape[0], capacity
+    dev = xyzs.device
+    st = capi.stream()
+    f32 = dict(device=dev, dtype=torch.float32)
+    half = dict(device=dev, dtype=torch.half)
     # ---- network ----
     enc = torch.empty(L, M, 2, **half)
     _check(capi.lib.ngp_grid_encode_forward_ex(xyzs.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
@@ -338,14 +356,43 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     target = target.contiguous().view(-1, 3)
     if target.shape[0] != rays_o.shape[0] or target.dtype != torch.float32:
         raise RuntimeError('fused_train_iteration: target must be [N,3] float32')
-    image, depth, weights_sum, saved = _render_train_forward(rays_o, rays_d, bufs[0], bufs[1], bufs[2], bg_t, model.encoder.offsets,
-                                                             model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
-    loss = torch.empty(1, device=rays_o.device, dtype=torch.float32)
+    marched = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
+    return _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg)
+
+
+def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg, rcfg):
+    image, depth, weights_sum, saved = _render_train_network(marched, bufs[0], bufs[1], bufs[2], bg_t, offsets, cfg, rcfg)
+    loss = torch.empty(1, device=image.device, dtype=torch.float32)
     grad_image = torch.empty_like(image)
     _check(capi.lib.ngp_pipeline_mse_loss(image.data_ptr(), target.data_ptr(), image.numel(), capi.ptr(loss_scale), loss.data_ptr(),
                                           grad_image.data_ptr(), capi.stream()))
     _render_train_backward(saved, cfg, rcfg, grad_image, None, bufs[3], bufs[4].view(-1), bufs[5].view(-1))
     return loss, image, depth, weights_sum
+
+
+@torch.no_grad()
+def fused_train_iteration_split(model, rays_o, rays_d, target, box, counter, capacity, loss_scale, bg_color=1, perturb=False, dt_gamma=0,
+                                max_steps=1024, T_thresh=1e-4, noise_seed=None):
+    """`fused_train_iteration` in two halves for data-parallel training: returns (march, rest) callables -- `march()` issues the
+    parameter-independent launches (near/far, ray marching), `rest()` everything that reads the weights (encode, MLPs, composite, loss,
+    backward).  graph.GraphedTrainStep captures them into separate HIP graphs so that the all-gather of the updated fp16 shadow weights
+    (optim.NGPAdam, sharded mode) runs underneath the marcher.  Same launches, same arithmetic as the unsplit call."""
+    cfg = network_cfg(model.encoder, model.sigma_net, model.color_net, model.bound, True)
+    bg_t, rcfg = _render_cfg(model, capacity, bg_color, perturb, dt_gamma, max_steps, T_thresh)
+    bufs = _optimizer_buffers((model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights))
+    if bufs is None:
+        raise RuntimeError('fused_train_iteration: the parameters are not managed by optim.NGPAdam(deposit=True)')
+    rays_o = rays_o.contiguous().view(-1, 3)
+    rays_d = rays_d.contiguous().view(-1, 3)
+    target = target.contiguous().view(-1, 3)
+    box_ = {}
+
+    def march():
+        box_['m'] = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
+
+    def rest():
+        return _train_iteration_rest(box_['m'], bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg)
+    return march, rest
 
 
 @torch.no_grad()

@@ -171,12 +171,36 @@ class GraphedTrainStep:
         self.loss = None
         gc.collect()  # drop autograd graphs of earlier eager iterations (their AccumulateGrad nodes are stream-bound)
         torch.cuda.synchronize()
+        self.sharded = False
         if self.averager is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.loss = self._iteration_front().detach()
                 self._iteration_back()
             self.graphs = (g,)
+        elif self.averager is self.optimizer and getattr(self.optimizer, 'shard', False) and self._direct_ok():
+            # sharded data-parallel update (optim.NGPAdam, shard=True): three graphs around the two collectives,
+            #   [march] -> wait for the shadow all-gather of the previous step -> [encode .. backward, local non-finite sweep]
+            #   -> reduce-scatter + verdict -> [Adam on my shard, commit] -> all-gather of the shadows (side stream, overlaps the next [march])
+            from fused import fused_train_iteration_split
+            m, kw, opt = self.model, self.render_kwargs, self.optimizer
+            bg = kw.get('bg_color', None)
+            march, rest = fused_train_iteration_split(m, self.rays_o, self.rays_d, self.target, m.aabb_train, self.counter[0], self.captured_capacity,
+                                                      opt.scalars[0:1], 1 if bg is None else bg, kw.get('perturb', False), kw.get('dt_gamma', 0),
+                                                      kw.get('max_steps', 1024), kw.get('T_thresh', 1e-4), noise_seed=opt.scalars[3:4])
+            opt.wait_shadows()
+            torch.cuda.synchronize()
+            ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                march()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                self.loss = rest()[0][0].detach()
+                opt.pre_reduce_check()
+            with torch.cuda.graph(gc_, pool=ga.pool()):
+                opt.apply()
+            self.graphs = (ga, gb, gc_)
+            self.sharded = True
+            self.used_direct = True
         else:  # the RCCL all-reduce stays eager between the two halves
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
@@ -236,9 +260,9 @@ class GraphedTrainStep:
             out = self.model.render(rays_o, rays_d, **self.render_kwargs)
             loss = self.loss_fn(out, target)
         self._scaled(loss).backward()
-        if self.averager is not None:
+        if self.averager is not None and not getattr(self.optimizer, 'shard', False):
             self.averager.all_reduce()
-        self._iteration_back()
+        self._iteration_back()  # (a sharded optim.NGPAdam exchanges inside step(): reduce-scatter, update, all-gather)
         # detached: a caller holding the loss must not keep this iteration's autograd graph (and its AccumulateGrad nodes,
         # bound to the eager stream) alive into a later capture
         return loss.detach()
@@ -248,6 +272,8 @@ class GraphedTrainStep:
         """one training iteration on rays_o/rays_d [1,N,3], target [N,3]; returns the (device) loss of this step"""
         m = self.model
         if self.global_step % self.update_interval == 0:
+            if getattr(self.optimizer, 'shard', False):
+                self.optimizer.wait_shadows()  # the occupancy refresh evaluates the density network on the fp16 shadows
             self._update_extra_state()
             if self.after_update is not None:
                 self.after_update(m)
@@ -276,10 +302,19 @@ class GraphedTrainStep:
         # the batch into the static input buffers: ONE multi-tensor copy kernel (three separate copies cost ~5 us each plus the gaps)
         torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
                              non_blocking=True)
-        self.graphs[0].replay()
-        if len(self.graphs) == 2:
-            self.averager.all_reduce()
-            self.graphs[1].replay()
+        if getattr(self, 'sharded', False):
+            opt = self.optimizer
+            self.graphs[0].replay()            # near/far + ray marching: needs no weights, overlaps the shadow all-gather of the last step
+            opt.wait_shadows()
+            self.graphs[1].replay()            # encode .. backward (deposit) + local non-finite sweep
+            opt.reduce_gradients()             # reduce-scatter (average of my shard) + global skip verdict
+            self.graphs[2].replay()            # Adam on my shard, scale / step commit, deposit buffer zeroed
+            opt.gather_shadows()               # all-gather of the fp16 shadows on the side stream
+        else:
+            self.graphs[0].replay()
+            if len(self.graphs) == 2:
+                self.averager.all_reduce()
+                self.graphs[1].replay()
         # hand the sample count to the model's 16-slot ring exactly where the eager renderer would have put it
         m.step_counter[m.local_step % 16].copy_(self.counter[0], non_blocking=True)
         m.local_step += 1

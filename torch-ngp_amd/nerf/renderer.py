@@ -224,30 +224,70 @@ class NeRFRenderer(nn.Module):
             weights_sum = torch.zeros(n_rays, dtype=torch.float32, device=dev)
             depth = torch.zeros(n_rays, dtype=torch.float32, device=dev)
             image = torch.zeros(n_rays, 3, dtype=torch.float32, device=dev)
-            rays_alive = torch.arange(n_rays, dtype=torch.int32, device=dev)
             rays_t = nears.clone()
-            step = 0
             from fused import pinned_half_weights
             with pinned_half_weights(self):  # one fp16 cast of the parameters per frame instead of one per loop iteration
-                while step < max_steps:
-                    n_alive = rays_alive.shape[0]
-                    if n_alive <= 0:
-                        break
-                    n_step = max(min(n_rays // n_alive, 8), 1)  # more samples per ray and launch as rays die
-                    xyzs, dirs, deltas = raymarching.march_rays(
-                        n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                        self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
-                    sigmas, rgbs = self(xyzs, dirs)
-                    sigmas = self.density_scale * sigmas
-                    raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
-                                               T_thresh)
-                    rays_alive = rays_alive[rays_alive >= 0]
-                    step += n_step
+                if getattr(self, 'device_loop', True):
+                    self._render_loop_on_device(rays_o, rays_d, nears, fars, rays_t, weights_sum, depth, image, perturb, dt_gamma, max_steps,
+                                                T_thresh)
+                else:  # the reference's host-driven loop (renderer.py:341-367): one device->host read-back per iteration
+                    rays_alive = torch.arange(n_rays, dtype=torch.int32, device=dev)
+                    step = 0
+                    while step < max_steps:
+                        n_alive = rays_alive.shape[0]
+                        if n_alive <= 0:
+                            break
+                        n_step = max(min(n_rays // n_alive, 8), 1)  # more samples per ray and launch as rays die
+                        xyzs, dirs, deltas = raymarching.march_rays(
+                            n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                            self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
+                        sigmas, rgbs = self(xyzs, dirs)
+                        sigmas = self.density_scale * sigmas
+                        raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
+                                                   T_thresh)
+                        rays_alive = rays_alive[rays_alive >= 0]
+                        step += n_step
             image, depth = self._finish(image, depth, weights_sum, bg_color, nears, fars, lead)
 
         results['depth'] = depth
         results['image'] = image
         return results
+
+    def _render_loop_on_device(self, rays_o, rays_d, nears, fars, rays_t, weights_sum, depth, image, perturb, dt_gamma, max_steps, T_thresh,
+                               sync_every=8):
+        """the eval loop of run_cuda (renderer.py:341-367) with its state on the device (extension): the alive count,
+        the per-iteration n_step = max(min(N // n_alive, 8), 1) and the marched-step total live in a device word pair that the march /
+        composite / compaction kernels read, so the host issues `sync_every` iterations back to back and reads the count back once per
+        batch (the reference reads it every iteration through `rays_alive[rays_alive >= 0]`).  Between read-backs launches are sized for
+        the last known count; lanes and sample rows beyond the true count do nothing / are zero rows.  Same slot layout, n_step sequence
+        and compaction order as the host-driven loop: same image."""
+        from raymarching.backend import _backend as rb
+        import _ngp_capi as capi
+        n_rays, dev = rays_o.shape[0], rays_o.device
+        alive = [torch.arange(n_rays, dtype=torch.int32, device=dev), torch.empty(n_rays, dtype=torch.int32, device=dev)]
+        state = torch.zeros(2, 2, dtype=torch.int32, device=dev)
+        state[0, 0] = n_rays
+        ws = torch.empty(int(capi.lib.ngp_compact_rays_workspace_bytes(n_rays)), dtype=torch.uint8, device=dev)
+        bits = self.density_bitfield.contiguous()
+        cur, bound_alive, iteration = 0, n_rays, 0
+        while bound_alive > 0 and iteration < max_steps:
+            rows = min(n_rays, 8 * bound_alive)
+            rows += 128 - rows % 128  # the marchers' padding rule (raymarching.py:328-331): the fused network path wants multiples of 128
+            for _ in range(sync_every if iteration else 2):  # the first batch is short: opaque scenes lose most rays at once
+                xyzs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
+                dirs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
+                deltas = torch.empty(rows, 2, dtype=torch.float32, device=dev)
+                noises = torch.rand(n_rays, dtype=torch.float32, device=dev) if (perturb and iteration == 0) else None
+                rb.march_rays_dev(state[cur], bound_alive, n_rays, alive[cur], rays_t, rays_o, rays_d, self.bound, dt_gamma, max_steps,
+                                  self.cascade, self.grid_size, bits, nears, fars, xyzs, dirs, deltas, noises, rows)
+                sigmas, rgbs = self(xyzs, dirs)
+                sigmas = (self.density_scale * sigmas).float().contiguous()
+                rb.composite_rays_dev(state[cur], bound_alive, n_rays, T_thresh, alive[cur], rays_t, sigmas, rgbs.float().contiguous(), deltas,
+                                      weights_sum, depth, image)
+                rb.compact_rays_dev(state[cur], bound_alive, n_rays, max_steps, alive[cur], alive[1 - cur], state[1 - cur], ws)
+                cur ^= 1
+                iteration += 1
+            bound_alive = int(state[cur, 0].item())
 
     # -- occupancy grid maintenance -------------------------------------------------------------
     def _cascade_points(self, coords, cas):

@@ -18,8 +18,18 @@ gradient for that parameter).  Parameters whose gradient arrives the ordinary wa
 are handled by the same kernel.  With gradient deposit, run ONE backward per step (the MLP weight gradients are accumulated by the
 kernels, but a second backward before `step()` would also re-read stale shadows).
 
-Multi-GPU: `all_reduce()` sums the fp16 buffers over ranks (24.5 MB instead of 49 MB for the table) and the update kernel applies
-the 1/world_size; an fp16 overflow of the sum is caught like any other non-finite gradient (skipped step, scale backs off).
+Multi-GPU (one process per GPU, torch.distributed; 'nccl' is RCCL over xGMI), two modes:
+  * replicated (`shard=False`): `all_reduce()` AVERAGES the one flat fp16 gradient buffer over ranks (24.5 MB instead of 49 MB of fp32):
+    RCCL's AVG pre-multiplies by 1/world before summing, so the loss-scaled fp16 sum cannot overflow where a single rank's gradient did
+    not (a plain SUM of 8 x 65536-scaled gradients would); every rank then runs the full update.
+  * sharded (`shard=True`, ZeRO-1 style): the flat buffer is cut into world_size equal shards; `reduce_gradients()` = ONE
+    reduce-scatter (each rank receives the average of its shard), the rank updates only its 1/world of the moments, fp32 master weights
+    and fp16 shadows (Adam's 30 B/parameter sweep shrinks by world_size), and `gather_shadows()` = ONE all-gather of the fp16 shadows
+    on a side stream, which the next iteration's parameter-independent ray marching overlaps.  Same bytes on the wire as the ring
+    all-reduce (which is a reduce-scatter + all-gather), 1/world of the optimizer traffic, and the gather leaves the critical path.
+    The "step skipped as a whole" rule needs a global verdict: every rank sweeps its LOCAL gradient before the exchange and poisons one
+    flag slot per shard, so after the reduce-scatter each owner sees a non-finite value iff any rank had one -- no extra collective.
+    The fp32 parameters are re-pointed into one flat master buffer (`gather_master()` completes them on every rank for checkpoints).
 """
 import ctypes
 
@@ -32,8 +42,10 @@ _MAX = 8
 
 
 class NGPAdam:
+    _require_cuda = True   # tests of the multi-rank orchestration subclass this with a torch stand-in for the kernels (tests/ only)
+
     def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5,
-                 growth_interval=2000, world_size=1, deposit=True):
+                 growth_interval=2000, world_size=1, deposit=True, shard=False, rank=None, process_group=None):
         groups = list(params)
         if groups and not isinstance(groups[0], dict):
             groups = [{'params': groups}]
@@ -44,33 +56,61 @@ class NGPAdam:
         self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
         self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), float(growth_interval)
         self.world_size = int(world_size)
+        self.group = process_group
+        self.shard = bool(shard) and self.world_size > 1
+        if self.shard and not deposit:
+            raise RuntimeError('NGPAdam: shard=True needs deposit=True (the flat fp16 gradient buffer is what gets reduce-scattered)')
+        self.rank = (dist.get_rank(process_group) if rank is None else int(rank)) if self.shard else 0
         self.check_mixed_gradients = False  # debugging aid: costs a device read-back per deposited parameter and step
         self.state = {}
         dev = None
         flat_params = [p for g in self.param_groups for p in g['params']]
         for p in flat_params:
-            if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+            if not ((p.is_cuda or not self._require_cuda) and p.dtype == torch.float32 and p.is_contiguous()):
                 raise RuntimeError('NGPAdam: parameters must be contiguous float32 CUDA tensors')
             dev = p.device
-        # one contiguous fp16 gradient buffer for all parameters (each slice 16-byte aligned): ONE all-reduce message per step
-        self.flat_grad16 = None
-        offsets, total = [], 0
+        self.flat_params = flat_params
+        # packed coordinates: parameter k occupies [offsets[k], offsets[k] + numel) of every flat buffer (slices 16-byte aligned)
+        self.offsets, total = [], 0
         for p in flat_params:
-            offsets.append(total)
+            self.offsets.append(total)
             total += (p.numel() + 7) // 8 * 8
+        self.payload = total
+        if self.shard:  # world_size equal shards of the packed range (a parameter may straddle a boundary)
+            self.payload = ((total + self.world_size - 1) // self.world_size + 7) // 8 * 8
+            total = self.payload * self.world_size
+        self.total = total
+        # ONE contiguous fp16 gradient buffer and ONE fp16 shadow buffer: one collective message each per step
+        self.flat_grad16 = self.flat_p16 = self.flat_master = None
         if deposit:
             self.flat_grad16 = torch.zeros(total, dtype=torch.half, device=dev)
-        for p, off in zip(flat_params, offsets):
-            st = {'exp_avg': torch.zeros_like(p), 'exp_avg_sq': torch.zeros_like(p)}
+            self.flat_p16 = torch.zeros(total, dtype=torch.half, device=dev)
+        if self.shard:
+            self.flat_master = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.shard_grad = torch.zeros(self.payload, dtype=torch.half, device=dev)     # my averaged shard (reduce-scatter output)
+            self.exp_avg = torch.zeros(self.payload, dtype=torch.float32, device=dev)     # moments of my shard only
+            self.exp_avg_sq = torch.zeros(self.payload, dtype=torch.float32, device=dev)
+            self.shard_range = (self.rank * self.payload, (self.rank + 1) * self.payload)
+        for p, off in zip(flat_params, self.offsets):
+            n = p.numel()
+            st = {}
+            if self.shard:
+                self.flat_master[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_master[off:off + n].view_as(p)  # the parameter now lives in the flat master buffer
+            else:
+                st.update(exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
             if deposit:
-                st['fp16'] = p.detach().to(torch.half)
-                st['grad16'] = self.flat_grad16[off:off + p.numel()].view_as(p)
+                st['fp16'] = self.flat_p16[off:off + n].view_as(p)
+                st['fp16'].copy_(p.detach())
+                st['grad16'] = self.flat_grad16[off:off + n].view_as(p)
                 p._ngp_fp16, p._ngp_grad16, p._ngp_version = st['fp16'], st['grad16'], p._version
             self.state[p] = st
         # device-resident scalars: loss scale, growth tracker, found_inf, Adam step count, lr multiplier (schedulers write this one)
         self.scalars = torch.tensor([init_scale, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
         self._scale_view = self.scalars[0]
         self._keep = None
+        self._comm_stream = None
+        self._shadows_ready = None
 
     # -- GradScaler-like surface -------------------------------------------------------------------
     def scale(self, loss):
@@ -105,21 +145,118 @@ class NGPAdam:
 
     def sync_shadows(self):
         """refresh the fp16 shadow copies after the fp32 parameters were changed from outside (checkpoint load, manual init)"""
+        self.wait_shadows()
         for p, st in self.state.items():
             if 'fp16' in st:
                 st['fp16'].copy_(p.detach())
                 p._ngp_version = p._version
 
+    # -- gradient exchange ---------------------------------------------------------------------------
+    def _avg_native(self):
+        return dist.get_backend(self.group) == 'nccl'  # RCCL: AVG = pre-multiply by 1/world, then sum (no fp16 overflow of the sum)
+
     @torch.no_grad()
     def all_reduce(self):
-        """sum the gradients over ranks (call between backward and step); the 1/world_size is applied inside step()"""
+        """replicated mode: average the gradients over ranks (call between backward and step).  The loss-scaled fp16 buffer is
+        pre-multiplied by 1/world (inside RCCL's AVG, or explicitly on backends without it) BEFORE the sum: exact for power-of-two
+        world sizes, and the sum cannot overflow fp16 where no single rank's gradient did."""
         if self.world_size <= 1:
             return
+        if self.shard:
+            raise RuntimeError('NGPAdam: sharded mode exchanges gradients with reduce_gradients() / step()')
         eager = [p for g in self.param_groups for p in g['params'] if p.grad is not None]
         for p in eager:
-            dist.all_reduce(p.grad)
+            self._average(p.grad)
         if self.flat_grad16 is not None and len(eager) < len(self.state):
-            dist.all_reduce(self.flat_grad16)
+            self._average(self.flat_grad16)
+
+    def _average(self, t):
+        if self._avg_native():
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            t.mul_(1.0 / self.world_size)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    # ---- sharded mode: pre_reduce_check (capturable) -> reduce_gradients (collectives) -> apply (capturable) -> gather_shadows (async) ----
+    @torch.no_grad()
+    def pre_reduce_check(self):
+        """sweep the LOCAL flat gradient for non-finite values into found_inf (scalars[2]); capturable"""
+        self._launch([(self.total, None, None, None, self.flat_grad16, None, 1, 0.0, None)], capi.NGP_OPT_PHASE_CHECK, 0.0)
+
+    @torch.no_grad()
+    def reduce_gradients(self):
+        """ONE reduce-scatter: every rank receives the average of its shard of the flat fp16 gradient; the per-rank found_inf verdicts
+        are combined (MAX) so that a step is skipped on all ranks or on none"""
+        view = self.flat_grad16.view(self.world_size, self.payload)
+        if self._avg_native():
+            dist.reduce_scatter_tensor(self.shard_grad, self.flat_grad16, op=dist.ReduceOp.AVG, group=self.group)
+        else:  # backends without reduce-scatter / AVG (gloo in the CPU tests): same result through an all-reduce
+            self.flat_grad16.mul_(1.0 / self.world_size)
+            dist.all_reduce(self.flat_grad16, op=dist.ReduceOp.SUM, group=self.group)
+            self.shard_grad.copy_(view[self.rank])
+        dist.all_reduce(self.scalars[2:3], op=dist.ReduceOp.MAX, group=self.group)
+
+    def _shard_entries(self):
+        """the pieces of parameters inside my shard, as kernel entries (n, p, m, v, g, p16, is_half, lr, ema)"""
+        lo, hi = self.shard_range
+        out = []
+        lr_of = {id(p): g['lr'] for g in self.param_groups for p in g['params']}
+        for p, off in zip(self.flat_params, self.offsets):
+            a, b = max(off, lo), min(off + p.numel(), hi)
+            if a < b:
+                out.append((b - a, self.flat_master[a:b], self.exp_avg[a - lo:b - lo], self.exp_avg_sq[a - lo:b - lo], self.shard_grad[a - lo:b - lo],
+                            self.flat_p16[a:b], 1, lr_of[id(p)], None))
+        return out
+
+    @torch.no_grad()
+    def apply(self):
+        """Adam on my shard (skipped everywhere when any rank saw a non-finite gradient), loss-scale / step-count commit, and the flat
+        deposit buffer zeroed for the next backward; capturable"""
+        entries = self._shard_entries()
+        for i in range(0, len(entries), _MAX):
+            self._launch(entries[i:i + _MAX], capi.NGP_OPT_PHASE_UPDATE, 0.0)
+        self._launch([], capi.NGP_OPT_PHASE_COMMIT, 0.0)
+        self.flat_grad16.zero_()
+
+    @torch.no_grad()
+    def gather_shadows(self, async_op=True):
+        """ONE all-gather of the fp16 shadow weights (every rank contributes its freshly updated shard).  Issued on a side stream after
+        the update; `wait_shadows()` makes the consumer's stream wait -- the next iteration's ray marching does not need the weights and
+        runs meanwhile."""
+        lo, hi = self.shard_range
+        mine = self.flat_p16[lo:hi]
+        if not (async_op and self.flat_p16.is_cuda):
+            self._all_gather(self.flat_p16, mine)
+            return
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.flat_p16.device)
+            self._shadows_ready = torch.cuda.Event()
+        self._comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm_stream):
+            self._all_gather(self.flat_p16, mine)
+            self._shadows_ready.record(self._comm_stream)
+        self._pending = True
+
+    def _all_gather(self, full, mine):
+        if dist.get_backend(self.group) == 'nccl':
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.world_size)]
+            dist.all_gather(parts, mine.contiguous(), group=self.group)
+            full.view(self.world_size, -1).copy_(torch.stack(parts))
+
+    def wait_shadows(self):
+        if getattr(self, '_pending', False):
+            torch.cuda.current_stream().wait_event(self._shadows_ready)
+            self._pending = False
+
+    @torch.no_grad()
+    def gather_master(self):
+        """complete the fp32 master weights on every rank (each rank only keeps its own shard current): before checkpoints / evaluation
+        through the module-by-module path"""
+        if self.shard:
+            lo, hi = self.shard_range
+            self._all_gather(self.flat_master, self.flat_master[lo:hi])
 
     # -- the step ----------------------------------------------------------------------------------
     def _entries(self):
@@ -149,50 +286,57 @@ class NGPAdam:
             return False
         return bool(st['grad16'].ne(0).any().item())
 
+    def _launch(self, entries, phases, omd):
+        """one ngp_optim_adam_step_ex call.  entries: up to 8 tuples (n, param, exp_avg, exp_avg_sq, grad, fp16 shadow or None, grad_is_half,
+        lr, ema shadow or None) of flat tensors (param / moments may be None for a CHECK-only call)"""
+        k = len(entries)
+        vp = ctypes.c_void_p
+
+        def ptrs(i):
+            return (vp * k)(*[(e[i].data_ptr() if e[i] is not None else None) for e in entries])
+        if k:
+            n = (ctypes.c_uint64 * k)(*[int(e[0]) for e in entries])
+            arrs = (n, ptrs(1), ptrs(2), ptrs(3), ptrs(4), ptrs(5), (ctypes.c_int * k)(*[int(e[6]) for e in entries]),
+                    (ctypes.c_float * k)(*[float(e[7]) for e in entries]), ptrs(8) if omd > 0.0 else None)
+            self._keep.append((arrs, entries))
+            cast = [ctypes.cast(a, vp) if a is not None else None for a in arrs]
+        else:
+            cast = [None] * 9
+        capi.check(capi.lib.ngp_optim_adam_step_ex(k, cast[0], cast[1], cast[2], cast[3], cast[4], cast[5], cast[6], cast[7], self.betas[0],
+                                                   self.betas[1], self.eps, 1.0, self.growth_factor, self.backoff_factor, self.growth_interval,
+                                                   self.scalars.data_ptr(), cast[8], float(omd), phases, capi.stream()))
+
     @torch.no_grad()
     def step(self, update_ema=None):
         """one optimizer + loss-scaling step.  `update_ema`: an `NGPEma` whose moving average is advanced inside the same sweep (the
-        Trainer does that once per epoch, nerf/utils.py:760-761,891-892; call it with the last step of the epoch)"""
-        entries = self._entries()
-        stream = capi.stream()
-        omd = 0.0
-        if update_ema is not None:
-            omd = update_ema.begin_update()
-        keep = []
-        chunks = [entries[i:i + _MAX] for i in range(0, len(entries), _MAX)]
+        Trainer does that once per epoch, nerf/utils.py:760-761,891-892; call it with the last step of the epoch).
+        Sharded mode: the whole exchange-and-update sequence (pre_reduce_check -> reduce_gradients -> apply -> gather_shadows)."""
+        self._keep = []
         CHECK, UPDATE, COMMIT = capi.NGP_OPT_PHASE_CHECK, capi.NGP_OPT_PHASE_UPDATE, capi.NGP_OPT_PHASE_COMMIT
-
-        def call(chunk, phases):
-            k = len(chunk)
-            n = (ctypes.c_uint64 * k)(*[e[0].numel() for e in chunk])
-            ps = (ctypes.c_void_p * k)(*[e[0].data_ptr() for e in chunk])
-            ms = (ctypes.c_void_p * k)(*[e[1]['exp_avg'].data_ptr() for e in chunk])
-            vs = (ctypes.c_void_p * k)(*[e[1]['exp_avg_sq'].data_ptr() for e in chunk])
-            gs = (ctypes.c_void_p * k)(*[e[2].data_ptr() for e in chunk])
-            p16 = (ctypes.c_void_p * k)(*[(e[1]['fp16'].data_ptr() if 'fp16' in e[1] else None) for e in chunk])
-            gh = (ctypes.c_int * k)(*[e[3] for e in chunk])
-            lrs = (ctypes.c_float * k)(*[e[4] for e in chunk])
-            em = (ctypes.c_void_p * k)(*[update_ema.shadow_of(e[0]).data_ptr() for e in chunk]) if update_ema is not None else None
-            keep.append((n, ps, ms, vs, gs, p16, gh, lrs, em))
-            vp = ctypes.c_void_p
-            capi.check(capi.lib.ngp_optim_adam_step_ex(
-                k, ctypes.cast(n, vp), ctypes.cast(ps, vp), ctypes.cast(ms, vp), ctypes.cast(vs, vp), ctypes.cast(gs, vp),
-                ctypes.cast(p16, vp), ctypes.cast(gh, vp), ctypes.cast(lrs, vp), self.betas[0], self.betas[1], self.eps,
-                1.0 / self.world_size, self.growth_factor, self.backoff_factor, self.growth_interval, self.scalars.data_ptr(),
-                None if em is None else ctypes.cast(em, vp), float(omd), phases, stream))
-
+        if self.shard:
+            if update_ema is not None:
+                raise RuntimeError('NGPAdam(shard=True): fold-in EMA is not available; call gather_master() then ema.update() once per epoch')
+            if any(p.grad is not None for p in self.flat_params):
+                raise RuntimeError('NGPAdam(shard=True): gradients must be deposited by the fused path (found an autograd .grad)')
+            self.pre_reduce_check()
+            self.reduce_gradients()
+            self.apply()
+            self.gather_shadows()
+            self.wait_shadows()
+            return
+        omd = update_ema.begin_update() if update_ema is not None else 0.0
+        entries = [(p.numel(), p, st['exp_avg'], st['exp_avg_sq'], grad, st.get('fp16'), is_half, lr,
+                    update_ema.shadow_of(p) if update_ema is not None else None) for p, st, grad, is_half, lr in self._entries()]
+        chunks = [entries[i:i + _MAX] for i in range(0, len(entries), _MAX)]
         if len(chunks) == 1:
-            call(chunks[0], CHECK | UPDATE | COMMIT)
+            self._launch(chunks[0], CHECK | UPDATE | COMMIT, omd)
         else:
             # "skipped as a whole": every chunk is swept for non-finite values BEFORE any chunk is updated (GradScaler.step semantics)
             for c in chunks:
-                call(c, CHECK)
+                self._launch(c, CHECK, 0.0)
             for c in chunks:
-                call(c, UPDATE)
-            capi.check(capi.lib.ngp_optim_adam_step_ex(0, None, None, None, None, None, None, None, None, self.betas[0], self.betas[1], self.eps,
-                                                       1.0, self.growth_factor, self.backoff_factor, self.growth_interval,
-                                                       self.scalars.data_ptr(), None, 0.0, COMMIT, stream))
-        self._keep = keep
+                self._launch(c, UPDATE, omd)
+            self._launch([], COMMIT, 0.0)
 
     # -- checkpointing -----------------------------------------------------------------------------
     def load_torch_adam_state(self, adam_sd, scaler_sd=None):
@@ -207,8 +351,7 @@ class NGPAdam:
             st = adam_sd['state'].get(i)
             if st is None:
                 continue
-            self.state[p]['exp_avg'].copy_(st['exp_avg'])
-            self.state[p]['exp_avg_sq'].copy_(st['exp_avg_sq'])
+            self._set_moments(p, st['exp_avg'], st['exp_avg_sq'])
             step = max(step, float(st['step']))
         self.scalars[3:4].fill_(step)
         # learning rate: the group keeps the scheduler-free base rate, the scheduler's current factor (LambdaLR writes lr =
@@ -232,17 +375,50 @@ class NGPAdam:
         self.sync_shadows()
 
 
+    def _shard_piece(self, p):
+        """(a, b, off): the packed range [a, b) of parameter p inside my shard (a >= b: nothing) and p's packed offset"""
+        off = self.offsets[[id(q) for q in self.flat_params].index(id(p))]
+        lo, hi = self.shard_range
+        return max(off, lo), min(off + p.numel(), hi), off
+
+    def _set_moments(self, p, m, v):
+        if not self.shard:
+            self.state[p]['exp_avg'].copy_(m)
+            self.state[p]['exp_avg_sq'].copy_(v)
+            return
+        a, b, off = self._shard_piece(p)
+        if a < b:
+            lo = self.shard_range[0]
+            self.exp_avg[a - lo:b - lo].copy_(m.reshape(-1)[a - off:b - off])
+            self.exp_avg_sq[a - lo:b - lo].copy_(v.reshape(-1)[a - off:b - off])
+
+    def _get_moments(self, p):
+        if not self.shard:
+            return self.state[p]['exp_avg'].clone(), self.state[p]['exp_avg_sq'].clone()
+        m, v = torch.zeros_like(p).reshape(-1), torch.zeros_like(p).reshape(-1)
+        a, b, off = self._shard_piece(p)
+        if a < b:
+            lo = self.shard_range[0]
+            m[a - off:b - off].copy_(self.exp_avg[a - lo:b - lo])
+            v[a - off:b - off].copy_(self.exp_avg_sq[a - lo:b - lo])
+        dist.all_reduce(m, group=self.group)  # every element is owned by exactly one rank: the sum assembles the full tensor
+        dist.all_reduce(v, group=self.group)
+        return m.view_as(p), v.view_as(p)
+
     def state_dict(self):
+        """full (unsharded) optimizer state; in sharded mode a collective call (every rank assembles the complete moments)"""
         flat = [p for g in self.param_groups for p in g['params']]
-        return {'scalars': self.scalars.clone(), 'exp_avg': [self.state[p]['exp_avg'].clone() for p in flat],
-                'exp_avg_sq': [self.state[p]['exp_avg_sq'].clone() for p in flat], 'lr': [g['lr'] for g in self.param_groups]}
+        if self.shard:
+            self.gather_master()
+        mv = [self._get_moments(p) for p in flat]
+        return {'scalars': self.scalars.clone(), 'exp_avg': [m for m, _ in mv], 'exp_avg_sq': [v for _, v in mv],
+                'lr': [g['lr'] for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         flat = [p for g in self.param_groups for p in g['params']]
         self.scalars.copy_(sd['scalars'])
         for p, m, v in zip(flat, sd['exp_avg'], sd['exp_avg_sq']):
-            self.state[p]['exp_avg'].copy_(m)
-            self.state[p]['exp_avg_sq'].copy_(v)
+            self._set_moments(p, m, v)
         for g, lr in zip(self.param_groups, sd['lr']):
             g['lr'] = lr
         self.sync_shadows()

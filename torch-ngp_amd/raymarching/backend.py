@@ -135,7 +135,62 @@ def compact_rays(rays_alive, n_alive, out_alive, out_count):
                                          capi.stream()))
 
 
+def march_rays_dev(state, alive_bound, n_total, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars,
+                   xyzs, dirs, deltas, noises, rows):
+    """extension (include/ngp_hip.h, on-device inference loop): march_rays with the alive count / n_step taken from the device `state`"""
+    for t, n in ((rays_t, 'rays_t'), (rays_o, 'rays_o'), (rays_d, 'rays_d'), (nears, 'nears'), (fars, 'fars'), (xyzs, 'xyzs'),
+                 (dirs, 'dirs'), (deltas, 'deltas')):
+        _f32(t, n)
+    _i32(rays_alive, 'rays_alive'); _i32(state, 'state')
+    capi.dense(grid, 'grid')
+    capi.check(capi.lib.ngp_march_rays_dev(capi.ptr(state), alive_bound, n_total, capi.ptr(rays_alive), capi.ptr(rays_t), capi.ptr(rays_o),
+                                           capi.ptr(rays_d), float(bound), float(dt_gamma), max_steps, C, H, capi.ptr(grid), capi.ptr(nears),
+                                           capi.ptr(fars), capi.ptr(xyzs), capi.ptr(dirs), capi.ptr(deltas), capi.ptr(noises), rows, capi.stream()))
+
+
+def composite_rays_dev(state, alive_bound, n_total, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+    for t, n in ((rays_t, 'rays_t'), (sigmas, 'sigmas'), (rgbs, 'rgbs'), (deltas, 'deltas'), (weights_sum, 'weights_sum'),
+                 (depth, 'depth'), (image, 'image')):
+        _f32(t, n)
+    _i32(rays_alive, 'rays_alive'); _i32(state, 'state')
+    capi.check(capi.lib.ngp_composite_rays_dev(capi.ptr(state), alive_bound, n_total, float(T_thresh), capi.ptr(rays_alive), capi.ptr(rays_t),
+                                               capi.ptr(sigmas), capi.ptr(rgbs), capi.ptr(deltas), capi.ptr(weights_sum), capi.ptr(depth),
+                                               capi.ptr(image), capi.stream()))
+
+
+def compact_rays_dev(state, alive_bound, n_total, max_steps, rays_alive, out_alive, out_state, workspace):
+    _i32(rays_alive, 'rays_alive'); _i32(out_alive, 'out_alive'); _i32(out_state, 'out_state'); _i32(state, 'state')
+    capi.check(capi.lib.ngp_compact_rays_dev(capi.ptr(state), alive_bound, n_total, max_steps, capi.ptr(rays_alive), capi.ptr(out_alive),
+                                             capi.ptr(out_state), capi.ptr(workspace), capi.stream()))
+
+
+def _accept_half(fn):
+    """the reference dispatches its raymarching entry points on the tensor dtype (AT_DISPATCH_FLOATING_TYPES_AND_HALF, raymarching.cu:486);
+    its own wrappers always hand over fp32 (custom_fwd(cast_inputs=float32)), so fp16 is unreachable from them.  For direct `_backend`
+    callers: fp16 tensors are computed through fp32 copies of the same kernels and every floating tensor argument is copied back
+    (outputs are caller-allocated arguments), i.e. fp32 arithmetic rounded once to fp16."""
+    import functools
+
+    @functools.wraps(fn)
+    def call(*args):
+        if not any(torch.is_tensor(a) and a.dtype == torch.float16 for a in args):
+            return fn(*args)
+        up = [a.float() if torch.is_tensor(a) and a.dtype == torch.float16 else a for a in args]
+        out = fn(*up)
+        for a, u in zip(args, up):
+            if torch.is_tensor(a) and a.dtype == torch.float16:
+                a.copy_(u)
+        return out
+    return call
+
+
+near_far_from_aabb, sph_from_ray, packbits = _accept_half(near_far_from_aabb), _accept_half(sph_from_ray), _accept_half(packbits)
+march_rays_train, march_rays, composite_rays = _accept_half(march_rays_train), _accept_half(march_rays), _accept_half(composite_rays)
+composite_rays_train_forward = _accept_half(composite_rays_train_forward)
+composite_rays_train_backward = _accept_half(composite_rays_train_backward)
+
 _backend = types.SimpleNamespace(
+    march_rays_dev=march_rays_dev, composite_rays_dev=composite_rays_dev, compact_rays_dev=compact_rays_dev,
     near_far_from_aabb=near_far_from_aabb, sph_from_ray=sph_from_ray, morton3D=morton3D, morton3D_invert=morton3D_invert,
     packbits=packbits, packbits_capped=packbits_capped, march_rays_train=march_rays_train, composite_rays_train_forward=composite_rays_train_forward,
     composite_rays_train_backward=composite_rays_train_backward, march_rays=march_rays, march_rays_ex=march_rays_ex,

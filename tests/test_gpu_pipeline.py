@@ -46,14 +46,19 @@ def test_training_step_matches_oracle_pipeline(fused):
     # bit-exact point count
     assert model.step_counter[0].tolist() == [ref['n_samples'], n_rays]
     img = out['image'][0].detach().float().cpu().numpy()
-    np.testing.assert_allclose(img, ref['image'], rtol=0, atol=4e-3)   # colours are sums of ~60 fp16-rounded rgb * weight terms
-    assert abs(loss.item() - ref['loss']) < 2e-3 * max(1.0, ref['loss'])
+    # the oracle applies the same fp16 rounding points (table, encoder output, MLP activations and outputs, sigmoid output), so what is
+    # left is fp32 summation order and exp / sigmoid implementations.  Measured on MI355X (tools/measure_pipeline_error.py, 3 batches x both
+    # paths): image 1.6e-6 .. 4.2e-6, loss 2e-8 .. 4e-8, gradients 1.9e-4 .. 3.9e-4 relative L2 -- the bars are the north-star's 1e-3 for the
+    # colours (met with two orders of magnitude to spare) and 2e-3 for the gradients (a ReLU unit whose fp16 pre-activation rounds to the
+    # other side of zero moves one weight column; the weight-gradient tests of test_gpu_ffmlp.py quantify that)
+    np.testing.assert_allclose(img, ref['image'], rtol=0, atol=1e-4)
+    assert abs(loss.item() - ref['loss']) < 1e-5 * max(1.0, ref['loss'])
     g_emb, g_ws, g_wc = ref['grads']
     for got, want, name in ((model.encoder.embeddings.grad, g_emb, 'embeddings'), (model.sigma_net.weights.grad, g_ws, 'sigma_net'),
                             (model.color_net.weights.grad, g_wc, 'color_net')):
         got = got.float().cpu().numpy().astype(np.float64).reshape(want.shape) / scale
         rel = np.linalg.norm(got - want) / np.linalg.norm(want)
-        assert rel < 2e-2, (name, rel)
+        assert rel < 2e-3, (name, rel)
 
 
 def test_render_eval_image_matches_oracle_loop():
@@ -90,7 +95,8 @@ def test_on_device_render_loop_equals_host_driven_loop(density_scale, perturb):
         with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
             out = model.render(ot, dt_, staged=True, bg_color=1, perturb=perturb, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
         res.append((out['image'].clone(), out['depth'].clone()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # rays that miss the box carry depth = 0/0 on both paths (renderer.py:317, as in the reference)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(torch.nan_to_num(res[0][1], nan=-1.0), torch.nan_to_num(res[1][1], nan=-1.0))
     assert float(res[0][0].std()) > 0
 
 

@@ -310,7 +310,7 @@ def test_time_indexed_bitfields_dnerf_layout():
         assert row.data_ptr() == bitfield[t].data_ptr()
         assert np.array_equal(bitfield[t].cpu().numpy(), oracle.packbits(grids[t], 10.0))
     flat = torch.zeros_like(bitfield)
-    rm.packbits(density_grid.view(-1), 10.0, flat.view(-1))
+    rm.packbits(density_grid.view(T * C, -1), 10.0, flat.view(-1))   # [T*cascade, H^3]: the wrapper's 2-D contract (raymarching.py:148-153)
     assert torch.equal(flat, bitfield)
     o, d = _random_rays(1024, 5, radius=3.0)
     aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)

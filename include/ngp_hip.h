@@ -253,6 +253,18 @@ int ngp_ffmlp_backward_ws(const void* grad, const void* inputs, const void* weig
                           uint32_t output_activation, int calc_grad_inputs, void* backward_buffer, void* grad_inputs, void* grad_weights,
                           uint32_t flags, void* workspace, size_t workspace_bytes, ngp_stream_t stream);
 
+/* The whole network of nerf/network_ff.py:51-74 behind the encoder in ONE launch (64-wide ReLU networks with 32 inputs, the instant-ngp
+ * configuration): sigma FFMLP -> trunc_exp / SH(4) / feature shuffle -> colour FFMLP -> sigmoid.  enc: the encoder output, [M,32] fp16
+ * row-major or (flags & NGP_FF_INPUT_PLANAR) the encoder's own [16][M][2] layout; dirs [M_valid,3] fp32 (rows >= M_valid use dir = 0);
+ * -> sigma [M] fp32 (= density_scale * exp(h0)), rgb [M,3] fp32.  training != 0 also writes what ngp_ffmlp_backward* and the
+ * ngp_pipeline_*_backward kernels read: forward_buffer_sigma [nl_s,M,64], h16 [M,16], color_in [M,32], forward_buffer_color [nl_c,M,64]
+ * (all fp16, the forward buffers in this library's private layout).  Bit-identical to the sequence ngp_ffmlp_forward_ex ->
+ * ngp_pipeline_mid_forward -> ngp_ffmlp_forward_ex -> ngp_pipeline_rgb_forward it replaces. */
+int ngp_network_forward(const void* enc, const float* dirs, uint32_t M, uint32_t M_valid, const void* w_sigma, const void* w_color,
+                        uint32_t num_layers_sigma, uint32_t num_layers_color, float density_scale, int training,
+                        void* forward_buffer_sigma, void* h16, float* sigma, void* color_in, void* forward_buffer_color, float* rgb,
+                        uint32_t flags, ngp_stream_t stream);
+
 /* network_ff.py:55-72 between the two MLPs: h16 [M,16] fp16 (sigma-net output), dirs [M_valid,3] fp32 ->
  * sigma [M] fp32 = exp(h[:,0]) (trunc_exp), color_in [M,32] fp16 = [SH deg 4 | h[:,1:16] | 0]; rows >= M_valid use dir = 0 */
 int ngp_pipeline_mid_forward(const void* h16, const float* dirs, float* sigma, void* color_in, uint32_t M, uint32_t M_valid,

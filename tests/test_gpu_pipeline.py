@@ -78,26 +78,36 @@ def test_render_eval_image_matches_oracle_loop():
 
 @pytest.mark.parametrize('density_scale,perturb', [(1.0, False), (40.0, False), (300.0, True)])
 def test_on_device_render_loop_equals_host_driven_loop(density_scale, perturb):
-    """the eval loop with its state on the device (one read-back per batch of iterations) against the reference's host-driven loop (one
-    per iteration, renderer.py:341-367): same slots, same n_step sequence, same compaction order -> the same image, bit for bit"""
+    """the eval loop with its state on the device (one read-back per batch of iterations; batches replayed from HIP graphs, or issued
+    eagerly with graph_loop = False) against the reference's host-driven loop (one read-back per iteration, renderer.py:341-367): same
+    slots, same n_step sequence, same compaction order -> the same image, bit for bit.  Two frames per mode: the second one replays the
+    graphs captured by the first on different rays."""
     model, orc, bits, dev = _setup(emb_scale=0.5)
-    rng = np.random.default_rng(3)
-    pose = sc.camera_pose(rng)
-    pix = rng.integers(0, sc.RES * sc.RES, 5000)
-    o, d = sc.rays_for_pixels(pose, pix)
-    ot, dt_ = torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev)
     model.eval()
     model.density_scale = density_scale
-    res = []
-    for on_device in (True, False):
-        model.device_loop = on_device
-        torch.manual_seed(5)
-        with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
-            out = model.render(ot, dt_, staged=True, bg_color=1, perturb=perturb, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
-        res.append((out['image'].clone(), out['depth'].clone()))
-    # rays that miss the box carry depth = 0/0 on both paths (renderer.py:317, as in the reference)
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(torch.nan_to_num(res[0][1], nan=-1.0), torch.nan_to_num(res[1][1], nan=-1.0))
-    assert float(res[0][0].std()) > 0
+    frames = []
+    for seed in (3, 4):
+        rng = np.random.default_rng(seed)
+        pose = sc.camera_pose(rng)
+        pix = rng.integers(0, sc.RES * sc.RES, 20000)
+        o, d = sc.rays_for_pixels(pose, pix)
+        frames.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev)))
+    res = {}
+    for mode, (on_device, graphs) in {'graphs': (True, True), 'eager': (True, False), 'host': (False, False)}.items():
+        model.device_loop, model.graph_loop = on_device, graphs
+        model._loop_cache = None
+        for k, (ot, dt_) in enumerate(frames):
+            torch.manual_seed(5 + k)
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+                out = model.render(ot, dt_, staged=True, bg_color=1, perturb=perturb, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+            # rays that miss the box carry depth = 0/0 on every path (renderer.py:317, as in the reference)
+            res[(mode, k)] = (out['image'].clone(), torch.nan_to_num(out['depth'], nan=-1.0).clone())
+        if mode == 'graphs':
+            assert model._loop_cache['failed'] is False and (len(model._loop_cache['graphs']) > 0 or density_scale > 100)
+    for k in range(2):
+        for mode in ('graphs', 'eager'):
+            assert torch.equal(res[(mode, k)][0], res[('host', k)][0]) and torch.equal(res[(mode, k)][1], res[('host', k)][1]), (mode, k)
+        assert float(res[('host', k)][0].std()) > 0
 
 
 def test_update_extra_state_and_training_loop_run():
@@ -198,3 +208,40 @@ def test_fused_training_render_equals_module_path(bg_kind):
     for x, y, name in zip(a['grads'], b['grads'], ('embeddings', 'sigma_net', 'color_net')):
         rel = np.linalg.norm(x - y) / np.linalg.norm(y)
         assert rel < 5e-3, (name, rel)
+
+
+@pytest.mark.parametrize('nl_s,nl_c', [(2, 3), (3, 2), (4, 4)])
+@pytest.mark.parametrize('M', [128, 33408])
+def test_fused_network_forward_is_bit_identical_to_the_four_kernels(nl_s, nl_c, M):
+    """ngp_network_forward (sigma MLP -> trunc_exp / SH / feature shuffle -> colour MLP -> sigmoid in one launch) against the sequence
+    ngp_ffmlp_forward_ex -> ngp_pipeline_mid_forward -> ngp_ffmlp_forward_ex -> ngp_pipeline_rgb_forward: the same MFMA sequence and the
+    same fp16 rounding points, so every output and every stored activation must agree bit for bit (training and inference variants)"""
+    import fused
+    import _ngp_capi as capi
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(nl_s * 10 + nl_c)
+    enc = (torch.rand(16, M, 2, device=dev, generator=g) - 0.5).half()
+    dirs = torch.nn.functional.normalize(torch.randn(M - 37, 3, device=dev, generator=g), dim=-1)   # fewer direction rows than samples
+    ws = ((torch.rand(64 * (32 + 64 * (nl_s - 1) + 16), device=dev, generator=g) * 2 - 1) * (3 / 64) ** 0.5).half()
+    wc = ((torch.rand(64 * (32 + 64 * (nl_c - 1) + 16), device=dev, generator=g) * 2 - 1) * (3 / 64) ** 0.5).half()
+    res = {}
+    for training in (True, False):
+        for fused_net in (True, False):
+            fused.USE_FUSED_NETWORK = fused_net
+            try:
+                half = dict(device=dev, dtype=torch.half)
+                fb_s = torch.zeros(nl_s, M, 64, **half) if training else None
+                fb_c = torch.zeros(nl_c, M, 64, **half) if training else None
+                h16, color_in, out16 = torch.zeros(M, 16, **half), torch.zeros(M, 32, **half), torch.zeros(M, 16, **half)
+                sigma, rgb = torch.zeros(M, device=dev), torch.zeros(M, 3, device=dev)
+                fused._network_forward(enc, dirs, dirs.shape[0], ws, wc, nl_s, nl_c, 1.7, training, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M,
+                                       capi.stream())
+                res[(training, fused_net)] = (sigma, rgb, fb_s, fb_c, h16 if training else None, color_in if training else None)
+            finally:
+                fused.USE_FUSED_NETWORK = True
+    for training in (True, False):
+        a, b = res[(training, True)], res[(training, False)]
+        for x, y, name in zip(a, b, ('sigma', 'rgb', 'fb_s', 'fb_c', 'h16', 'color_in')):
+            assert (x is None and y is None) or torch.equal(x, y), (training, name)
+    assert torch.equal(res[(True, True)][0], res[(False, True)][0]) and torch.equal(res[(True, True)][1], res[(False, True)][1])
+    assert float(res[(True, True)][1].std()) > 0 and torch.isfinite(res[(True, True)][0]).all()

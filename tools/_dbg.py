@@ -1,26 +1,32 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, 'torch-ngp_amd'), ROOT, os.path.join(ROOT, 'tests')]
-import numpy as np, torch, oracle
-from test_gpu_ffmlp import _run_forward, cu16, _be
-for (din, hid, nl, B) in [(32,128,5,128),(32,128,2,4224),(32,64,6,4224),(32,128,2,128),(64,128,3,4224),(32,256,2,4224)]:
-    rng = np.random.default_rng(din * 1000 + hid * 10 + nl)
-    n_params = hid * (din + hid * (nl - 1) + 16)
-    w = oracle.round_fp16(rng.uniform(-1, 1, n_params) * np.sqrt(3 / hid))
-    x = oracle.round_fp16(rng.uniform(-1, 1, (B, din)))
-    out, fb, xt, wt = _run_forward(x, w, din, hid, nl)
-    ref, rfb = oracle.ffmlp_forward(x, w, din, 16, hid, nl)
-    g = oracle.round_fp16(rng.normal(size=(B, 16)) * 0.1)
-    gi = torch.zeros(B, din, device='cuda', dtype=torch.half); gw = torch.zeros(n_params, device='cuda', dtype=torch.half)
-    bb = torch.zeros(nl, B, hid, device='cuda', dtype=torch.half)
-    _be().ffmlp_backward(cu16(g), xt, wt, fb, B, din, 16, hid, nl, 0, 6, True, bb, gi, gw)
-    rgx, rgw = oracle.ffmlp_backward(g, x, w, rfb, din, 16, hid, nl)
-    gwn = gw.float().cpu().numpy()
-    # per-matrix errors
-    sizes = [hid*din] + [hid*hid]*(nl-1) + [16*hid]
-    o = 0; per = []
-    for s in sizes:
-        a, b = gwn[o:o+s], rgw[o:o+s]; per.append((float(np.abs(a-b).max()/np.abs(rgw).max()), float(np.linalg.norm(a-b)/np.linalg.norm(b)))); o += s
-    gx = gi.float().cpu().numpy()
-    okfrac = (np.abs(gx - rgx) <= 4e-3*np.abs(rgx) + 4e-3*np.abs(rgx).max()).mean()
-    print((din,hid,nl,B), 'fwd', float(np.abs(out.float().cpu().numpy()-ref).max()/np.abs(ref).max()), 'gx okfrac', okfrac, 'gw per-matrix (max/scale, relL2)', [(round(a,5), round(b,5)) for a,b in per])
+import numpy as np, torch
+import fused, _ngp_capi as capi, oracle
+dev = torch.device('cuda')
+M = 33408; nl_s, nl_c = 2, 3
+g = torch.Generator(device='cuda').manual_seed(23)
+enc = (torch.rand(16, M, 2, device=dev, generator=g) - 0.5).half()
+dirs = torch.nn.functional.normalize(torch.randn(M - 37, 3, device=dev, generator=g), dim=-1)
+ws = ((torch.rand(64 * (32 + 64 * (nl_s - 1) + 16), device=dev, generator=g) * 2 - 1) * (3 / 64) ** 0.5).half()
+wc = ((torch.rand(64 * (32 + 64 * (nl_c - 1) + 16), device=dev, generator=g) * 2 - 1) * (3 / 64) ** 0.5).half()
+def run(fused_net):
+    fused.USE_FUSED_NETWORK = fused_net
+    half = dict(device=dev, dtype=torch.half)
+    fb_s, fb_c = torch.zeros(nl_s, M, 64, **half), torch.zeros(nl_c, M, 64, **half)
+    h16, color_in, out16 = torch.zeros(M, 16, **half), torch.zeros(M, 32, **half), torch.zeros(M, 16, **half)
+    sigma, rgb = torch.zeros(M, device=dev), torch.zeros(M, 3, device=dev)
+    fused._network_forward(enc, dirs, dirs.shape[0], ws, wc, nl_s, nl_c, 1.7, True, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M, capi.stream())
+    torch.cuda.synchronize()
+    fused.USE_FUSED_NETWORK = True
+    return color_in
+a1, a2, b1, b2 = run(True), run(True), run(False), run(False)
+print('fused deterministic', torch.equal(a1, a2), 'separate deterministic', torch.equal(b1, b2))
+sh = oracle.sh_forward(dirs.cpu().numpy(), 4)   # fp32 CPU oracle
+sh16 = torch.from_numpy(sh.astype(np.float16)).to(dev)
+n = dirs.shape[0]
+print('fused   vs oracle-half mismatches', int((a1[:n, :16] != sh16).sum()))
+print('separate vs oracle-half mismatches', int((b1[:n, :16] != sh16).sum()))
+bad = (a1 != b1).nonzero()
+for r, c in bad[:8].tolist():
+    print(r, c, 'fused', float(a1[r, c]), 'separate', float(b1[r, c]), 'oracle fp32', float(sh[r, c]) if r < n and c < 16 else None, 'dir', dirs[r].tolist() if r < n else None)

@@ -70,6 +70,7 @@ _SIGNATURES = {
     'ngp_ffmlp_inference_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_backward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_backward_ws': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp, _sz, _vp],
+    'ngp_network_forward': [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     'ngp_pipeline_mid_forward': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp],
     'ngp_pipeline_rgb_forward': [_vp, _vp, _u32, _vp],
     'ngp_pipeline_rgb_backward': [_vp, _vp, _vp, _u32, _vp],

@@ -46,6 +46,14 @@ inline uint64_t cdiv64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 inline hipStream_t as_stream(ngp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- device helpers ----
+// fp32 -> fp16, round-to-nearest-even of the fp32 VALUE.  Without the barrier the compiler folds `(half)(a * b)` into v_fma_mixlo_f16, which
+// rounds the exact product once: a different result on exact ties than "compute in fp32, then cast" -- what the reference's autocast path
+// does (a fp32 tensor, then .to(half)) and what two kernels sharing this arithmetic must agree on bit for bit.
+__device__ __forceinline__ _Float16 to_half_rne(float v) {
+    asm volatile("" : "+v"(v));
+    return (_Float16)v;
+}
+
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
 
 // wave64 inclusive prefix sum of a uint32 (DPP-free, 6 shuffles)

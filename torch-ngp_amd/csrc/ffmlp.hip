@@ -36,6 +36,7 @@
 //     backward_buffer; a second tiny kernel adds the slabs in a fixed order and rounds once to fp16 -- deterministic, no
 //     atomics, no side streams (this replaces the reference's num_layers+1 split-K GEMMs).
 #include "common.h"
+#include "sh_poly.inc"
 
 namespace ngp {
 
@@ -295,6 +296,157 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const half_t* __restrict__ inputs, const half_t* __restrict__ weights, half_t* __restrict__ forward_buffer, half_t* __restrict__ outputs,
     uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act, uint32_t out_act, bool in_planar) {
     ffmlp_forward_body<WIDTH, TRAIN, PLAIN>(inputs, weights, forward_buffer, outputs, n_tiles, in_dim, num_layers, act, out_act, in_planar);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// FUSED NETWORK FORWARD (extension): nerf/network_ff.py:51-74 between the encoder and the compositor in ONE launch --
+//   sigma FFMLP (32 -> 64 x nl_s -> 16) -> [sigma = density_scale * exp(h0); colour input = half(SH_4(dir)) | h1..h15 | 0]
+//   -> colour FFMLP (32 -> 64 x nl_c -> 16) -> rgb = half(sigmoid(out[:3])) as fp32.
+// The four-kernel sequence it replaces (ffmlp_forward, mid_forward, ffmlp_forward, rgb_forward) spends most of its time outside the
+// matrix core: every launch rebuilds a weight image (~8 us), a wave sees ~2 tiles per launch, and h16 / colour input / out16 round-trip
+// through HBM.  Here both weight images are built once, a tile's activations stay in the lane's registers from the encoder output to
+// the colour, and the sigma-net output reaches the colour net's B operand through one half-wave exchange (the C/D layout leaves lane
+// (n, h) with output features {4h..4h+3, 8+4h..11+4h}; the colour input's k slots want features 8h..8h+7 contiguous).
+// Same MFMA sequence and the same fp16 rounding points as the separate kernels: bit-identical sigma / rgb / stored activations.
+// TRAIN additionally stores what the backward kernels read: both forward buffers (fragment order), h16 and the colour input (row-major).
+// ------------------------------------------------------------------------------------------------
+// hidden layers + output layer of a 64-wide ReLU network for one tile: first-layer accumulators in, output accumulators out; the hidden
+// post-activations are streamed to `fb` (fragment order) when TRAIN
+template <bool TRAIN>
+__device__ __forceinline__ float16_t relu_network_tail(float16_t (&acc)[2], const half8_t* __restrict__ hid_img, const half8_t* __restrict__ out_img,
+                                                       uint32_t nl, half_t* __restrict__ fb, size_t layer_stride, uint32_t tile, int lane) {
+    constexpr int WIDTH = 64, NIB = 2, NKB = 4;
+    half8_t hid[NKB];
+    for (uint32_t l = 0;; l++) {
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
+        pack_hidden<WIDTH>(acc, hid);
+        if (TRAIN) {
+            half8_t* dst = reinterpret_cast<half8_t*>(fb) + l * layer_stride + (size_t)tile * NKB * 64 + lane;
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++) dst[kb * 64] = hid[kb];
+        }
+        if (l + 1 == nl) break;
+        const half8_t* wl = hid_img + (size_t)l * NIB * NKB * 64;
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++) {
+            acc[ib] = zero16();
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++) acc[ib] = mfma(wl[(ib * NKB + kb) * 64], hid[kb], acc[ib]);
+        }
+    }
+    float16_t o = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++) o = mfma(out_img[kb * 64], hid[kb], o);
+    return o;
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_network_forward(
+    const half_t* __restrict__ enc, bool enc_planar, const float* __restrict__ dirs, uint32_t M_valid, const half_t* __restrict__ w_sigma,
+    const half_t* __restrict__ w_color, half_t* __restrict__ fb_s, half_t* __restrict__ h16, float* __restrict__ sigma,
+    half_t* __restrict__ color_in, half_t* __restrict__ fb_c, float* __restrict__ rgb, uint32_t n_tiles, uint32_t nl_s, uint32_t nl_c,
+    float density_scale) {
+    constexpr int WIDTH = 64, NIB = 2, NKB = 4;
+    constexpr uint32_t in_kb = 2;  // both networks take 32 inputs
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half8_t* img_s = reinterpret_cast<half8_t*>(smem);
+    const uint32_t frags_s = NIB * in_kb + (nl_s - 1) * NIB * NKB + NKB;
+    half8_t* img_c = img_s + (size_t)frags_s * 64;
+    build_forward_image<WIDTH>(img_s, w_sigma, 32, nl_s);
+    build_forward_image<WIDTH>(img_c, w_color, 32, nl_c);
+    const size_t rows = (size_t)n_tiles * FF_TILE;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const size_t layer_stride = (size_t)n_tiles * NKB * 64;  // half8 units
+    const half8_t* s_l0 = img_s + lane;
+    const half8_t* s_hid = s_l0 + (size_t)NIB * in_kb * 64;
+    const half8_t* s_out = s_hid + (size_t)(nl_s - 1) * NIB * NKB * 64;
+    const half8_t* c_l0 = img_c + lane;
+    const half8_t* c_hid = c_l0 + (size_t)NIB * in_kb * 64;
+    const half8_t* c_out = c_hid + (size_t)(nl_c - 1) * NIB * NKB * 64;
+
+    for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += gridDim.x * FF_WAVES) {
+        const size_t srow = (size_t)tile * FF_TILE + n;
+        // ---- sigma network ----
+        float16_t acc[NIB];
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
+#pragma unroll
+        for (uint32_t kb = 0; kb < in_kb; kb++) {
+            const half8_t x = load_features8(enc, enc_planar, rows, srow, 32, 16 * kb + 8 * h);
+#pragma unroll
+            for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(s_l0[(ib * in_kb + kb) * 64], x, acc[ib]);
+        }
+        const float16_t o = relu_network_tail<TRAIN>(acc, s_hid, s_out, nl_s, fb_s, layer_stride, tile, lane);
+        // h16 = half(o): this lane owns output features 4h + c (lo) and 8 + 4h + c (hi) of its sample
+        half4_t lo, hi;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { lo[c] = (half_t)o[c]; hi[c] = (half_t)o[4 + c]; }
+        if (TRAIN) {
+            half_t* hrow = h16 + srow * 16 + 4 * h;
+            *reinterpret_cast<half4_t*>(hrow) = lo;
+            *reinterpret_cast<half4_t*>(hrow + 8) = hi;
+        }
+        if (h == 0) sigma[srow] = density_scale * expf((float)lo[0]);  // trunc_exp forward on the fp16 output (activation.py:9-10)
+        // ---- colour-net input: k block 0 = half(SH_4(dir))[8h .. 8h+7], k block 1 = h16[1 + 8h + j] (j < 8; feature 16 -> the zero pad) ----
+        half8_t cin[2];
+        {
+            float x = 0.0f, y = 0.0f, z = 0.0f;
+            if (srow < M_valid) { x = dirs[srow * 3]; y = dirs[srow * 3 + 1]; z = dirs[srow * 3 + 2]; }
+            // component i goes to half-wave i >> 3, slot i & 7 (no array: the polynomial values are consumed as they are produced)
+#define SH_OUT(i, v) { const float sh_v_ = (v); if (((i) >> 3) == h) cin[0][(i) & 7] = to_half_rne(sh_v_); }
+            SH_BAND_0_VALUES;
+            SH_BAND_1_VALUES;
+            SH_BAND_2_VALUES;
+            SH_BAND_3_VALUES;
+#undef SH_OUT
+            // exchange the eight fp16 outputs with the partner half-wave (lane ^ 32): mine[q] = feature (q < 4 ? 4h + q : 8 + 4h + q - 4)
+            const uint32_t m0 = __builtin_bit_cast(uint32_t, half2_t{lo[0], lo[1]}), m1 = __builtin_bit_cast(uint32_t, half2_t{lo[2], lo[3]});
+            const uint32_t m2 = __builtin_bit_cast(uint32_t, half2_t{hi[0], hi[1]}), m3 = __builtin_bit_cast(uint32_t, half2_t{hi[2], hi[3]});
+            const half2_t p0 = __builtin_bit_cast(half2_t, (uint32_t)__shfl_xor((int)m0, 32, 64)), p1 = __builtin_bit_cast(half2_t, (uint32_t)__shfl_xor((int)m1, 32, 64));
+            const half2_t p2 = __builtin_bit_cast(half2_t, (uint32_t)__shfl_xor((int)m2, 32, 64)), p3 = __builtin_bit_cast(half2_t, (uint32_t)__shfl_xor((int)m3, 32, 64));
+            // p0, p1 = the partner's lo quad (features 4(1-h) + 0..3), p2, p3 = its hi quad (8 + 4(1-h) + 0..3)
+            // feature f of the full row: half-wave (f >> 2) & 1 holds it, in lo (f < 8) or hi, at position f & 3
+            // h == 0 wants features 1..8 : mine lo[1..3], partner lo[0..3] (4..7), mine hi[0] (8)
+            // h == 1 wants features 9..15, pad: partner hi[1..3] (9..11), mine hi[0..3] (12..15), 0
+            if (h == 0) {
+                cin[1][0] = lo[1]; cin[1][1] = lo[2]; cin[1][2] = lo[3];
+                cin[1][3] = p0.x; cin[1][4] = p0.y; cin[1][5] = p1.x; cin[1][6] = p1.y;
+                cin[1][7] = hi[0];
+            } else {
+                cin[1][0] = p2.y; cin[1][1] = p3.x; cin[1][2] = p3.y;
+                cin[1][3] = hi[0]; cin[1][4] = hi[1]; cin[1][5] = hi[2]; cin[1][6] = hi[3];
+                cin[1][7] = (half_t)0.0f;
+            }
+        }
+        if (TRAIN) {
+            half_t* crow = color_in + srow * 32 + 8 * h;
+            *reinterpret_cast<half8_t*>(crow) = cin[0];
+            *reinterpret_cast<half8_t*>(crow + 16) = cin[1];
+        }
+        // ---- colour network ----
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
+#pragma unroll
+        for (uint32_t kb = 0; kb < in_kb; kb++)
+#pragma unroll
+            for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(c_l0[(ib * in_kb + kb) * 64], cin[kb], acc[ib]);
+        const float16_t oc = relu_network_tail<TRAIN>(acc, c_hid, c_out, nl_c, fb_c, layer_stride, tile, lane);
+        if (h == 0) {  // rgb = fp16-rounded sigmoid of the fp16-rounded outputs 0..2 (network_ff.py:72)
+            float* prgb = rgb + srow * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float v = (float)(half_t)oc[c];
+                prgb[c] = (float)to_half_rne(1.0f / (1.0f + expf(-v)));
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1625,6 +1777,40 @@ extern "C" int ngp_ffmlp_backward_ex(const void* grad, const void* inputs, const
                                      void* grad_weights, uint32_t flags, ngp_stream_t stream) {
     return ngp_ffmlp_backward_ws(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers, activation,
                                  output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, flags, nullptr, 0, stream);
+}
+
+
+extern "C" int ngp_network_forward(const void* enc, const float* dirs, uint32_t M, uint32_t M_valid, const void* w_sigma, const void* w_color,
+                                   uint32_t num_layers_sigma, uint32_t num_layers_color, float density_scale, int training,
+                                   void* forward_buffer_sigma, void* h16, float* sigma, void* color_in, void* forward_buffer_color,
+                                   float* rgb, uint32_t flags, ngp_stream_t stream) {
+    NGP_REQUIRE(M % 128 == 0, NGP_ERR_INVALID, "network_forward: sample count must be 128 * m, but got %u", M);
+    NGP_REQUIRE(num_layers_sigma >= 2 && num_layers_color >= 2, NGP_ERR_INVALID, "network_forward: num_layers should be larger than 2");
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(enc && dirs && w_sigma && w_color && sigma && rgb, NGP_ERR_INVALID, "network_forward: NULL tensor");
+    NGP_REQUIRE(!training || (forward_buffer_sigma && h16 && color_in && forward_buffer_color), NGP_ERR_INVALID,
+                "network_forward: the training variant needs forward_buffer_sigma, h16, color_in and forward_buffer_color");
+    const size_t lds = forward_image_bytes<64>(32, num_layers_sigma) + forward_image_bytes<64>(32, num_layers_color);
+    NGP_REQUIRE(lds <= 152 * 1024, NGP_ERR_INVALID, "network_forward: weights (%zu B) exceed the LDS of a CU", lds);
+    const void* kern = training ? reinterpret_cast<const void*>(k_network_forward<true>) : reinterpret_cast<const void*>(k_network_forward<false>);
+    int rc = raise_lds(kern, lds, "network_forward");
+    if (rc) return rc;
+    const uint32_t n_tiles = M / FF_TILE;
+    const uint32_t per_cu = (uint32_t)((160 * 1024) / (lds + 1024));
+    uint32_t blocks = (uint32_t)device_info().cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    const uint32_t need = cdiv(n_tiles, FF_WAVES);
+    if (blocks > need) blocks = need;
+    hipStream_t st = as_stream(stream);
+    const bool planar = (flags & NGP_FF_INPUT_PLANAR) != 0;
+    if (training)
+        hipLaunchKernelGGL(k_network_forward<true>, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)enc, planar, dirs, M_valid, (const half_t*)w_sigma,
+                           (const half_t*)w_color, (half_t*)forward_buffer_sigma, (half_t*)h16, sigma, (half_t*)color_in, (half_t*)forward_buffer_color, rgb,
+                           n_tiles, num_layers_sigma, num_layers_color, density_scale);
+    else
+        hipLaunchKernelGGL(k_network_forward<false>, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)enc, planar, dirs, M_valid, (const half_t*)w_sigma,
+                           (const half_t*)w_color, (half_t*)nullptr, (half_t*)nullptr, sigma, (half_t*)nullptr, (half_t*)nullptr, rgb, n_tiles,
+                           num_layers_sigma, num_layers_color, density_scale);
+    return check_launch("network_forward");
 }
 
 extern "C" int ngp_ffmlp_forward(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,

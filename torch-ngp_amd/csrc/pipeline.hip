@@ -33,7 +33,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_mid_forward(const half_t* __rest
 #undef SH_OUT
     half8_t o[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { o[0][i] = (half_t)sh[i]; o[1][i] = (half_t)sh[8 + i]; }
+    for (int i = 0; i < 8; i++) { o[0][i] = to_half_rne(sh[i]); o[1][i] = to_half_rne(sh[8 + i]); }
 #pragma unroll
     for (int i = 0; i < 7; i++) o[2][i] = h0[i + 1];
     o[2][7] = h1[0];
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_rgb_forward(const half_t* __rest
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const float s = 1.0f / (1.0f + expf(-(float)o[c]));
-        rgb[(size_t)b * 3 + c] = (float)(half_t)s;
+        rgb[(size_t)b * 3 + c] = (float)to_half_rne(s);
     }
 }
 

@@ -54,23 +54,15 @@ class _fused_ngp(Function):
         out16 = torch.empty(M, 16, **half)
         sigma = torch.empty(M, device=dev, dtype=torch.float32)
         rgb = torch.empty(M, 3, device=dev, dtype=torch.float32)
+        # sigma MLP -> trunc_exp / SH / feature shuffle -> colour MLP -> sigmoid in ONE launch (ngp_network_forward); USE_FUSED_NETWORK = False
+        # issues the four kernels it replaces (bit-identical, tests/test_gpu_pipeline.py)
+        d_valid = d.shape[0]
         if training:
             fb_s = torch.empty(nl_sigma, M, 64, **half)
             fb_c = torch.empty(nl_color, M, 64, **half)
-            _check(capi.lib.ngp_ffmlp_forward_ex(enc.data_ptr(), ws16.data_ptr(), M, 32, 16, 64, nl_sigma, 0, 6, fb_s.data_ptr(),
-                                                 h16.data_ptr(), _PLANAR_IN, st))
         else:
             fb_s = fb_c = None
-            _check(capi.lib.ngp_ffmlp_inference_ex(enc.data_ptr(), ws16.data_ptr(), M, 32, 16, 64, nl_sigma, 0, 6, None, h16.data_ptr(),
-                                                   _PLANAR_IN, st))
-        _check(capi.lib.ngp_pipeline_mid_forward(h16.data_ptr(), d.data_ptr(), sigma.data_ptr(), color_in.data_ptr(), M, d.shape[0], 1.0, st))
-        if training:
-            _check(capi.lib.ngp_ffmlp_forward_ex(color_in.data_ptr(), wc16.data_ptr(), M, 32, 16, 64, nl_color, 0, 6, fb_c.data_ptr(),
-                                                 out16.data_ptr(), 0, st))
-        else:
-            _check(capi.lib.ngp_ffmlp_inference_ex(color_in.data_ptr(), wc16.data_ptr(), M, 32, 16, 64, nl_color, 0, 6, None,
-                                                   out16.data_ptr(), 0, st))
-        _check(capi.lib.ngp_pipeline_rgb_forward(out16.data_ptr(), rgb.data_ptr(), M, st))
+        _network_forward(enc, d, d_valid, ws16, wc16, nl_sigma, nl_color, 1.0, training, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M, st)
         if training:
             ctx.save_for_backward(x, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb)
             ctx.cfg = cfg
@@ -106,6 +98,29 @@ class _fused_ngp(Function):
         if deposited:
             return None, None, None, None, None, None, None, None
         return None, None, g_emb, g_ws, g_wc, None, None, None
+
+
+USE_FUSED_NETWORK = True  # one launch for the whole network behind the encoder (False: the four kernels it replaces, for comparison)
+
+
+def _network_forward(enc, dirs, d_valid, ws16, wc16, nl_sigma, nl_color, density_scale, training, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M, st):
+    """enc [L,M,2] fp16 (planar) + dirs -> sigma [M] fp32, rgb [M,3] fp32 (+ the activations the backward reads when training)"""
+    if USE_FUSED_NETWORK:
+        _check(capi.lib.ngp_network_forward(enc.data_ptr(), dirs.data_ptr(), M, d_valid, ws16.data_ptr(), wc16.data_ptr(), nl_sigma, nl_color,
+                                            float(density_scale), 1 if training else 0, capi.ptr(fb_s), capi.ptr(h16) if training else None,
+                                            sigma.data_ptr(), capi.ptr(color_in) if training else None, capi.ptr(fb_c), rgb.data_ptr(), _PLANAR_IN, st))
+        return
+    if training:
+        _check(capi.lib.ngp_ffmlp_forward_ex(enc.data_ptr(), ws16.data_ptr(), M, 32, 16, 64, nl_sigma, 0, 6, fb_s.data_ptr(), h16.data_ptr(),
+                                             _PLANAR_IN, st))
+    else:
+        _check(capi.lib.ngp_ffmlp_inference_ex(enc.data_ptr(), ws16.data_ptr(), M, 32, 16, 64, nl_sigma, 0, 6, None, h16.data_ptr(), _PLANAR_IN, st))
+    _check(capi.lib.ngp_pipeline_mid_forward(h16.data_ptr(), dirs.data_ptr(), sigma.data_ptr(), color_in.data_ptr(), M, d_valid, float(density_scale), st))
+    if training:
+        _check(capi.lib.ngp_ffmlp_forward_ex(color_in.data_ptr(), wc16.data_ptr(), M, 32, 16, 64, nl_color, 0, 6, fb_c.data_ptr(), out16.data_ptr(), 0, st))
+    else:
+        _check(capi.lib.ngp_ffmlp_inference_ex(color_in.data_ptr(), wc16.data_ptr(), M, 32, 16, 64, nl_color, 0, 6, None, out16.data_ptr(), 0, st))
+    _check(capi.lib.ngp_pipeline_rgb_forward(out16.data_ptr(), rgb.data_ptr(), M, st))
 
 
 def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st):
@@ -232,13 +247,7 @@ def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg):
     rgb = torch.empty(M, 3, **f32)
     fb_s = torch.empty(nl_sigma, M, 64, **half)
     fb_c = torch.empty(nl_color, M, 64, **half)
-    _check(capi.lib.ngp_ffmlp_forward_ex(enc.data_ptr(), ws16.data_ptr(), M, 32, 16, 64, nl_sigma, 0, 6, fb_s.data_ptr(), h16.data_ptr(),
-                                         _PLANAR_IN, st))
-    _check(capi.lib.ngp_pipeline_mid_forward(h16.data_ptr(), dirs.data_ptr(), sigma.data_ptr(), color_in.data_ptr(), M, M,
-                                             float(density_scale), st))
-    _check(capi.lib.ngp_ffmlp_forward_ex(color_in.data_ptr(), wc16.data_ptr(), M, 32, 16, 64, nl_color, 0, 6, fb_c.data_ptr(),
-                                         out16.data_ptr(), 0, st))
-    _check(capi.lib.ngp_pipeline_rgb_forward(out16.data_ptr(), rgb.data_ptr(), M, st))
+    _network_forward(enc, dirs, M, ws16, wc16, nl_sigma, nl_color, float(density_scale), True, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M, st)
     # ---- composite + epilogue ----
     weights_sum = torch.empty(N, **f32)
     depth_raw = torch.empty(N, **f32)
@@ -437,7 +446,14 @@ class pinned_half_weights:
     def __enter__(self):
         if all(p is not None and p.is_cuda for p in self.params) and not torch.is_grad_enabled():
             for p in self.params:
-                p._ngp_fp16_pin = p.detach().to(torch.half)
+                # persistent buffers (same device pointers from frame to frame: the render loop's HIP graphs hold them), refreshed by
+                # one cast kernel per frame
+                buf = getattr(p, '_ngp_fp16_pinbuf', None)
+                if buf is None or buf.shape != p.shape or buf.device != p.device:
+                    buf = torch.empty_like(p, dtype=torch.half)
+                    p._ngp_fp16_pinbuf = buf
+                buf.copy_(p.detach())
+                p._ngp_fp16_pin = buf
         return self
 
     def __exit__(self, *exc):

@@ -260,34 +260,94 @@ class NeRFRenderer(nn.Module):
         composite / compaction kernels read, so the host issues `sync_every` iterations back to back and reads the count back once per
         batch (the reference reads it every iteration through `rays_alive[rays_alive >= 0]`).  Between read-backs launches are sized for
         the last known count; lanes and sample rows beyond the true count do nothing / are zero rows.  Same slot layout, n_step sequence
-        and compaction order as the host-driven loop: same image."""
+        and compaction order as the host-driven loop: same image.
+        Batches grow 2, 2, 4, 8, 8, ... iterations (an opaque frame is over after ~6 iterations, a transparent one needs ~100).
+        `graph_loop = True` replays the batches after the first from HIP graphs (one graph of two iterations per row-count bucket N, N/2,
+        N/4, ..., captured on first use and kept on the model).  Measured on MI355X (tools/bench_render.py, 800x800): host-driven 27.5 /
+        2.30 ms (transparent / opaque), device state 23.5 / 2.6 ms, + graphs 23.1 / 2.7 ms -- the n_step refill keeps ~N sample rows in
+        flight per iteration until fewer than N/8 rays are alive, so the frame is bound by the network kernels, not by launches; graphs are
+        therefore off by default."""
         from raymarching.backend import _backend as rb
         import _ngp_capi as capi
         n_rays, dev = rays_o.shape[0], rays_o.device
-        alive = [torch.arange(n_rays, dtype=torch.int32, device=dev), torch.empty(n_rays, dtype=torch.int32, device=dev)]
-        state = torch.zeros(2, 2, dtype=torch.int32, device=dev)
+        key = (n_rays, str(dev), float(dt_gamma), int(max_steps), float(T_thresh), float(self.density_scale), self.density_bitfield.data_ptr(),
+               torch.is_autocast_enabled('cuda'), self.training)
+        cache = getattr(self, '_loop_cache', None)
+        if cache is None or cache['key'] != key:
+            cache = {'key': key, 'graphs': {}, 'failed': False,
+                     'alive': [torch.empty(n_rays, dtype=torch.int32, device=dev), torch.empty(n_rays, dtype=torch.int32, device=dev)],
+                     'state': torch.zeros(2, 2, dtype=torch.int32, device=dev),
+                     'ws': torch.empty(int(capi.lib.ngp_compact_rays_workspace_bytes(n_rays)), dtype=torch.uint8, device=dev),
+                     'bufs': [torch.empty_like(t) for t in (rays_o, rays_d, nears, fars, rays_t, weights_sum, depth, image)],
+                     'arange': torch.arange(n_rays, dtype=torch.int32, device=dev)}
+            self._loop_cache = cache
+        # static buffers (the graphs hold their addresses): this frame's inputs and accumulators are copied in, the results copied out
+        s_o, s_d, s_near, s_far, s_t, s_ws, s_depth, s_image = cache['bufs']
+        for dst, src in zip(cache['bufs'], (rays_o, rays_d, nears, fars, rays_t, weights_sum, depth, image)):
+            dst.copy_(src)
+        alive, state, ws = cache['alive'], cache['state'], cache['ws']
+        alive[0].copy_(cache['arange'])
+        state.zero_()
         state[0, 0] = n_rays
-        ws = torch.empty(int(capi.lib.ngp_compact_rays_workspace_bytes(n_rays)), dtype=torch.uint8, device=dev)
         bits = self.density_bitfield.contiguous()
-        cur, bound_alive, iteration = 0, n_rays, 0
-        while bound_alive > 0 and iteration < max_steps:
-            rows = min(n_rays, 8 * bound_alive)
-            rows += 128 - rows % 128  # the marchers' padding rule (raymarching.py:328-331): the fused network path wants multiples of 128
-            for _ in range(sync_every if iteration else 2):  # the first batch is short: opaque scenes lose most rays at once
-                xyzs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
-                dirs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
-                deltas = torch.empty(rows, 2, dtype=torch.float32, device=dev)
-                noises = torch.rand(n_rays, dtype=torch.float32, device=dev) if (perturb and iteration == 0) else None
-                rb.march_rays_dev(state[cur], bound_alive, n_rays, alive[cur], rays_t, rays_o, rays_d, self.bound, dt_gamma, max_steps,
-                                  self.cascade, self.grid_size, bits, nears, fars, xyzs, dirs, deltas, noises, rows)
-                sigmas, rgbs = self(xyzs, dirs)
-                sigmas = (self.density_scale * sigmas).float().contiguous()
-                rb.composite_rays_dev(state[cur], bound_alive, n_rays, T_thresh, alive[cur], rays_t, sigmas, rgbs.float().contiguous(), deltas,
-                                      weights_sum, depth, image)
-                rb.compact_rays_dev(state[cur], bound_alive, n_rays, max_steps, alive[cur], alive[1 - cur], state[1 - cur], ws)
-                cur ^= 1
-                iteration += 1
-            bound_alive = int(state[cur, 0].item())
+
+        def iteration(cur, lanes, rows, noises):
+            xyzs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
+            dirs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
+            deltas = torch.empty(rows, 2, dtype=torch.float32, device=dev)
+            rb.march_rays_dev(state[cur], lanes, n_rays, alive[cur], s_t, s_o, s_d, self.bound, dt_gamma, max_steps, self.cascade,
+                              self.grid_size, bits, s_near, s_far, xyzs, dirs, deltas, noises, rows)
+            sigmas, rgbs = self(xyzs, dirs)
+            sigmas = (self.density_scale * sigmas).float().contiguous()
+            rb.composite_rays_dev(state[cur], lanes, n_rays, T_thresh, alive[cur], s_t, sigmas, rgbs.float().contiguous(), deltas, s_ws, s_depth,
+                                  s_image)
+            rb.compact_rays_dev(state[cur], lanes, n_rays, max_steps, alive[cur], alive[1 - cur], state[1 - cur], ws)
+
+        def pad(rows):
+            return rows + 128 - rows % 128  # the marchers' padding rule (raymarching.py:328-331); the fused network wants multiples of 128
+
+        # the first two iterations: full-frame sized, kernel-bound, the only ones that may perturb -- issued eagerly
+        full = pad(n_rays)
+        noises = torch.rand(n_rays, dtype=torch.float32, device=dev) if perturb else None
+        iteration(0, n_rays, full, noises)
+        iteration(1, n_rays, full, None)
+        done = 2
+        use_graphs = getattr(self, 'graph_loop', False) and not cache['failed']
+        batch = 2
+        bound_alive = int(state[0, 0].item())
+        while bound_alive > 0 and done < max_steps:
+            # row bucket: the smallest of N, N/2, N/4, ... that holds min(N, 8 * alive) rows (>= 2048)
+            need = min(n_rays, 8 * bound_alive)
+            bucket = n_rays
+            while bucket // 2 >= max(need, 2048):
+                bucket //= 2
+            rows = pad(bucket)
+            lanes = n_rays if bucket == n_rays else bucket // 8 + 1
+            g = cache['graphs'].get(bucket) if use_graphs else None
+            if use_graphs and g is None:
+                try:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        iteration(0, lanes, rows, None)
+                        iteration(1, lanes, rows, None)
+                    cache['graphs'][bucket] = g
+                except Exception as e:  # noqa: BLE001 -- keep rendering eagerly; the caller can inspect _loop_cache['failed']
+                    cache['failed'] = repr(e)
+                    use_graphs, g = False, None
+                    torch.cuda.synchronize()
+            for _ in range(max(1, batch // 2)):
+                if g is not None:
+                    g.replay()
+                else:
+                    iteration(0, lanes, rows, None)
+                    iteration(1, lanes, rows, None)
+                done += 2
+            batch = min(sync_every, batch * 2) if done >= 6 else batch
+            bound_alive = int(state[0, 0].item())
+        weights_sum.copy_(s_ws)
+        depth.copy_(s_depth)
+        image.copy_(s_image)
 
     # -- occupancy grid maintenance -------------------------------------------------------------
     def _cascade_points(self, coords, cas):

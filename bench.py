@@ -170,6 +170,19 @@ class TrainingRun:
             # --replicated-optim selects the all-reduce + full update on every rank instead
             optimizer = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, world_size=world,
                                 shard=world > 1 and not args.replicated_optim)
+            self.shard_fallback = None
+            if optimizer.shard:
+                # the three collectives of the sharded update, exercised once on zero gradients before anything is captured: if this
+                # RCCL build refuses one of them (reduce_scatter_tensor with AVG on fp16, in-place all_gather_into_tensor), every rank sees
+                # the same exception and the run continues with the replicated update instead of dying
+                try:
+                    optimizer.reduce_gradients()
+                    optimizer.gather_shadows()
+                    optimizer.wait_shadows()
+                    torch.cuda.synchronize()
+                except Exception as e:  # noqa: BLE001
+                    self.shard_fallback = repr(e)[:200]
+                    optimizer = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, world_size=world, shard=False)
             scaler = None
             averager = optimizer if world > 1 else None
         # a pool of pre-generated batches resident in HBM (one camera each, 4096 random pixels)
@@ -450,7 +463,8 @@ def main():
             'config': {'workload': 'nerf_synthetic/lego-shaped --fp16 --cuda_ray --ff training step (hashgrid L=16 F=2 T=2^19, SH deg 4, '
                                    'FFMLP 64x2 / 64x3), bound=1, 128^3 occupancy grid, dt_gamma=0, max_steps=1024',
                        'rays_per_gpu_per_step': args.rays, 'samples_per_step_per_gpu': round(samples / args.steps / world, 1),
-                       'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}' + ('' if world == 1 else (' (all-reduce, replicated Adam)' if (args.replicated_optim or args.torch_optim) else ' (reduce-scatter, sharded Adam, all-gather of fp16 shadows)')),
+                       'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}' + ('' if world == 1 else (' (reduce-scatter, sharded Adam, all-gather of fp16 shadows)' if getattr(run.optimizer, 'shard', False) else ' (all-reduce, replicated Adam)')),
+                       'sharded_update_fallback': getattr(run, 'shard_fallback', None),
                        'execution': run.execution(), 'setup_iterations_untimed': SETUP_ITERATIONS,
                        'captures_in_timed_region': res['captures'],
                        'autograd_free_iteration': bool(stepper.used_direct), 'fused_pipeline': bool(model.fused),

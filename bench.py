@@ -67,7 +67,7 @@ TIMED = {
     'ngp_ffmlp_forward_ex': ('ffmlp_forward', 2, lambda a: _ff_fwd_bytes(a[6]), lambda a: _ff_flops(a[6]), 'sample'),
     # the whole network behind the encoder in one launch: enc 64 B + dir 12 B in, both forward buffers + h16 32 B + colour input 64 B + sigma 4 B +
     # rgb 12 B out per sample; flops of both MLPs
-    'ngp_network_forward': ('network_forward (sigma MLP + SH/exp + colour MLP + sigmoid)', 2,
+    'ngp_network_forward': ('network_forward', 2,
                             lambda a: 64.0 + 12.0 + 128.0 * (a[6] + a[7]) + 32.0 + 64.0 + 4.0 + 12.0, lambda a: _ff_flops(a[6]) + _ff_flops(a[7]), 'sample'),
     'ngp_ffmlp_backward_ex': ('ffmlp_backward', 4, lambda a: _ff_bwd_bytes(a[8]), lambda a: 2.0 * _ff_flops(a[8]), 'sample'),
 }
@@ -421,7 +421,7 @@ def main():
         for name, scale in (('transparent_random_init', 1.0), ('opaque_density_scale_300', 300.0)):
             model.density_scale = scale
             ts = []
-            for f in range(3):
+            for f in range(6):
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):

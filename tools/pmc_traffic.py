@@ -20,6 +20,7 @@ KERNELS = {  # substring of the kernel name (first match wins) -> (label used by
     'k_grid_backward_accumulate': ('grid_encode_backward', 2.0),
     'k_grid_backward': ('grid_encode_backward', 1.0),
     'k_grid_forward_pair': ('grid_encode_forward', 1.0),
+    'k_network_forward': ('network_forward', 2.0),  # sigma MLP + exp/SH + colour MLP + sigmoid in one launch
     'k_ffmlp_forward': ('ffmlp_forward', 2.0),
     'k_ffmlp_backward': ('ffmlp_backward', 2.0),
     'k_march_train_wave': ('march_rays_train', 1.0),

@@ -346,6 +346,8 @@ def main():
     ap.add_argument('--replicated-optim', action='store_true', help='N > 1: all-reduce + full Adam on every rank instead of the sharded update')
     ap.add_argument('--no-render', action='store_true', help='skip the 800x800 inference-frame timing')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second, drop-in-surface-only measurement')
+    ap.add_argument('--ab-off', default='', help='A/B measurement: comma-separated optional launch fusions of fused.py to switch OFF '
+                    '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID); recorded in config.fusions_off')
     ap.add_argument('--dropin-steps', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -355,6 +357,12 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP extension has no CPU fallback)'
+    fusions_off = [n for n in args.ab_off.split(',') if n]
+    if fusions_off:
+        import fused as _fused
+        for n in fusions_off:
+            assert n.startswith('USE_FUSED_') and hasattr(_fused, n), f'--ab-off: unknown fusion switch {n}'
+            setattr(_fused, n, False)
     # functional-test hooks (not used by the driver): NGP_BENCH_SHARE_GPU=1 lets several ranks share cuda:0 and
     # NGP_BENCH_BACKEND=gloo replaces RCCL, so the N>1 code path can be exercised on a one-GPU box
     if os.environ.get('NGP_BENCH_SHARE_GPU') == '1':
@@ -465,7 +473,7 @@ def main():
                        'rays_per_gpu_per_step': args.rays, 'samples_per_step_per_gpu': round(samples / args.steps / world, 1),
                        'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}' + ('' if world == 1 else (' (reduce-scatter, sharded Adam, all-gather of fp16 shadows)' if getattr(run.optimizer, 'shard', False) else ' (all-reduce, replicated Adam)')),
                        'sharded_update_fallback': getattr(run, 'shard_fallback', None),
-                       'execution': run.execution(), 'setup_iterations_untimed': SETUP_ITERATIONS,
+                       'execution': run.execution(), 'setup_iterations_untimed': SETUP_ITERATIONS, 'fusions_off': fusions_off,
                        'captures_in_timed_region': res['captures'],
                        'autograd_free_iteration': bool(stepper.used_direct), 'fused_pipeline': bool(model.fused),
                        'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',

@@ -232,6 +232,8 @@ int ngp_grid_encode_backward_ws(const void* grad, const float* inputs, const voi
 #define NGP_FF_DX_PLANAR 2u    /* grad_inputs is written in that planar layout = what grid_encode_backward reads */
 #define NGP_FF_LAYERED 4u      /* testing: force the layered kernels on shapes the register-resident ones would serve */
 #define NGP_FF_SINGLE_WAVE 8u  /* testing: backward with one wave per tile stream instead of the paired kernel (2- and 3-layer nets) */
+#define NGP_FF_DEFER_REDUCE 16u /* backward of a 2- / 3-layer net: leave the per-workgroup fp32 weight-gradient slabs in backward_buffer; the
+                                 * caller sums them later (ngp_ffmlp_reduce_slabs_pair), e.g. two networks' slabs in one launch */
 int ngp_ffmlp_forward_ex(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                          uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                          void* forward_buffer, void* outputs, uint32_t flags, ngp_stream_t stream);
@@ -264,6 +266,22 @@ int ngp_network_forward(const void* enc, const float* dirs, uint32_t M, uint32_t
                         uint32_t num_layers_sigma, uint32_t num_layers_color, float density_scale, int training,
                         void* forward_buffer_sigma, void* h16, float* sigma, void* color_in, void* forward_buffer_color, float* rgb,
                         uint32_t flags, ngp_stream_t stream);
+
+/* Extensions for the fused training iteration (the backward of network_ff.py:40-74):
+ *  - ngp_network_backward_color = ngp_ffmlp_backward_ex of the colour MLP (32 -> 64 x (n-1) -> 16, ReLU, n = 2 or 3) whose input-gradient
+ *    epilogue writes the sigma net's output gradient grad_h16 [M,16] directly (what ngp_pipeline_mid_backward would assemble from
+ *    grad_sigma [M], h16 [M,16] and dL/d(colour input)[:,16:31]); same bits, one launch and a [M,32] round trip less.
+ *    flags: 0 or NGP_FF_DEFER_REDUCE.
+ *  - ngp_ffmlp_backward_slab_count: how many fp32 slabs [n_params] a deferred backward of that shape leaves at the start of its
+ *    backward_buffer (0: the gradients were stored directly, nothing to sum).
+ *  - ngp_ffmlp_reduce_slabs_pair: sums two slab sets (n_slabs x n_params fp32 each, either may be empty) into fp16 weight
+ *    gradients in ONE launch, in the fixed order of the single-set reduction (deterministic, same bits). */
+int ngp_network_backward_color(const void* grad_out16, const void* color_in, const void* w_color, const void* forward_buffer_color, uint32_t M,
+                               uint32_t num_layers_color, void* backward_buffer, const float* grad_sigma, const void* h16,
+                               float density_scale, void* grad_h16, void* grad_w_color, uint32_t flags, ngp_stream_t stream);
+uint32_t ngp_ffmlp_backward_slab_count(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers);
+int ngp_ffmlp_reduce_slabs_pair(const void* slabs_a, uint32_t n_slabs_a, uint32_t n_params_a, void* grad_weights_a, const void* slabs_b,
+                                uint32_t n_slabs_b, uint32_t n_params_b, void* grad_weights_b, ngp_stream_t stream);
 
 /* network_ff.py:55-72 between the two MLPs: h16 [M,16] fp16 (sigma-net output), dirs [M_valid,3] fp32 ->
  * sigma [M] fp32 = exp(h[:,0]) (trunc_exp), color_in [M,32] fp16 = [SH deg 4 | h[:,1:16] | 0]; rows >= M_valid use dir = 0 */
@@ -301,6 +319,12 @@ int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint
                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                             const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
                             const float* noises, void* workspace, uint32_t flags, ngp_stream_t stream);
+/* the same with near_far_from_aabb (raymarching.cu:92-145) folded into the first pass: nears / fars [N] are OUTPUTS, computed from the
+ * box aabb [6] and min_near with that function's arithmetic (one launch less per training iteration) */
+int ngp_march_rays_train_aabb(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* aabb, float min_near,
+                              float* nears, float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                              const float* noises, void* workspace, uint32_t flags, ngp_stream_t stream);
 
 /* march_rays (inference) that zeroes every sample slot it does not fill: the unused tail of each ray's n_step slots and the rows
  * between n_alive*n_step and zero_rows (>= n_alive*n_step), so the buffers need no memset; noises may be NULL (= no perturbation). */
@@ -344,6 +368,23 @@ int ngp_composite_rays_train_backward_ex(const float* grad_weights_sum, const fl
                                          const float* weights_sum, const float* image, uint32_t M, uint32_t N,
                                          float T_thresh, float* grad_sigmas, float* grad_rgbs, int bg_mode, float bg_scalar,
                                          const float* bg, const uint32_t* rows_used, ngp_stream_t stream);
+
+/* The image-space middle of one TRAINING iteration in one launch (optional extension; what the four calls
+ * ngp_composite_rays_train_forward_ex -> ngp_pipeline_mse_loss -> ngp_composite_rays_train_backward_ex -> ngp_pipeline_rgb_backward
+ * compute, expression for expression: raymarching.cu:501-577 forward, renderer.py:316-318 finish, nerf/utils.py:516,557 loss,
+ * raymarching.cu:602-682 backward, the sigmoid of network_ff.py:72 backward).  One wavefront per ray.
+ *   in : sigmas [M], rgbs [M,3], deltas [M,2] fp32, rays [N,3] int32 (index, offset, count), bg as in the _ex calls (bg_mode 1 or 2),
+ *        nears / fars [N], target [N,3] fp32, loss_scale (device scalar, NULL = 1)
+ *   out: weights_sum [N], image_out [N,3], depth_out [N] (finished), loss [1] = mean((image_out - target)^2) (deterministic),
+ *        grad_sigmas [M] fp32, grad_out16 [M,16] fp16 (columns 0..2 = dL/d(colour-net output) * loss_scale, rest 0) -- both may arrive
+ *        uninitialised, every row is written (zeros where no gradient flows)
+ *   ray_err [N] fp32: scratch.  march_workspace: the workspace ngp_march_rays_train_ex filled for these rays (word 0 = rows handed
+ *        out, word 1 = a ticket that call leaves at 0). */
+int ngp_composite_train_loss_backward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays, uint32_t M,
+                                      uint32_t N, float T_thresh, int bg_mode, float bg_scalar, const float* bg, const float* nears,
+                                      const float* fars, const float* target, const float* loss_scale, float* weights_sum,
+                                      float* image_out, float* depth_out, float* loss, float* ray_err, float* grad_sigmas,
+                                      void* grad_out16, void* march_workspace, ngp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * freqencoder       (reference: freqencoder/src/freqencoder.h:6-10, bindings.cpp:5-8) -- SURVEY.md 8(f).3, fp32 only.

@@ -217,3 +217,34 @@ def test_sync_free_occupancy_refresh():
     b = raymarching.packbits(grid0, 0.5, torch.empty_like(model.density_bitfield))
     c = raymarching.packbits_capped(grid0, 0.25, cap, torch.empty_like(model.density_bitfield))
     assert torch.equal(a, b) and torch.equal(c, raymarching.packbits(grid0, 0.25, torch.empty_like(model.density_bitfield)))
+
+
+@pytest.mark.parametrize('toggle', ['USE_FUSED_MID', 'USE_FUSED_COMPOSITE'])
+def test_iteration_fusions_are_bit_identical_to_the_unfused_launches(toggle):
+    """the optional launch fusions of the autograd-free iteration (colour-head epilogue + one slab reduction; composite + loss + backward in
+    one kernel) against the launches they replace: every deposited gradient, the image and the counters bit for bit."""
+    import fused
+    dev = torch.device('cuda')
+    n_rays = 1024
+    o, d, gt = sc.training_batch(n_rays, seed=11)
+    o, d, gt = torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)
+    res = {}
+    for on in (True, False):
+        model, opt = _make_ngp(dev)
+        model.mean_count = 60 * n_rays
+        params = (model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights)
+        counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        capacity = model.mean_count + (128 - model.mean_count % 128)
+        setattr(fused, toggle, on)
+        try:
+            loss, image, depth, ws = fused.fused_train_iteration(model, o, d, gt, model.aabb_train, counter, capacity, opt.scalars[0:1], 1, False, 0,
+                                                                 1024, 1e-4)
+        finally:
+            setattr(fused, toggle, True)
+        res[on] = ([p._ngp_grad16.clone() for p in params], image.clone(), ws.clone(), counter.clone(), float(loss))
+    a, b = res[True], res[False]
+    assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for x, y, name in zip(a[0], b[0], ('embeddings', 'sigma_net', 'color_net')):
+        assert float(x.float().abs().max()) > 0
+        assert torch.equal(x, y), (name, float((x.float() - y.float()).abs().max()))
+    assert abs(a[4] - b[4]) <= 2e-6 * abs(b[4])

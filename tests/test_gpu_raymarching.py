@@ -168,6 +168,48 @@ def test_march_rays_train_seeded_noise_matches_explicit_noise():
     assert not np.array_equal(draws(1), draws(2))
 
 
+@pytest.mark.parametrize('dt_gamma', [0.0, 1.0 / 128])
+def test_march_rays_train_aabb_folds_near_far_and_tail_zeroing(dt_gamma):
+    """ngp_march_rays_train_aabb (near/far computed in the count pass, the unowned tail rows zeroed by extra workgroups of the write
+    pass) against the oracle's near_far_from_aabb + march_rays_train: everything bit-exact, nears / fars included; rays that miss the
+    box and a sample buffer that is too small for the last rays are part of the input."""
+    import _ngp_capi as capi
+    N, bound = 3001, 1.0
+    bits = _scene(1.0, 1)
+    o, d = _random_rays(N, 21, radius=3.2, spread=1.4)      # wide spread: a good part of the rays misses the box
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    assert (nears == np.finfo(np.float32).max).sum() > 50
+    noises = np.random.default_rng(3).random(N, dtype=np.float32)
+    full = oracle.march_rays_train(o, d, bound, bits, 1, 128, nears, fars, noises, dt_gamma=dt_gamma)
+    total = int(full[4][0])
+    for M in (total + 777, total - total // 7):
+        ref = oracle.march_rays_train(o, d, bound, bits, 1, 128, nears, fars, noises, dt_gamma=dt_gamma, M=M) if M < total else full
+        nan = float('nan')
+        xyzs = torch.full((M, 3), nan, device='cuda'); dirs = torch.full((M, 3), nan, device='cuda'); deltas = torch.full((M, 2), nan, device='cuda')
+        rays = torch.empty(N, 3, dtype=torch.int32, device='cuda'); counter = torch.full((2,), 99, dtype=torch.int32, device='cuda')
+        tn, tf = torch.full((N,), nan, device='cuda'), torch.full((N,), nan, device='cuda')
+        ws = torch.full((capi.lib.ngp_march_rays_train_workspace_bytes(N),), 255, dtype=torch.uint8, device='cuda')
+        to, td, tb, ta, tz = cu(o), cu(d), cu(bits), cu(aabb), cu(noises)
+        capi.check(capi.lib.ngp_march_rays_train_aabb(to.data_ptr(), td.data_ptr(), tb.data_ptr(), bound, dt_gamma, 1024, N, 1, 128, M, ta.data_ptr(),
+                                                      0.2, tn.data_ptr(), tf.data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(),
+                                                      rays.data_ptr(), counter.data_ptr(), tz.data_ptr(), ws.data_ptr(),
+                                                      capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL, capi.stream()))
+        torch.cuda.synchronize()
+        assert np.array_equal(tn.cpu().numpy(), nears) and np.array_equal(tf.cpu().numpy(), fars)
+        assert counter.cpu().numpy().tolist() == ref[4].tolist()
+        assert np.array_equal(rays.cpu().numpy(), ref[3])
+        r = rays.cpu().numpy()
+        fits = (r[:, 2] > 0) & (r[:, 1] + r[:, 2] <= M)
+        end = int((r[fits, 1] + r[fits, 2]).max())
+        assert np.array_equal(xyzs[:end].cpu().numpy(), ref[0][:end]) and np.array_equal(deltas[:end].cpu().numpy(), ref[2][:end])
+        assert np.array_equal(dirs[:end].cpu().numpy(), ref[1][:end])
+        words = ws.view(torch.int32)[:2].cpu().numpy()
+        assert words[1] == 0 and words[0] == end      # rows handed out (the fitting rays are a prefix); the ticket word is cleared
+        first_tail = int(words[0])
+        assert float(xyzs[first_tail:].abs().sum()) == 0 and float(dirs[first_tail:].abs().sum()) == 0 and float(deltas[first_tail:].abs().sum()) == 0
+
+
 def test_march_rays_train_wrapper_semantics():
     bits = _scene(1.0, 1)
     o, d = _random_rays(4096, 6)

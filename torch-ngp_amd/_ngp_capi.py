@@ -19,10 +19,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libngp_hip.so')
 
 NGP_F32, NGP_F16 = 0, 1
-NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR, NGP_FF_LAYERED, NGP_FF_SINGLE_WAVE = 1, 2, 4, 8
+NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR, NGP_FF_LAYERED, NGP_FF_SINGLE_WAVE, NGP_FF_DEFER_REDUCE = 1, 2, 4, 8, 16
 NGP_MARCH_RESET_COUNTER, NGP_MARCH_ZERO_TAIL, NGP_MARCH_NOISE_FROM_SEED = 1, 2, 4
 NGP_OPT_PHASE_CHECK, NGP_OPT_PHASE_UPDATE, NGP_OPT_PHASE_COMMIT = 1, 2, 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -78,8 +78,14 @@ _SIGNATURES = {
     'ngp_pipeline_mse_loss': [_vp, _vp, _u32, _vp, _vp, _vp, _vp],
     'ngp_rays_from_pixels': [_vp, _u32, _f32, _f32, _f32, _f32, _u32, _vp, _u32, _u32, _vp, _vp, _vp],
     'ngp_march_rays_train_ex': [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    'ngp_march_rays_train_aabb': [_vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _u32, _u32, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
+                                  _vp],
     'ngp_composite_rays_train_forward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_composite_rays_train_backward_ex': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _i32, _f32, _vp, _vp, _vp],
+    'ngp_composite_train_loss_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp],
+    'ngp_network_backward_color': [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _f32, _vp, _vp, _u32, _vp],
+    'ngp_ffmlp_reduce_slabs_pair': [_vp, _u32, _u32, _vp, _vp, _u32, _u32, _vp, _vp],
     'ngp_optim_adam_step': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
     'ngp_optim_adam_step_ex': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _u32, _vp],
     'ngp_optim_ema_update': [_i32, _vp, _vp, _vp, _f32, _vp],
@@ -93,6 +99,8 @@ for _name, _args in _SIGNATURES.items():
 lib.ngp_last_error.restype = ctypes.c_char_p
 lib.ngp_target_arch.restype = ctypes.c_char_p
 lib.ngp_abi_version.restype = ctypes.c_int
+lib.ngp_ffmlp_backward_slab_count.argtypes = [_u32, _u32, _u32, _u32]
+lib.ngp_ffmlp_backward_slab_count.restype = _u32
 lib.ngp_march_rays_train_workspace_bytes.argtypes = [_u32]
 lib.ngp_march_rays_train_workspace_bytes.restype = _sz
 lib.ngp_compact_rays_workspace_bytes.argtypes = [_u32]
@@ -107,7 +115,8 @@ if lib.ngp_abi_version() != ABI_VERSION:
 
 EXPORTED = sorted(list(_SIGNATURES) + ['ngp_last_error', 'ngp_target_arch', 'ngp_abi_version',
                                        'ngp_march_rays_train_workspace_bytes', 'ngp_compact_rays_workspace_bytes',
-                                       'ngp_grid_backward_workspace_bytes', 'ngp_ffmlp_backward_workspace_bytes'])
+                                       'ngp_grid_backward_workspace_bytes', 'ngp_ffmlp_backward_workspace_bytes',
+                                       'ngp_ffmlp_backward_slab_count'])
 
 
 def check(rc):

@@ -901,12 +901,24 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
 constexpr int FP_PAIRS = 4;
 constexpr int FP_THREADS = 2 * FP_PAIRS * 64;
 
+// Optional epilogue of the colour head of the fused network (ngp_network_backward_color): instead of storing dL/d(colour input) [M,32]
+// for a separate kernel to reshuffle, role 1 writes the sigma net's output gradient grad_h16 [M,16] itself -- column 0 =
+// to_half(density_scale * grad_sigma * exp(clamp(h0, -15, 15))) (trunc_exp backward, activation.py:12-17), columns 1..15 = the input
+// gradient of features 16..30 (the geometric features; the SH block 0..15 has no gradient to carry, feature 31 is padding):
+// pipeline.hip's k_mid_backward, bit for bit, without its launch and without the [M,32] round trip.
+struct MidEpilogue {
+    const float* grad_sigma;  // [M] fp32; NULL = epilogue off (the plain dL/dx store)
+    const half_t* h16;        // [M,16] fp16, the sigma net's output
+    half_t* grad_h16;         // [M,16] fp16, out
+    float density_scale;
+};
+
 template <int WIDTH, int IN_JB, int NHM /* 1 or 2 */, bool RELU>
 __global__ __launch_bounds__(FP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
                              const half_t* __restrict__ forward_buffer, uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
                              bool with_dx, half_t* __restrict__ grad_inputs, float* __restrict__ slabs,
-                             half_t* __restrict__ grad_weights_direct, bool in_planar, bool dx_planar, uint32_t pf_depth) {
+                             half_t* __restrict__ grad_weights_direct, bool in_planar, bool dx_planar, uint32_t pf_depth, MidEpilogue mid) {
     static_assert(NHM == 1 || NHM == 2, "the paired backward covers 2- and 3-layer networks");
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1101,7 +1113,34 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
 #pragma unroll
                         for (int ib = 0; ib < NIB; ib++) gw_in[ib][jb] = mfma(zT[ib][g], xT[g], gw_in[ib][jb]);
                 }
-                if (with_dx) {
+                if (with_dx && mid.grad_sigma) {
+                    if constexpr (IN_JB == 1) {
+                        // features 16..31 of this lane's sample: q = 2 -> 16 + 4h .. 19 + 4h, q = 3 -> 24 + 4h .. 27 + 4h; the output row is
+                        // [gs, f16 .. f30] in four 8-byte pieces -- h = 0 stores pieces 0 and 2, h = 1 pieces 1 and 3; each needs one
+                        // value of the sibling lane (f19 / f23 and f27): lane ^ 32
+                        float16_t dx = zero16();
+#pragma unroll
+                        for (int kb = 0; kb < NKB; kb++) dx = mfma(img_in[kb * 64], dz[kb], dx);
+                        const size_t srow = (size_t)tile * FF_TILE + n;
+                        half_t v2[4], v3[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { v2[j] = (half_t)dx[8 + j]; v3[j] = (half_t)dx[12 + j]; }
+                        const float sib2 = __shfl_xor((float)v2[3], 32, 64), sib3 = __shfl_xor((float)v3[3], 32, 64);
+                        half4_t a, b;
+                        if (h == 0) {
+                            const float x0 = (float)mid.h16[srow * 16];
+                            const float gs = (mid.density_scale * mid.grad_sigma[srow]) * expf(fminf(15.0f, fmaxf(-15.0f, x0)));
+                            a = half4_t{to_half_rne(gs), v2[0], v2[1], v2[2]};          // columns 0..3
+                            b = half4_t{(half_t)sib2, v3[0], v3[1], v3[2]};             // columns 8..11 (f23 from the sibling)
+                        } else {
+                            a = half4_t{(half_t)sib2, v2[0], v2[1], v2[2]};             // columns 4..7 (f19 from the sibling)
+                            b = half4_t{(half_t)sib3, v3[0], v3[1], v3[2]};             // columns 12..15 (f27 from the sibling)
+                        }
+                        half_t* grow = mid.grad_h16 + srow * 16 + 4 * h;
+                        *reinterpret_cast<half4_t*>(grow) = a;
+                        *reinterpret_cast<half4_t*>(grow + 8) = b;
+                    }
+                } else if (with_dx) {
 #pragma unroll
                     for (int ib = 0; ib < IN_JB; ib++) {
                         float16_t dx = zero16();
@@ -1450,6 +1489,32 @@ __global__ __launch_bounds__(RS_PARAMS * RS_GROUPS) void k_ffmlp_reduce_slabs(co
     }
 }
 
+// the same for TWO slab sets in one launch (the two MLPs of the fused network): workgroups [0, blocks_a) take set a, the rest set b
+__global__ __launch_bounds__(RS_PARAMS * RS_GROUPS) void k_ffmlp_reduce_slabs_pair(const float* __restrict__ slabs_a, uint32_t n_slabs_a,
+                                                                                    uint32_t n_params_a, half_t* __restrict__ gw_a,
+                                                                                    uint32_t blocks_a, const float* __restrict__ slabs_b,
+                                                                                    uint32_t n_slabs_b, uint32_t n_params_b,
+                                                                                    half_t* __restrict__ gw_b) {
+    __shared__ float part[RS_GROUPS][RS_PARAMS];
+    const bool second = blockIdx.x >= blocks_a;
+    const float* __restrict__ slabs = second ? slabs_b : slabs_a;
+    const uint32_t n_slabs = second ? n_slabs_b : n_slabs_a, n_params = second ? n_params_b : n_params_a;
+    half_t* __restrict__ grad_weights = second ? gw_b : gw_a;
+    const uint32_t li = threadIdx.x & (RS_PARAMS - 1), g = threadIdx.x / RS_PARAMS;
+    const uint32_t i = (blockIdx.x - (second ? blocks_a : 0u)) * RS_PARAMS + li;
+    float s = 0.0f;
+    if (i < n_params)
+        for (uint32_t k = g; k < n_slabs; k += RS_GROUPS) s += slabs[(size_t)k * n_params + i];
+    part[g][li] = s;
+    __syncthreads();
+    if (g == 0 && i < n_params) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < RS_GROUPS; q++) t += part[q][li];
+        grad_weights[i] = (half_t)t;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1612,11 +1677,26 @@ static int launch_backward_layered(const void* grad, const void* inputs, const v
     return check_launch("ffmlp_backward(reduce)");
 }
 
+// workgroups of the register-resident backward = fp32 weight-gradient slabs it leaves in backward_buffer ([num_layers, B, hidden] fp16)
+template <int WIDTH>
+static uint32_t backward_slab_count(uint32_t B, uint32_t in_dim, uint32_t num_layers) {
+    const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
+    const size_t buf_bytes = (size_t)num_layers * B * WIDTH * sizeof(half_t);
+    uint32_t blocks = (uint32_t)device_info().cus;
+    const uint32_t need = cdiv(B / FF_TILE, FF_WAVES);
+    if (blocks > need) blocks = need;
+    const size_t fit = buf_bytes / ((size_t)n_params * 4);
+    if (blocks > fit) blocks = (uint32_t)fit;
+    return blocks;
+}
+
 template <int WIDTH, int IN_JB, int NHM, bool RELU>
 static int launch_backward_t(const void* grad, const void* inputs, const void* weights, const void* fwd, uint32_t B, uint32_t in_dim,
                            uint32_t num_layers, uint32_t act, bool with_dx, void* backward_buffer, void* grad_inputs,
-                           void* grad_weights, uint32_t flags, hipStream_t st) {
+                           void* grad_weights, uint32_t flags, hipStream_t st, const MidEpilogue* mid_in) {
     const bool in_planar = (flags & NGP_FF_INPUT_PLANAR) != 0, dx_planar = (flags & NGP_FF_DX_PLANAR) != 0;
+    const bool defer = (flags & NGP_FF_DEFER_REDUCE) != 0;
+    const MidEpilogue mid = mid_in ? *mid_in : MidEpilogue{nullptr, nullptr, nullptr, 0.0f};
     constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
     const uint32_t n_tiles = B / FF_TILE;
     const uint32_t nfrag = NIB + (num_layers - 1) * NIB * NKB + (with_dx ? ((in_dim + 31) / 32) * NKB : 0);
@@ -1629,12 +1709,7 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
     if (lds < (size_t)n_params * 4) lds = (size_t)n_params * 4;
     NGP_REQUIRE(lds <= 160 * 1024, NGP_ERR_INVALID, "ffmlp_backward: LDS need (%zu B) exceeds 160 KiB", lds);
     // one fp32 slab per workgroup lives in the caller's backward_buffer ([num_layers, B, hidden] fp16)
-    const size_t buf_bytes = (size_t)num_layers * B * WIDTH * sizeof(half_t);
-    uint32_t blocks = (uint32_t)device_info().cus;
-    const uint32_t need = cdiv(n_tiles, FF_WAVES);
-    if (blocks > need) blocks = need;
-    const size_t fit = buf_bytes / ((size_t)n_params * 4);
-    if (blocks > fit) blocks = (uint32_t)fit;
+    const uint32_t blocks = backward_slab_count<WIDTH>(B, in_dim, num_layers);
     if constexpr (NHM == 1 || NHM == 2) {
         // 2- and 3-layer networks: two sibling waves per tile stream split the weight-gradient accumulators (see the kernel)
         if (!(flags & NGP_FF_SINGLE_WAVE)) {
@@ -1647,14 +1722,15 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
             hipLaunchKernelGGL(pk, dim3(direct ? 1 : blocks), dim3(FP_THREADS), lds, st, (const half_t*)grad, (const half_t*)inputs,
                                (const half_t*)weights, (const half_t*)fwd, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs,
                                direct ? (float*)nullptr : (float*)backward_buffer, direct ? (half_t*)grad_weights : (half_t*)nullptr, in_planar,
-                               dx_planar, pf_depth);
+                               dx_planar, pf_depth, mid);
             int rc = check_launch("ffmlp_backward");
-            if (rc || direct) return rc;
+            if (rc || direct || defer) return rc;  // deferred: the caller sums the slabs (ngp_ffmlp_reduce_slabs_pair)
             hipLaunchKernelGGL(k_ffmlp_reduce_slabs, dim3(cdiv(n_params, RS_PARAMS)), dim3(RS_PARAMS * RS_GROUPS), 0, st,
                                (const float*)backward_buffer, blocks, n_params, (half_t*)grad_weights);
             return check_launch("ffmlp_backward(reduce)");
         }
     }
+    NGP_REQUIRE(!mid.grad_sigma && !defer, NGP_ERR_INVALID, "ffmlp_backward: this extension needs the paired kernel (2 or 3 layers)");
     auto kern = k_ffmlp_backward<WIDTH, IN_JB, NHM, RELU>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1679,12 +1755,12 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
 template <int WIDTH, int IN_JB, int NHM>
 static int launch_backward(const void* grad, const void* inputs, const void* weights, const void* fwd, uint32_t B, uint32_t in_dim,
                            uint32_t num_layers, uint32_t act, bool with_dx, void* backward_buffer, void* grad_inputs,
-                           void* grad_weights, uint32_t flags, hipStream_t st) {
+                           void* grad_weights, uint32_t flags, hipStream_t st, const MidEpilogue* mid = nullptr) {
     if (act == ACT_RELU)
         return launch_backward_t<WIDTH, IN_JB, NHM, true>(grad, inputs, weights, fwd, B, in_dim, num_layers, act, with_dx, backward_buffer,
-                                                          grad_inputs, grad_weights, flags, st);
+                                                          grad_inputs, grad_weights, flags, st, mid);
     return launch_backward_t<WIDTH, IN_JB, NHM, false>(grad, inputs, weights, fwd, B, in_dim, num_layers, act, with_dx, backward_buffer,
-                                                       grad_inputs, grad_weights, flags, st);
+                                                       grad_inputs, grad_weights, flags, st, mid);
 }
 
 }  // namespace ngp
@@ -1747,6 +1823,7 @@ extern "C" int ngp_ffmlp_backward_ws(const void* grad, const void* inputs, const
     hipStream_t st = as_stream(stream);
     const bool dx = calc_grad_inputs != 0;
     const bool fast = (hidden_dim == 32 || hidden_dim == 64) && num_layers <= 4 && input_dim <= 64 && !(flags & NGP_FF_LAYERED);
+    NGP_REQUIRE(fast || !(flags & NGP_FF_DEFER_REDUCE), NGP_ERR_INVALID, "ffmlp_backward: NGP_FF_DEFER_REDUCE needs a 2- or 3-layer network of width 32 / 64");
     if (!fast) {
 #define FF_LAY(W) launch_backward_layered<W>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, dx, backward_buffer, grad_inputs, grad_weights, flags, workspace, workspace_bytes, st)
         FF_WIDTHS(FF_LAY)
@@ -1779,6 +1856,45 @@ extern "C" int ngp_ffmlp_backward_ex(const void* grad, const void* inputs, const
                                  output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights, flags, nullptr, 0, stream);
 }
 
+
+extern "C" uint32_t ngp_ffmlp_backward_slab_count(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers) {
+    if ((hidden_dim != 32 && hidden_dim != 64) || num_layers < 2 || num_layers > 3 || input_dim > 64 || B == 0) return 0;
+    const uint32_t blocks = hidden_dim == 64 ? backward_slab_count<64>(B, input_dim, num_layers) : backward_slab_count<32>(B, input_dim, num_layers);
+    return blocks <= 1 ? 0u : blocks;  // one workgroup stores the gradients directly: nothing left to sum
+}
+
+extern "C" int ngp_ffmlp_reduce_slabs_pair(const void* slabs_a, uint32_t n_slabs_a, uint32_t n_params_a, void* grad_weights_a,
+                                           const void* slabs_b, uint32_t n_slabs_b, uint32_t n_params_b, void* grad_weights_b,
+                                           ngp_stream_t stream) {
+    const uint32_t blocks_a = n_slabs_a ? cdiv(n_params_a, RS_PARAMS) : 0u, blocks_b = n_slabs_b ? cdiv(n_params_b, RS_PARAMS) : 0u;
+    if (blocks_a + blocks_b == 0) return NGP_OK;
+    NGP_REQUIRE((!n_slabs_a || (slabs_a && grad_weights_a)) && (!n_slabs_b || (slabs_b && grad_weights_b)), NGP_ERR_INVALID,
+                "ffmlp_reduce_slabs_pair: NULL tensor");
+    hipLaunchKernelGGL(k_ffmlp_reduce_slabs_pair, dim3(blocks_a + blocks_b), dim3(RS_PARAMS * RS_GROUPS), 0, as_stream(stream),
+                       (const float*)slabs_a, n_slabs_a, n_params_a, (half_t*)grad_weights_a, blocks_a, (const float*)slabs_b, n_slabs_b,
+                       n_params_b, (half_t*)grad_weights_b);
+    return check_launch("ffmlp_reduce_slabs_pair");
+}
+
+extern "C" int ngp_network_backward_color(const void* grad_out16, const void* color_in, const void* w_color, const void* forward_buffer_color,
+                                          uint32_t M, uint32_t num_layers_color, void* backward_buffer, const float* grad_sigma,
+                                          const void* h16, float density_scale, void* grad_h16, void* grad_w_color, uint32_t flags,
+                                          ngp_stream_t stream) {
+    NGP_REQUIRE(num_layers_color == 2 || num_layers_color == 3, NGP_ERR_INVALID,
+                "network_backward_color: 2 or 3 layers (got %u); use ngp_ffmlp_backward_ex + ngp_pipeline_mid_backward", num_layers_color);
+    NGP_REQUIRE(!(flags & ~NGP_FF_DEFER_REDUCE), NGP_ERR_INVALID, "network_backward_color: only NGP_FF_DEFER_REDUCE is accepted");
+    int rc = check_ff_args("network_backward_color", M, 32, 16, 64, num_layers_color);
+    if (rc) return rc;
+    if (M == 0) return NGP_OK;
+    NGP_REQUIRE(grad_out16 && color_in && w_color && forward_buffer_color && backward_buffer && grad_sigma && h16 && grad_h16 && grad_w_color,
+                NGP_ERR_INVALID, "network_backward_color: NULL tensor");
+    const MidEpilogue mid{grad_sigma, (const half_t*)h16, (half_t*)grad_h16, density_scale};
+    if (num_layers_color == 2)
+        return launch_backward<64, 1, 1>(grad_out16, color_in, w_color, forward_buffer_color, M, 32, 2, ACT_RELU, true, backward_buffer, nullptr,
+                                         grad_w_color, flags, as_stream(stream), &mid);
+    return launch_backward<64, 1, 2>(grad_out16, color_in, w_color, forward_buffer_color, M, 32, 3, ACT_RELU, true, backward_buffer, nullptr,
+                                     grad_w_color, flags, as_stream(stream), &mid);
+}
 
 extern "C" int ngp_network_forward(const void* enc, const float* dirs, uint32_t M, uint32_t M_valid, const void* w_sigma, const void* w_color,
                                    uint32_t num_layers_sigma, uint32_t num_layers_color, float density_scale, int training,

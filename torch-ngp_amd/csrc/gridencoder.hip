@@ -730,10 +730,20 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
 // The result is the exact sum rounded once -- more accurate than the reference's fp16 atomics and bit-reproducible run to run
 // (integer addition commutes); non-finite contributions poison their entry with NaN (the loss scaler skips the step either way).
 // ------------------------------------------------------------------------------------------------
-constexpr int BIN_THREADS = 512;
-constexpr int BIN_ITERS = 2;                                   // wave-steps per workgroup
+// (tuning knobs of the record sort, compile-time: -DNGP_BIN_THREADS=... -DNGP_BIN_ITERS=...)
+#ifndef NGP_BIN_THREADS
+#define NGP_BIN_THREADS 512
+#endif
+#ifndef NGP_BIN_ITERS
+#define NGP_BIN_ITERS 2
+#endif
+constexpr int BIN_THREADS = NGP_BIN_THREADS;
+constexpr int BIN_ITERS = NGP_BIN_ITERS;                       // wave-steps per workgroup
 constexpr int BIN_PPB = BIN_ITERS * (BIN_THREADS / 64) * 32;   // samples per workgroup (2 lanes per sample)
-constexpr int BIN_SLICE_BITS = 12;                             // 4096 table entries per slice / bin
+#ifndef NGP_BIN_SLICE_BITS
+#define NGP_BIN_SLICE_BITS 12
+#endif
+constexpr int BIN_SLICE_BITS = NGP_BIN_SLICE_BITS;             // 4096 table entries per slice / bin
 constexpr int BIN_SLICE = 1 << BIN_SLICE_BITS;
 constexpr int BIN_MAX_BINS = 512;                              // one thread per bin in the layout step
 constexpr int ACC_THREADS = 1024;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_rgb_backward(const float* __rest
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const float y = rgb[(size_t)b * 3 + c];
-        lo[c] = (half_t)(grad_rgb[(size_t)b * 3 + c] * (y * (1.0f - y)));
+        lo[c] = to_half_rne(grad_rgb[(size_t)b * 3 + c] * (y * (1.0f - y)));
     }
     half8_t* dst = reinterpret_cast<half8_t*>(grad_out16 + (size_t)b * 16);
     dst[0] = lo;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_mid_backward(const float* __rest
     const half8_t g2 = *reinterpret_cast<const half8_t*>(grad_color_in + (size_t)b * 32 + 16);
     const half8_t g3 = *reinterpret_cast<const half8_t*>(grad_color_in + (size_t)b * 32 + 24);
     half8_t lo, hi;
-    lo[0] = (half_t)gs;
+    lo[0] = to_half_rne(gs);
 #pragma unroll
     for (int i = 0; i < 7; i++) lo[i + 1] = g2[i];
     hi[0] = g2[7];

@@ -26,26 +26,35 @@ constexpr int RM_THREADS = 256;
 // small utilities
 // ---------------------------------------------------------------------------------------------
 // raymarching.cu:92-145
+__device__ __forceinline__ void near_far_from_aabb(float ox, float oy, float oz, float dx, float dy, float dz, const float* __restrict__ aabb,
+                                                   float min_near, float& near_out, float& far_out) {
+    const float rdx = 1.0f / dx, rdy = 1.0f / dy, rdz = 1.0f / dz;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, t;
+    near_out = far_out = FLT_MAX;
+    if (near > far) { t = near; near = far; far = t; }
+    float ny = (aabb[1] - oy) * rdy, fy = (aabb[4] - oy) * rdy;
+    if (ny > fy) { t = ny; ny = fy; fy = t; }
+    if (near > fy || ny > far) return;
+    if (ny > near) near = ny;
+    if (fy < far) far = fy;
+    float nz = (aabb[2] - oz) * rdz, fz = (aabb[5] - oz) * rdz;
+    if (nz > fz) { t = nz; nz = fz; fz = t; }
+    if (near > fz || nz > far) return;
+    if (nz > near) near = nz;
+    if (fz < far) far = fz;
+    if (near < min_near) near = min_near;
+    near_out = near;
+    far_out = far;
+}
+
 __global__ void k_near_far_from_aabb(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                      const float* __restrict__ aabb, uint32_t N, float min_near, float* __restrict__ nears,
                                      float* __restrict__ fars) {
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-    const float rdx = 1.0f / rays_d[n * 3], rdy = 1.0f / rays_d[n * 3 + 1], rdz = 1.0f / rays_d[n * 3 + 2];
-    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx, t;
-    if (near > far) { t = near; near = far; far = t; }
-    float ny = (aabb[1] - oy) * rdy, fy = (aabb[4] - oy) * rdy;
-    if (ny > fy) { t = ny; ny = fy; fy = t; }
-    if (near > fy || ny > far) { nears[n] = fars[n] = FLT_MAX; return; }
-    if (ny > near) near = ny;
-    if (fy < far) far = fy;
-    float nz = (aabb[2] - oz) * rdz, fz = (aabb[5] - oz) * rdz;
-    if (nz > fz) { t = nz; nz = fz; fz = t; }
-    if (near > fz || nz > far) { nears[n] = fars[n] = FLT_MAX; return; }
-    if (nz > near) near = nz;
-    if (fz < far) far = fz;
-    if (near < min_near) near = min_near;
+    float near, far;
+    near_far_from_aabb(rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2], rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2], aabb, min_near,
+                       near, far);
     nears[n] = near;
     fars[n] = far;
 }
@@ -320,19 +329,37 @@ template <bool WRITE, bool CONST_DT>
 __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                                     const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                                     uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                                                                    const float* __restrict__ nears, const float* __restrict__ fars,
+                                                                    float* __restrict__ nears, float* __restrict__ fars,
                                                                     float* __restrict__ xyzs, float* __restrict__ dirs,
                                                                     float* __restrict__ deltas, int32_t* __restrict__ rays,
                                                                     const float* __restrict__ noises, uint32_t* __restrict__ n_windows,
-                                                                    uint64_t* __restrict__ masks, bool noise_from_seed) {
+                                                                    uint64_t* __restrict__ masks, bool noise_from_seed,
+                                                                    const float* __restrict__ aabb, float min_near,
+                                                                    const uint32_t* __restrict__ fit_end, uint32_t ray_blocks) {
     const uint32_t lane = threadIdx.x & 63;
+    if (WRITE && blockIdx.x >= ray_blocks) {
+        // (fit_end != NULL) the sample rows [*fit_end, M) that no ray writes: the extra workgroups of the write pass zero them
+        const uint32_t stride = (gridDim.x - ray_blocks) * MW_WAVES * 64;
+        for (uint32_t row = fit_end[0] + (blockIdx.x - ray_blocks) * MW_WAVES * 64 + threadIdx.x; row < M; row += stride) {
+            xyzs[(size_t)row * 3] = 0.0f; xyzs[(size_t)row * 3 + 1] = 0.0f; xyzs[(size_t)row * 3 + 2] = 0.0f;
+            dirs[(size_t)row * 3] = 0.0f; dirs[(size_t)row * 3 + 1] = 0.0f; dirs[(size_t)row * 3 + 2] = 0.0f;
+            *reinterpret_cast<float2_t*>(deltas + (size_t)row * 2) = float2_t{0.0f, 0.0f};
+        }
+        return;
+    }
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n = blockIdx.x * MW_WAVES + wid;  // wave-uniform
     if (n >= N) return;
     const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
     const Ray r = load_ray(rays_o, rays_d, n);
-    const float far = fars[n];
-    const float near = nears[n];
+    float far, near;
+    if (!WRITE && aabb) {  // near_far_from_aabb folded into the count pass: same arithmetic, one launch less; the write pass reads it back
+        near_far_from_aabb(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, aabb, min_near, near, far);
+        if (lane == 0) { nears[n] = near; fars[n] = far; }
+    } else {
+        far = fars[n];
+        near = nears[n];
+    }
     const float dt_const = step_dt(p, 0.0f);  // value of dt(t) when dt_gamma == 0
 
     uint32_t limit = max_steps, offset = 0;
@@ -545,17 +572,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_march_train_scan(int32_t* __re
         counter[1] = rays_before + (int32_t)N;
         const uint32_t fit_end = first_unfit != 0xFFFFFFFFu ? first_unfit : running;
         ws[0] = fit_end < M ? fit_end : M;
-    }
-}
-
-// zero the sample rows [ws[0], M) that no ray writes (replaces the caller's three full-buffer memsets)
-__global__ __launch_bounds__(256) void k_march_train_zero_tail(float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
-                                                               uint32_t M, const uint32_t* __restrict__ ws) {
-    const uint32_t begin = ws[0];
-    for (uint32_t r = begin + blockIdx.x * blockDim.x + threadIdx.x; r < M; r += gridDim.x * blockDim.x) {
-        xyzs[(size_t)r * 3] = 0.0f; xyzs[(size_t)r * 3 + 1] = 0.0f; xyzs[(size_t)r * 3 + 2] = 0.0f;
-        dirs[(size_t)r * 3] = 0.0f; dirs[(size_t)r * 3 + 1] = 0.0f; dirs[(size_t)r * 3 + 2] = 0.0f;
-        *reinterpret_cast<float2_t*>(deltas + (size_t)r * 2) = float2_t{0.0f, 0.0f};
+        ws[1] = 0u;  // the ticket of k_composite_train_loss_bwd
     }
 }
 
@@ -629,22 +646,35 @@ __global__ __launch_bounds__(RM_THREADS) void k_march_rays(uint32_t n_alive, uin
 // ---------------------------------------------------------------------------------------------
 // compositing (training): one wavefront per ray           raymarching.cu:501-577, 602-682
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float n = __shfl_up(v, o, 64);
-        if (lane >= o) v *= n;
-    }
+// Wave-wide inclusive scans on the VALU (DPP: row shifts inside the 16-lane rows, then row_bcast:15 / row_bcast:31 carry the row totals
+// across -- profiles/r01_dpp_probe.txt), no LDS crossbar: the compositing kernels are one latency chain per ray, and a ds_bpermute
+// round trip per scan step (__shfl_up) was most of it.  A lane without a source keeps `identity`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or(float identity, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, src), CTRL, ROW_MASK,
+                                                                 0xF, false));
+}
+__device__ __forceinline__ float wave_incl_prod(float v, int) {
+    v *= dpp_or<0x111, 0xF>(1.0f, v);  // row_shr:1
+    v *= dpp_or<0x112, 0xF>(1.0f, v);  // row_shr:2
+    v *= dpp_or<0x114, 0xF>(1.0f, v);  // row_shr:4
+    v *= dpp_or<0x118, 0xF>(1.0f, v);  // row_shr:8
+    v *= dpp_or<0x142, 0xA>(1.0f, v);  // row_bcast:15 into rows 1 and 3
+    v *= dpp_or<0x143, 0xC>(1.0f, v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
-__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float n = __shfl_up(v, o, 64);
-        if (lane >= o) v += n;
-    }
+__device__ __forceinline__ float wave_incl_sum(float v, int) {
+    v += dpp_or<0x111, 0xF>(0.0f, v);
+    v += dpp_or<0x112, 0xF>(0.0f, v);
+    v += dpp_or<0x114, 0xF>(0.0f, v);
+    v += dpp_or<0x118, 0xF>(0.0f, v);
+    v += dpp_or<0x142, 0xA>(0.0f, v);
+    v += dpp_or<0x143, 0xC>(0.0f, v);
     return v;
 }
+__device__ __forceinline__ float lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ __forceinline__ float wave_total(float v) { return lane63(wave_incl_sum(v, 0)); }   // wave-uniform sum
+__device__ __forceinline__ float prev_lane(float identity, float v) { return dpp_or<0x138, 0xF>(identity, v); }  // wave_shr:1, lane 0 keeps identity
 
 constexpr int CT_WAVES = 4;  // rays per workgroup
 
@@ -686,18 +716,17 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_fwd(const flo
             const float alpha = valid ? 1.0f - __expf(-sg * d0) : 0.0f;
             const float om = 1.0f - alpha;
             const float pin = wave_incl_prod(om, lane);          // prod_{j<=lane} (1-alpha_j)
-            const float pex = __shfl_up(pin, 1, 64);
-            const float T_before = T * (lane == 0 ? 1.0f : pex);  // transmittance in front of this sample
+                        const float T_before = T * prev_lane(1.0f, pin);  // transmittance in front of this sample
             const float tt = tcarry + wave_incl_sum(d1, lane);    // t after this sample
             // the sample that drives T below the threshold is still composited (raymarching.cu:557-560)
             const bool live = valid && !(T_before < T_thresh);
             const float w = live ? alpha * T_before : 0.0f;
             r += w * cr; g += w * cg; b += w * cb; ws += w; d += w * tt;
-            T = T * __shfl(pin, 63, 64);
-            tcarry = __shfl(tt, 63, 64);
+            T = T * lane63(pin);
+            tcarry = lane63(tt);
             if (T < T_thresh) break;  // wave-uniform
         }
-        r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); d = wave_sum(d);
+        r = wave_total(r); g = wave_total(g); b = wave_total(b); ws = wave_total(ws); d = wave_total(d);
     }
     if (lane == 0) {
         weights_sum[index] = ws;
@@ -763,8 +792,7 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_bwd(const flo
         }
         const float alpha = valid ? 1.0f - __expf(-sg * d0) : 0.0f;
         const float pin = wave_incl_prod(1.0f - alpha, lane);
-        const float pex = __shfl_up(pin, 1, 64);
-        const float T_before = T * (lane == 0 ? 1.0f : pex);
+                const float T_before = T * prev_lane(1.0f, pin);
         const float T_after = T * pin;
         const bool live = valid && !(T_before < T_thresh);
         const float w = live ? alpha * T_before : 0.0f;
@@ -783,8 +811,8 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_bwd(const flo
             grad_rgbs[(size_t)o * 3] = 0.0f; grad_rgbs[(size_t)o * 3 + 1] = 0.0f; grad_rgbs[(size_t)o * 3 + 2] = 0.0f;
             grad_sigmas[o] = 0.0f;
         }
-        T = T * __shfl(pin, 63, 64);
-        rc = __shfl(ra, 63, 64); gc = __shfl(ga, 63, 64); bc = __shfl(ba, 63, 64);
+        T = T * lane63(pin);
+        rc = lane63(ra); gc = lane63(ga); bc = lane63(ba);
         if (T < T_thresh) {
             if (zero_fill)
                 for (uint32_t z = s0 + 64 + lane; z < num; z += 64) {
@@ -794,6 +822,158 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_bwd(const flo
                 }
             break;
         }
+    }
+}
+
+// The image-space middle of a training iteration in ONE launch, one wavefront per ray:
+//   k_composite_train_fwd (+ finish)  ->  the Trainer's MSE loss and its scaled gradient (k_mse_loss)  ->  k_composite_train_bwd  ->
+//   the colour head's sigmoid backward (k_rgb_backward),
+// with the arithmetic of those four kernels expression for expression, so the gradients are the same bits.  What a ray needs from the
+// loss is its own three pixels, so nothing crosses rays except the loss VALUE (a logged scalar): every ray deposits its squared error,
+// the last workgroup to finish (a ticket) adds them up in a fixed order -> deterministic.  Four launches, their tails and the
+// [N,3] / [M,3] fp32 intermediates (grad_image, grad_rgbs) are gone; the second sweep re-reads sigma / rgb / delta from L2.
+// ticket[0] must be 0 on entry (k_march_train_scan clears it every step); the kernel leaves it 0.
+__global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_loss_bwd(
+    const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+    uint32_t M, uint32_t N, float T_thresh, float* __restrict__ weights_sum, Finish fin, const float* __restrict__ target,
+    const float* __restrict__ loss_scale, float* __restrict__ ray_err, uint32_t* __restrict__ ticket, float* __restrict__ loss,
+    float* __restrict__ grad_sigmas, half_t* __restrict__ grad_out16, const uint32_t* __restrict__ rows_used, uint32_t ray_blocks) {
+    const int lane = threadIdx.x & 63;
+    auto zero_row = [&](uint32_t o) {
+        half8_t z;
+#pragma unroll
+        for (int i = 0; i < 8; i++) z[i] = (half_t)0.0f;
+        half8_t* dst = reinterpret_cast<half8_t*>(grad_out16 + (size_t)o * 16);
+        dst[0] = z; dst[1] = z;
+        grad_sigmas[o] = 0.0f;
+    };
+    if (blockIdx.x >= ray_blocks) {  // rows >= *rows_used that no ray owns
+        const uint32_t first = min(rows_used[0], M);
+        const uint32_t stride = (gridDim.x - ray_blocks) * CT_WAVES * 64;
+        for (uint32_t o = first + (blockIdx.x - ray_blocks) * CT_WAVES * 64 + threadIdx.x; o < M; o += stride) zero_row(o);
+        return;
+    }
+    const uint32_t n = blockIdx.x * CT_WAVES + (threadIdx.x >> 6);
+    if (n < N) {
+        const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num = (uint32_t)rays[n * 3 + 2];
+        const bool has_rows = num != 0 && offset + num <= M;
+        // ---- forward sweep (k_composite_train_fwd) ----
+        float r = 0, g = 0, b = 0, ws = 0, d = 0;
+        if (has_rows) {
+            float T = 1.0f, tcarry = 0.0f;
+            for (uint32_t s0 = 0; s0 < num; s0 += 64) {
+                const uint32_t s = s0 + lane;
+                const bool valid = s < num;
+                float sg = 0.0f, d0 = 0.0f, d1 = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+                if (valid) {
+                    sg = sigmas[offset + s];
+                    const float2_t dl = *reinterpret_cast<const float2_t*>(deltas + (size_t)(offset + s) * 2);
+                    d0 = dl.x; d1 = dl.y;
+                    cr = rgbs[(size_t)(offset + s) * 3];
+                    cg = rgbs[(size_t)(offset + s) * 3 + 1];
+                    cb = rgbs[(size_t)(offset + s) * 3 + 2];
+                }
+                const float alpha = valid ? 1.0f - __expf(-sg * d0) : 0.0f;
+                const float om = 1.0f - alpha;
+                const float pin = wave_incl_prod(om, lane);
+                                const float T_before = T * prev_lane(1.0f, pin);
+                const float tt = tcarry + wave_incl_sum(d1, lane);
+                const bool live = valid && !(T_before < T_thresh);
+                const float w = live ? alpha * T_before : 0.0f;
+                r += w * cr; g += w * cg; b += w * cb; ws += w; d += w * tt;
+                T = T * lane63(pin);
+                tcarry = lane63(tt);
+                if (T < T_thresh) break;
+            }
+            r = wave_total(r); g = wave_total(g); b = wave_total(b); ws = wave_total(ws); d = wave_total(d);
+        }
+        // ---- finish (renderer.py:316-318) + loss (nerf/utils.py:516,557), every lane the same values ----
+        const float b0 = fin.mode == 2 ? fin.bg[index * 3] : fin.bg_scalar, b1 = fin.mode == 2 ? fin.bg[index * 3 + 1] : fin.bg_scalar,
+                    b2 = fin.mode == 2 ? fin.bg[index * 3 + 2] : fin.bg_scalar;
+        const float t1 = 1.0f - ws;
+        const float i0 = r + t1 * b0, i1 = g + t1 * b1, i2 = b + t1 * b2;
+        const float scale = loss_scale ? loss_scale[0] : 1.0f;
+        const float norm = 2.0f / (float)(3u * N);
+        const float e0 = i0 - target[index * 3], e1 = i1 - target[index * 3 + 1], e2 = i2 - target[index * 3 + 2];
+        const float gi0 = (norm * e0) * scale, gi1 = (norm * e1) * scale, gi2 = (norm * e2) * scale;
+        if (lane == 0) {
+            weights_sum[index] = ws;
+            fin.image_out[index * 3] = i0; fin.image_out[index * 3 + 1] = i1; fin.image_out[index * 3 + 2] = i2;
+            const float nr = fin.nears[index], fr = fin.fars[index];
+            fin.depth_out[index] = fmaxf(d - nr, 0.0f) / (fr - nr);
+            // write-through store (agent scope): the last workgroup reads it from another XCD without anybody flushing an L2
+            __hip_atomic_store(&ray_err[n], __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- backward sweep (k_composite_train_bwd with grad_weights_sum = 0, then k_rgb_backward) ----
+        if (has_rows) {
+            const float gw = 0.0f - (gi0 * b0 + gi1 * b1 + gi2 * b2);
+            const float rf = r, gf = g, bf = b, wsf = ws;
+            float T = 1.0f, rc = 0.0f, gc = 0.0f, bc = 0.0f;
+            for (uint32_t s0 = 0; s0 < num; s0 += 64) {
+                const uint32_t s = s0 + lane;
+                const bool valid = s < num;
+                float sg = 0.0f, d0 = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+                if (valid) {
+                    sg = sigmas[offset + s];
+                    d0 = deltas[(size_t)(offset + s) * 2];
+                    cr = rgbs[(size_t)(offset + s) * 3];
+                    cg = rgbs[(size_t)(offset + s) * 3 + 1];
+                    cb = rgbs[(size_t)(offset + s) * 3 + 2];
+                }
+                const float alpha = valid ? 1.0f - __expf(-sg * d0) : 0.0f;
+                const float pin = wave_incl_prod(1.0f - alpha, lane);
+                                const float T_before = T * prev_lane(1.0f, pin);
+                const float T_after = T * pin;
+                const bool live = valid && !(T_before < T_thresh);
+                const float w = live ? alpha * T_before : 0.0f;
+                const float ra = rc + wave_incl_sum(w * cr, lane);
+                const float ga = gc + wave_incl_sum(w * cg, lane);
+                const float ba = bc + wave_incl_sum(w * cb, lane);
+                if (live) {
+                    const uint32_t o = offset + s;
+                    half8_t lo, hi;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { lo[i] = (half_t)0.0f; hi[i] = (half_t)0.0f; }
+                    lo[0] = to_half_rne((gi0 * w) * (cr * (1.0f - cr)));
+                    lo[1] = to_half_rne((gi1 * w) * (cg * (1.0f - cg)));
+                    lo[2] = to_half_rne((gi2 * w) * (cb * (1.0f - cb)));
+                    half8_t* dst = reinterpret_cast<half8_t*>(grad_out16 + (size_t)o * 16);
+                    dst[0] = lo; dst[1] = hi;
+                    grad_sigmas[o] = d0 * (gi0 * (T_after * cr - (rf - ra)) + gi1 * (T_after * cg - (gf - ga)) +
+                                           gi2 * (T_after * cb - (bf - ba)) + gw * (1.0f - wsf));
+                } else if (valid) {
+                    zero_row(offset + s);
+                }
+                T = T * lane63(pin);
+                rc = lane63(ra); gc = lane63(ga); bc = lane63(ba);
+                if (T < T_thresh) {
+                    for (uint32_t z = s0 + 64 + lane; z < num; z += 64) zero_row(offset + z);
+                    break;
+                }
+            }
+        }
+    }
+    // ---- the loss value: the last workgroup sums the per-ray errors in a fixed order ----
+    // (no agent-scope release fence: on this chip it writes back the XCD's whole dirty L2, once per workgroup -- measured 15 -> 130 us.
+    // The per-ray errors are write-through atomic stores; a workgroup-scope release waits for them to complete before the ticket moves.)
+    __shared__ float part[CT_WAVES];
+    __shared__ bool last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ray_blocks - 1u;
+    __syncthreads();
+    if (!last) return;
+    float acc = 0.0f;
+    for (uint32_t i = threadIdx.x; i < N; i += CT_WAVES * 64) acc += __hip_atomic_load(&ray_err[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc = wave_total(acc);
+    if (lane == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < CT_WAVES; w++) v += part[w];
+        loss[0] = v / (float)(3u * N);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -938,7 +1118,7 @@ extern "C" int ngp_packbits(const float* grid, uint32_t N, float density_thresh,
     return ngp_packbits_ex(grid, N, density_thresh, nullptr, bitfield, stream);
 }
 
-// workspace: [0] fit_end, [1] pad, [2 .. 2+N) windows per ray, then N x MARCH_MASK_WINDOWS 64-bit emit masks
+// workspace: [0] fit_end, [1] ticket of the fused composite/loss/backward kernel (cleared by the scan), [2 .. 2+N) windows per ray, then N x MARCH_MASK_WINDOWS 64-bit emit masks
 extern "C" size_t ngp_march_rays_train_workspace_bytes(uint32_t N) {
     return sizeof(uint32_t) * (size_t)(2 + ((N + 1u) & ~1u)) + sizeof(uint64_t) * (size_t)N * MARCH_MASK_WINDOWS;
 }
@@ -950,10 +1130,10 @@ static int check_march_args(const char* fn, uint32_t C, uint32_t H, uint32_t max
     return NGP_OK;
 }
 
-extern "C" int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid_in, float bound, float dt_gamma,
-                                       uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
-                                       const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
-                                       const float* noises, void* workspace, uint32_t flags, ngp_stream_t stream) {
+static int march_rays_train_impl(const float* rays_o, const float* rays_d, const uint8_t* grid_in, float bound, float dt_gamma,
+                                 uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* aabb, float min_near,
+                                 float* nears, float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                 const float* noises, void* workspace, uint32_t flags, ngp_stream_t stream) {
     int rc = check_march_args("march_rays_train", C, H, max_steps);
     if (rc) return rc;
     if (N == 0) return NGP_OK;
@@ -961,11 +1141,15 @@ extern "C" int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d,
                 NGP_ERR_INVALID, "march_rays_train: NULL tensor");
     hipStream_t st = as_stream(stream);
     uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
-    const dim3 grid(cdiv(N, MW_WAVES)), block(MW_WAVES * 64);
+    const uint32_t ray_blocks = cdiv(N, MW_WAVES);
+    const bool zero_tail = (flags & NGP_MARCH_ZERO_TAIL) && M > 0;
+    const dim3 block(MW_WAVES * 64);
     const bool const_dt = dt_gamma == 0.0f;
-#define MARCH_WAVE(WRITE, CDT)                                                                                                     \
-    hipLaunchKernelGGL((k_march_train_wave<WRITE, CDT>), grid, block, 0, st, rays_o, rays_d, grid_bits, bound, dt_gamma, max_steps, N, C, H, \
-                       M, nears, fars, xyzs, dirs, deltas, rays, noises, ws_windows, ws_masks, (flags & NGP_MARCH_NOISE_FROM_SEED) != 0)
+    // the write pass carries a few extra workgroups that zero the unowned tail rows (usually a few hundred)
+#define MARCH_WAVE(WRITE, CDT)                                                                                                              \
+    hipLaunchKernelGGL((k_march_train_wave<WRITE, CDT>), dim3(ray_blocks + ((WRITE) && zero_tail ? 16u : 0u)), block, 0, st, rays_o, rays_d,   \
+                       grid_bits, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, noises, ws_windows, ws_masks,   \
+                       (flags & NGP_MARCH_NOISE_FROM_SEED) != 0, aabb, min_near, (const uint32_t*)ws, ray_blocks)
     const uint8_t* grid_bits = grid_in;
     uint32_t* ws_windows = ws + 2;                                                               // [N]
     uint64_t* ws_masks = reinterpret_cast<uint64_t*>(ws + 2 + ((N + 1u) & ~1u));                 // [N][MARCH_MASK_WINDOWS], 8-byte aligned
@@ -977,14 +1161,25 @@ extern "C" int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d,
     if (rc) return rc;
     if (const_dt) MARCH_WAVE(true, true); else MARCH_WAVE(true, false);
 #undef MARCH_WAVE
-    rc = check_launch("march_rays_train(write)");
-    if (rc) return rc;
-    if ((flags & NGP_MARCH_ZERO_TAIL) && M > 0) {
-        // usually a few hundred padding rows: a small fixed grid, grid-stride
-        hipLaunchKernelGGL(k_march_train_zero_tail, dim3(64), dim3(256), 0, st, xyzs, dirs, deltas, M, (const uint32_t*)ws);
-        rc = check_launch("march_rays_train(zero tail)");
-    }
-    return rc;
+    return check_launch("march_rays_train(write)");
+}
+
+extern "C" int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid_in, float bound, float dt_gamma,
+                                       uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                       const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                       const float* noises, void* workspace, uint32_t flags, ngp_stream_t stream) {
+    // (nears / fars are only read when no box is given)
+    return march_rays_train_impl(rays_o, rays_d, grid_in, bound, dt_gamma, max_steps, N, C, H, M, nullptr, 0.0f, const_cast<float*>(nears),
+                                 const_cast<float*>(fars), xyzs, dirs, deltas, rays, counter, noises, workspace, flags, stream);
+}
+
+extern "C" int ngp_march_rays_train_aabb(const float* rays_o, const float* rays_d, const uint8_t* grid_in, float bound, float dt_gamma,
+                                         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* aabb, float min_near,
+                                         float* nears, float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                         const float* noises, void* workspace, uint32_t flags, ngp_stream_t stream) {
+    NGP_REQUIRE(aabb || N == 0, NGP_ERR_INVALID, "march_rays_train_aabb: NULL box");
+    return march_rays_train_impl(rays_o, rays_d, grid_in, bound, dt_gamma, max_steps, N, C, H, M, aabb, min_near, nears, fars, xyzs, dirs, deltas,
+                                 rays, counter, noises, workspace, flags, stream);
 }
 
 extern "C" int ngp_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid_in, float bound, float dt_gamma,
@@ -1046,6 +1241,27 @@ extern "C" int ngp_composite_rays_train_backward_ex(const float* grad_weights_su
                        grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs, fin, rows_used,
                        ray_blocks);
     return check_launch("composite_rays_train_backward");
+}
+
+extern "C" int ngp_composite_train_loss_backward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays, uint32_t M,
+                                                 uint32_t N, float T_thresh, int bg_mode, float bg_scalar, const float* bg, const float* nears,
+                                                 const float* fars, const float* target, const float* loss_scale, float* weights_sum,
+                                                 float* image_out, float* depth_out, float* loss, float* ray_err, float* grad_sigmas,
+                                                 void* grad_out16, void* march_workspace, ngp_stream_t stream) {
+    NGP_REQUIRE(N > 0, NGP_ERR_INVALID, "composite_train_loss_backward: no rays");
+    NGP_REQUIRE(sigmas && rgbs && deltas && rays && target && weights_sum && loss && ray_err && grad_sigmas && grad_out16 && march_workspace,
+                NGP_ERR_INVALID, "composite_train_loss_backward: NULL tensor");
+    NGP_REQUIRE(bg_mode == 1 || bg_mode == 2, NGP_ERR_INVALID, "composite_train_loss_backward: bg_mode must be 1 (scalar) or 2 (per ray)");
+    NGP_REQUIRE((uint64_t)N * 3u <= 0xffffffffull, NGP_ERR_INVALID, "composite_train_loss_backward: too many rays");
+    Finish fin;
+    int rc = make_finish("composite_train_loss_backward", bg_mode, bg_scalar, bg, nears, fars, image_out, depth_out, true, &fin);
+    if (rc) return rc;
+    uint32_t* ws = reinterpret_cast<uint32_t*>(march_workspace);
+    const uint32_t ray_blocks = cdiv(N, CT_WAVES), tail_blocks = 32u;
+    hipLaunchKernelGGL(k_composite_train_loss_bwd, dim3(ray_blocks + tail_blocks), dim3(CT_WAVES * 64), 0, as_stream(stream), sigmas, rgbs,
+                       deltas, rays, M, N, T_thresh, weights_sum, fin, target, loss_scale, ray_err, ws + 1, loss, grad_sigmas,
+                       (half_t*)grad_out16, (const uint32_t*)ws, ray_blocks);
+    return check_launch("composite_train_loss_backward");
 }
 
 extern "C" int ngp_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,

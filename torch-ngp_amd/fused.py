@@ -196,7 +196,7 @@ def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfie
 
 
 def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, noise_seed=None):
-    """the parameter-independent front of the iteration: near/far + march_rays_train.  Needs neither the table nor the MLP weights, so
+    """the parameter-independent front of the iteration: near/far + march_rays_train (one C call, three launches).  Needs neither the table nor the MLP weights, so
     in data-parallel training it overlaps the all-gather of the freshly updated fp16 shadows (optim.NGPAdam.gather_shadows)."""
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
     (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
@@ -207,8 +207,6 @@ def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, nois
     f32 = dict(device=dev, dtype=torch.float32)
     nears = torch.empty(N, **f32)
     fars = torch.empty(N, **f32)
-    _check(capi.lib.ngp_near_far_from_aabb(rays_o.data_ptr(), rays_d.data_ptr(), aabb.data_ptr(), N, min_near, nears.data_ptr(),
-                                           fars.data_ptr(), st))
     xyzs = torch.empty(M, 3, **f32)
     dirs = torch.empty(M, 3, **f32)
     deltas = torch.empty(M, 2, **f32)
@@ -220,14 +218,15 @@ def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, nois
     else:
         noises = torch.rand(N, **f32) if perturb else torch.zeros(N, **f32)
     ws = torch.empty(capi.lib.ngp_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device=dev)
-    _check(capi.lib.ngp_march_rays_train_ex(rays_o.data_ptr(), rays_d.data_ptr(), bitfield.data_ptr(), float(bound), float(dt_gamma),
-                                            max_steps, N, cascade, grid_size, M, nears.data_ptr(), fars.data_ptr(), xyzs.data_ptr(),
-                                            dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(), counter.data_ptr(), noises.data_ptr(),
-                                            ws.data_ptr(), march_flags, st))
+    # near_far_from_aabb rides in the marcher's first pass (nears / fars are outputs)
+    _check(capi.lib.ngp_march_rays_train_aabb(rays_o.data_ptr(), rays_d.data_ptr(), bitfield.data_ptr(), float(bound), float(dt_gamma),
+                                              max_steps, N, cascade, grid_size, M, aabb.data_ptr(), float(min_near), nears.data_ptr(),
+                                              fars.data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(),
+                                              counter.data_ptr(), noises.data_ptr(), ws.data_ptr(), march_flags, st))
     return (xyzs, dirs, deltas, rays, nears, fars, ws)
 
 
-def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg):
+def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg, composite=True):
     (xyzs, dirs, deltas, rays, nears, fars, ws) = marched
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
     (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
@@ -248,6 +247,8 @@ def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg):
     fb_s = torch.empty(nl_sigma, M, 64, **half)
     fb_c = torch.empty(nl_color, M, 64, **half)
     _network_forward(enc, dirs, M, ws16, wc16, nl_sigma, nl_color, float(density_scale), True, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M, st)
+    if not composite:
+        return (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, None, None, bg, ws)
     # ---- composite + epilogue ----
     weights_sum = torch.empty(N, **f32)
     depth_raw = torch.empty(N, **f32)
@@ -282,17 +283,45 @@ def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g
                                                          float(bg_scalar), capi.ptr(bg), march_ws.data_ptr(), st))
     g_out16 = torch.empty(M, 16, **half)
     _check(capi.lib.ngp_pipeline_rgb_backward(g_rgb.data_ptr(), rgb.data_ptr(), g_out16.data_ptr(), M, st))
-    g_color_in = torch.empty(M, 32, **half)
-    scratch = torch.empty(nl_color, M, 64, **half)
-    _check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), fb_c.data_ptr(), M, 32, 16, 64,
-                                          nl_color, 0, 6, 1, scratch.data_ptr(), g_color_in.data_ptr(), g_wc.data_ptr(), 0, st))
-    g_h16 = g_out16
-    _check(capi.lib.ngp_pipeline_mid_backward(g_sigma.data_ptr(), h16.data_ptr(), g_color_in.data_ptr(), g_h16.data_ptr(), M,
-                                              float(density_scale), st))
+    _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc)
+
+
+def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc):
+    """colour MLP -> exp / feature shuffle -> sigma MLP -> grid scatter, from g_sigma [M] fp32 and g_out16 [M,16] fp16 (CONSUMED: reused as
+    the sigma net's output gradient)"""
+    (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, march_ws) = saved
+    (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
+    density_scale = rcfg[8]
+    M = xyzs.shape[0]
+    st = capi.stream()
+    half = dict(device=xyzs.device, dtype=torch.half)
     g_enc = torch.empty(L, M, 2, **half)
-    _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
-                                          0, 6, 1, scratch[:nl_sigma].data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
-                                          _PLANAR_IN | _PLANAR_DX, st))
+    if USE_FUSED_MID and nl_color in (2, 3) and nl_sigma in (2, 3):
+        # the colour head writes the sigma net's output gradient itself (exp backward + feature shuffle in its epilogue) and both
+        # networks' weight-gradient slabs are summed by ONE launch at the end: 3 launches instead of 5
+        scratch_c = torch.empty(nl_color, M, 64, **half)
+        scratch_s = torch.empty(nl_sigma, M, 64, **half)
+        g_h16 = torch.empty(M, 16, **half)
+        _check(capi.lib.ngp_network_backward_color(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), fb_c.data_ptr(), M, nl_color,
+                                                   scratch_c.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), float(density_scale),
+                                                   g_h16.data_ptr(), g_wc.data_ptr(), capi.NGP_FF_DEFER_REDUCE, st))
+        _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
+                                              0, 6, 1, scratch_s.data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
+                                              _PLANAR_IN | _PLANAR_DX | capi.NGP_FF_DEFER_REDUCE, st))
+        _check(capi.lib.ngp_ffmlp_reduce_slabs_pair(scratch_c.data_ptr(), capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_color),
+                                                    g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(),
+                                                    capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_sigma), g_ws.numel(), g_ws.data_ptr(), st))
+    else:
+        g_color_in = torch.empty(M, 32, **half)
+        scratch = torch.empty(max(nl_color, nl_sigma), M, 64, **half)
+        _check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), fb_c.data_ptr(), M, 32, 16, 64,
+                                              nl_color, 0, 6, 1, scratch.data_ptr(), g_color_in.data_ptr(), g_wc.data_ptr(), 0, st))
+        g_h16 = g_out16
+        _check(capi.lib.ngp_pipeline_mid_backward(g_sigma.data_ptr(), h16.data_ptr(), g_color_in.data_ptr(), g_h16.data_ptr(), M,
+                                                  float(density_scale), st))
+        _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
+                                              0, 6, 1, scratch[:nl_sigma].data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
+                                              _PLANAR_IN | _PLANAR_DX, st))
     _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st)
 
 
@@ -369,13 +398,36 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     return _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg)
 
 
+USE_FUSED_MID = True        # colour-head backward writes grad_h16 itself; one slab reduction for both MLPs (False: five launches)
+USE_FUSED_COMPOSITE = True  # composite forward + loss + composite backward + sigmoid backward in ONE launch (False: the four kernels)
+
+
 def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg, rcfg):
-    image, depth, weights_sum, saved = _render_train_network(marched, bufs[0], bufs[1], bufs[2], bg_t, offsets, cfg, rcfg)
-    loss = torch.empty(1, device=image.device, dtype=torch.float32)
-    grad_image = torch.empty_like(image)
-    _check(capi.lib.ngp_pipeline_mse_loss(image.data_ptr(), target.data_ptr(), image.numel(), capi.ptr(loss_scale), loss.data_ptr(),
-                                          grad_image.data_ptr(), capi.stream()))
-    _render_train_backward(saved, cfg, rcfg, grad_image, None, bufs[3], bufs[4].view(-1), bufs[5].view(-1))
+    if not USE_FUSED_COMPOSITE:
+        image, depth, weights_sum, saved = _render_train_network(marched, bufs[0], bufs[1], bufs[2], bg_t, offsets, cfg, rcfg)
+        loss = torch.empty(1, device=image.device, dtype=torch.float32)
+        grad_image = torch.empty_like(image)
+        _check(capi.lib.ngp_pipeline_mse_loss(image.data_ptr(), target.data_ptr(), image.numel(), capi.ptr(loss_scale), loss.data_ptr(),
+                                              grad_image.data_ptr(), capi.stream()))
+        _render_train_backward(saved, cfg, rcfg, grad_image, None, bufs[3], bufs[4].view(-1), bufs[5].view(-1))
+        return loss, image, depth, weights_sum
+    saved = _render_train_network(marched, bufs[0], bufs[1], bufs[2], bg_t, offsets, cfg, rcfg, composite=False)
+    (xyzs, _, _, _, _, _, _, _, _, rgb, sigma, deltas, rays, _, _, bg, march_ws) = saved
+    (_, _, _, _, _, _, _, T_thresh, _, bg_scalar) = rcfg
+    nears, fars = marched[4], marched[5]
+    N, M, dev = rays.shape[0], xyzs.shape[0], xyzs.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    weights_sum, image, depth = torch.empty(N, **f32), torch.empty(N, 3, **f32), torch.empty(N, **f32)
+    loss, ray_err = torch.empty(1, **f32), torch.empty(N, **f32)
+    g_sigma = torch.empty(M, **f32)
+    g_out16 = torch.empty(M, 16, device=dev, dtype=torch.half)
+    _check(capi.lib.ngp_composite_train_loss_backward(sigma.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), rays.data_ptr(), M, N,
+                                                      float(T_thresh), 2 if bg is not None else 1, float(bg_scalar), capi.ptr(bg),
+                                                      nears.data_ptr(), fars.data_ptr(), target.data_ptr(), capi.ptr(loss_scale),
+                                                      weights_sum.data_ptr(), image.data_ptr(), depth.data_ptr(), loss.data_ptr(),
+                                                      ray_err.data_ptr(), g_sigma.data_ptr(), g_out16.data_ptr(), march_ws.data_ptr(),
+                                                      capi.stream()))
+    _network_backward(saved, cfg, rcfg, g_sigma, g_out16, bufs[3], bufs[4].view(-1), bufs[5].view(-1))
     return loss, image, depth, weights_sum
 
 

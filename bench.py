@@ -347,7 +347,7 @@ def main():
     ap.add_argument('--no-render', action='store_true', help='skip the 800x800 inference-frame timing')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second, drop-in-surface-only measurement')
     ap.add_argument('--ab-off', default='', help='A/B measurement: comma-separated optional launch fusions of fused.py to switch OFF '
-                    '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID); recorded in config.fusions_off')
+                    '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID, USE_FUSED_SCAN); recorded in config.fusions_off')
     ap.add_argument('--dropin-steps', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)

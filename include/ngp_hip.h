@@ -313,6 +313,8 @@ int ngp_rays_from_pixels(const float* poses, uint32_t B, float fx, float fy, flo
  * writes are zeroed in-kernel (the reference contract keeps both with the caller: counter.zero_(), torch.zeros buffers). */
 #define NGP_MARCH_RESET_COUNTER 1u
 #define NGP_MARCH_ZERO_TAIL 2u
+#define NGP_MARCH_SCAN_LAUNCH 8u /* testing: keep the separate scan launch between the passes (default with NGP_MARCH_RESET_COUNTER and
+                                  * N <= 8192 rays: the write pass hands out the sample slots itself -- same slots, one launch less) */
 #define NGP_MARCH_NOISE_FROM_SEED 4u /* `noises` points to ONE device uint32 (a seed that the caller changes from step to step) instead of N
                                       * floats: ray n starts at near + dt * u(n, seed), u a counter-based uniform draw in [0, 1) */
 int ngp_march_rays_train_ex(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,

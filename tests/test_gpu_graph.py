@@ -219,7 +219,7 @@ def test_sync_free_occupancy_refresh():
     assert torch.equal(a, b) and torch.equal(c, raymarching.packbits(grid0, 0.25, torch.empty_like(model.density_bitfield)))
 
 
-@pytest.mark.parametrize('toggle', ['USE_FUSED_MID', 'USE_FUSED_COMPOSITE'])
+@pytest.mark.parametrize('toggle', ['USE_FUSED_MID', 'USE_FUSED_COMPOSITE', 'USE_FUSED_SCAN'])
 def test_iteration_fusions_are_bit_identical_to_the_unfused_launches(toggle):
     """the optional launch fusions of the autograd-free iteration (colour-head epilogue + one slab reduction; composite + loss + backward in
     one kernel) against the launches they replace: every deposited gradient, the image and the counters bit for bit."""

@@ -168,10 +168,11 @@ def test_march_rays_train_seeded_noise_matches_explicit_noise():
     assert not np.array_equal(draws(1), draws(2))
 
 
+@pytest.mark.parametrize('scan_launch', [False, True])
 @pytest.mark.parametrize('dt_gamma', [0.0, 1.0 / 128])
-def test_march_rays_train_aabb_folds_near_far_and_tail_zeroing(dt_gamma):
+def test_march_rays_train_aabb_folds_near_far_and_tail_zeroing(dt_gamma, scan_launch):
     """ngp_march_rays_train_aabb (near/far computed in the count pass, the unowned tail rows zeroed by extra workgroups of the write
-    pass) against the oracle's near_far_from_aabb + march_rays_train: everything bit-exact, nears / fars included; rays that miss the
+    pass, sample slots handed out by the write pass itself or -- scan_launch -- by the scan kernel) against the oracle's near_far_from_aabb + march_rays_train: everything bit-exact, nears / fars included; rays that miss the
     box and a sample buffer that is too small for the last rays are part of the input."""
     import _ngp_capi as capi
     N, bound = 3001, 1.0
@@ -194,7 +195,8 @@ def test_march_rays_train_aabb_folds_near_far_and_tail_zeroing(dt_gamma):
         capi.check(capi.lib.ngp_march_rays_train_aabb(to.data_ptr(), td.data_ptr(), tb.data_ptr(), bound, dt_gamma, 1024, N, 1, 128, M, ta.data_ptr(),
                                                       0.2, tn.data_ptr(), tf.data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(),
                                                       rays.data_ptr(), counter.data_ptr(), tz.data_ptr(), ws.data_ptr(),
-                                                      capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL, capi.stream()))
+                                                      capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL |
+                                                      (capi.NGP_MARCH_SCAN_LAUNCH if scan_launch else 0), capi.stream()))
         torch.cuda.synchronize()
         assert np.array_equal(tn.cpu().numpy(), nears) and np.array_equal(tf.cpu().numpy(), fars)
         assert counter.cpu().numpy().tolist() == ref[4].tolist()

@@ -335,20 +335,77 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
                                                                     const float* __restrict__ noises, uint32_t* __restrict__ n_windows,
                                                                     uint64_t* __restrict__ masks, bool noise_from_seed,
                                                                     const float* __restrict__ aabb, float min_near,
-                                                                    const uint32_t* __restrict__ fit_end, uint32_t ray_blocks) {
+                                                                    uint32_t* __restrict__ fit_end, uint32_t ray_blocks,
+                                                                    int32_t* __restrict__ self_scan_counter, bool zero_tail) {
     const uint32_t lane = threadIdx.x & 63;
+    // Write pass with self_scan_counter != NULL: no scan launch between the passes.  Sample slots are still handed out in ray order: a
+    // workgroup adds up the counts of all rays in front of its own (a few thousand L2-resident words), and the workgroups behind the
+    // ray ones redo the whole prefix to find the end of the rows that will be written (fit_end), publish it together with the counter,
+    // and zero the unowned tail.  (Used for N <= 8192 rays with the counter reset in-kernel; otherwise k_march_train_scan runs.)
+    __shared__ uint32_t part[MW_WAVES], part2[MW_WAVES];
     if (WRITE && blockIdx.x >= ray_blocks) {
-        // (fit_end != NULL) the sample rows [*fit_end, M) that no ray writes: the extra workgroups of the write pass zero them
-        const uint32_t stride = (gridDim.x - ray_blocks) * MW_WAVES * 64;
-        for (uint32_t row = fit_end[0] + (blockIdx.x - ray_blocks) * MW_WAVES * 64 + threadIdx.x; row < M; row += stride) {
-            xyzs[(size_t)row * 3] = 0.0f; xyzs[(size_t)row * 3 + 1] = 0.0f; xyzs[(size_t)row * 3 + 2] = 0.0f;
-            dirs[(size_t)row * 3] = 0.0f; dirs[(size_t)row * 3 + 1] = 0.0f; dirs[(size_t)row * 3 + 2] = 0.0f;
-            *reinterpret_cast<float2_t*>(deltas + (size_t)row * 2) = float2_t{0.0f, 0.0f};
+        uint32_t first_row;
+        if (self_scan_counter) {
+            constexpr uint32_t T = MW_WAVES * 64;
+            const uint32_t per = (N + T - 1) / T, lo = min(N, threadIdx.x * per), hi = min(N, lo + per);
+            uint32_t seg = 0;
+            for (uint32_t i = lo; i < hi; i++) seg += (uint32_t)rays[i * 3 + 2];
+            const uint32_t incl = wave_inclusive_scan(seg);
+            if (lane == 63) part[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < MW_WAVES; w++) { before += (uint32_t)w < (threadIdx.x >> 6) ? part[w] : 0u; total += part[w]; }
+            uint32_t off = before + incl - seg, unfit = 0xFFFFFFFFu;  // offset of my segment's first ray; first ray that does not fit
+            for (uint32_t i = lo; i < hi; i++) {
+                const uint32_t c = (uint32_t)rays[i * 3 + 2];
+                if (c != 0u && off + c > M && unfit == 0xFFFFFFFFu) unfit = off;
+                off += c;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) unfit = min(unfit, (uint32_t)__shfl_xor((int)unfit, o, 64));
+            if (lane == 0) part2[threadIdx.x >> 6] = unfit;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < MW_WAVES; w++) unfit = min(unfit, part2[w]);
+            const uint32_t end = unfit != 0xFFFFFFFFu ? unfit : total;
+            first_row = end < M ? end : M;
+            if (blockIdx.x == ray_blocks && threadIdx.x == 0) {
+                self_scan_counter[0] = (int32_t)total;
+                self_scan_counter[1] = (int32_t)N;
+                fit_end[0] = first_row;
+                fit_end[1] = 0u;  // the ticket of k_composite_train_loss_bwd
+            }
+        } else {
+            first_row = fit_end[0];
+        }
+        if (zero_tail) {
+            // the sample rows [fit_end, M) that no ray writes: the extra workgroups of the write pass zero them
+            const uint32_t stride = (gridDim.x - ray_blocks) * MW_WAVES * 64;
+            for (uint32_t row = first_row + (blockIdx.x - ray_blocks) * MW_WAVES * 64 + threadIdx.x; row < M; row += stride) {
+                xyzs[(size_t)row * 3] = 0.0f; xyzs[(size_t)row * 3 + 1] = 0.0f; xyzs[(size_t)row * 3 + 2] = 0.0f;
+                dirs[(size_t)row * 3] = 0.0f; dirs[(size_t)row * 3 + 1] = 0.0f; dirs[(size_t)row * 3 + 2] = 0.0f;
+                *reinterpret_cast<float2_t*>(deltas + (size_t)row * 2) = float2_t{0.0f, 0.0f};
+            }
         }
         return;
     }
     const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n = blockIdx.x * MW_WAVES + wid;  // wave-uniform
+    uint32_t scanned_offset = 0;
+    if (WRITE && self_scan_counter) {
+        uint32_t sum = 0;
+        const uint32_t first = blockIdx.x * MW_WAVES;
+        for (uint32_t i = threadIdx.x; i < first; i += MW_WAVES * 64) sum += (uint32_t)rays[i * 3 + 2];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += (uint32_t)__shfl_xor((int)sum, o, 64);
+        if (lane == 0) part[wid] = sum;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < MW_WAVES; w++) scanned_offset += part[w];
+        for (uint32_t w = 0; w < wid; w++) scanned_offset += first + w < N ? (uint32_t)rays[(first + w) * 3 + 2] : 0u;
+        if (n < N && lane == 0) rays[n * 3 + 1] = (int32_t)scanned_offset;
+    }
     if (n >= N) return;
     const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
     const Ray r = load_ray(rays_o, rays_d, n);
@@ -364,7 +421,7 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
 
     uint32_t limit = max_steps, offset = 0;
     if (WRITE) {
-        offset = (uint32_t)rays[n * 3 + 1];
+        offset = self_scan_counter ? scanned_offset : (uint32_t)rays[n * 3 + 1];
         limit = (uint32_t)rays[n * 3 + 2];
         if (limit == 0 || offset + limit > M) return;  // raymarching.cu:405-416: recorded, nothing written
     }
@@ -1143,22 +1200,27 @@ static int march_rays_train_impl(const float* rays_o, const float* rays_d, const
     uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
     const uint32_t ray_blocks = cdiv(N, MW_WAVES);
     const bool zero_tail = (flags & NGP_MARCH_ZERO_TAIL) && M > 0;
+    // few rays and an in-kernel counter reset: the write pass hands out the sample slots itself (no scan launch between the passes)
+    const bool self_scan = (flags & NGP_MARCH_RESET_COUNTER) && !(flags & NGP_MARCH_SCAN_LAUNCH) && N <= 8192u;
+    const uint32_t extra = zero_tail ? 16u : (self_scan ? 1u : 0u);
     const dim3 block(MW_WAVES * 64);
     const bool const_dt = dt_gamma == 0.0f;
-    // the write pass carries a few extra workgroups that zero the unowned tail rows (usually a few hundred)
 #define MARCH_WAVE(WRITE, CDT)                                                                                                              \
-    hipLaunchKernelGGL((k_march_train_wave<WRITE, CDT>), dim3(ray_blocks + ((WRITE) && zero_tail ? 16u : 0u)), block, 0, st, rays_o, rays_d,   \
-                       grid_bits, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, noises, ws_windows, ws_masks,   \
-                       (flags & NGP_MARCH_NOISE_FROM_SEED) != 0, aabb, min_near, (const uint32_t*)ws, ray_blocks)
+    hipLaunchKernelGGL((k_march_train_wave<WRITE, CDT>), dim3(ray_blocks + ((WRITE) ? extra : 0u)), block, 0, st, rays_o, rays_d, grid_bits,   \
+                       bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays, noises, ws_windows, ws_masks,              \
+                       (flags & NGP_MARCH_NOISE_FROM_SEED) != 0, aabb, min_near, ws, ray_blocks, self_scan ? counter : (int32_t*)nullptr,       \
+                       zero_tail)
     const uint8_t* grid_bits = grid_in;
     uint32_t* ws_windows = ws + 2;                                                               // [N]
     uint64_t* ws_masks = reinterpret_cast<uint64_t*>(ws + 2 + ((N + 1u) & ~1u));                 // [N][MARCH_MASK_WINDOWS], 8-byte aligned
     if (const_dt) MARCH_WAVE(false, true); else MARCH_WAVE(false, false);
     rc = check_launch("march_rays_train(count)");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, st, rays, counter, N, M, (int)((flags & NGP_MARCH_RESET_COUNTER) != 0), ws);
-    rc = check_launch("march_rays_train(scan)");
-    if (rc) return rc;
+    if (!self_scan) {
+        hipLaunchKernelGGL(k_march_train_scan, dim3(1), dim3(SCAN_THREADS), 0, st, rays, counter, N, M, (int)((flags & NGP_MARCH_RESET_COUNTER) != 0), ws);
+        rc = check_launch("march_rays_train(scan)");
+        if (rc) return rc;
+    }
     if (const_dt) MARCH_WAVE(true, true); else MARCH_WAVE(true, false);
 #undef MARCH_WAVE
     return check_launch("march_rays_train(write)");

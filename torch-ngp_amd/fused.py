@@ -211,7 +211,7 @@ def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, nois
     dirs = torch.empty(M, 3, **f32)
     deltas = torch.empty(M, 2, **f32)
     rays = torch.empty(N, 3, device=dev, dtype=torch.int32)
-    march_flags = capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL
+    march_flags = capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL | (0 if USE_FUSED_SCAN else capi.NGP_MARCH_SCAN_LAUNCH)
     if perturb and noise_seed is not None:
         # start offsets drawn in-kernel from (ray index, *noise_seed): no rand launch, no generator bookkeeping in a captured graph
         noises, march_flags = noise_seed, march_flags | capi.NGP_MARCH_NOISE_FROM_SEED
@@ -398,6 +398,7 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     return _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg)
 
 
+USE_FUSED_SCAN = True       # the marcher's write pass hands out the sample slots itself (False: scan launch between the passes)
 USE_FUSED_MID = True        # colour-head backward writes grad_h16 itself; one slab reduction for both MLPs (False: five launches)
 USE_FUSED_COMPOSITE = True  # composite forward + loss + composite backward + sigmoid backward in ONE launch (False: the four kernels)
 

@@ -64,6 +64,7 @@ TIMED = {
     'ngp_grid_encode_forward_ex': ('grid_encode_forward', 4, lambda a: 588.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_ex': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_ws': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
+    'ngp_grid_encode_backward_checked': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_ffmlp_forward_ex': ('ffmlp_forward', 2, lambda a: _ff_fwd_bytes(a[6]), lambda a: _ff_flops(a[6]), 'sample'),
     # the whole network behind the encoder in one launch: enc 64 B + dir 12 B in, both forward buffers + h16 32 B + colour input 64 B + sigma 4 B +
     # rgb 12 B out per sample; flops of both MLPs
@@ -347,7 +348,7 @@ def main():
     ap.add_argument('--no-render', action='store_true', help='skip the 800x800 inference-frame timing')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second, drop-in-surface-only measurement')
     ap.add_argument('--ab-off', default='', help='A/B measurement: comma-separated optional launch fusions of fused.py to switch OFF '
-                    '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID, USE_FUSED_SCAN); recorded in config.fusions_off')
+                    '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID, USE_FUSED_SCAN, USE_FUSED_CHECK); recorded in config.fusions_off')
     ap.add_argument('--dropin-steps', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)

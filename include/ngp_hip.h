@@ -221,6 +221,14 @@ int ngp_grid_encode_backward_ex(const void* grad, const float* inputs, const voi
  * (= ngp_grid_encode_backward_ex).  Small batches and other dtypes/shapes use the atomic path as well (workspace_bytes() == 0). */
 size_t ngp_grid_backward_workspace_bytes(const int32_t* offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                          uint32_t gridtype, int align_corners, int dtype);
+/* ngp_grid_encode_backward_ws that also does the optimizer's non-finite sweep over the gradient table where the values are produced:
+ * found_inf (optional device float) is set to 1 when a gradient entry this call wrote is not finite (needs offsets_host; levels that
+ * went through atomics are swept by one extra launch).  With it, ngp_optim_adam_step_ex can be called without its CHECK phase. */
+int ngp_grid_encode_backward_checked(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                     void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                     const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
+                                     int dtype, float bound, const int32_t* offsets_host, void* workspace, size_t workspace_bytes,
+                                     float* found_inf, ngp_stream_t stream);
 int ngp_grid_encode_backward_ws(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                 const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
@@ -275,13 +283,15 @@ int ngp_network_forward(const void* enc, const float* dirs, uint32_t M, uint32_t
  *  - ngp_ffmlp_backward_slab_count: how many fp32 slabs [n_params] a deferred backward of that shape leaves at the start of its
  *    backward_buffer (0: the gradients were stored directly, nothing to sum).
  *  - ngp_ffmlp_reduce_slabs_pair: sums two slab sets (n_slabs x n_params fp32 each, either may be empty) into fp16 weight
- *    gradients in ONE launch, in the fixed order of the single-set reduction (deterministic, same bits). */
+ *    gradients in ONE launch, in the fixed order of the single-set reduction (deterministic, same bits).  found_inf (optional device
+ *    float): set to 1 when a resulting gradient is not finite -- the optimizer's non-finite sweep (ngp_optim_adam_step_ex, phase
+ *    CHECK) done by the producer; a set with n_slabs = 0 (gradients already stored) is then only swept. */
 int ngp_network_backward_color(const void* grad_out16, const void* color_in, const void* w_color, const void* forward_buffer_color, uint32_t M,
                                uint32_t num_layers_color, void* backward_buffer, const float* grad_sigma, const void* h16,
                                float density_scale, void* grad_h16, void* grad_w_color, uint32_t flags, ngp_stream_t stream);
 uint32_t ngp_ffmlp_backward_slab_count(uint32_t B, uint32_t input_dim, uint32_t hidden_dim, uint32_t num_layers);
 int ngp_ffmlp_reduce_slabs_pair(const void* slabs_a, uint32_t n_slabs_a, uint32_t n_params_a, void* grad_weights_a, const void* slabs_b,
-                                uint32_t n_slabs_b, uint32_t n_params_b, void* grad_weights_b, ngp_stream_t stream);
+                                uint32_t n_slabs_b, uint32_t n_params_b, void* grad_weights_b, float* found_inf, ngp_stream_t stream);
 
 /* network_ff.py:55-72 between the two MLPs: h16 [M,16] fp16 (sigma-net output), dirs [M_valid,3] fp32 ->
  * sigma [M] fp32 = exp(h[:,0]) (trunc_exp), color_in [M,32] fp16 = [SH deg 4 | h[:,1:16] | 0]; rows >= M_valid use dir = 0 */

@@ -31,6 +31,39 @@ def test_library_exports_every_declared_symbol():
     assert set(capi.EXPORTED) == set(declared)
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """every prototype of include/ngp_hip.h against the ctypes argtypes of _ngp_capi: same parameter count, and per parameter the same
+    kind (pointer / uint32 / int / float / size_t) -- a missing argtype lets ctypes pass a 64-bit stream handle as a 32-bit int"""
+    import _ngp_capi as capi
+    text = open(os.path.join(ROOT, 'include', 'ngp_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    text = re.sub(r'^\s*#.*$', '', text, flags=re.M)
+    kinds = {ctypes.c_void_p: 'ptr', ctypes.c_char_p: 'ptr', ctypes.c_uint32: 'u32', ctypes.c_int: 'int', ctypes.c_float: 'f32',
+             ctypes.c_size_t: 'w64', ctypes.c_uint64: 'w64'}   # (c_size_t IS c_uint64 on this platform)
+
+    def kind(param):
+        param = param.strip()
+        if '*' in param or param.startswith('ngp_stream_t'):
+            return 'ptr'
+        base = param.replace('const ', '').split()[0]
+        return {'uint32_t': 'u32', 'int': 'int', 'int32_t': 'int', 'float': 'f32', 'size_t': 'w64', 'uint64_t': 'w64'}[base]
+
+    protos = re.findall(r'\b(?:int|size_t|uint32_t|const char\s*\*)\s*(ngp_[a-zA-Z0-9_]+)\s*\(([^;]*?)\)\s*;', text, flags=re.S)
+    assert len(protos) >= 60
+    checked = 0
+    for name, params in protos:
+        fn = getattr(capi.lib, name)
+        params = params.strip()
+        want = [] if params in ('', 'void') else [kind(p) for p in params.split(',')]
+        if fn.argtypes is None:
+            assert want == [], f'{name}: no argtypes bound for {len(want)} parameters'
+            continue
+        got = [kinds[t] for t in fn.argtypes]
+        assert got == want, f'{name}: ctypes {got} != header {want}'
+        checked += 1
+    assert checked >= 55
+
+
 def test_host_side_argument_validation_needs_no_gpu():
     import _ngp_capi as capi
     lib = capi.lib

@@ -248,3 +248,49 @@ def test_iteration_fusions_are_bit_identical_to_the_unfused_launches(toggle):
         assert float(x.float().abs().max()) > 0
         assert torch.equal(x, y), (name, float((x.float() - y.float()).abs().max()))
     assert abs(a[4] - b[4]) <= 2e-6 * abs(b[4])
+
+
+def test_producer_side_nonfinite_sweep_equals_the_optimizer_sweep():
+    """USE_FUSED_CHECK: found_inf is set by the kernels that produce the gradients (slab reduction, slice accumulation) instead of
+    NGPAdam's CHECK launch.  Started from an absurd loss scale, both variants must skip exactly the same (overflowing) steps, back the
+    scale off identically and end with bit-identical parameters."""
+    import fused
+    from graph import GraphedTrainStep
+    from optim import NGPAdam
+    dev = torch.device('cuda')
+    occ = torch.from_numpy(sc.occupancy_density()).to(dev)
+    bits = torch.from_numpy(oracle.packbits(sc.occupancy_density(), 10.0)).to(dev)
+    n_rays = 1024
+    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    batches = []
+    for i in range(30):
+        o, d, gt = sc.training_batch(n_rays, seed=700 + i)
+        batches.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
+
+    def keep(m):
+        m.density_grid.copy_(occ)
+        m.density_bitfield.copy_(bits)
+
+    runs = {}
+    for on in (True, False):
+        fused.USE_FUSED_CHECK = on
+        try:
+            model, _ = _make_ngp(dev)
+            opt = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, init_scale=2.0 ** 40)
+            st = GraphedTrainStep(model, opt, None, n_rays, kw, after_update=keep, direct=True)
+            scales = []
+            for i in range(30):
+                st.step(*batches[i])
+                scales.append(float(opt.scalars[0]))
+            assert st.n_captures >= 1 and st.capture_error is None and st.used_direct
+            assert st.producers_check == on
+            params = [p.detach().clone() for p in (model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights)]
+            runs[on] = (scales, params, float(opt.scalars[3]), float(opt.scalars[2]))
+        finally:
+            fused.USE_FUSED_CHECK = True
+    a, b = runs[True], runs[False]
+    assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3] == 0.0
+    assert a[0][0] < 2.0 ** 40 and a[0][-1] < 2.0 ** 30, 'the absurd scale must have overflowed and backed off'
+    assert 0 < a[2] < 30, 'some steps skipped, some applied'
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x, y)

@@ -257,6 +257,35 @@ def _ray_points(n_rays, per_ray, rng):
     return np.clip(o + d * t, 0.0, 1.0).reshape(-1, 3).astype(np.float32)
 
 
+@pytest.mark.parametrize('magnitude', [40.0, 600.0, 6000.0])
+def test_backward_binned_is_exact_and_reproducible_at_loss_scaled_magnitudes(magnitude):
+    """loss-scaled gradients: contributions of 128 and more (outside the int32 range of value * 2^24) take the other scaling of the
+    fixed-point addend; sums that leave the fp16 range come out +-inf (and the caller's found_inf is raised), NaN never appears from
+    finite inputs, and ten repeats are bit-identical.  (A divergent special case for these values lost contributions at random: seen as
+    spurious skipped steps whenever the loss scale was high.)"""
+    import _ngp_capi as capi
+    rng = np.random.default_rng(5)
+    offs, pls = oracle.grid_offsets(**LEGO)
+    S = float(np.log2(pls))
+    x = _ray_points(1024, 48, rng)
+    B = x.shape[0]
+    g = oracle.round_fp16(rng.normal(size=(16, B, 2)).astype(np.float32) * magnitude)
+    outs = [_backward_ws(g, x, offs, S, True)[0] for _ in range(10)]
+    assert all(torch.equal(o.view(torch.int16), outs[0].view(torch.int16)) for o in outs[1:])
+    got = outs[0].float().cpu().numpy().astype(np.float64)
+    assert not np.isnan(got).any()
+    ref, _ = oracle.grid_backward(g, x, offs, int(offs[-1]), 2, S, 16)
+    ref = ref.astype(np.float64)
+    over = np.abs(ref) > 65504.0 * (1 - 2e-3)
+    assert np.array_equal(np.isinf(got), np.isinf(got) & (np.abs(ref) > 65504.0 * (1 - 2e-3))), 'inf only where the true sum leaves the fp16 range'
+    ok = ~over & ~np.isinf(got)
+    # same budget as the small-magnitude test below (every contribution is rounded to fp16 once, the sum is exact and rounded once)
+    assert np.abs(got - ref)[ok].max() <= 1.5e-3 * np.abs(ref[ok]).max()
+    assert np.linalg.norm((got - ref)[ok]) / np.linalg.norm(ref[ok]) < 6e-4
+    if magnitude >= 600.0:
+        assert (np.abs(ref) >= 128).sum() > 1000 and (np.abs(got[ok]) >= 128).sum() > 1000
+
+
 def test_backward_binned_matches_oracle_and_is_reproducible():
     rng = np.random.default_rng(11)
     offs, pls = oracle.grid_offsets(**LEGO)

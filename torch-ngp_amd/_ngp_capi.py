@@ -66,6 +66,8 @@ _SIGNATURES = {
     'ngp_grid_encode_backward_ex': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
     'ngp_grid_encode_backward_ws': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp, _vp,
                                     _sz, _vp],
+    'ngp_grid_encode_backward_checked': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp,
+                                         _vp, _sz, _vp, _vp],
     'ngp_ffmlp_forward_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_inference_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_backward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp],
@@ -85,7 +87,7 @@ _SIGNATURES = {
     'ngp_composite_train_loss_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp],
     'ngp_network_backward_color': [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _f32, _vp, _vp, _u32, _vp],
-    'ngp_ffmlp_reduce_slabs_pair': [_vp, _u32, _u32, _vp, _vp, _u32, _u32, _vp, _vp],
+    'ngp_ffmlp_reduce_slabs_pair': [_vp, _u32, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     'ngp_optim_adam_step': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
     'ngp_optim_adam_step_ex': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _u32, _vp],
     'ngp_optim_ema_update': [_i32, _vp, _vp, _vp, _f32, _vp],

@@ -1494,7 +1494,7 @@ __global__ __launch_bounds__(RS_PARAMS * RS_GROUPS) void k_ffmlp_reduce_slabs_pa
                                                                                     uint32_t n_params_a, half_t* __restrict__ gw_a,
                                                                                     uint32_t blocks_a, const float* __restrict__ slabs_b,
                                                                                     uint32_t n_slabs_b, uint32_t n_params_b,
-                                                                                    half_t* __restrict__ gw_b) {
+                                                                                    half_t* __restrict__ gw_b, float* __restrict__ found_inf) {
     __shared__ float part[RS_GROUPS][RS_PARAMS];
     const bool second = blockIdx.x >= blocks_a;
     const float* __restrict__ slabs = second ? slabs_b : slabs_a;
@@ -1507,12 +1507,22 @@ __global__ __launch_bounds__(RS_PARAMS * RS_GROUPS) void k_ffmlp_reduce_slabs_pa
         for (uint32_t k = g; k < n_slabs; k += RS_GROUPS) s += slabs[(size_t)k * n_params + i];
     part[g][li] = s;
     __syncthreads();
+    bool nonfinite = false;
     if (g == 0 && i < n_params) {
-        float t = 0.0f;
+        half_t r;
+        if (n_slabs) {
+            float t = 0.0f;
 #pragma unroll
-        for (int q = 0; q < RS_GROUPS; q++) t += part[q][li];
-        grad_weights[i] = (half_t)t;
+            for (int q = 0; q < RS_GROUPS; q++) t += part[q][li];
+            r = (half_t)t;
+            grad_weights[i] = r;
+        } else {
+            r = grad_weights[i];  // stored directly by the (single-workgroup) backward: only swept
+        }
+        nonfinite = !__builtin_isfinite((float)r);
     }
+    // found_inf: the optimizer's non-finite sweep over the MLP gradients, done where the final values are produced
+    if (found_inf && __any(nonfinite) && (threadIdx.x & 63) == 0) found_inf[0] = 1.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1865,14 +1875,16 @@ extern "C" uint32_t ngp_ffmlp_backward_slab_count(uint32_t B, uint32_t input_dim
 
 extern "C" int ngp_ffmlp_reduce_slabs_pair(const void* slabs_a, uint32_t n_slabs_a, uint32_t n_params_a, void* grad_weights_a,
                                            const void* slabs_b, uint32_t n_slabs_b, uint32_t n_params_b, void* grad_weights_b,
-                                           ngp_stream_t stream) {
-    const uint32_t blocks_a = n_slabs_a ? cdiv(n_params_a, RS_PARAMS) : 0u, blocks_b = n_slabs_b ? cdiv(n_params_b, RS_PARAMS) : 0u;
+                                           float* found_inf, ngp_stream_t stream) {
+    // a set without slabs (its backward stored the gradients directly) still gets workgroups when found_inf asks for the sweep
+    const uint32_t blocks_a = (n_slabs_a || found_inf) && n_params_a ? cdiv(n_params_a, RS_PARAMS) : 0u;
+    const uint32_t blocks_b = (n_slabs_b || found_inf) && n_params_b ? cdiv(n_params_b, RS_PARAMS) : 0u;
     if (blocks_a + blocks_b == 0) return NGP_OK;
-    NGP_REQUIRE((!n_slabs_a || (slabs_a && grad_weights_a)) && (!n_slabs_b || (slabs_b && grad_weights_b)), NGP_ERR_INVALID,
-                "ffmlp_reduce_slabs_pair: NULL tensor");
+    NGP_REQUIRE((!blocks_a || ((slabs_a || !n_slabs_a) && grad_weights_a)) && (!blocks_b || ((slabs_b || !n_slabs_b) && grad_weights_b)),
+                NGP_ERR_INVALID, "ffmlp_reduce_slabs_pair: NULL tensor");
     hipLaunchKernelGGL(k_ffmlp_reduce_slabs_pair, dim3(blocks_a + blocks_b), dim3(RS_PARAMS * RS_GROUPS), 0, as_stream(stream),
                        (const float*)slabs_a, n_slabs_a, n_params_a, (half_t*)grad_weights_a, blocks_a, (const float*)slabs_b, n_slabs_b,
-                       n_params_b, (half_t*)grad_weights_b);
+                       n_params_b, (half_t*)grad_weights_b, found_inf);
     return check_launch("ffmlp_reduce_slabs_pair");
 }
 

@@ -890,17 +890,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
     for (uint32_t r = tid; 2u * r < total; r += BIN_THREADS) chunk[r] = staging2[r];  // an odd tail writes one unused slot of the chunk
 }
 
-// fp16 bit pattern (finite) -> signed multiple of 2^-24
-__device__ __forceinline__ long long half_bits_to_fixed(uint32_t h) {
-    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
-    const unsigned long long mag = e ? ((unsigned long long)(1024u + m) << (e - 1u)) : (unsigned long long)m;
-    return (h & 0x8000u) ? -(long long)mag : (long long)mag;
-}
-
 template <int D>
 __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_grid_backward_accumulate(const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid,
                                                                           BinPlan plan, const uint32_t* __restrict__ descriptors,
-                                                                          const uint2* __restrict__ records) {
+                                                                          const uint2* __restrict__ records, float* __restrict__ found_inf) {
     constexpr int MAX_REC = BIN_PPB * (1 << D);
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_smem);                                // [BIN_SLICE][2]
@@ -921,28 +914,24 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     // the loads of RUNS_AHEAD runs back to back -- unconditionally, at clamped addresses -- before it touches the accumulator.
     constexpr int GROUP = 16, GROUPS = ACC_THREADS / GROUP, RUNS_AHEAD = 4;
     const int grp = tid / GROUP, gl = tid % GROUP, lane = tid & 63, group_base = lane & ~(GROUP - 1);
-    // (this kernel is bound by its VALU work per record, so the usual case is straight-line code: fp16 -> fp32 -> * 2^24 -> int32 is
-    // exact for |value| < 128, one sign extension makes it the 64-bit addend, both channels are added unconditionally (a zero addend
-    // is harmless); values >= 128 and non-finite ones are rare and handled behind ONE branch per record)
+    // Exact fixed-point addend of a finite fp16 value v (11 significant bits), straight-line for BOTH magnitude ranges:
+    //   |v| <  128: v * 2^24 is an integer below 2^31                      -> q = (int32) (v * 2^24), addend = q
+    //   |v| >= 128: v is a multiple of 2^-3 (ulp of the binade of 128)     -> q = (int32) (v * 8) (<= 524032), addend = q << 21
+    // one multiply, one conversion, one 64-bit shift by a selected amount; both channels are added unconditionally (a zero addend is
+    // harmless).  Only inf / NaN leave the straight line: they poison their channel behind one (rare) branch per record.
     const bool interleaved = plan.interleaved[li] != 0;
+    auto fixed_addend = [](float v) -> unsigned long long {
+        const bool big = __builtin_fabsf(v) >= 128.0f;
+        const int32_t q = (int32_t)(v * (big ? 8.0f : 0x1p24f));
+        return (unsigned long long)(long long)q << (big ? 21 : 0);  // (shifted as unsigned: two's complement, exact mod 2^64)
+    };
     auto add_record = [&](const uint32_t key, const uint32_t val) {
         const uint32_t idx = interleaved ? (key >> BIN_DENSE_BITS) : (key & (BIN_SLICE - 1u));
         const half2_t hv = __builtin_bit_cast(half2_t, val);
-        const float s0 = (float)hv.x * 0x1p24f, s1 = (float)hv.y * 0x1p24f;  // exact: 11 significant bits
-        const bool ok0 = __builtin_fabsf(s0) < 0x1p31f, ok1 = __builtin_fabsf(s1) < 0x1p31f;  // false for large values, inf and NaN
-        const int32_t q0 = (int32_t)(ok0 ? s0 : 0.0f), q1 = (int32_t)(ok1 ? s1 : 0.0f);
-        __hip_atomic_fetch_add(&acc[2 * idx], (unsigned long long)(long long)q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&acc[2 * idx + 1], (unsigned long long)(long long)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!(ok0 && ok1)) {
-            const uint32_t bits[2] = {val & 0xffffu, val >> 16};
-            const bool ok[2] = {ok0, ok1};
-#pragma unroll
-            for (uint32_t ch = 0; ch < 2; ch++) {
-                if (ok[ch]) continue;
-                if ((bits[ch] & 0x7c00u) == 0x7c00u) atomicOr(&poison[idx >> 4], (1u + ch) << ((idx & 15u) * 2u));
-                else __hip_atomic_fetch_add(&acc[2 * idx + ch], (unsigned long long)half_bits_to_fixed(bits[ch]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
+        const bool fin0 = (val & 0x7c00u) != 0x7c00u, fin1 = (val & 0x7c000000u) != 0x7c000000u;
+        __hip_atomic_fetch_add(&acc[2 * idx], fixed_addend(fin0 ? (float)hv.x : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[2 * idx + 1], fixed_addend(fin1 ? (float)hv.y : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!(fin0 && fin1)) atomicOr(&poison[idx >> 4], ((fin0 ? 0u : 1u) | (fin1 ? 0u : 2u)) << ((idx & 15u) * 2u));
     };
     const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(level_records);  // 2 words per record
     auto load2 = [&](uint32_t first_record) {  // records first_record, first_record + 1
@@ -987,6 +976,7 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
     half2_t* __restrict__ gtable = reinterpret_cast<half2_t*>(grad_grid + (size_t)off0 * 2);
+    bool nonfinite = false;
     for (uint32_t i = tid; i < (uint32_t)BIN_SLICE; i += ACC_THREADS) {
         const uint32_t e = interleaved ? (i << BIN_DENSE_BITS) + bin : bin * BIN_SLICE + i;
         if (e >= hashmap_size) break;
@@ -999,7 +989,10 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         nu.x = (half_t)((float)old.x + ((bad & 1u) ? nan : (float)s0 * 0x1p-24f));
         nu.y = (half_t)((float)old.y + ((bad & 2u) ? nan : (float)s1 * 0x1p-24f));
         gtable[e] = nu;
+        nonfinite = nonfinite || !__builtin_isfinite((float)nu.x) || !__builtin_isfinite((float)nu.y);
     }
+    // the optimizer's non-finite sweep over the table, done where the final values are produced (benign race: every writer stores 1)
+    if (found_inf && __any(nonfinite) && (tid & 63) == 0) found_inf[0] = 1.0f;
 }
 
 // gridencoder.cu:343-369
@@ -1117,22 +1110,28 @@ static int launch_forward(const float* inputs, const void* emb, const int32_t* o
     return check_launch("grid_encode_forward");
 }
 
-static int grid_backward_variant() {  // NGP_GRID_BWD=nomerge disables the run merge (benchmarks / experiments)
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("NGP_GRID_BWD");
-        mode = (e && e[0] == 'n') ? 1 : (e && e[0] == 'r') ? 2 : (e && e[0] == 'b') ? 3 : 0;  // none / row / bpermute-wave / default
-    }
-    return mode;
-}
+// Compile-time experiment knobs of the backward (no run-time switches in the product path):
+//   -DNGP_GRID_BWD_VARIANT=1 no run merge in the atomic kernel, 2 merge inside 16-lane rows, 3 wave-wide merge through ds_bpermute; 0 = default
+//   -DNGP_GRID_BWD_BIN_FROM=<level> first level that may be binned (99 = never); -1 = every eligible level
+//   -DNGP_GRID_BWD_SEPARATE=1 atomic levels in a launch of their own instead of riding in the record sort's
+#ifndef NGP_GRID_BWD_VARIANT
+#define NGP_GRID_BWD_VARIANT 0
+#endif
+#ifndef NGP_GRID_BWD_BIN_FROM
+#define NGP_GRID_BWD_BIN_FROM -1
+#endif
+#ifndef NGP_GRID_BWD_SEPARATE
+#define NGP_GRID_BWD_SEPARATE 0
+#endif
+static constexpr int grid_backward_variant() { return NGP_GRID_BWD_VARIANT; }
 
-// ---- host-side plan of a backward call: which levels go through the bins, and where their chunks live in the workspace ----
 struct BackwardPlan {
     LevelList atomic_levels;
     uint32_t n_atomic = 0;
     BinPlan bins;
     uint32_t n_binned = 0, total_desc = 0, max_bins = 0;
     uint64_t total_records = 0;
+    float* found_inf = nullptr;  // optional: set to 1 when a gradient value this call produced is not finite
     size_t desc_bytes() const { return ((size_t)total_desc * sizeof(uint32_t) + 255) & ~(size_t)255; }
     // (+64: the 16-byte load of a one-record run at the very end of the last chunk reads 8 bytes past it)
     size_t workspace_bytes() const { return n_binned ? desc_bytes() + (size_t)total_records * sizeof(uint2) + 64 : 0; }
@@ -1141,14 +1140,7 @@ struct BackwardPlan {
 constexpr uint32_t BIN_MIN_SAMPLES = 16384;       // below this the launch overheads of the two extra kernels win
 constexpr uint32_t BIN_MAX_SAMPLES = 1u << 24;
 
-static int bin_first_level() {  // NGP_GRID_BWD_BIN_FROM=<level>: first level that may be binned (benchmarks / experiments); 99 = never
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("NGP_GRID_BWD_BIN_FROM");
-        v = e ? atoi(e) : -1;
-    }
-    return v;
-}
+static constexpr int bin_first_level() { return NGP_GRID_BWD_BIN_FROM; }
 
 // Every level of an eligible call is binned: hashed levels in contiguous slices, dense levels in round-robin bins.
 static void plan_backward(BackwardPlan& p, const int32_t* offsets_host, const GridLevels& lv, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
@@ -1211,7 +1203,7 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     int rc = check_launch("grid_encode_backward(bin)");
     if (rc) return rc;
     hipLaunchKernelGGL((k_grid_backward_accumulate<D>), dim3(p.max_bins, p.n_binned), dim3(ACC_THREADS), acc_smem, st, offsets,
-                       (half_t*)grad_emb, p.bins, (const uint32_t*)descriptors, (const uint2*)records);
+                       (half_t*)grad_emb, p.bins, (const uint32_t*)descriptors, (const uint2*)records, p.found_inf);
     return check_launch("grid_encode_backward(accumulate)");
 }
 
@@ -1223,7 +1215,7 @@ static int launch_backward(const void* grad, const float* inputs, const int32_t*
     constexpr bool can_bin = sizeof(T) == 2 && C == 2 && (D == 2 || D == 3);
     // the atomic levels ride in the launch of the record sort when there is one (and the merge variant is the default one)
     const int variant = grid_backward_variant();
-    const bool mixed = can_bin && plan.n_binned > 0 && (variant == 0 || variant == 3) && getenv("NGP_GRID_BWD_SEPARATE") == nullptr;
+    const bool mixed = can_bin && plan.n_binned > 0 && (variant == 0 || variant == 3) && !NGP_GRID_BWD_SEPARATE;
     if (plan.n_atomic && !mixed) {
         // one block covers `ppb` consecutive points of one level; >= ~4 blocks per CU over all levels fills the chip
         uint32_t ppb = 2048;
@@ -1267,6 +1259,14 @@ atomic_done:
         rc = check_launch("grid_encode_backward(input)");
     }
     return rc;
+}
+
+// found_inf for gradient entries written by atomics (their results are never observed by the writer): one sweep over the table
+template <typename T>
+__global__ __launch_bounds__(256) void k_flag_nonfinite(const T* __restrict__ g, uint64_t n, float* __restrict__ found_inf) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) bad = bad || !__builtin_isfinite((float)g[i]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[0] = 1.0f;
 }
 
 template <typename T, int D, int C>
@@ -1374,13 +1374,23 @@ extern "C" size_t ngp_grid_backward_workspace_bytes(const int32_t* offsets_host,
     return plan.workspace_bytes();
 }
 
-extern "C" int ngp_grid_encode_backward_ws(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
-                                           void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
-                                           uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
-                                           uint32_t interp, int dtype, float bound, const int32_t* offsets_host, void* workspace,
-                                           size_t workspace_bytes, ngp_stream_t stream) {
+template <typename T>
+static int dispatch_backward(uint32_t D, uint32_t C, const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
+                             uint32_t L, const GridLevels& lv, const void* dy_dx, void* grad_inputs, uint32_t gridtype, bool ac, uint32_t interp,
+                             InputMap im, const BackwardPlan& plan, void* workspace, hipStream_t st) {
+    NGP_DISPATCH_DC(launch_backward, T, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, im, plan, workspace, st)
+    set_error("grid_encode_backward: unsupported (D=%u, C=%u)", D, C);
+    return NGP_ERR_INVALID;
+}
+
+extern "C" int ngp_grid_encode_backward_checked(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                                void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                                uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                                                uint32_t interp, int dtype, float bound, const int32_t* offsets_host, void* workspace,
+                                                size_t workspace_bytes, float* found_inf, ngp_stream_t stream) {
     (void)embeddings;
     NGP_REQUIRE(!(bound > 0.0f && dy_dx), NGP_ERR_INVALID, "grid_encode_backward: the fused input mapping does not provide grad_inputs");
+    NGP_REQUIRE(!found_inf || offsets_host, NGP_ERR_INVALID, "grid_encode_backward: found_inf needs the host copy of the offsets");
     const InputMap im = make_input_map(bound);
     int rc = check_grid_args("grid_encode_backward", B, D, C, L, dtype);
     if (rc) return rc;
@@ -1390,18 +1400,34 @@ extern "C" int ngp_grid_encode_backward_ws(const void* grad, const float* inputs
     fill_levels(lv, L, S, H);
     BackwardPlan plan;
     plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0, workspace != nullptr);
+    plan.found_inf = found_inf;
     NGP_REQUIRE(plan.workspace_bytes() <= workspace_bytes, NGP_ERR_INVALID,
                 "grid_encode_backward: workspace of %zu bytes, ngp_grid_backward_workspace_bytes() asks for %zu", workspace_bytes,
                 plan.workspace_bytes());
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
-    if (dtype == NGP_F16) {
-        NGP_DISPATCH_DC(launch_backward, half_t, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, im, plan, workspace, st)
-    } else {
-        NGP_DISPATCH_DC(launch_backward, float, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp, im, plan, workspace, st)
-    }
-    set_error("grid_encode_backward: unsupported (D=%u, C=%u)", D, C);
-    return NGP_ERR_INVALID;
+    rc = dtype == NGP_F16 ? dispatch_backward<half_t>(D, C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac,
+                                                      interp, im, plan, workspace, st)
+                          : dispatch_backward<float>(D, C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp,
+                                                     im, plan, workspace, st);
+    if (rc || !found_inf || plan.n_atomic == 0) return rc;
+    // some levels went through atomics: their sums are swept here (the record-sort path flags its own)
+    const uint64_t n = (uint64_t)offsets_host[L] * C;
+    const uint32_t blocks = (uint32_t)(cdiv64(n, 256 * 8) > 2048 ? 2048 : cdiv64(n, 256 * 8));
+    if (dtype == NGP_F16)
+        hipLaunchKernelGGL(k_flag_nonfinite<half_t>, dim3(blocks ? blocks : 1), dim3(256), 0, st, (const half_t*)grad_embeddings, n, found_inf);
+    else
+        hipLaunchKernelGGL(k_flag_nonfinite<float>, dim3(blocks ? blocks : 1), dim3(256), 0, st, (const float*)grad_embeddings, n, found_inf);
+    return check_launch("grid_encode_backward(non-finite sweep)");
+}
+
+extern "C" int ngp_grid_encode_backward_ws(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                           void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                           uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                                           uint32_t interp, int dtype, float bound, const int32_t* offsets_host, void* workspace,
+                                           size_t workspace_bytes, ngp_stream_t stream) {
+    return ngp_grid_encode_backward_checked(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
+                                            align_corners, interp, dtype, bound, offsets_host, workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" int ngp_grid_encode_backward_ex(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,

@@ -123,12 +123,17 @@ def _network_forward(enc, dirs, d_valid, ws16, wc16, nl_sigma, nl_color, density
     _check(capi.lib.ngp_pipeline_rgb_forward(out16.data_ptr(), rgb.data_ptr(), M, st))
 
 
-def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st):
-    """hash-grid scatter of the level-major fp16 gradient; large batches take the binned atomic-free path (needs scratch memory)"""
+def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf=None):
+    """hash-grid scatter of the level-major fp16 gradient; large batches take the binned atomic-free path (needs scratch memory).
+    found_inf: optional device float that the kernels set when a table gradient comes out non-finite (the optimizer's sweep, done here)"""
     arr, ws, nbytes = capi.grid_backward_workspace(offsets, M, 3, 2, L, S, H, gridtype, align, capi.NGP_F16)
-    _check(capi.lib.ngp_grid_encode_backward_ws(g_enc.data_ptr(), x.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
-                                                 None, None, gridtype, align, interp, capi.NGP_F16, float(bound),
-                                                 None if arr is None else ctypes.cast(arr, ctypes.c_void_p), capi.ptr(ws), nbytes, st))
+    if found_inf is not None and arr is None:
+        raise RuntimeError('fused: the in-kernel non-finite sweep needs the host copy of the encoder offsets (call iteration_checks_gradients '
+                           'outside stream capture first)')
+    _check(capi.lib.ngp_grid_encode_backward_checked(g_enc.data_ptr(), x.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
+                                                      None, None, gridtype, align, interp, capi.NGP_F16, float(bound),
+                                                      None if arr is None else ctypes.cast(arr, ctypes.c_void_p), capi.ptr(ws), nbytes,
+                                                      capi.ptr(found_inf), st))
 
 
 def _half_weights(embeddings, w_sigma, w_color, bufs):
@@ -264,7 +269,7 @@ def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg, co
     return image, depth, weights_sum, saved
 
 
-def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g_wc):
+def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g_wc, found_inf=None):
     """the backward launches: grad_image [N,3] fp32 (and optionally grad_ws [N]) -> gradients accumulated into g_emb (scatter-add, must
     hold the running sum / zeros) and written to g_ws / g_wc (fp16, flat)"""
     (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, march_ws) = saved
@@ -283,10 +288,10 @@ def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g
                                                          float(bg_scalar), capi.ptr(bg), march_ws.data_ptr(), st))
     g_out16 = torch.empty(M, 16, **half)
     _check(capi.lib.ngp_pipeline_rgb_backward(g_rgb.data_ptr(), rgb.data_ptr(), g_out16.data_ptr(), M, st))
-    _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc)
+    _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf)
 
 
-def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc):
+def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf=None):
     """colour MLP -> exp / feature shuffle -> sigma MLP -> grid scatter, from g_sigma [M] fp32 and g_out16 [M,16] fp16 (CONSUMED: reused as
     the sigma net's output gradient)"""
     (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, march_ws) = saved
@@ -310,8 +315,11 @@ def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc):
                                               _PLANAR_IN | _PLANAR_DX | capi.NGP_FF_DEFER_REDUCE, st))
         _check(capi.lib.ngp_ffmlp_reduce_slabs_pair(scratch_c.data_ptr(), capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_color),
                                                     g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(),
-                                                    capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_sigma), g_ws.numel(), g_ws.data_ptr(), st))
+                                                    capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_sigma), g_ws.numel(), g_ws.data_ptr(),
+                                                    capi.ptr(found_inf), st))
     else:
+        if found_inf is not None:
+            raise RuntimeError('fused: found_inf needs the fused colour-head / slab-reduction path (see iteration_checks_gradients)')
         g_color_in = torch.empty(M, 32, **half)
         scratch = torch.empty(max(nl_color, nl_sigma), M, 64, **half)
         _check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), fb_c.data_ptr(), M, 32, 16, 64,
@@ -322,7 +330,7 @@ def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc):
         _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
                                               0, 6, 1, scratch[:nl_sigma].data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
                                               _PLANAR_IN | _PLANAR_DX, st))
-    _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st)
+    _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf)
 
 
 class _fused_render_train(Function):
@@ -374,7 +382,7 @@ def _render_cfg(model, capacity, bg_color, perturb, dt_gamma, max_steps, T_thres
 
 @torch.no_grad()
 def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity, loss_scale, bg_color=1, perturb=False, dt_gamma=0,
-                          max_steps=1024, T_thresh=1e-4, noise_seed=None):
+                          max_steps=1024, T_thresh=1e-4, noise_seed=None, found_inf=None):
     """One training iteration's forward + MSE loss + backward WITHOUT autograd: the launches of `_fused_render_train` forward, the
     Trainer's loss (nerf/utils.py:516,557) and its scaled gradient in one kernel, then the backward launches, depositing the gradients
     into the optimizer's fp16 buffers (optim.NGPAdam with deposit=True must manage the three parameter tensors).  28 launches instead
@@ -395,22 +403,31 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     if target.shape[0] != rays_o.shape[0] or target.dtype != torch.float32:
         raise RuntimeError('fused_train_iteration: target must be [N,3] float32')
     marched = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
-    return _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg)
+    return _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf)
 
 
+USE_FUSED_CHECK = True      # the optimizer's non-finite sweep is done by the gradient-producing kernels (False: NGPAdam's CHECK launch)
 USE_FUSED_SCAN = True       # the marcher's write pass hands out the sample slots itself (False: scan launch between the passes)
 USE_FUSED_MID = True        # colour-head backward writes grad_h16 itself; one slab reduction for both MLPs (False: five launches)
 USE_FUSED_COMPOSITE = True  # composite forward + loss + composite backward + sigmoid backward in ONE launch (False: the four kernels)
 
 
-def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg, rcfg):
+def iteration_checks_gradients(model):
+    """True when `fused_train_iteration(..., found_inf=...)` can do the optimizer's non-finite sweep inside the kernels that produce the
+    gradients (slab reduction of both MLPs, slice accumulation of the table).  Call it OUTSIDE stream capture: it caches the host copy of
+    the encoder offsets that the in-capture call needs."""
+    nl = (int(model.sigma_net.num_layers), int(model.color_net.num_layers))
+    return bool(USE_FUSED_CHECK and USE_FUSED_MID and all(n in (2, 3) for n in nl) and capi.host_offsets(model.encoder.offsets) is not None)
+
+
+def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg, rcfg, found_inf=None):
     if not USE_FUSED_COMPOSITE:
         image, depth, weights_sum, saved = _render_train_network(marched, bufs[0], bufs[1], bufs[2], bg_t, offsets, cfg, rcfg)
         loss = torch.empty(1, device=image.device, dtype=torch.float32)
         grad_image = torch.empty_like(image)
         _check(capi.lib.ngp_pipeline_mse_loss(image.data_ptr(), target.data_ptr(), image.numel(), capi.ptr(loss_scale), loss.data_ptr(),
                                               grad_image.data_ptr(), capi.stream()))
-        _render_train_backward(saved, cfg, rcfg, grad_image, None, bufs[3], bufs[4].view(-1), bufs[5].view(-1))
+        _render_train_backward(saved, cfg, rcfg, grad_image, None, bufs[3], bufs[4].view(-1), bufs[5].view(-1), found_inf)
         return loss, image, depth, weights_sum
     saved = _render_train_network(marched, bufs[0], bufs[1], bufs[2], bg_t, offsets, cfg, rcfg, composite=False)
     (xyzs, _, _, _, _, _, _, _, _, rgb, sigma, deltas, rays, _, _, bg, march_ws) = saved
@@ -428,13 +445,13 @@ def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg,
                                                       weights_sum.data_ptr(), image.data_ptr(), depth.data_ptr(), loss.data_ptr(),
                                                       ray_err.data_ptr(), g_sigma.data_ptr(), g_out16.data_ptr(), march_ws.data_ptr(),
                                                       capi.stream()))
-    _network_backward(saved, cfg, rcfg, g_sigma, g_out16, bufs[3], bufs[4].view(-1), bufs[5].view(-1))
+    _network_backward(saved, cfg, rcfg, g_sigma, g_out16, bufs[3], bufs[4].view(-1), bufs[5].view(-1), found_inf)
     return loss, image, depth, weights_sum
 
 
 @torch.no_grad()
 def fused_train_iteration_split(model, rays_o, rays_d, target, box, counter, capacity, loss_scale, bg_color=1, perturb=False, dt_gamma=0,
-                                max_steps=1024, T_thresh=1e-4, noise_seed=None):
+                                max_steps=1024, T_thresh=1e-4, noise_seed=None, found_inf=None):
     """`fused_train_iteration` in two halves for data-parallel training: returns (march, rest) callables -- `march()` issues the
     parameter-independent launches (near/far, ray marching), `rest()` everything that reads the weights (encode, MLPs, composite, loss,
     backward).  graph.GraphedTrainStep captures them into separate HIP graphs so that the all-gather of the updated fp16 shadow weights
@@ -453,7 +470,7 @@ def fused_train_iteration_split(model, rays_o, rays_d, target, box, counter, cap
         box_['m'] = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
 
     def rest():
-        return _train_iteration_rest(box_['m'], bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg)
+        return _train_iteration_rest(box_['m'], bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf)
     return march, rest
 
 

@@ -61,6 +61,8 @@ class GraphedTrainStep:
         self.loss = None
         self.n_captures = 0
         self.capture_error = None
+        self._checked_ok = False
+        self.producers_check = False
         self.used_direct = False
         self.graph_updates = True   # replay the occupancy refresh from a HIP graph as well (see _update_extra_state)
         self.update_graphs = {}     # {full sweep?: (graph, device mean density)}
@@ -130,13 +132,18 @@ class GraphedTrainStep:
             kw = self.render_kwargs
             bg = kw.get('bg_color', None)
             self.optimizer.zero_grad(set_to_none=True)
+            # single rank (or local gradients before a sharded exchange): the producers flag non-finite gradients, no separate sweep.
+            # After an all-reduce the sweep has to see the REDUCED values, so the replicated data-parallel path keeps it.
+            self.producers_check = self._checked_ok and (self.averager is None)
             loss, _, _, _ = fused_train_iteration(m, self.rays_o, self.rays_d, self.target, m.aabb_train, self.counter[0],
                                                   self.captured_capacity, self.optimizer.scalars[0:1], 1 if bg is None else bg,
                                                   kw.get('perturb', False), kw.get('dt_gamma', 0), kw.get('max_steps', 1024),
-                                                  kw.get('T_thresh', 1e-4), noise_seed=self.optimizer.scalars[3:4])
+                                                  kw.get('T_thresh', 1e-4), noise_seed=self.optimizer.scalars[3:4],
+                                                  found_inf=self.optimizer.scalars[2:3] if self.producers_check else None)
             self.used_direct = True
             return loss[0]
         self.used_direct = False
+        self.producers_check = False
         saved_counter, saved_mc, saved_ls = m._buffers['step_counter'], m.mean_count, m.local_step
         m._buffers['step_counter'] = self.counter
         m.mean_count = self.captured_capacity - 128  # march_rays_train sizes its buffers as mean_count + 128 (raymarching.py:200-203)
@@ -159,6 +166,8 @@ class GraphedTrainStep:
         if self.scaler is not None:
             self.scaler.step(self.optimizer)
             self.scaler.update()
+        elif getattr(self, 'producers_check', False):
+            self.optimizer.step(gradients_checked=True)
         else:
             self.optimizer.step()
 
@@ -172,6 +181,11 @@ class GraphedTrainStep:
         gc.collect()  # drop autograd graphs of earlier eager iterations (their AccumulateGrad nodes are stream-bound)
         torch.cuda.synchronize()
         self.sharded = False
+        # (outside capture: caches the host copy of the encoder offsets the in-kernel non-finite sweep needs)
+        self._checked_ok = False
+        if self._direct_ok():
+            from fused import iteration_checks_gradients
+            self._checked_ok = iteration_checks_gradients(self.model)
         if self.averager is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -187,7 +201,8 @@ class GraphedTrainStep:
             bg = kw.get('bg_color', None)
             march, rest = fused_train_iteration_split(m, self.rays_o, self.rays_d, self.target, m.aabb_train, self.counter[0], self.captured_capacity,
                                                       opt.scalars[0:1], 1 if bg is None else bg, kw.get('perturb', False), kw.get('dt_gamma', 0),
-                                                      kw.get('max_steps', 1024), kw.get('T_thresh', 1e-4), noise_seed=opt.scalars[3:4])
+                                                      kw.get('max_steps', 1024), kw.get('T_thresh', 1e-4), noise_seed=opt.scalars[3:4],
+                                                      found_inf=opt.scalars[2:3] if self._checked_ok else None)
             opt.wait_shadows()
             torch.cuda.synchronize()
             ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -195,7 +210,8 @@ class GraphedTrainStep:
                 march()
             with torch.cuda.graph(gb, pool=ga.pool()):
                 self.loss = rest()[0][0].detach()
-                opt.pre_reduce_check()
+                if not self._checked_ok:
+                    opt.pre_reduce_check()     # (else the kernels that deposited the local gradients flagged them)
             with torch.cuda.graph(gc_, pool=ga.pool()):
                 opt.apply()
             self.graphs = (ga, gb, gc_)

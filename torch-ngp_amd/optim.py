@@ -307,9 +307,12 @@ class NGPAdam:
                                                    self.scalars.data_ptr(), cast[8], float(omd), phases, capi.stream()))
 
     @torch.no_grad()
-    def step(self, update_ema=None):
+    def step(self, update_ema=None, gradients_checked=False):
         """one optimizer + loss-scaling step.  `update_ema`: an `NGPEma` whose moving average is advanced inside the same sweep (the
         Trainer does that once per epoch, nerf/utils.py:760-761,891-892; call it with the last step of the epoch).
+        gradients_checked: the kernels that deposited the fp16 gradients already set found_inf (scalars[2]) where a value came out
+        non-finite (fused.fused_train_iteration(found_inf=...)), so the sweep of the CHECK phase is not launched; ignored (the sweep runs)
+        when any parameter carries an autograd `.grad`.
         Sharded mode: the whole exchange-and-update sequence (pre_reduce_check -> reduce_gradients -> apply -> gather_shadows)."""
         self._keep = []
         CHECK, UPDATE, COMMIT = capi.NGP_OPT_PHASE_CHECK, capi.NGP_OPT_PHASE_UPDATE, capi.NGP_OPT_PHASE_COMMIT
@@ -318,7 +321,8 @@ class NGPAdam:
                 raise RuntimeError('NGPAdam(shard=True): fold-in EMA is not available; call gather_master() then ema.update() once per epoch')
             if any(p.grad is not None for p in self.flat_params):
                 raise RuntimeError('NGPAdam(shard=True): gradients must be deposited by the fused path (found an autograd .grad)')
-            self.pre_reduce_check()
+            if not gradients_checked:
+                self.pre_reduce_check()
             self.reduce_gradients()
             self.apply()
             self.gather_shadows()
@@ -328,11 +332,12 @@ class NGPAdam:
         entries = [(p.numel(), p, st['exp_avg'], st['exp_avg_sq'], grad, st.get('fp16'), is_half, lr,
                     update_ema.shadow_of(p) if update_ema is not None else None) for p, st, grad, is_half, lr in self._entries()]
         chunks = [entries[i:i + _MAX] for i in range(0, len(entries), _MAX)]
+        checked = gradients_checked and all(e[6] for e in entries)   # every gradient is a deposited fp16 buffer
         if len(chunks) == 1:
-            self._launch(chunks[0], CHECK | UPDATE | COMMIT, omd)
+            self._launch(chunks[0], (0 if checked else CHECK) | UPDATE | COMMIT, omd)
         else:
             # "skipped as a whole": every chunk is swept for non-finite values BEFORE any chunk is updated (GradScaler.step semantics)
-            for c in chunks:
+            for c in ([] if checked else chunks):
                 self._launch(c, CHECK, 0.0)
             for c in chunks:
                 self._launch(c, UPDATE, omd)

@@ -203,8 +203,9 @@ class TrainingRun:
             m.density_bitfield.copy_(fixed_bits)
         self.keep_scene = keep_scene
         self.model, self.optimizer = model, optimizer
+        self.lookahead = graph and fused and not torch_optim and not autograd and world == 1 and not getattr(args, 'no_lookahead', False)
         self.stepper = GraphedTrainStep(model, optimizer, scaler, args.rays, self.opt_kwargs, loss_fn=mse_loss, averager=averager,
-                                        after_update=keep_scene, direct=not autograd)
+                                        after_update=keep_scene, direct=not autograd, lookahead=self.lookahead)
         self.step_no = 0
         self.caps, self.slots = [], []
         self.count_log = None
@@ -224,7 +225,12 @@ class TrainingRun:
             loss = stepper._eager(rays_o, rays_d, gt)
             stepper.global_step += 1
         else:
-            loss = stepper.step(rays_o, rays_d, gt)
+            if self.lookahead:
+                # the data loader's next batch is known one step early: its march runs under this iteration
+                nxt = self.pool[self.step_no % self.n_pool]
+                loss = stepper.step(rays_o, rays_d, gt, next_rays=(nxt[0], nxt[1]))
+            else:
+                loss = stepper.step(rays_o, rays_d, gt)
             cap = stepper.capacity if stepper.capacity is not None else args.rays * 1024
         if count:
             # log the sample counts: the model keeps the last 16 in its counter ring (renderer.py:352), so one 128-byte device copy every
@@ -288,7 +294,8 @@ class TrainingRun:
             return 'eager'
         if st.capture_error is not None:
             return f'eager (graph capture failed: {st.capture_error[:120]})'
-        return f'hip-graph replay ({st.n_captures} iteration + {st.n_update_captures} refresh capture(s), all before the timed region)'
+        la = f'; next batch marched on a side stream under the iteration ({st.la_hits} steps so far)' if getattr(st, 'la', None) is not None else ''
+        return f'hip-graph replay ({st.n_captures} iteration + {st.n_update_captures} refresh capture(s), all before the timed region){la}'
 
 
 def cpu_baselines(args):
@@ -346,6 +353,8 @@ def main():
     ap.add_argument('--torch-optim', action='store_true', help='torch.optim.Adam(fused) + GradScaler instead of optim.NGPAdam')
     ap.add_argument('--replicated-optim', action='store_true', help='N > 1: all-reduce + full Adam on every rank instead of the sharded update')
     ap.add_argument('--no-render', action='store_true', help='skip the 800x800 inference-frame timing')
+    ap.add_argument('--no-lookahead', action='store_true', help='do not march the next batch on a side stream under the current iteration '
+                    '(graph.GraphedTrainStep(lookahead=True): single rank, fused + graph + NGPAdam only)')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second, drop-in-surface-only measurement')
     ap.add_argument('--ab-off', default='', help='A/B measurement: comma-separated optional launch fusions of fused.py to switch OFF '
                     '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID, USE_FUSED_SCAN, USE_FUSED_CHECK); recorded in config.fusions_off')

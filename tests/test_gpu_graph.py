@@ -294,3 +294,48 @@ def test_producer_side_nonfinite_sweep_equals_the_optimizer_sweep():
     assert 0 < a[2] < 30, 'some steps skipped, some applied'
     for x, y in zip(a[1], b[1]):
         assert torch.equal(x, y)
+
+
+def test_lookahead_march_is_the_same_training():
+    """GraphedTrainStep(lookahead=True): the next batch is marched on a side stream under the current iteration.  With perturb=False the
+    arithmetic per batch is unchanged, so 40 steps end with bit-identical parameters and sample counts; the steps around an occupancy
+    refresh and a step whose announced next batch does not arrive fall back to marching in line."""
+    from graph import GraphedTrainStep
+    dev = torch.device('cuda')
+    occ = torch.from_numpy(sc.occupancy_density()).to(dev)
+    bits = torch.from_numpy(oracle.packbits(sc.occupancy_density(), 10.0)).to(dev)
+    n_rays = 1024
+    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    batches = []
+    for i in range(41):
+        o, d, gt = sc.training_batch(n_rays, seed=900 + i)
+        batches.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
+
+    def keep(m):
+        m.density_grid.copy_(occ)
+        m.density_bitfield.copy_(bits)
+
+    runs = {}
+    for look in (True, False):
+        model, opt = _make_ngp(dev)
+        st = GraphedTrainStep(model, opt, None, n_rays, kw, after_update=keep, direct=True, lookahead=look)
+        losses, counts = [], []
+        for i in range(40):
+            if look:
+                # step 25 announces a batch that never comes: the following step must notice and march its real batch itself
+                nxt = batches[i + 1] if i != 25 else batches[0]
+                loss = st.step(*batches[i], next_rays=(nxt[0], nxt[1]))
+            else:
+                loss = st.step(*batches[i])
+            losses.append(float(loss))
+            counts.append(model.step_counter[(model.local_step - 1) % 16].tolist())
+        assert st.capture_error is None and st.n_captures >= 1
+        if look:
+            assert st.la is not None and 15 <= st.la_hits <= 23, st.la_hits     # 24 graph steps minus refresh boundaries and the miss
+        params = [p.detach().clone() for p in (model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights)]
+        runs[look] = (losses, counts, params)
+    a, b = runs[True], runs[False]
+    assert a[1] == b[1]
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-6, atol=0)
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x, y)

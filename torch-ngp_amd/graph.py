@@ -21,6 +21,14 @@ estimate grows past the captured buffer or falls well below it.  `precapture()` 
 (the iteration and the occupancy refresh) up front, so that no one-time capture cost lands inside a measured or latency-critical
 stretch of steps.
 
+`lookahead=True` (single rank, autograd-free iteration): `step(rays_o, rays_d, target, next_rays=(o, d))` also marches the NEXT batch
+-- near/far + march_rays_train need no weights -- on a side stream while this iteration's encode .. Adam run.  The marcher is latency-bound
+(one wavefront per ray, ~60 us with the chip mostly idle), so about half of it disappears under the rest of the step.  Two sample-buffer
+sets alternate; per set one march graph and one "rest" graph (separate memory pools: they replay concurrently).  Same arithmetic in
+the same order per batch; only the in-kernel start offsets of `perturb=True` are seeded by the step index instead of the optimizer's
+step count (the two agree unless a step was skipped).  The step before an occupancy refresh does not look ahead: the refreshed bitfield
+must be marched.
+
 Requirements: a torch optimizer constructed with `capturable=True` (and preferably `fused=True`) plus a GradScaler, or
 `optim.NGPAdam` with `scaler=None` (it owns the loss scale; `averager` may then be the optimizer itself); the model has completed at least
 one `update_extra_state` after 16 eager steps (`model.mean_count > 0`) -- before that the sample buffer is sized for the
@@ -36,7 +44,7 @@ def mse_loss(out, target):
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, scaler, n_rays, render_kwargs, loss_fn=mse_loss, averager=None, capacity_quantum=8192,
-                 update_interval=16, after_update=None, autocast_dtype=torch.float16, direct=True, capacity_slack=2):
+                 update_interval=16, after_update=None, autocast_dtype=torch.float16, direct=True, capacity_slack=2, lookahead=False):
         self.model, self.optimizer, self.scaler = model, optimizer, scaler
         self.loss_fn, self.averager = loss_fn, averager
         if averager is not None and averager is not optimizer and getattr(optimizer, 'flat_grad16', None) is not None:
@@ -72,6 +80,19 @@ class GraphedTrainStep:
         # autograd-free iteration (fused.fused_train_iteration): needs the default loss, an optimizer that owns its loss scale and
         # deposits gradients (optim.NGPAdam), and a model/render configuration the fused training render accepts
         self.direct = bool(direct) and loss_fn is mse_loss and scaler is None and getattr(optimizer, 'flat_grad16', None) is not None
+        # lookahead: the next batch's march under this iteration (see the module docstring); single rank + autograd-free iteration only
+        self.lookahead = bool(lookahead) and self.direct and averager is None
+        self.la = None                      # [(march graph, rest graph, loss)] x 2 once captured
+        self.la_cur = 0                     # buffer set of the CURRENT batch
+        self.la_ready = [None, None]        # what is marched into each set: (key of the rays, occupancy epoch)
+        self.la_hits = 0                    # steps whose march had been done ahead
+        self.occupancy_epoch = 0
+        if self.lookahead:
+            self.la_rays_o = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
+            self.la_rays_d = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
+            self.la_seed = torch.zeros(2, dtype=torch.int32, device=dev)
+            self.la_side = torch.cuda.Stream(device=dev)
+            self.la_event = [torch.cuda.Event(), torch.cuda.Event()]
 
     # ------------------------------------------------------------------------------------------
     def _capacity(self):
@@ -186,7 +207,11 @@ class GraphedTrainStep:
         if self._direct_ok():
             from fused import iteration_checks_gradients
             self._checked_ok = iteration_checks_gradients(self.model)
-        if self.averager is None:
+        self.la = None
+        self.la_ready = [None, None]
+        if self.averager is None and self.lookahead and self._direct_ok():
+            self._capture_lookahead()
+        elif self.averager is None:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.loss = self._iteration_front().detach()
@@ -226,6 +251,34 @@ class GraphedTrainStep:
             self.graphs = (g1, g2)
         self.n_captures += 1
 
+    def _capture_lookahead(self):
+        """two buffer sets, per set a march graph (static rays of the set -> its samples) and a rest graph (samples + target -> loss,
+        gradients, optimizer step).  The march graphs allocate from their own pool: a march replays while the OTHER set's rest graph runs."""
+        from fused import fused_train_iteration_split
+        m, kw, opt = self.model, self.render_kwargs, self.optimizer
+        bg = kw.get('bg_color', None)
+        self.producers_check = self._checked_ok
+        pool_march, pool_rest = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        la = []
+        for p in range(2):
+            march, rest = fused_train_iteration_split(m, self.la_rays_o[p], self.la_rays_d[p], self.target, m.aabb_train, self.counter[p],
+                                                      self.captured_capacity, opt.scalars[0:1], 1 if bg is None else bg,
+                                                      kw.get('perturb', False), kw.get('dt_gamma', 0), kw.get('max_steps', 1024),
+                                                      kw.get('T_thresh', 1e-4), noise_seed=self.la_seed[p:p + 1],
+                                                      found_inf=opt.scalars[2:3] if self._checked_ok else None)
+            gm, gr = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gm, pool=pool_march):
+                march()
+            with torch.cuda.graph(gr, pool=pool_rest):
+                opt.zero_grad(set_to_none=True)
+                loss = rest()[0][0].detach()
+                self._iteration_back()
+            la.append((gm, gr, loss, march, rest))   # (the closures keep the marched buffers alive)
+        self.la = la
+        self.graphs = tuple(g for e in la for g in e[:2])
+        self._rest_pool = pool_rest
+        self.used_direct = True
+
     def _capture_update(self, full):
         """record model.refresh_occupancy(full) into a graph of its own (nothing executes); False when capture is not possible"""
         if full in self.update_graphs:
@@ -237,7 +290,7 @@ class GraphedTrainStep:
             gc.collect()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.graphs[0].pool()):
+            with torch.cuda.graph(g, pool=self._rest_pool if self.la is not None else self.graphs[0].pool()):
                 with torch.autocast('cuda', dtype=self.autocast_dtype):
                     mean = self.model.refresh_occupancy(full=full)
             self.update_graphs[full] = (g, mean)
@@ -284,13 +337,56 @@ class GraphedTrainStep:
         return loss.detach()
 
     # ------------------------------------------------------------------------------------------
-    def step(self, rays_o, rays_d, target):
-        """one training iteration on rays_o/rays_d [1,N,3], target [N,3]; returns the (device) loss of this step"""
+    @staticmethod
+    def _rays_key(rays_o, rays_d):
+        return (rays_o.data_ptr(), rays_o._version, rays_d.data_ptr(), rays_d._version, tuple(rays_o.shape))
+
+    def _step_lookahead(self, rays_o, rays_d, target, next_rays):
+        m = self.model
+        p = self.la_cur
+        gm, gr, loss = self.la[p][:3]
+        main = torch.cuda.current_stream()
+        ready = self.la_ready[p]
+        hit = ready is not None and ready == (self._rays_key(rays_o, rays_d), self.occupancy_epoch)
+        if hit:
+            self.target.copy_(target, non_blocking=True)
+            main.wait_event(self.la_event[p])       # the march of this batch ran on the side stream during the previous step
+            self.la_hits += 1
+        else:
+            torch._foreach_copy_([self.la_rays_o[p], self.la_rays_d[p], self.target],
+                                 [rays_o.view_as(self.la_rays_o[p]), rays_d.view_as(self.la_rays_d[p]), target], non_blocking=True)
+            self.la_seed[p:p + 1].fill_(self.global_step)
+            gm.replay()
+        self.la_ready[p] = None
+        q = 1 - p
+        if next_rays is not None and (self.global_step + 1) % self.update_interval != 0:
+            side = self.la_side
+            side.wait_stream(main)                  # set q was read by the previous step's rest graph, queued on `main` before this point
+            with torch.cuda.stream(side):
+                no, nd = next_rays
+                torch._foreach_copy_([self.la_rays_o[q], self.la_rays_d[q]], [no.view_as(self.la_rays_o[q]), nd.view_as(self.la_rays_d[q])],
+                                     non_blocking=True)
+                self.la_seed[q:q + 1].fill_(self.global_step + 1)
+                self.la[q][0].replay()
+                self.la_event[q].record(side)
+            self.la_ready[q] = (self._rays_key(*next_rays), self.occupancy_epoch)
+        gr.replay()
+        m.step_counter[m.local_step % 16].copy_(self.counter[p], non_blocking=True)
+        self.la_cur = q
+        return loss
+
+    def step(self, rays_o, rays_d, target, next_rays=None):
+        """one training iteration on rays_o/rays_d [1,N,3], target [N,3]; returns the (device) loss of this step.
+        next_rays=(rays_o, rays_d) of the FOLLOWING step (lookahead=True only): marched on a side stream under this iteration; the
+        following step recognises the batch by the identity of these tensors."""
         m = self.model
         if self.global_step % self.update_interval == 0:
             if getattr(self.optimizer, 'shard', False):
                 self.optimizer.wait_shadows()  # the occupancy refresh evaluates the density network on the fp16 shadows
+            if self.la is not None:
+                torch.cuda.current_stream().wait_stream(self.la_side)
             self._update_extra_state()
+            self.occupancy_epoch += 1
             if self.after_update is not None:
                 self.after_update(m)
         cap = self._capacity()
@@ -315,6 +411,11 @@ class GraphedTrainStep:
                 self.global_step += 1
                 return loss
         self.capacity = self.captured_capacity
+        if self.la is not None:
+            loss = self._step_lookahead(rays_o, rays_d, target, next_rays)
+            m.local_step += 1
+            self.global_step += 1
+            return loss
         # the batch into the static input buffers: ONE multi-tensor copy kernel (three separate copies cost ~5 us each plus the gaps)
         torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
                              non_blocking=True)

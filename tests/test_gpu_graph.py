@@ -321,6 +321,8 @@ def test_lookahead_march_is_the_same_training():
         st = GraphedTrainStep(model, opt, None, n_rays, kw, after_update=keep, direct=True, lookahead=look)
         losses, counts = [], []
         for i in range(40):
+            if i == 18:
+                st.precapture()    # records the refresh graphs up front (as bench.py does), so that step 31 can already pre-sample
             if look:
                 # step 25 announces a batch that never comes: the following step must notice and march its real batch itself
                 nxt = batches[i + 1] if i != 25 else batches[0]
@@ -332,6 +334,7 @@ def test_lookahead_march_is_the_same_training():
         assert st.capture_error is None and st.n_captures >= 1
         if look:
             assert st.la is not None and 15 <= st.la_hits <= 23, st.la_hits     # 24 graph steps minus refresh boundaries and the miss
+            assert st.la_presample_hits >= 1 and st.update_capture_error is None   # the refresh at step 32: its cell sampling ran under step 31
         params = [p.detach().clone() for p in (model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights)]
         runs[look] = (losses, counts, params)
     a, b = runs[True], runs[False]

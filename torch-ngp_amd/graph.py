@@ -87,12 +87,15 @@ class GraphedTrainStep:
         self.la_ready = [None, None]        # what is marched into each set: (key of the rays, occupancy epoch)
         self.la_hits = 0                    # steps whose march had been done ahead
         self.occupancy_epoch = 0
+        self.la_presampled = None           # refresh mode (full sweep?) whose cell sampling already ran on the side stream
+        self.la_presample_hits = 0
         if self.lookahead:
             self.la_rays_o = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
             self.la_rays_d = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
             self.la_seed = torch.zeros(2, dtype=torch.int32, device=dev)
             self.la_side = torch.cuda.Stream(device=dev)
             self.la_event = [torch.cuda.Event(), torch.cuda.Event()]
+            self.la_sample_event = torch.cuda.Event()
 
     # ------------------------------------------------------------------------------------------
     def _capacity(self):
@@ -280,7 +283,9 @@ class GraphedTrainStep:
         self.used_direct = True
 
     def _capture_update(self, full):
-        """record model.refresh_occupancy(full) into a graph of its own (nothing executes); False when capture is not possible"""
+        """record the occupancy refresh into graphs of its own (nothing executes); False when capture is not possible.  Lookahead mode
+        records its two halves separately -- (cell sampling, pool of its own: replays on the side stream under a training iteration) and
+        (density evaluation + grid / bitfield update) -- otherwise one graph."""
         if full in self.update_graphs:
             return True
         if self.update_capture_error is not None or self.graphs is None:
@@ -289,11 +294,23 @@ class GraphedTrainStep:
             import gc
             gc.collect()
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._rest_pool if self.la is not None else self.graphs[0].pool()):
-                with torch.autocast('cuda', dtype=self.autocast_dtype):
-                    mean = self.model.refresh_occupancy(full=full)
-            self.update_graphs[full] = (g, mean)
+            m = self.model
+            if self.la is not None and hasattr(m, 'refresh_sample'):
+                gs, ga = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                if getattr(self, '_sample_pool', None) is None:
+                    self._sample_pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(gs, pool=self._sample_pool):
+                    samples = m.refresh_sample(full=full)
+                with torch.cuda.graph(ga, pool=self._rest_pool):
+                    with torch.autocast('cuda', dtype=self.autocast_dtype):
+                        mean = m.refresh_apply(samples)
+                self.update_graphs[full] = (ga, mean, gs, samples)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.graphs[0].pool()):
+                    with torch.autocast('cuda', dtype=self.autocast_dtype):
+                        mean = m.refresh_occupancy(full=full)
+                self.update_graphs[full] = (g, mean)
             self.n_update_captures += 1
             return True
         except Exception as e:  # noqa: BLE001 -- keep refreshing eagerly; the caller can inspect .update_capture_error
@@ -316,7 +333,15 @@ class GraphedTrainStep:
         if use_graph and full not in self.update_graphs:
             use_graph = self._capture_update(full)
         if use_graph:
-            g, mean = self.update_graphs[full]
+            entry = self.update_graphs[full]
+            g, mean = entry[0], entry[1]
+            if len(entry) == 4:                      # split refresh: the sampling half may already have run under the previous iteration
+                if self.la_presampled == full:
+                    torch.cuda.current_stream().wait_event(self.la_sample_event)
+                    self.la_presample_hits += 1
+                else:
+                    entry[2].replay()
+                self.la_presampled = None
             g.replay()
         else:
             with torch.autocast('cuda', dtype=self.autocast_dtype):
@@ -370,6 +395,17 @@ class GraphedTrainStep:
                 self.la[q][0].replay()
                 self.la_event[q].record(side)
             self.la_ready[q] = (self._rays_key(*next_rays), self.occupancy_epoch)
+        elif (self.global_step + 1) % self.update_interval == 0 and self.graph_updates and self.update_capture_error is None:
+            # the next step starts with an occupancy refresh: its weight-independent half (which cells, where inside them) runs here instead
+            full = m.iter_density < 16
+            entry = self.update_graphs.get(full)
+            if entry is not None and len(entry) == 4:
+                side = self.la_side
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    entry[2].replay()
+                    self.la_sample_event.record(side)
+                self.la_presampled = full
         gr.replay()
         m.step_counter[m.local_step % 16].copy_(self.counter[p], non_blocking=True)
         self.la_cur = q

@@ -408,15 +408,16 @@ class NeRFRenderer(nn.Module):
         self._mean_density, self._mean_density_dev = float(value), None
 
     @torch.no_grad()
-    def refresh_occupancy(self, decay=0.95, S=128, full=None):
-        """the device part of update_extra_state (renderer.py:444-529): re-evaluate the density on the grid cells, EMA-max update,
-        bitfield.  No host synchronisation anywhere (so it can be captured in a HIP graph, graph.GraphedTrainStep does): the
-        `torch.nonzero` + random choice of the reference's partial sweep is replaced by an equivalent draw (uniform over the occupied
-        cells, with replacement) through a prefix sum and a binary search, and the bitfield is packed against
-        min(mean_density, density_thresh) with the mean still on the device (ngp_packbits_ex)."""
+    def refresh_sample(self, S=128, full=None):
+        """the weight-INDEPENDENT half of the occupancy refresh: which cells are re-evaluated, and where inside them (renderer.py:444-514).
+        Full sweep: every cell; else a quarter of the cells at random plus as many drawn from the currently occupied ones -- the
+        `torch.nonzero` + random choice of the reference becomes an equivalent draw (uniform over the occupied cells, with replacement)
+        through a prefix sum and a binary search, so nothing is read back.  Returns [(cascade, cell ids, jittered world positions)].
+        Depends only on the density grid and the random stream: graph.GraphedTrainStep runs it on a side stream under the previous
+        training iteration."""
         dev = self.density_bitfield.device
-        fresh = -torch.ones_like(self.density_grid)
         full = (self.iter_density < 16) if full is None else full
+        samples = []
         if full:  # full sweep
             axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
             for xs in axis:
@@ -426,7 +427,7 @@ class NeRFRenderer(nn.Module):
                         coords = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
                         cell_ids = raymarching.morton3D(coords).long()
                         for cas in range(self.cascade):
-                            fresh[cas, cell_ids] = self._query_sigma(self._cascade_points(coords, cas))
+                            samples.append((cas, cell_ids, self._cascade_points(coords, cas)))
         else:  # a quarter of the cells at random plus as many drawn from the currently occupied ones
             n = self.grid_size ** 3 // 4
             for cas in range(self.cascade):
@@ -439,15 +440,28 @@ class NeRFRenderer(nn.Module):
                 occ_coords = raymarching.morton3D_invert(occ_ids)
                 cell_ids = torch.cat([rand_ids, occ_ids], 0)
                 coords = torch.cat([rand_coords, occ_coords], 0)
-                fresh[cas, cell_ids] = self._query_sigma(self._cascade_points(coords, cas))
+                samples.append((cas, cell_ids, self._cascade_points(coords, cas)))
+        return samples
 
-        # EMA-max update of the cells that are valid on both sides (renderer.py:521-522), written as a select so that no boolean-index
-        # gather/scatter (and its host synchronisation) is needed: identical values
+    @torch.no_grad()
+    def refresh_apply(self, samples, decay=0.95):
+        """the weight-dependent half: density at the sampled positions, EMA-max update of the cells that are valid on both sides
+        (renderer.py:515-529), bitfield packed against min(mean_density, density_thresh) with the mean still on the device
+        (ngp_packbits_ex).  No host synchronisation (capturable).  Returns the device mean."""
+        fresh = -torch.ones_like(self.density_grid)
+        for cas, cell_ids, pts in samples:
+            fresh[cas, cell_ids] = self._query_sigma(pts)
+        # written as a select so that no boolean-index gather/scatter (and its host synchronisation) is needed: identical values
         both = (self.density_grid >= 0) & (fresh >= 0)
         self.density_grid.copy_(torch.where(both, torch.maximum(self.density_grid * decay, fresh), self.density_grid))
         mean = torch.mean(self.density_grid.clamp(min=0))
         raymarching.packbits_capped(self.density_grid, self.density_thresh, mean, self.density_bitfield)
         return mean
+
+    @torch.no_grad()
+    def refresh_occupancy(self, decay=0.95, S=128, full=None):
+        """the device part of update_extra_state (renderer.py:444-529): refresh_sample + refresh_apply"""
+        return self.refresh_apply(self.refresh_sample(S, full), decay)
 
     def finish_update(self, mean):
         """the host part of update_extra_state: bookkeeping and the sample-count estimate (one read-back, renderer.py:531-538)"""

@@ -228,7 +228,7 @@ class TrainingRun:
             if self.lookahead:
                 # the data loader's next batch is known one step early: its march runs under this iteration
                 nxt = self.pool[self.step_no % self.n_pool]
-                loss = stepper.step(rays_o, rays_d, gt, next_rays=(nxt[0], nxt[1]))
+                loss = stepper.step(rays_o, rays_d, gt, next_rays=nxt)
             else:
                 loss = stepper.step(rays_o, rays_d, gt)
             cap = stepper.capacity if stepper.capacity is not None else args.rays * 1024

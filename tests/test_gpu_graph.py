@@ -326,7 +326,7 @@ def test_lookahead_march_is_the_same_training():
             if look:
                 # step 25 announces a batch that never comes: the following step must notice and march its real batch itself
                 nxt = batches[i + 1] if i != 25 else batches[0]
-                loss = st.step(*batches[i], next_rays=(nxt[0], nxt[1]))
+                loss = st.step(*batches[i], next_rays=nxt if i % 2 else (nxt[0], nxt[1]))   # with and without the next target
             else:
                 loss = st.step(*batches[i])
             losses.append(float(loss))

@@ -92,6 +92,7 @@ class GraphedTrainStep:
         if self.lookahead:
             self.la_rays_o = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
             self.la_rays_d = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
+            self.la_target = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
             self.la_seed = torch.zeros(2, dtype=torch.int32, device=dev)
             self.la_side = torch.cuda.Stream(device=dev)
             self.la_event = [torch.cuda.Event(), torch.cuda.Event()]
@@ -264,7 +265,7 @@ class GraphedTrainStep:
         pool_march, pool_rest = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
         la = []
         for p in range(2):
-            march, rest = fused_train_iteration_split(m, self.la_rays_o[p], self.la_rays_d[p], self.target, m.aabb_train, self.counter[p],
+            march, rest = fused_train_iteration_split(m, self.la_rays_o[p], self.la_rays_d[p], self.la_target[p], m.aabb_train, self.counter[p],
                                                       self.captured_capacity, opt.scalars[0:1], 1 if bg is None else bg,
                                                       kw.get('perturb', False), kw.get('dt_gamma', 0), kw.get('max_steps', 1024),
                                                       kw.get('T_thresh', 1e-4), noise_seed=self.la_seed[p:p + 1],
@@ -372,29 +373,39 @@ class GraphedTrainStep:
         gm, gr, loss = self.la[p][:3]
         main = torch.cuda.current_stream()
         ready = self.la_ready[p]
-        hit = ready is not None and ready == (self._rays_key(rays_o, rays_d), self.occupancy_epoch)
+        hit = ready is not None and ready[:2] == (self._rays_key(rays_o, rays_d), self.occupancy_epoch)
+        slot = m.step_counter[m.local_step % 16]
         if hit:
-            self.target.copy_(target, non_blocking=True)
+            if ready[2] != (target.data_ptr(), target._version):   # the target was not announced with the rays: copy it now
+                self.la_target[p].copy_(target, non_blocking=True)
             main.wait_event(self.la_event[p])       # the march of this batch ran on the side stream during the previous step
             self.la_hits += 1
         else:
-            torch._foreach_copy_([self.la_rays_o[p], self.la_rays_d[p], self.target],
+            torch._foreach_copy_([self.la_rays_o[p], self.la_rays_d[p], self.la_target[p]],
                                  [rays_o.view_as(self.la_rays_o[p]), rays_d.view_as(self.la_rays_d[p]), target], non_blocking=True)
             self.la_seed[p:p + 1].fill_(self.global_step)
             gm.replay()
+            slot.copy_(self.counter[p], non_blocking=True)
         self.la_ready[p] = None
         q = 1 - p
         if next_rays is not None and (self.global_step + 1) % self.update_interval != 0:
             side = self.la_side
             side.wait_stream(main)                  # set q was read by the previous step's rest graph, queued on `main` before this point
             with torch.cuda.stream(side):
-                no, nd = next_rays
-                torch._foreach_copy_([self.la_rays_o[q], self.la_rays_d[q]], [no.view_as(self.la_rays_o[q]), nd.view_as(self.la_rays_d[q])],
-                                     non_blocking=True)
+                no, nd = next_rays[0], next_rays[1]
+                dst, src = [self.la_rays_o[q], self.la_rays_d[q]], [no.view_as(self.la_rays_o[q]), nd.view_as(self.la_rays_d[q])]
+                tkey = None
+                if len(next_rays) > 2:              # the next target too: its copy leaves the main stream as well
+                    dst.append(self.la_target[q])
+                    src.append(next_rays[2])
+                    tkey = (next_rays[2].data_ptr(), next_rays[2]._version)
+                torch._foreach_copy_(dst, src, non_blocking=True)
                 self.la_seed[q:q + 1].fill_(self.global_step + 1)
                 self.la[q][0].replay()
+                # the sample count of the next step goes to the model's ring from here (the slot the next step will own)
+                m.step_counter[(m.local_step + 1) % 16].copy_(self.counter[q], non_blocking=True)
                 self.la_event[q].record(side)
-            self.la_ready[q] = (self._rays_key(*next_rays), self.occupancy_epoch)
+            self.la_ready[q] = (self._rays_key(no, nd), self.occupancy_epoch, tkey)
         elif (self.global_step + 1) % self.update_interval == 0 and self.graph_updates and self.update_capture_error is None:
             # the next step starts with an occupancy refresh: its weight-independent half (which cells, where inside them) runs here instead
             full = m.iter_density < 16
@@ -407,14 +418,13 @@ class GraphedTrainStep:
                     self.la_sample_event.record(side)
                 self.la_presampled = full
         gr.replay()
-        m.step_counter[m.local_step % 16].copy_(self.counter[p], non_blocking=True)
         self.la_cur = q
         return loss
 
     def step(self, rays_o, rays_d, target, next_rays=None):
         """one training iteration on rays_o/rays_d [1,N,3], target [N,3]; returns the (device) loss of this step.
-        next_rays=(rays_o, rays_d) of the FOLLOWING step (lookahead=True only): marched on a side stream under this iteration; the
-        following step recognises the batch by the identity of these tensors."""
+        next_rays=(rays_o, rays_d[, target]) of the FOLLOWING step (lookahead=True only): marched (and, with the target, staged) on a side
+        stream under this iteration; the following step recognises the batch by the identity of these tensors."""
         m = self.model
         if self.global_step % self.update_interval == 0:
             if getattr(self.optimizer, 'shard', False):

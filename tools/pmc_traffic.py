@@ -24,6 +24,7 @@ KERNELS = {  # substring of the kernel name (first match wins) -> (label used by
     'k_ffmlp_forward': ('ffmlp_forward', 2.0),
     'k_ffmlp_backward': ('ffmlp_backward', 2.0),
     'k_march_train_wave': ('march_rays_train', 1.0),
+    'k_composite_train_loss_bwd': ('composite_train_loss_backward', 2.0),
     'k_composite_train_fwd': ('composite_rays_train_forward', 2.0),
     'k_composite_train_bwd': ('composite_rays_train_backward', 2.0),
 }

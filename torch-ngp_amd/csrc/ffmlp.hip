@@ -202,6 +202,13 @@ __device__ __forceinline__ half8_t load_features8(const half_t* __restrict__ inp
 // ------------------------------------------------------------------------------------------------
 // forward / inference
 // ------------------------------------------------------------------------------------------------
+// The activation streams are written once here and read once by the backward launches, hundreds of megabytes later: the stores are
+// marked non-temporal, so they stream past the L2 instead of displacing it (same-box A/B together with Adam's streams: -11 us per iteration).
+template <typename V>
+__device__ __forceinline__ void stream_store(V* dst, V v) {
+    __builtin_nontemporal_store(v, dst);
+}
+
 template <int WIDTH, bool TRAIN, bool PLAIN /* ReLU hidden layers, no output activation: the only case FFMLP produces (ffmlp.py:107) */>
 __device__ __forceinline__ void ffmlp_forward_body(const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
                                                    half_t* __restrict__ forward_buffer, half_t* __restrict__ outputs, uint32_t n_tiles,
@@ -254,7 +261,7 @@ __device__ __forceinline__ void ffmlp_forward_body(const half_t* __restrict__ in
             if (TRAIN && !(diag & 1u)) {
                 half8_t* dst = reinterpret_cast<half8_t*>(forward_buffer) + l * layer_stride + (size_t)tile * NKB * 64 + lane;
 #pragma unroll
-                for (int kb = 0; kb < NKB; kb++) dst[kb * 64] = hid[kb];
+                for (int kb = 0; kb < NKB; kb++) stream_store(dst + kb * 64, hid[kb]);
             }
             if (l + 1 == num_layers) break;
             const half8_t* wl = img_hid + (size_t)l * NIB * NKB * 64;
@@ -313,13 +320,6 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // ------------------------------------------------------------------------------------------------
 // hidden layers + output layer of a 64-wide ReLU network for one tile: first-layer accumulators in, output accumulators out; the hidden
 // post-activations are streamed to `fb` (fragment order) when TRAIN
-// The activation streams are written once here and read once by the backward launches, hundreds of megabytes later: the stores are
-// marked non-temporal, so they stream past the L2 instead of displacing it (same-box A/B together with Adam's streams: -11 us per iteration).
-template <typename V>
-__device__ __forceinline__ void stream_store(V* dst, V v) {
-    __builtin_nontemporal_store(v, dst);
-}
-
 template <bool TRAIN>
 __device__ __forceinline__ float16_t relu_network_tail(float16_t (&acc)[2], const half8_t* __restrict__ hid_img, const half8_t* __restrict__ out_img,
                                                        uint32_t nl, half_t* __restrict__ fb, size_t layer_stride, uint32_t tile, int lane) {

@@ -898,7 +898,9 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_smem);                                // [BIN_SLICE][2]
     uint32_t* poison = reinterpret_cast<uint32_t*>(acc_smem + sizeof(unsigned long long) * 2 * BIN_SLICE);  // [BIN_SLICE / 16], 2 bits per entry
-    const uint32_t li = blockIdx.y, bin = blockIdx.x;
+    // levels in REVERSE order: the sort wrote the last level's records last, so they are the ones still in the memory-side cache
+    // (same-box A/B: -4 us per iteration)
+    const uint32_t li = gridDim.y - 1u - blockIdx.y, bin = blockIdx.x;
     if (bin >= plan.n_bins[li]) return;
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * BIN_SLICE; i += ACC_THREADS) acc[i] = 0ull;

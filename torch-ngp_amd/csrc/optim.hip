@@ -84,6 +84,36 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
         const bool gh = ts.g_is_half[k] != 0;
         half_t* g16 = reinterpret_cast<half_t*>(ts.g[k]);
         float* g32 = reinterpret_cast<float*>(ts.g[k]);
+        // Fast path of the training configuration (fp16 gradient + fp16 shadow, no EMA, length a multiple of 4, 16-byte aligned streams):
+        // four elements per lane and iteration, 16-byte accesses (8-byte global accesses run at 0.5-0.7x the 16-byte rate on this chip).
+        // Same arithmetic per element as the general loop below; -7 us per iteration in a same-box A/B.
+        const bool wide = gh && p16 && !ema && (n & 3u) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(g16) | reinterpret_cast<uintptr_t>(p16)) & 7u) == 0;
+        if (wide) {
+            const uint64_t n4 = n / 4;
+            for (uint64_t i = (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * OPT_THREADS) {
+                const half4_t x = reinterpret_cast<half4_t*>(g16)[i];
+                reinterpret_cast<half4_t*>(g16)[i] = half4_t{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+                if (skip) continue;
+                float4_t pm = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(m) + i), pv = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(v) + i),
+                         pp = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(p) + i);
+                half4_t ph;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float g = (float)x[c] * inv_scale;
+                    pm[c] = beta1 * pm[c] + (1.0f - beta1) * g;
+                    pv[c] = beta2 * pv[c] + (1.0f - beta2) * g * g;
+                    pp[c] -= step_size * pm[c] / (sqrtf(pv[c]) / bc2_sqrt + eps);
+                    ph[c] = (half_t)pp[c];
+                }
+                __builtin_nontemporal_store(pm, reinterpret_cast<float4_t*>(m) + i);
+                __builtin_nontemporal_store(pv, reinterpret_cast<float4_t*>(v) + i);
+                __builtin_nontemporal_store(pp, reinterpret_cast<float4_t*>(p) + i);
+                reinterpret_cast<half4_t*>(p16)[i] = ph;
+            }
+            continue;
+        }
         // two elements per lane and iteration (all our tensors have an even length; a trailing odd element is handled below)
         const uint64_t n2 = n / 2;
         for (uint64_t i = (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n2; i += (uint64_t)gridDim.x * OPT_THREADS) {

@@ -14,6 +14,10 @@ occupancy (the refreshed grid is computed and discarded) so that the number of s
 metric  : training samples/s = sum over steps and ranks of the samples actually marched (counter[0]) / wall time
 execution: the iteration is captured once into a HIP graph (torch-ngp_amd/graph.py) and replayed per step; --no-graph issues
           every launch eagerly, --no-fused uses the reference-style module-by-module network path.
+lookahead (N = 1, default; --no-lookahead switches it off): the batch pool plays the data loader, which knows its next batch one step early;
+          near/far + march_rays_train of batch k+1 (they need no weights) run on a side stream while the iteration of batch k runs.  Work per
+          timed step is unchanged: K timed steps contain K marches (the first step's march ran just before t0, the last step marches the
+          batch after the region), every sample that is counted was marched, encoded, evaluated, composited and trained on.
 roofline: `roofline` = the dominant kernel (grid_encode_backward, 1100 B per point), `rooflines` = all timed kernels
           (grid fwd/bwd, ffmlp fwd/bwd with their MFMA fraction).  HIP graphs cannot carry timing events, so after the
           timed region the same iteration is run eagerly for a few steps with HIP-event pairs around the named kernels on

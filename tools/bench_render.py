@@ -24,8 +24,9 @@ kw = dict(staged=True, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024, T_
 for scale in (1.0, 300.0):
     model.density_scale = scale
     ref = None
-    for mode, (on_device, graphs) in {'host': (False, False), 'device': (True, False), 'graphs': (True, True)}.items():
-        model.device_loop, model.graph_loop, model._loop_cache = on_device, graphs, None
+    for mode, (on_device, graphs, adaptive) in {'host': (False, False, False), 'device': (True, False, True), 'fixed n_step': (True, False, False),
+                                               'graphs': (True, True, False), 'device ': (True, False, True)}.items():
+        model.device_loop, model.graph_loop, model.adaptive_n_step, model._loop_cache = on_device, graphs, adaptive, None
         times = []
         for f in range(args.frames + 1):
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -35,5 +36,5 @@ for scale in (1.0, 300.0):
         img = out['image']
         ref = img if ref is None else ref
         extra = '' if not on_device else f", graphs {sorted(model._loop_cache['graphs'])} failed={model._loop_cache['failed']}"
-        print(f'density_scale {scale:5.0f} {mode:7s}: min {min(times[1:]):7.2f} ms  mean {np.mean(times[1:]):7.2f} ms  (first frame {times[0]:7.1f} ms)  '
+        print(f'density_scale {scale:5.0f} {mode:12s}: min {min(times[1:]):7.2f} ms  mean {np.mean(times[1:]):7.2f} ms  (first frame {times[0]:7.1f} ms)  '
               f'identical to host: {bool(torch.equal(img, ref))}{extra}')

@@ -291,17 +291,19 @@ class NeRFRenderer(nn.Module):
         state[0, 0] = n_rays
         bits = self.density_bitfield.contiguous()
 
-        def iteration(cur, lanes, rows, noises):
+        def iteration(cur, lanes, rows, noises, n_total=n_rays):
+            # n_total: what the kernels divide by the alive count to get n_step = clamp(n_total // n_alive, 1, 8) -- the frame's ray count
+            # (the reference's rule) times the host-chosen `boost` below
             xyzs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
             dirs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
             deltas = torch.empty(rows, 2, dtype=torch.float32, device=dev)
-            rb.march_rays_dev(state[cur], lanes, n_rays, alive[cur], s_t, s_o, s_d, self.bound, dt_gamma, max_steps, self.cascade,
+            rb.march_rays_dev(state[cur], lanes, n_total, alive[cur], s_t, s_o, s_d, self.bound, dt_gamma, max_steps, self.cascade,
                               self.grid_size, bits, s_near, s_far, xyzs, dirs, deltas, noises, rows)
             sigmas, rgbs = self(xyzs, dirs)
             sigmas = (self.density_scale * sigmas).float().contiguous()
-            rb.composite_rays_dev(state[cur], lanes, n_rays, T_thresh, alive[cur], s_t, sigmas, rgbs.float().contiguous(), deltas, s_ws, s_depth,
+            rb.composite_rays_dev(state[cur], lanes, n_total, T_thresh, alive[cur], s_t, sigmas, rgbs.float().contiguous(), deltas, s_ws, s_depth,
                                   s_image)
-            rb.compact_rays_dev(state[cur], lanes, n_rays, max_steps, alive[cur], alive[1 - cur], state[1 - cur], ws)
+            rb.compact_rays_dev(state[cur], lanes, n_total, max_steps, alive[cur], alive[1 - cur], state[1 - cur], ws)
 
         def pad(rows):
             return rows + 128 - rows % 128  # the marchers' padding rule (raymarching.py:328-331); the fused network wants multiples of 128
@@ -313,16 +315,35 @@ class NeRFRenderer(nn.Module):
         iteration(1, n_rays, full, None)
         done = 2
         use_graphs = getattr(self, 'graph_loop', False) and not cache['failed']
+        adaptive = getattr(self, 'adaptive_n_step', True) and not use_graphs
         batch = 2
         bound_alive = int(state[0, 0].item())
+        # Samples per ray and iteration.  The reference marches n_step = clamp(N // n_alive, 1, 8): about N sample rows per iteration.  A ray's
+        # samples and their compositing order do not depend on that chunking (same image, bit for bit), but the COST does: every
+        # march_rays call walks the rays that leave the surface to the far plane, ~0.1-0.3 ms of voxel stepping however few samples it
+        # emits (tools/march_probe.py), so a frame in which rays survive long (semi-transparent volume) pays for ~70 calls of 2-3 samples
+        # per ray.  From the 6th iteration on, while at least 9 of 10 rays survive an iteration, the row budget is doubled (n_step up to 8:
+        # `boost` x N rows), and halved again when rays start to terminate early (an opaque frame is over by then and never leaves
+        # boost = 1: no sample is evaluated in vain).
+        boost, prev_alive, prev_iters = 1, n_rays, 2
         while bound_alive > 0 and done < max_steps:
-            # row bucket: the smallest of N, N/2, N/4, ... that holds min(N, 8 * alive) rows (>= 2048)
-            need = min(n_rays, 8 * bound_alive)
-            bucket = n_rays
+            if adaptive:
+                survival = (bound_alive / max(prev_alive, 1)) ** (1.0 / max(prev_iters, 1))
+                if survival >= 0.9 and boost < 8 and done >= 6:   # (an opaque frame is over by then: its rays saturate within ~10 samples)
+                    boost *= 2
+                elif survival < 0.75 and boost > 1:
+                    boost //= 2
+            n_total = boost * n_rays
+            if getattr(self, '_loop_debug', None) is not None:
+                self._loop_debug.append((done, bound_alive, boost, round(survival, 3) if adaptive else None))
+            # row bucket: the smallest of B, B/2, B/4, ... (B = boost * N) that holds min(B, 8 * alive) rows (>= 2048)
+            need = min(n_total, 8 * bound_alive)
+            bucket = n_total
             while bucket // 2 >= max(need, 2048):
                 bucket //= 2
-            rows = pad(bucket)
-            lanes = n_rays if bucket == n_rays else bucket // 8 + 1
+            # (row buckets exist for the graphs: one captured batch per bucket; without graphs the buffers are sized exactly)
+            rows = pad(bucket if use_graphs else need)
+            lanes = min(n_rays, bound_alive) if not use_graphs else (n_rays if bucket == n_rays else bucket // 8 + 1)
             g = cache['graphs'].get(bucket) if use_graphs else None
             if use_graphs and g is None:
                 try:
@@ -336,13 +357,15 @@ class NeRFRenderer(nn.Module):
                     cache['failed'] = repr(e)
                     use_graphs, g = False, None
                     torch.cuda.synchronize()
+            prev_alive, prev_iters = bound_alive, 0
             for _ in range(max(1, batch // 2)):
                 if g is not None:
                     g.replay()
                 else:
-                    iteration(0, lanes, rows, None)
-                    iteration(1, lanes, rows, None)
+                    iteration(0, lanes, rows, None, n_total)
+                    iteration(1, lanes, rows, None, n_total)
                 done += 2
+                prev_iters += 2
             batch = min(sync_every, batch * 2) if done >= 6 else batch
             bound_alive = int(state[0, 0].item())
         weights_sum.copy_(s_ws)

@@ -263,10 +263,11 @@ class NeRFRenderer(nn.Module):
         and compaction order as the host-driven loop: same image.
         Batches grow 2, 2, 4, 8, 8, ... iterations (an opaque frame is over after ~6 iterations, a transparent one needs ~100).
         `graph_loop = True` replays the batches after the first from HIP graphs (one graph of two iterations per row-count bucket N, N/2,
-        N/4, ..., captured on first use and kept on the model).  Measured on MI355X (tools/bench_render.py, 800x800): host-driven 27.5 /
-        2.30 ms (transparent / opaque), device state 23.5 / 2.6 ms, + graphs 23.1 / 2.7 ms -- the n_step refill keeps ~N sample rows in
-        flight per iteration until fewer than N/8 rays are alive, so the frame is bound by the network kernels, not by launches; graphs are
-        therefore off by default."""
+        N/4, ..., captured on first use and kept on the model; fixed reference n_step rule).  Measured on MI355X (tools/bench_render.py,
+        800x800, transparent / opaque frame): host-driven loop 26.0 / 2.2 ms, device state with the reference's n_step rule 21.3 / 1.93 ms,
+        + graphs 21.3 / 2.0 ms (the frame is bound by its kernels, not by launches: graphs are off by default), device state with the adaptive
+        row budget below (`adaptive_n_step`, default) 17.3 / 1.95 ms.  `_loop_debug = []` collects (iterations done, alive bound, boost,
+        survival per iteration) at every read-back (tools/render_loop_trace.py)."""
         from raymarching.backend import _backend as rb
         import _ngp_capi as capi
         n_rays, dev = rays_o.shape[0], rays_o.device

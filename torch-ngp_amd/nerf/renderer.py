@@ -259,8 +259,9 @@ class NeRFRenderer(nn.Module):
         the per-iteration n_step = max(min(N // n_alive, 8), 1) and the marched-step total live in a device word pair that the march /
         composite / compaction kernels read, so the host issues `sync_every` iterations back to back and reads the count back once per
         batch (the reference reads it every iteration through `rays_alive[rays_alive >= 0]`).  Between read-backs launches are sized for
-        the last known count; lanes and sample rows beyond the true count do nothing / are zero rows.  Same slot layout, n_step sequence
-        and compaction order as the host-driven loop: same image.
+        the last known count; lanes and sample rows beyond the true count do nothing / are zero rows.  Same slot layout and compaction
+        order as the host-driven loop, and a ray's samples and their compositing order do not depend on how they are chunked into
+        iterations: same image, bit for bit (tests/test_gpu_pipeline.py).
         Batches grow 2, 2, 4, 8, 8, ... iterations (an opaque frame is over after ~6 iterations, a transparent one needs ~100).
         `graph_loop = True` replays the batches after the first from HIP graphs (one graph of two iterations per row-count bucket N, N/2,
         N/4, ..., captured on first use and kept on the model; fixed reference n_step rule).  Measured on MI355X (tools/bench_render.py,

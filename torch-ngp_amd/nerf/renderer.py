@@ -331,7 +331,7 @@ class NeRFRenderer(nn.Module):
         while bound_alive > 0 and done < max_steps:
             if adaptive:
                 survival = (bound_alive / max(prev_alive, 1)) ** (1.0 / max(prev_iters, 1))
-                if survival >= 0.9 and boost < 8 and done >= 6:   # (an opaque frame is over by then: its rays saturate within ~10 samples)
+                if survival >= 0.9 and boost < 8 and done >= 6 and 2 * boost * n_rays <= int(getattr(self, 'loop_max_rows', 1 << 26)):   # (an opaque frame is over by then: its rays saturate within ~10 samples)
                     boost *= 2
                 elif survival < 0.75 and boost > 1:
                     boost //= 2

@@ -79,9 +79,9 @@ def test_render_eval_image_matches_oracle_loop():
 @pytest.mark.parametrize('density_scale,perturb', [(1.0, False), (40.0, False), (300.0, True)])
 def test_on_device_render_loop_equals_host_driven_loop(density_scale, perturb):
     """the eval loop with its state on the device (one read-back per batch of iterations; batches replayed from HIP graphs, or issued
-    eagerly with graph_loop = False) against the reference's host-driven loop (one read-back per iteration, renderer.py:341-367): same
-    slots, same n_step sequence, same compaction order -> the same image, bit for bit.  Two frames per mode: the second one replays the
-    graphs captured by the first on different rays."""
+    eagerly with graph_loop = False and the adaptive samples-per-iteration policy) against the reference's host-driven loop (one read-back
+    per iteration, renderer.py:341-367): same slots, same compaction order, and a ray's samples do not depend on how they are chunked into
+    iterations -> the same image, bit for bit.  Two frames per mode: the second one replays the graphs captured by the first on different rays."""
     model, orc, bits, dev = _setup(emb_scale=0.5)
     model.eval()
     model.density_scale = density_scale
@@ -96,12 +96,15 @@ def test_on_device_render_loop_equals_host_driven_loop(density_scale, perturb):
     for mode, (on_device, graphs) in {'graphs': (True, True), 'eager': (True, False), 'host': (False, False)}.items():
         model.device_loop, model.graph_loop = on_device, graphs
         model._loop_cache = None
+        model._loop_debug = [] if mode == 'eager' else None
         for k, (ot, dt_) in enumerate(frames):
             torch.manual_seed(5 + k)
             with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
                 out = model.render(ot, dt_, staged=True, bg_color=1, perturb=perturb, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
             # rays that miss the box carry depth = 0/0 on every path (renderer.py:317, as in the reference)
             res[(mode, k)] = (out['image'].clone(), torch.nan_to_num(out['depth'], nan=-1.0).clone())
+        if mode == 'eager' and density_scale == 1.0:
+            assert max(b for _, _, b, _ in model._loop_debug) >= 4, 'a semi-transparent frame must have raised the row budget'
         if mode == 'graphs':
             assert model._loop_cache['failed'] is False and (len(model._loop_cache['graphs']) > 0 or density_scale > 100)
     for k in range(2):

@@ -83,7 +83,7 @@ class KernelTimers:
     stream, which is what `_ngp_capi.stream()` hands to the library)."""
 
     def __init__(self, capi):
-        self.capi, self.records, self.enabled, self.orig = capi, {}, False, {}
+        self.capi, self.records, self.enabled, self.orig, self.step = capi, {}, False, {}, 0
         for sym in TIMED:
             self.orig[sym] = getattr(capi.lib, sym)
             setattr(capi.lib, sym, self._wrap(sym))
@@ -99,23 +99,27 @@ class KernelTimers:
             a.record()
             rc = inner(*args)
             b.record()
-            self.records.setdefault(label, []).append((a, b, int(args[b_idx]), fbytes(args), fflops(args), unit))
+            self.records.setdefault(label, []).append((a, b, int(args[b_idx]), fbytes(args), fflops(args), unit, self.step))
             return rc
         return call
 
-    def summary(self, traffic=None):
+    def summary(self, traffic=None, marched=None):
+        """marched[k]: samples iteration k really marched.  A launch is sized for the (padded) sample buffer; the rows behind the marched
+        ones are zero rows that move no algorithmic bytes, so a launch's units are min(rows launched, samples marched)."""
         out = []
         for label, recs in self.records.items():
             ms = np.array([a.elapsed_time(b) for a, b, *_ in recs])
-            units = np.array([r[2] for r in recs], dtype=np.float64)
-            byts = np.array([r[2] * r[3] for r in recs])
-            flops = np.array([r[2] * r[4] for r in recs])
+            unit_of = [min(r[2], marched[r[6]]) if marched and r[6] < len(marched) and marched[r[6]] > 0 else r[2] for r in recs]
+            units = np.array(unit_of, dtype=np.float64)
+            byts = np.array([u * r[3] for u, r in zip(unit_of, recs)])
+            flops = np.array([u * r[4] for u, r in zip(unit_of, recs)])
             t = float(ms.mean()) * 1e-3
             gbs = float(byts.mean()) / t / 1e9
             row = {'kernel': label, 'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_kernel_ms': round(float(ms.mean()), 4),
                    'units_per_launch': round(float(units.mean()), 1), 'bytes_per_unit': round(float(byts.mean() / units.mean()), 1),
-                   'unit_name': recs[0][5], 'launches': len(recs), 'total_ms': round(float(ms.sum()), 3)}
+                   'unit_name': recs[0][5], 'launches': len(recs), 'total_ms': round(float(ms.sum()), 3),
+                   'rows_per_launch': round(float(np.mean([r[2] for r in recs])), 1)}
             if flops.mean() > 0:
                 tf = float(flops.mean()) / t / 1e12
                 row['mfma'] = {'achieved': round(tf, 2), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 5)}
@@ -139,13 +143,14 @@ def load_pmc_traffic():
         return None, None
 
 
+RING_BLOCK = 8         # steps between snapshots of the model's 16-slot sample-counter ring (see TrainingRun.train_step)
 SETUP_ITERATIONS = 33  # 16 worst-case-sized eager steps + the first estimate-sized one (graph capture) + one refresh period from graphs
 
 
 class TrainingRun:
     """one configuration of the training workload (model + optimizer + stepper + resident batches) and its timing protocol"""
 
-    def __init__(self, args, dev, world, rank, fused, graph, torch_optim, autograd):
+    def __init__(self, args, dev, world, rank, fused, graph, torch_optim, autograd, rays=None):
         import raymarching
         import synthetic_scene as sc
         import ddp
@@ -153,6 +158,7 @@ class TrainingRun:
         from ddp import GradientAverager
         from graph import GraphedTrainStep, mse_loss
         self.args, self.dev, self.world, self.rank, self.use_graph, self.torch_optim = args, dev, world, rank, graph, torch_optim
+        self.rays = int(rays if rays is not None else args.rays)   # rays per GPU and step
         torch.manual_seed(0)  # identical parameters on every rank (FFMLP reseeds to 42 itself)
         model = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
         model.train()
@@ -194,7 +200,7 @@ class TrainingRun:
         self.n_pool = 16
         self.pool = []
         for k in range(self.n_pool):
-            o, d, gt = sc.training_batch(args.rays, seed=1000 * rank + k)
+            o, d, gt = sc.training_batch(self.rays, seed=1000 * rank + k)
             self.pool.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
         self.opt_kwargs = dict(staged=False, bg_color=1, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
 
@@ -208,7 +214,7 @@ class TrainingRun:
         self.keep_scene = keep_scene
         self.model, self.optimizer = model, optimizer
         self.lookahead = graph and fused and not torch_optim and not autograd and world == 1 and not getattr(args, 'no_lookahead', False)
-        self.stepper = GraphedTrainStep(model, optimizer, scaler, args.rays, self.opt_kwargs, loss_fn=mse_loss, averager=averager,
+        self.stepper = GraphedTrainStep(model, optimizer, scaler, self.rays, self.opt_kwargs, loss_fn=mse_loss, averager=averager,
                                         after_update=keep_scene, direct=not autograd, lookahead=self.lookahead)
         self.step_no = 0
         self.caps, self.slots = [], []
@@ -225,7 +231,7 @@ class TrainingRun:
                     model.update_extra_state()
                 self.keep_scene(model)
             mc = model.mean_count
-            cap = mc + (128 - mc % 128) if mc > 0 else args.rays * 1024
+            cap = mc + (128 - mc % 128) if mc > 0 else self.rays * 1024
             loss = stepper._eager(rays_o, rays_d, gt)
             stepper.global_step += 1
         else:
@@ -235,16 +241,17 @@ class TrainingRun:
                 loss = stepper.step(rays_o, rays_d, gt, next_rays=nxt)
             else:
                 loss = stepper.step(rays_o, rays_d, gt)
-            cap = stepper.capacity if stepper.capacity is not None else args.rays * 1024
+            cap = stepper.capacity if stepper.capacity is not None else self.rays * 1024
         if count:
             # log the sample counts: the model keeps the last 16 in its counter ring (renderer.py:352), so one 128-byte device copy every
-            # 16 steps is enough; the clamp to the buffer capacity and the sum happen after the timed region.  Samples that were marched
-            # AND evaluated: rays that do not fit the estimated buffer are dropped whole by march_rays_train (raymarching.cu:416), so at
-            # most `cap` samples are processed in a step
+            # RING_BLOCK = 8 steps is enough (8, not 16: in lookahead mode the side stream hands the NEXT step's count to its ring slot
+            # while this step runs, so a snapshot may only rely on slots younger than 15 steps); the clamp to the buffer capacity and
+            # the sum happen after the timed region.  Samples that were marched AND evaluated: rays that do not fit the estimated buffer
+            # are dropped whole by march_rays_train (raymarching.cu:416), so at most `cap` samples are processed in a step
             self.caps.append(cap)
             self.slots.append((model.local_step - 1) % 16)
-            if len(self.caps) % 16 == 0:
-                self.count_log[len(self.caps) // 16 - 1].copy_(model.step_counter, non_blocking=True)
+            if len(self.caps) % RING_BLOCK == 0:
+                self.count_log[len(self.caps) // RING_BLOCK - 1].copy_(model.step_counter, non_blocking=True)
         return loss
 
     def setup(self, warmup):
@@ -263,7 +270,7 @@ class TrainingRun:
 
     def timed(self, steps):
         dev, world, model = self.dev, self.world, self.model
-        self.count_log = torch.zeros(steps // 16 + 2, 16, 2, dtype=torch.int32, device=dev)  # snapshots of the model's 16-slot counter ring
+        self.count_log = torch.zeros(steps // RING_BLOCK + 2, 16, 2, dtype=torch.int32, device=dev)  # snapshots of the model's 16-slot counter ring
         self.caps, self.slots = [], []
         captures0 = self.stepper.captures
         torch.cuda.synchronize()
@@ -281,9 +288,9 @@ class TrainingRun:
         captures = self.stepper.captures - captures0
         final_loss = float(loss.item())
         caps, slots = self.caps, self.slots
-        if len(caps) % 16:  # the ring still holds the steps since the last snapshot
-            self.count_log[len(caps) // 16].copy_(model.step_counter)
-        blocks = torch.arange(len(caps), device=dev) // 16
+        if len(caps) % RING_BLOCK:  # the ring still holds the steps since the last snapshot
+            self.count_log[len(caps) // RING_BLOCK].copy_(model.step_counter)
+        blocks = torch.arange(len(caps), device=dev) // RING_BLOCK
         marched = self.count_log[blocks, torch.tensor(slots, dtype=torch.int64, device=dev), 0].to(torch.int64)
         total = torch.minimum(marched, torch.tensor(caps, dtype=torch.int64, device=dev)).sum()
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -319,8 +326,8 @@ def cpu_baselines(args):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='',
                    MALLOC_TRIM_THRESHOLD_='34359738368', MALLOC_MMAP_MAX_='0', MALLOC_TOP_PAD_='1073741824')
         try:
-            out = subprocess.run([sys.executable, '-m', 'oracle.torch_cpu', '1024', str(half), str(threads)], cwd=ROOT, env=env, capture_output=True,
-                                 text=True, timeout=6 * half + 45)
+            out = subprocess.run([sys.executable, '-m', 'oracle.torch_cpu', str(args.rays), str(half), str(threads)], cwd=ROOT, env=env, capture_output=True,
+                                 text=True, timeout=10 * half + 60)
             r = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001 -- timeout / crash: try fewer threads
             tried.append(f'{threads} threads: {type(e).__name__}')
@@ -341,6 +348,27 @@ def cpu_baselines(args):
                           'sample': f"{q['steps']} full oracle training step(s) of the cuda_ray-shaped workload (forward+backward, no optimiser) "
                                     f"of {args.rays} rays = {q['samples']} samples in {q['seconds']:.1f} s, one host thread"}
     return cpu
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: replace this process by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`,
+    one rank per GPU.  Fails loudly when the node has fewer than N devices (NGP_BENCH_SHARE_GPU=1, the one-GPU functional-test hook,
+    lifts that check) -- it never falls back to measuring one GPU under an `n_gpus: N` request."""
+    import socket
+    have = torch.cuda.device_count()
+    if have < args.gpus and os.environ.get('NGP_BENCH_SHARE_GPU') != '1':
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to benchmark fewer ranks than asked for')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', NGP_BENCH_SELF_LAUNCHED='1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
 
 
 def main():
@@ -365,12 +393,20 @@ def main():
     ap.add_argument('--dropin-steps', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='N > 1: weak = --rays per GPU (global batch grows with N, the headline); strong = --rays in total, --rays / N per GPU')
+    ap.add_argument('--no-strong', action='store_true', help='N > 1, --scaling weak: skip the secondary strong-scaling measurement (`strong_scaling`)')
+    ap.add_argument('--strong-steps', type=int, default=128)
     args = ap.parse_args()
 
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP extension has no CPU fallback)'
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)   # does not return: this process becomes the launcher of N ranks
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP extension has no CPU fallback)'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)')
     fusions_off = [n for n in args.ab_off.split(',') if n]
     if fusions_off:
         import fused as _fused
@@ -383,21 +419,37 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    comm = {'backend': None, 'rccl_ranks': None}
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('NGP_BENCH_BACKEND', 'nccl')  # 'nccl' is RCCL on ROCm
         if backend == 'nccl':
+            if os.environ.get('NGP_BENCH_SHARE_GPU') != '1' and torch.cuda.device_count() < world:
+                raise SystemExit(f'bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s)')
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+        # proof that the collective library joined every rank: a SUM of ones over the data-parallel group, on the device
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        joined = int(ones.item())
+        if joined != world or dist.get_world_size() != args.gpus:
+            raise SystemExit(f'bench.py: all_reduce over {dist.get_backend()} saw {joined} rank(s), expected {world}')
+        comm = {'backend': dist.get_backend() + (' (RCCL over xGMI)' if dist.get_backend() == 'nccl' else ' (functional-test backend, host memory)'),
+                'rccl_ranks': dist.get_world_size() if dist.get_backend() == 'nccl' else 0, 'ranks': dist.get_world_size(),
+                'self_launched': os.environ.get('NGP_BENCH_SELF_LAUNCHED') == '1'}
+        dev_ids = [None] * world
+        dist.all_gather_object(dev_ids, torch.cuda.current_device())
+        comm['devices'] = dev_ids
 
     import _ngp_capi as capi
     import synthetic_scene as sc
     timers = KernelTimers(capi)
 
+    rays_per_gpu = args.rays if args.scaling == 'weak' else max(128, args.rays // world)
     run = TrainingRun(args, dev, world, rank, fused=not args.no_fused, graph=not args.no_graph, torch_optim=args.torch_optim,
-                      autograd=args.autograd)
+                      autograd=args.autograd, rays=rays_per_gpu)
     run.setup(args.warmup)
     res = run.timed(args.steps)
     elapsed, samples = res['elapsed'], res['samples']
@@ -409,50 +461,83 @@ def main():
     if not args.no_roofline:
         # every rank runs these iterations (the data-parallel exchange inside them is collective); only rank 0 times its kernels
         timers.enabled = rank == 0
+        marched = []
         for k in range(min(16, max(4, args.steps))):
             rays_o, rays_d, gt = run.pool[(run.step_no + k) % run.n_pool]
             saved = (model.mean_count, model.local_step)
             if stepper.captured_capacity:
                 model.mean_count = stepper.captured_capacity - 128
+            timers.step = k
+            slot = model.local_step % 16
             stepper._eager(rays_o, rays_d, gt)
+            marched.append(model.step_counter[slot, 0].clone())   # samples this iteration really marched (the launches are sized for the buffer)
             model.mean_count, model.local_step = saved
         torch.cuda.synchronize()
         timers.enabled = False
         if rank == 0:
             traffic, traffic_source = load_pmc_traffic()
-            roofs = timers.summary(traffic)
+            roofs = timers.summary(traffic, marched=[int(m.item()) for m in marched])
             for r in roofs:
                 r['traffic_source'] = (f'{traffic_source} (committed rocprofv3 --pmc pass of the same workload; not measured in this run)'
                                        if r['traffic'] is not None else None)
     if world > 1 and getattr(run.optimizer, 'shard', False):
         run.optimizer.wait_shadows()
-        run.optimizer.gather_master()  # collective: every rank's fp32 master weights complete again (rank 0 renders with them below)
+        run.optimizer.gather_master()  # collective: every rank's fp32 master weights complete again (every rank renders with them below)
         torch.cuda.synchronize()
 
     render = None
-    if rank == 0 and not args.no_render:
+    if not args.no_render:
         # second half of BASELINE.json's metric: wall time of one 800x800 inference frame through NeRFRenderer.run_cuda's eval branch
         # (renderer.py:322-367), same scene, same (randomly initialised) network.  Two bracketing cases: the random-init density
         # (~1 everywhere: no ray terminates early, every one of the ~43 M samples is evaluated) and the same network with
         # density_scale = 300 (opaque surfaces: rays saturate after a few samples, as in a trained scene).
+        # N > 1 (strong scaling by construction: ONE frame): every rank renders its block of pixel rows, the [N/R, 4] blocks are
+        # all-gathered (ddp.render_sharded); timed on all ranks between barriers, the MAX over ranks is reported.
+        import ddp
         model.eval()
         o, d = sc.full_image_rays(seed=0)
         ro, rd = torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev)
         rkw = dict(staged=True, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
-        render = {'unit': 'ms per 800x800 frame (640000 rays), 1 GPU'}
+        render = {'unit': f'ms per 800x800 frame (640000 rays), {world} GPU(s)' + ('' if world == 1 else ', pixel rows sharded over the ranks, image all-gathered'),
+                  'n_gpus': world, 'scaling': 'strong' if world > 1 else None}
         for name, scale in (('transparent_random_init', 1.0), ('opaque_density_scale_300', 300.0)):
             model.density_scale = scale
             ts = []
             for f in range(6):
                 torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
                 t1 = time.perf_counter()
                 with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
-                    model.render(ro, rd, **rkw)
+                    if world > 1:
+                        ddp.render_sharded(model, ro, rd, **rkw)
+                    else:
+                        model.render(ro, rd, **rkw)
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t1) * 1e3)
-            render[name] = round(min(ts[1:]), 2)
+            best = torch.tensor([min(ts[1:])], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(best, op=dist.ReduceOp.MAX)
+            render[name] = round(float(best.item()), 2)
         model.density_scale = 1
         model.train()
+
+    strong = None
+    if world > 1 and args.scaling == 'weak' and not args.no_strong:
+        # secondary line: the SAME global batch as one GPU (--rays in total, --rays / N per rank), same protocol, shorter run
+        s_rays = max(128, args.rays // world)
+        s_run = TrainingRun(args, dev, world, rank, fused=not args.no_fused, graph=not args.no_graph, torch_optim=args.torch_optim,
+                            autograd=args.autograd, rays=s_rays)
+        s_run.setup(min(args.warmup, 16))
+        s_res = s_run.timed(args.strong_steps)
+        strong = {'scaling': 'strong', 'value': round(s_res['samples'] / s_res['elapsed'], 1), 'unit': 'samples/s', 'steps': args.strong_steps,
+                  'ms_per_step': round(s_res['elapsed'] / args.strong_steps * 1e3, 4), 'rays_per_gpu_per_step': s_rays,
+                  'global_rays_per_step': s_rays * world, 'samples_per_step_global': round(s_res['samples'] / args.strong_steps, 1),
+                  'captures_in_timed_region': s_res['captures'], 'execution': s_run.execution()}
+        if getattr(s_run.optimizer, 'shard', False):
+            s_run.optimizer.wait_shadows()
+            torch.cuda.synchronize()
+        del s_run
 
     dropin = None
     if rank == 0 and world == 1 and not args.no_dropin and not (args.no_fused and args.no_graph and args.torch_optim):
@@ -477,25 +562,37 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baselines(args)
+        sharded = bool(getattr(run.optimizer, 'shard', False))
+        fallback = getattr(run, 'shard_fallback', None)
+        if world == 1:
+            par = 'dp1'
+        elif sharded:
+            par = f'dp{world} (reduce-scatter, sharded Adam, all-gather of fp16 shadows)'
+        else:
+            par = f'dp{world} (all-reduce, replicated Adam' + ('; FALLBACK: the sharded collectives were refused by this backend' if fallback else '') + ')'
         line = {
             'metric': 'training samples/s (rays x steps), lego-shaped synthetic, fp16 autocast, full step incl. Adam',
             'value': round(samples / elapsed, 1), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f16', 'data': 'synthetic',
+            'rccl_ranks': comm['rccl_ranks'], 'comm': comm, 'sharded_update_fallback': fallback,
             'config': {'workload': 'nerf_synthetic/lego-shaped --fp16 --cuda_ray --ff training step (hashgrid L=16 F=2 T=2^19, SH deg 4, '
                                    'FFMLP 64x2 / 64x3), bound=1, 128^3 occupancy grid, dt_gamma=0, max_steps=1024',
-                       'rays_per_gpu_per_step': args.rays, 'samples_per_step_per_gpu': round(samples / args.steps / world, 1),
-                       'rays_per_s': round(args.rays * world * args.steps / elapsed, 1), 'parallelism': f'dp{world}' + ('' if world == 1 else (' (reduce-scatter, sharded Adam, all-gather of fp16 shadows)' if getattr(run.optimizer, 'shard', False) else ' (all-reduce, replicated Adam)')),
-                       'sharded_update_fallback': getattr(run, 'shard_fallback', None),
+                       'rays_per_gpu_per_step': run.rays, 'global_rays_per_step': run.rays * world,
+                       'samples_per_step_per_gpu': round(samples / args.steps / world, 1),
+                       'rays_per_s': round(run.rays * world * args.steps / elapsed, 1), 'parallelism': par,
+                       'sharded_update_fallback': fallback,
                        'execution': run.execution(), 'setup_iterations_untimed': SETUP_ITERATIONS, 'fusions_off': fusions_off,
                        'captures_in_timed_region': res['captures'],
                        'autograd_free_iteration': bool(stepper.used_direct), 'fused_pipeline': bool(model.fused),
                        'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
                        'final_loss': res['final_loss']},
             'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'dropin_path': dropin, 'render_800x800_ms': render,
+            'strong_scaling': strong,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

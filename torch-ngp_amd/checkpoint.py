@@ -12,6 +12,11 @@ import torch
 def save_checkpoint(path, model, epoch=0, global_step=0, stats=None, optimizer=None, scaler=None, lr_scheduler=None, ema=None, full=False,
                     best=False):
     state = {'epoch': epoch, 'global_step': global_step, 'stats': stats if stats is not None else {}}
+    if optimizer is not None and getattr(optimizer, 'shard', False):
+        # optim.NGPAdam(shard=True): a rank keeps only its own 1/world of the fp32 master weights current between steps -- complete them
+        # from their owners before ANY state_dict (also the model-only "best" checkpoints); a collective: every rank calls save_checkpoint
+        optimizer.wait_shadows()
+        optimizer.gather_master()
     if getattr(model, 'cuda_ray', False):
         state['mean_count'] = model.mean_count
         state['mean_density'] = model.mean_density
@@ -69,7 +74,10 @@ def load_checkpoint(checkpoint, model, optimizer=None, scaler=None, lr_scheduler
 
 def _after_model_load(model, optimizer):
     # the fp16 shadow copies an NGPAdam keeps next to the parameters must follow a load
-    if optimizer is not None and hasattr(optimizer, 'sync_shadows'):
+    # (every rank loads the same complete file: nothing to gather in sharded mode)
+    if optimizer is not None and hasattr(optimizer, '_sync_shadows'):
+        optimizer._sync_shadows(assume_complete=True)
+    elif optimizer is not None and hasattr(optimizer, 'sync_shadows'):
         optimizer.sync_shadows()
 
 

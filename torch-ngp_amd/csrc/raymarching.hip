@@ -1015,6 +1015,9 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_loss_bwd(
     // The per-ray errors are write-through atomic stores; a workgroup-scope release waits for them to complete before the ticket moves.)
     __shared__ float part[CT_WAVES];
     __shared__ bool last;
+    // every lane waits for ITS OWN outstanding stores (the write-through ray_err store among them) before the barrier: a workgroup-scope
+    // release alone need not emit s_waitcnt vmcnt(0) outside tgsplit mode, and the ticket below is relaxed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ray_blocks - 1u;

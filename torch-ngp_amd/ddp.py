@@ -89,3 +89,35 @@ def shard_rays(n_rays, rank=None, world=None):
     world = dist.get_world_size() if world is None else world
     per = (n_rays + world - 1) // world
     return slice(rank * per, min(n_rays, (rank + 1) * per))
+
+
+@torch.no_grad()
+def render_sharded(model, rays_o, rays_d, rank=None, world=None, group=None, **kwargs):
+    """one inference frame over all ranks ("inference shards by pixel rows with an all_gather of [N/R,3] images"):
+    every rank holds the same rays [1,N,3] (pixel-row major, as get_rays emits them) and the same parameters, renders its
+    contiguous block of rows through `model.render` (the eval branch of run_cuda, renderer.py:322-367) and the blocks are
+    all-gathered, so every rank returns the full {'image' [1,N,3], 'depth' [1,N]}.  No exchange during marching.  A ray's samples
+    and their compositing order do not depend on which other rays share its launch (the eval loop's n_step only regroups samples into
+    iterations), so the gathered frame is bit-identical to the one-rank frame (tests/test_ddp_gloo.py, tests/test_gpu_ddp.py)."""
+    rank = dist.get_rank(group) if rank is None else rank
+    world = dist.get_world_size(group) if world is None else world
+    n = rays_o.shape[-2]
+    if world <= 1:
+        return model.render(rays_o, rays_d, **kwargs)
+    per = (n + world - 1) // world
+    sl = shard_rays(n, rank, world)
+    mine = model.render(rays_o[:, sl].contiguous(), rays_d[:, sl].contiguous(), **kwargs)
+    dev = rays_o.device
+    # [per, 4] = rgb + depth per ray; the last rank's block is padded to the common size for the fixed-size all-gather
+    block = torch.zeros(per, 4, dtype=torch.float32, device=dev)
+    k = sl.stop - sl.start
+    block[:k, :3] = mine['image'].reshape(-1, 3).float()
+    block[:k, 3] = mine['depth'].reshape(-1).float()
+    full = torch.empty(world * per, 4, dtype=torch.float32, device=dev)
+    if dist.get_backend(group) == 'nccl':
+        dist.all_gather_into_tensor(full, block, group=group)
+    else:
+        parts = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(parts, block, group=group)
+        full.copy_(torch.cat(parts, 0))
+    return {'image': full[:n, :3].reshape(1, n, 3), 'depth': full[:n, 3].reshape(1, n)}

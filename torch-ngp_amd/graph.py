@@ -84,7 +84,7 @@ class GraphedTrainStep:
         self.lookahead = bool(lookahead) and self.direct and averager is None
         self.la = None                      # [(march graph, rest graph, loss)] x 2 once captured
         self.la_cur = 0                     # buffer set of the CURRENT batch
-        self.la_ready = [None, None]        # what is marched into each set: (key of the rays, occupancy epoch)
+        self.la_ready = [None, None]        # what is marched into each set: references to the announced tensors + versions + occupancy epoch
         self.la_hits = 0                    # steps whose march had been done ahead
         self.occupancy_epoch = 0
         self.la_presampled = None           # refresh mode (full sweep?) whose cell sampling already ran on the side stream
@@ -364,8 +364,12 @@ class GraphedTrainStep:
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
-    def _rays_key(rays_o, rays_d):
-        return (rays_o.data_ptr(), rays_o._version, rays_d.data_ptr(), rays_d._version, tuple(rays_o.shape))
+    def _announced(ready, rays_o, rays_d, epoch):
+        """is the batch marched into a buffer set THIS batch?  `ready` = (rays_o, rays_d, versions, occupancy epoch, target, target version)
+        holds REFERENCES to the announced tensors, compared by identity: a freed tensor's address can be handed out again by the
+        caching allocator (same data_ptr, fresh _version 0), which an address/version key would take for a hit."""
+        return (ready is not None and ready[0] is rays_o and ready[1] is rays_d and ready[2] == (rays_o._version, rays_d._version)
+                and ready[3] == epoch)
 
     def _step_lookahead(self, rays_o, rays_d, target, next_rays):
         m = self.model
@@ -373,13 +377,16 @@ class GraphedTrainStep:
         gm, gr, loss = self.la[p][:3]
         main = torch.cuda.current_stream()
         ready = self.la_ready[p]
-        hit = ready is not None and ready[:2] == (self._rays_key(rays_o, rays_d), self.occupancy_epoch)
+        hit = self._announced(ready, rays_o, rays_d, self.occupancy_epoch)
         slot = m.step_counter[m.local_step % 16]
+        if ready is not None:
+            # hit or miss: whatever the side stream was asked to march into set p (its copies into la_rays_*/la_seed[p], the replay of
+            # gm_p, the ring-slot hand-over) must have finished before this stream reads OR overwrites that set
+            main.wait_event(self.la_event[p])
         if hit:
-            if ready[2] != (target.data_ptr(), target._version):   # the target was not announced with the rays: copy it now
+            if not (ready[4] is target and ready[5] == target._version):   # the target was not announced with the rays: copy it now
                 self.la_target[p].copy_(target, non_blocking=True)
-            main.wait_event(self.la_event[p])       # the march of this batch ran on the side stream during the previous step
-            self.la_hits += 1
+            self.la_hits += 1                       # the march of this batch ran on the side stream during the previous step
         else:
             torch._foreach_copy_([self.la_rays_o[p], self.la_rays_d[p], self.la_target[p]],
                                  [rays_o.view_as(self.la_rays_o[p]), rays_d.view_as(self.la_rays_d[p]), target], non_blocking=True)
@@ -394,18 +401,18 @@ class GraphedTrainStep:
             with torch.cuda.stream(side):
                 no, nd = next_rays[0], next_rays[1]
                 dst, src = [self.la_rays_o[q], self.la_rays_d[q]], [no.view_as(self.la_rays_o[q]), nd.view_as(self.la_rays_d[q])]
-                tkey = None
+                nt, ntv = None, None
                 if len(next_rays) > 2:              # the next target too: its copy leaves the main stream as well
                     dst.append(self.la_target[q])
                     src.append(next_rays[2])
-                    tkey = (next_rays[2].data_ptr(), next_rays[2]._version)
+                    nt, ntv = next_rays[2], next_rays[2]._version
                 torch._foreach_copy_(dst, src, non_blocking=True)
                 self.la_seed[q:q + 1].fill_(self.global_step + 1)
                 self.la[q][0].replay()
                 # the sample count of the next step goes to the model's ring from here (the slot the next step will own)
                 m.step_counter[(m.local_step + 1) % 16].copy_(self.counter[q], non_blocking=True)
                 self.la_event[q].record(side)
-            self.la_ready[q] = (self._rays_key(no, nd), self.occupancy_epoch, tkey)
+            self.la_ready[q] = (no, nd, (no._version, nd._version), self.occupancy_epoch, nt, ntv)
         elif (self.global_step + 1) % self.update_interval == 0 and self.graph_updates and self.update_capture_error is None:
             # the next step starts with an occupancy refresh: its weight-independent half (which cells, where inside them) runs here instead
             full = m.iter_density < 16

@@ -261,7 +261,11 @@ class NeRFRenderer(nn.Module):
         batch (the reference reads it every iteration through `rays_alive[rays_alive >= 0]`).  Between read-backs launches are sized for
         the last known count; lanes and sample rows beyond the true count do nothing / are zero rows.  Same slot layout and compaction
         order as the host-driven loop, and a ray's samples and their compositing order do not depend on how they are chunked into
-        iterations: same image, bit for bit (tests/test_gpu_pipeline.py).
+        iterations: same image, bit for bit (tests/test_gpu_pipeline.py) -- with one caveat: the loop ends when the SUM of the per-iteration
+        n_step reaches max_steps (renderer.py:341,367), and the adaptive row budget below changes that sequence, so a ray that is still
+        alive at that cutoff is truncated at a different sample than under the reference rule.  A ray emits at most n_step samples per
+        iteration, so the cutoff is only reachable by a ray that itself needs >= max_steps samples (none with dt_gamma = 0 inside bound 1,
+        where the longest chord is max_steps steps); `adaptive_n_step = False` keeps the reference sequence exactly.
         Batches grow 2, 2, 4, 8, 8, ... iterations (an opaque frame is over after ~6 iterations, a transparent one needs ~100).
         `graph_loop = True` replays the batches after the first from HIP graphs (one graph of two iterations per row-count bucket N, N/2,
         N/4, ..., captured on first use and kept on the model; fixed reference n_step rule).  Measured on MI355X (tools/bench_render.py,

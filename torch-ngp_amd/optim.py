@@ -27,8 +27,8 @@ Multi-GPU (one process per GPU, torch.distributed; 'nccl' is RCCL over xGMI), tw
     and fp16 shadows (Adam's 30 B/parameter sweep shrinks by world_size), and `gather_shadows()` = ONE all-gather of the fp16 shadows
     on a side stream, which the next iteration's parameter-independent ray marching overlaps.  Same bytes on the wire as the ring
     all-reduce (which is a reduce-scatter + all-gather), 1/world of the optimizer traffic, and the gather leaves the critical path.
-    The "step skipped as a whole" rule needs a global verdict: every rank sweeps its LOCAL gradient before the exchange and poisons one
-    flag slot per shard, so after the reduce-scatter each owner sees a non-finite value iff any rank had one -- no extra collective.
+    The "step skipped as a whole" rule needs a global verdict: every rank sweeps its LOCAL gradient before the exchange into found_inf
+    (scalars[2]) and `reduce_gradients()` combines the per-rank verdicts with ONE extra 4-byte all_reduce(MAX) next to the reduce-scatter.
     The fp32 parameters are re-pointed into one flat master buffer (`gather_master()` completes them on every rank for checkpoints).
 """
 import ctypes
@@ -108,7 +108,7 @@ class NGPAdam:
         # device-resident scalars: loss scale, growth tracker, found_inf, Adam step count, lr multiplier (schedulers write this one)
         self.scalars = torch.tensor([init_scale, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
         self._scale_view = self.scalars[0]
-        self._keep = None
+        self._keep = []   # ctypes argument arrays of the launches of the current step (kept alive until the next step / building block)
         self._comm_stream = None
         self._shadows_ready = None
 
@@ -144,8 +144,17 @@ class NGPAdam:
         # the fp16 deposit buffers were zeroed by the last update kernel
 
     def sync_shadows(self):
-        """refresh the fp16 shadow copies after the fp32 parameters were changed from outside (checkpoint load, manual init)"""
+        """refresh the fp16 shadow copies after the fp32 parameters were changed from outside (checkpoint load, manual init).
+        Sharded mode: a rank keeps only its own 1/world of the fp32 master weights current between steps, so the regions it does not own
+        are first completed from their owners (`gather_master()`, a collective: call on every rank) -- otherwise stale master values
+        would overwrite the freshly all-gathered shadows.  `assume_complete=True` skips that when the caller has just written the whole
+        parameter set itself on every rank (checkpoint load)."""
+        self._sync_shadows()
+
+    def _sync_shadows(self, assume_complete=False):
         self.wait_shadows()
+        if self.shard and not assume_complete:
+            self.gather_master()
         for p, st in self.state.items():
             if 'fp16' in st:
                 st['fp16'].copy_(p.detach())
@@ -180,7 +189,9 @@ class NGPAdam:
     # ---- sharded mode: pre_reduce_check (capturable) -> reduce_gradients (collectives) -> apply (capturable) -> gather_shadows (async) ----
     @torch.no_grad()
     def pre_reduce_check(self):
-        """sweep the LOCAL flat gradient for non-finite values into found_inf (scalars[2]); capturable"""
+        """sweep the LOCAL flat gradient for non-finite values into found_inf (scalars[2]); capturable.  First building block of a
+        sharded step: starts a fresh list of kept-alive launch arguments."""
+        self._keep = []
         self._launch([(self.total, None, None, None, self.flat_grad16, None, 1, 0.0, None)], capi.NGP_OPT_PHASE_CHECK, 0.0)
 
     @torch.no_grad()
@@ -212,6 +223,8 @@ class NGPAdam:
     def apply(self):
         """Adam on my shard (skipped everywhere when any rank saw a non-finite gradient), loss-scale / step-count commit, and the flat
         deposit buffer zeroed for the next backward; capturable"""
+        if len(self._keep) > 64:   # used standalone in a loop without pre_reduce_check()/step(): do not grow without bound
+            del self._keep[:-8]
         entries = self._shard_entries()
         for i in range(0, len(entries), _MAX):
             self._launch(entries[i:i + _MAX], capi.NGP_OPT_PHASE_UPDATE, 0.0)
@@ -377,7 +390,7 @@ class NGPAdam:
         if scaler_sd:
             self.scalars[0:1].fill_(float(scaler_sd.get('scale', self.get_scale())))
             self.scalars[1:2].fill_(float(scaler_sd.get('_growth_tracker', 0)))
-        self.sync_shadows()
+        self._sync_shadows(assume_complete=True)   # the caller loaded the full parameter set on every rank
 
 
     def _shard_piece(self, p):
@@ -426,7 +439,7 @@ class NGPAdam:
             self._set_moments(p, m, v)
         for g, lr in zip(self.param_groups, sd['lr']):
             g['lr'] = lr
-        self.sync_shadows()
+        self._sync_shadows(assume_complete=True)   # load_state_dict follows model.load_state_dict on every rank (checkpoint.py)
 
 
 class NGPEma:
@@ -446,9 +459,10 @@ class NGPEma:
         self.params = [p for p in parameters if p.requires_grad]
         self.decay = float(decay)
         self.num_updates = 0 if use_num_updates else None
+        self.optimizer = optimizer
+        self._complete_params()
         self.shadow_params = [p.detach().clone() for p in self.params]
         self.collected_params = None
-        self.optimizer = optimizer
         self._index = {id(p): i for i, p in enumerate(self.params)}
 
     def shadow_of(self, p):
@@ -462,8 +476,16 @@ class NGPEma:
             decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
         return 1.0 - decay
 
+    def _complete_params(self):
+        """sharded optimizer: the fp32 parameters this rank does not own are stale between steps -- complete them first (collective)"""
+        opt = self.optimizer
+        if opt is not None and getattr(opt, 'shard', False):
+            opt.wait_shadows()
+            opt.gather_master()
+
     @torch.no_grad()
     def update(self):
+        self._complete_params()
         omd = self.begin_update()
         stream = capi.stream()
         keep = []
@@ -483,10 +505,11 @@ class NGPEma:
         for s_, p in zip(self.shadow_params, self.params):
             p.copy_(s_)  # bumps the version counter: stale fp16 shadows are detected by fused._resync_stale_shadows
         if self.optimizer is not None:
-            self.optimizer.sync_shadows()
+            self.optimizer._sync_shadows(assume_complete=True)   # every rank just wrote the complete parameter set
 
     @torch.no_grad()
     def store(self):
+        self._complete_params()
         self.collected_params = [p.detach().clone() for p in self.params]
 
     @torch.no_grad()
@@ -496,7 +519,7 @@ class NGPEma:
         for c, p in zip(self.collected_params, self.params):
             p.copy_(c)
         if self.optimizer is not None:
-            self.optimizer.sync_shadows()
+            self.optimizer._sync_shadows(assume_complete=True)
 
     def state_dict(self):
         return {'decay': self.decay, 'num_updates': self.num_updates, 'shadow_params': self.shadow_params,

@@ -69,11 +69,6 @@ TIMED = {
     'ngp_grid_encode_backward_ex': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_ws': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_checked': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
-    # keyed record path: the VALUE phase (weight x gradient into precomputed slots + exact slice sums) is the backward on the critical path;
-    # the position-only KEY phase runs with the march (side stream in lookahead mode) and is reported as a kernel of its own
-    # (positions 12 B in; 2-byte keys + 2-byte slot words per corner and level + descriptors out: 16 * 8 * 4 = 512 B per point)
-    'ngp_grid_encode_backward_keyed': ('grid_encode_backward', 4, lambda a: 1100.0, lambda a: 0.0, 'point'),
-    'ngp_grid_backward_keys': ('grid_backward_keys', 2, lambda a: 12.0 + 512.0, lambda a: 0.0, 'point'),
     'ngp_ffmlp_forward_ex': ('ffmlp_forward', 2, lambda a: _ff_fwd_bytes(a[6]), lambda a: _ff_flops(a[6]), 'sample'),
     # the whole network behind the encoder in one launch: enc 64 B + dir 12 B in, both forward buffers + h16 32 B + colour input 64 B + sigma 4 B +
     # rgb 12 B out per sample; flops of both MLPs
@@ -394,7 +389,7 @@ def main():
                     '(graph.GraphedTrainStep(lookahead=True): single rank, fused + graph + NGPAdam only)')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second, drop-in-surface-only measurement')
     ap.add_argument('--ab-off', default='', help='A/B measurement: comma-separated optional launch fusions of fused.py to switch OFF '
-                    '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID, USE_FUSED_SCAN, USE_FUSED_CHECK, USE_KEYED_BACKWARD); recorded in config.fusions_off')
+                    '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID, USE_FUSED_SCAN, USE_FUSED_CHECK); recorded in config.fusions_off')
     ap.add_argument('--dropin-steps', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)

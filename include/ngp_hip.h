@@ -235,25 +235,6 @@ int ngp_grid_encode_backward_ws(const void* grad, const float* inputs, const voi
                                 int dtype, float bound, const int32_t* offsets_host, void* workspace, size_t workspace_bytes,
                                 ngp_stream_t stream);
 
-/* The record path of ngp_grid_encode_backward_ws split into a position-only KEY phase and a gradient VALUE phase.
- * Cell indices, run structure, histogram ranks, record slots and the per-slice descriptors depend only on the sample positions, which
- * exist as soon as the march is done (kernel_march_rays_train, raymarching.cu:312-480): ngp_grid_backward_keys computes them into
- * `key_workspace` -- typically on the marcher's side stream, off the critical path -- and ngp_grid_encode_backward_keyed then only
- * multiplies weight by gradient into the precomputed slots and sums the slices exactly (same scatter-add semantics as
- * kernel_grid_backward, gridencoder.cu:248-340; runs of equal table index are summed in fp32 and rounded to fp16 once per run, slices
- * are summed exactly: bit-reproducible).  Eligible calls: fp16 table, C = 2, D = 2 or 3, >= 16384 samples, every level binned;
- * ngp_grid_backward_keyed_bytes writes 0 / 0 otherwise (use ngp_grid_encode_backward_checked then).  `inputs`, B and the level
- * configuration must be the same in both calls; the value workspace may be shared by several key workspaces. */
-int ngp_grid_backward_keyed_bytes(const int32_t* offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                                  uint32_t gridtype, int align_corners, int dtype, size_t* key_bytes, size_t* value_bytes);
-int ngp_grid_backward_keys(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                           uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound, const int32_t* offsets_host,
-                           void* key_workspace, size_t key_bytes, ngp_stream_t stream);
-int ngp_grid_encode_backward_keyed(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
-                                   uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
-                                   uint32_t interp, int dtype, float bound, const int32_t* offsets_host, const void* key_workspace,
-                                   size_t key_bytes, void* value_workspace, size_t value_bytes, float* found_inf, ngp_stream_t stream);
-
 /* flags of the ffmlp *_ex entry points */
 #define NGP_FF_INPUT_PLANAR 1u /* inputs are [input_dim/2][B][2] fp16 planes = the grid encoder's [L,B,C=2] output */
 #define NGP_FF_DX_PLANAR 2u    /* grad_inputs is written in that planar layout = what grid_encode_backward reads */

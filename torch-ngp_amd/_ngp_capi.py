@@ -22,7 +22,7 @@ NGP_F32, NGP_F16 = 0, 1
 NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR, NGP_FF_LAYERED, NGP_FF_SINGLE_WAVE, NGP_FF_DEFER_REDUCE = 1, 2, 4, 8, 16
 NGP_MARCH_RESET_COUNTER, NGP_MARCH_ZERO_TAIL, NGP_MARCH_NOISE_FROM_SEED, NGP_MARCH_SCAN_LAUNCH = 1, 2, 4, 8
 NGP_OPT_PHASE_CHECK, NGP_OPT_PHASE_UPDATE, NGP_OPT_PHASE_COMMIT = 1, 2, 4
-ABI_VERSION = 6
+ABI_VERSION = 5
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -68,10 +68,6 @@ _SIGNATURES = {
                                     _sz, _vp],
     'ngp_grid_encode_backward_checked': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp,
                                          _vp, _sz, _vp, _vp],
-    'ngp_grid_backward_keyed_bytes': [_vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _i32, _vp, _vp],
-    'ngp_grid_backward_keys': [_vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _u32, _i32, _f32, _vp, _vp, _sz, _vp],
-    'ngp_grid_encode_backward_keyed': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _u32, _i32, _f32, _vp, _vp, _sz, _vp,
-                                       _sz, _vp, _vp],
     'ngp_ffmlp_forward_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_inference_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_backward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp],
@@ -196,15 +192,3 @@ def grid_backward_workspace(offsets, B, D, C, L, S, H, gridtype, align_corners, 
     if n == 0:
         return arr, None, 0
     return arr, torch.empty(n, dtype=torch.uint8, device=offsets.device), n
-
-
-def grid_backward_keyed_bytes(offsets, B, D, C, L, S, H, gridtype, align_corners, code):
-    """(offsets_host, key workspace bytes, value workspace bytes) of the keyed record path; (arr or None, 0, 0) when the call is not
-    eligible (ngp_grid_backward_keyed_bytes) or the host copy of the offsets cannot be made (stream capture)"""
-    arr = host_offsets(offsets)
-    if arr is None:
-        return None, 0, 0
-    kb, vb = ctypes.c_size_t(0), ctypes.c_size_t(0)
-    check(lib.ngp_grid_backward_keyed_bytes(ctypes.cast(arr, ctypes.c_void_p), B, D, C, L, float(S), H, gridtype, int(bool(align_corners)), code,
-                                            ctypes.cast(ctypes.byref(kb), ctypes.c_void_p), ctypes.cast(ctypes.byref(vb), ctypes.c_void_p)))
-    return arr, int(kb.value), int(vb.value)

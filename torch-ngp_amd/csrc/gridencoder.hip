@@ -997,384 +997,6 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     if (found_inf && __any(nonfinite) && (tid & 63) == 0) found_inf[0] = 1.0f;
 }
 
-// ------------------------------------------------------------------------------------------------
-// backward, KEYED variant of the record path: the sort split into a position-only KEY phase and a gradient VALUE phase.
-//
-// Half of the record sort depends only on where the samples are: cell, corner table indices, which consecutive samples continue a
-// run, which lane issues the run's record, the histogram rank of that record in its slice, the chunk layout, the descriptors.  The
-// sample positions exist as soon as the march is done -- before the forward pass starts, in lookahead mode a whole iteration
-// earlier -- so that half runs as a kernel of its own (k_grid_backward_keys, on the marcher's side stream) and leaves behind
-//   keys16      [level][chunk][slot]          u16   entry index inside the slice (key & 4095, or key >> 7 on round-robin levels),
-//                                                   sorted by slice; every slice's run starts at a multiple of 4 slots
-//   slots       [level][chunk][thread][it][j] u16   where this lane's record goes (13 bits) | REC (bit 13) | SAME (bit 14: the lane
-//                                                   continues its predecessor's run AND the wave voted to merge)
-//   descriptors [level][slice][chunk]         u32   run begin | count << 16
-//   totals      [level][chunk]                u32   slots in use (padded)
-// The critical path keeps k_grid_backward_values: weight x gradient (fp32), the segmented DPP row scan over the stored run structure,
-// ONE fp16x2 rounding per record, a 4-byte LDS store into the precomputed slot and a coalesced copy-out -- no hashing, no histogram
-// atomics, no layout scan, no descriptors -- and k_grid_backward_accumulate_keyed, which reads 6 bytes per record (2 key + 4 value)
-// instead of 8, four records per lane (16-byte value loads), and is otherwise the exact int64 accumulation above.
-// Records exist for every LIVE POSITION (the value-dependent "zero gradient -> no record" of the fused sort is gone: a zero adds
-// nothing); runs are defined by positions alone, summed in fp32 and rounded once per run, sums are exact: bit-reproducible.
-// ------------------------------------------------------------------------------------------------
-constexpr int KEY_PAD = 4;                                        // a slice's run starts at a multiple of 4 slots (16-byte value loads)
-constexpr uint32_t KEY_SLOT_MASK = 0x1fffu, KEY_REC = 0x2000u, KEY_SAME = 0x4000u;
-template <int D>
-struct KeyedLayout {
-    static constexpr int NJ = 1 << (D - 1);
-    static constexpr int MAX_REC = BIN_PPB * 2 * NJ;                          // records a chunk can produce
-    static constexpr int MAX_SLOTS = MAX_REC + (KEY_PAD - 1) * BIN_MAX_BINS;  // + alignment padding of every slice's run
-    static constexpr int SLOT_WORDS = BIN_THREADS * BIN_ITERS * NJ;           // u16 slot words per chunk
-    static_assert(MAX_SLOTS <= (int)KEY_SLOT_MASK + 1, "slot index must fit 13 bits");
-};
-
-struct KeyedPtrs {  // the four arrays of the key workspace (device pointers)
-    uint32_t* descriptors;
-    uint32_t* totals;
-    uint16_t* keys16;
-    uint16_t* slots;
-};
-
-// position-only half of corner_runs<half, D, 2, MERGE = 2>: table index per remaining-corner slot, who issues, who continues a run
-template <int D>
-__device__ __forceinline__ void corner_keys(const float (&x)[D], bool in_range, float scale, bool align_corners, uint32_t interp,
-                                            const LevelIndexer<D>& indexer, InputMap im, uint32_t xb, uint32_t (&addr)[1 << (D - 1)],
-                                            bool (&issue)[1 << (D - 1)], bool (&same_out)[1 << (D - 1)]) {
-    constexpr int NJ = 1 << (D - 1);
-    float frac[D], deriv[D];
-    uint32_t cell[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) { frac[d] = 0.0f; cell[d] = 0u; }
-    bool live = in_range;
-    if (live) live = locate<D>(x, scale, align_corners, interp, frac, deriv, cell, im);
-    uint32_t lower[D], upper[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-        lower[d] = indexer.term(d, cell[d]);
-        upper[d] = lower[d] + indexer.step(d);
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        uint32_t t[D];
-        const uint32_t bit0 = (xb ^ cell[0]) & 1u;
-        t[0] = bit0 ? upper[0] : lower[0];
-#pragma unroll
-        for (int d = 1; d < D; d++) {
-            const uint32_t bit = (((uint32_t)j >> (d - 1)) ^ cell[d]) & 1u;
-            t[d] = bit ? upper[d] : lower[d];
-        }
-        addr[j] = indexer.combine(t);
-    }
-    const uint32_t prev_live = row_shr<2>((uint32_t)live);
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        const uint32_t prev_addr1 = row_shr<2>(addr[j] + 1u);
-        const bool same = live & (prev_live != 0u) & (prev_addr1 == addr[j] + 1u);
-        issue[j] = live;
-        same_out[j] = false;
-        if (__popcll(__ballot(same)) >= 12) {  // the same vote as the fused sort (merge only when a fair share of the wave continues a run)
-            const uint32_t next_same = row_shl<2>((uint32_t)same);
-            issue[j] = live && !next_same;
-            same_out[j] = same;
-        }
-    }
-}
-
-template <int D>
-__global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_keys(const float* __restrict__ inputs, const int32_t* __restrict__ offsets,
-                                                                    uint32_t B, GridLevels lv, uint32_t gridtype, bool align_corners,
-                                                                    uint32_t interp, InputMap im, BinPlan plan, KeyedPtrs kp) {
-    using KL = KeyedLayout<D>;
-    constexpr int NJ = KL::NJ, PTS = 32, WAVES = BIN_THREADS / 64;
-    __shared__ __attribute__((aligned(16))) uint16_t staging[KL::MAX_SLOTS];
-    __shared__ uint32_t hist[BIN_MAX_BINS], loff[BIN_MAX_BINS], wsum[WAVES];
-    const uint32_t li = blockIdx.x / plan.n_chunks, chunk_x = blockIdx.x % plan.n_chunks;
-    const uint32_t level = plan.level[li];
-    const uint32_t n_bins = plan.n_bins[li];
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-    LevelIndexer<D> indexer;
-    indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
-    const float scale = lv.scale[level];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int pl = lane >> 1;
-    const uint32_t xb = (uint32_t)lane & 1u;
-    const uint32_t b_begin = chunk_x * BIN_PPB;
-    const uint32_t b_end = min(B, b_begin + BIN_PPB);
-    const bool interleaved = plan.interleaved[li] != 0;
-    // (the plan was made from the caller's HOST copy of the offsets; a device level that is larger than planned keeps its records inside
-    // the planned slices by clamping the slice -- the host refuses such calls, this only keeps a bad call in bounds)
-    auto bin_of = [&](uint32_t a) { const uint32_t b = interleaved ? (a & (uint32_t)(BIN_DENSE_BINS - 1)) : (a >> BIN_SLICE_BITS); return b < n_bins ? b : n_bins - 1u; };
-    auto local_of = [&](uint32_t a) { return interleaved ? (a >> BIN_DENSE_BITS) : (a & (uint32_t)(BIN_SLICE - 1)); };
-
-    float x[BIN_ITERS][D];
-    bool in_range[BIN_ITERS];
-#pragma unroll
-    for (int it = 0; it < BIN_ITERS; it++) {
-        const uint32_t b = b_begin + (uint32_t)(it * WAVES + wid) * PTS + pl;
-        in_range[it] = b < b_end;
-#pragma unroll
-        for (int d = 0; d < D; d++) x[it][d] = in_range[it] ? inputs[(size_t)b * D + d] : 0.0f;
-    }
-    if (tid < BIN_MAX_BINS) hist[tid] = 0u;
-    __syncthreads();
-    uint32_t raddr[BIN_ITERS * NJ], rrank[BIN_ITERS * NJ];
-    uint32_t rsame = 0u;
-#pragma unroll
-    for (int it = 0; it < BIN_ITERS; it++) {
-        uint32_t addr[NJ];
-        bool issue[NJ], same[NJ];
-        corner_keys<D>(x[it], in_range[it], scale, align_corners, interp, indexer, im, xb, addr, issue, same);
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            raddr[it * NJ + j] = addr[j];
-            rrank[it * NJ + j] = issue[j] ? atomicAdd(&hist[bin_of(addr[j])], 1u) : 0xffffffffu;
-            rsame |= same[j] ? (1u << (it * NJ + j)) : 0u;
-        }
-    }
-    __syncthreads();
-    {   // exclusive scan of the PADDED bin counts -> layout of the sorted chunk; one descriptor per bin
-        const uint32_t cnt = tid < BIN_MAX_BINS ? hist[tid] : 0u;
-        const uint32_t padded = (cnt + (uint32_t)(KEY_PAD - 1)) & ~(uint32_t)(KEY_PAD - 1);
-        uint32_t incl = padded;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wsum[wid] = incl;
-        __syncthreads();
-        uint32_t before = 0u;
-#pragma unroll
-        for (int w = 0; w < WAVES; w++) before += (w < wid) ? wsum[w] : 0u;
-        const uint32_t begin = before + incl - padded;
-        if (tid < BIN_MAX_BINS) loff[tid] = begin;
-        if ((uint32_t)tid < n_bins)
-            kp.descriptors[plan.desc_base[li] + (size_t)tid * plan.n_chunks + chunk_x] = begin | (cnt << 16);  // begin < 8192, cnt <= 4096
-    }
-    __syncthreads();
-    const size_t chunk_id = (size_t)li * plan.n_chunks + chunk_x;
-    uint16_t* __restrict__ slot_out = kp.slots + chunk_id * KL::SLOT_WORDS + (size_t)tid * (BIN_ITERS * NJ);
-    uint16_t words[BIN_ITERS * NJ];
-#pragma unroll
-    for (int r = 0; r < BIN_ITERS * NJ; r++) {
-        uint32_t w = (rsame >> r) & 1u ? KEY_SAME : 0u;
-        if (rrank[r] != 0xffffffffu) {
-            const uint32_t slot = loff[bin_of(raddr[r])] + rrank[r];
-            staging[slot] = (uint16_t)local_of(raddr[r]);
-            w |= KEY_REC | slot;
-        }
-        words[r] = (uint16_t)w;
-    }
-    if constexpr (BIN_ITERS * NJ == 8) {
-        uint4 q;
-        q.x = words[0] | ((uint32_t)words[1] << 16); q.y = words[2] | ((uint32_t)words[3] << 16);
-        q.z = words[4] | ((uint32_t)words[5] << 16); q.w = words[6] | ((uint32_t)words[7] << 16);
-        *reinterpret_cast<uint4*>(slot_out) = q;
-    } else {
-#pragma unroll
-        for (int r = 0; r < BIN_ITERS * NJ; r++) slot_out[r] = words[r];
-    }
-    __syncthreads();
-    uint32_t total = 0u;
-#pragma unroll
-    for (int w = 0; w < WAVES; w++) total += wsum[w];
-    if (tid == 0) kp.totals[chunk_id] = total;
-    // 16 bytes per lane = 8 keys (total is a multiple of 4: the last lane may copy 4 unused slots of the chunk)
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(kp.keys16 + chunk_id * KL::MAX_SLOTS);
-    const uint4* src = reinterpret_cast<const uint4*>(staging);
-    for (uint32_t r = tid; 8u * r < total; r += BIN_THREADS) dst[r] = src[r];
-}
-
-template <int D>
-__global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_values(const half_t* __restrict__ grad, const float* __restrict__ inputs,
-                                                                      uint32_t B, GridLevels lv, bool align_corners, uint32_t interp,
-                                                                      InputMap im, BinPlan plan, const uint32_t* __restrict__ totals,
-                                                                      const uint16_t* __restrict__ slots, uint32_t* __restrict__ values) {
-    using KL = KeyedLayout<D>;
-    constexpr int NJ = KL::NJ, PTS = 32, WAVES = BIN_THREADS / 64;
-    __shared__ __attribute__((aligned(16))) uint32_t staging[KL::MAX_SLOTS];
-    const uint32_t li = blockIdx.x / plan.n_chunks, chunk_x = blockIdx.x % plan.n_chunks;
-    const uint32_t level = plan.level[li];
-    const float scale = lv.scale[level];
-    const half_t* __restrict__ glevel = grad + (size_t)level * B * 2;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int pl = lane >> 1;
-    const uint32_t xb = (uint32_t)lane & 1u;
-    const uint32_t b_begin = chunk_x * BIN_PPB;
-    const uint32_t b_end = min(B, b_begin + BIN_PPB);
-    const size_t chunk_id = (size_t)li * plan.n_chunks + chunk_x;
-    // every global load of the workgroup is in flight before the first use
-    float x[BIN_ITERS][D], g[BIN_ITERS][2];
-    bool in_range[BIN_ITERS];
-    uint32_t words[BIN_ITERS * NJ];
-    {
-        const uint16_t* __restrict__ sl = slots + chunk_id * KL::SLOT_WORDS + (size_t)tid * (BIN_ITERS * NJ);
-        if constexpr (BIN_ITERS * NJ == 8) {
-            const uint4 q = *reinterpret_cast<const uint4*>(sl);
-            words[0] = q.x & 0xffffu; words[1] = q.x >> 16; words[2] = q.y & 0xffffu; words[3] = q.y >> 16;
-            words[4] = q.z & 0xffffu; words[5] = q.z >> 16; words[6] = q.w & 0xffffu; words[7] = q.w >> 16;
-        } else {
-#pragma unroll
-            for (int r = 0; r < BIN_ITERS * NJ; r++) words[r] = sl[r];
-        }
-    }
-    const uint32_t total = totals[chunk_id];
-#pragma unroll
-    for (int it = 0; it < BIN_ITERS; it++) {
-        const uint32_t b = b_begin + (uint32_t)(it * WAVES + wid) * PTS + pl;
-        in_range[it] = b < b_end;
-        g[it][0] = g[it][1] = 0.0f;
-#pragma unroll
-        for (int d = 0; d < D; d++) x[it][d] = in_range[it] ? inputs[(size_t)b * D + d] : 0.0f;
-        if (in_range[it]) {
-            const half2_t t = *reinterpret_cast<const half2_t*>(glevel + (size_t)b * 2);
-            g[it][0] = (float)t.x; g[it][1] = (float)t.y;
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < BIN_ITERS; it++) {
-        float frac[D], deriv[D];
-        uint32_t cell[D];
-#pragma unroll
-        for (int d = 0; d < D; d++) { frac[d] = 0.0f; cell[d] = 0u; }
-        bool live = in_range[it];
-        if (live) live = locate<D>(x[it], scale, align_corners, interp, frac, deriv, cell, im);
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            // this lane's corner of slot j: chosen by the ABSOLUTE parity of the vertex coordinates (corner_runs / corner_keys)
-            const uint32_t bit0 = (xb ^ cell[0]) & 1u;
-            float w = live ? (bit0 ? frac[0] : 1.0f - frac[0]) : 0.0f;
-#pragma unroll
-            for (int d = 1; d < D; d++) {
-                const uint32_t bit = (((uint32_t)j >> (d - 1)) ^ cell[d]) & 1u;
-                w *= bit ? frac[d] : (1.0f - frac[d]);
-            }
-            float v0 = w * g[it][0], v1 = w * g[it][1];
-            const uint32_t word = words[it * NJ + j];
-            const bool same = (word & KEY_SAME) != 0u;
-            if (__ballot(same) != 0ull) {  // the key phase decided to merge runs in this (wave, slot): segmented row scan over its structure
-                uint32_t closed = same ? 0u : 1u;
-#define NGP_KEYED_SCAN_STEP(N)                                                   \
-                {                                                                    \
-                    const uint32_t c_n = row_shr<N>(closed);                        \
-                    const float t0 = row_shr_f<N>(v0), t1 = row_shr_f<N>(v1);      \
-                    v0 += closed ? 0.0f : t0;                                       \
-                    v1 += closed ? 0.0f : t1;                                       \
-                    closed = closed ? 1u : c_n;                                      \
-                }
-                NGP_KEYED_SCAN_STEP(2)
-                NGP_KEYED_SCAN_STEP(4)
-                NGP_KEYED_SCAN_STEP(8)
-#undef NGP_KEYED_SCAN_STEP
-            }
-            if (word & KEY_REC) staging[word & KEY_SLOT_MASK] = pack_half2(v0, v1);
-        }
-    }
-    __syncthreads();
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(values + chunk_id * KL::MAX_SLOTS);
-    const uint4* src = reinterpret_cast<const uint4*>(staging);
-    for (uint32_t r = tid; 4u * r < total; r += BIN_THREADS) dst[r] = src[r];   // (padding slots carry stale LDS words: never read as records)
-}
-
-template <int D>
-__global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_grid_backward_accumulate_keyed(
-    const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid, BinPlan plan, const uint32_t* __restrict__ descriptors,
-    const uint16_t* __restrict__ keys16, const uint32_t* __restrict__ values, float* __restrict__ found_inf) {
-    using KL = KeyedLayout<D>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_smem);                                // [BIN_SLICE][2]
-    uint32_t* poison = reinterpret_cast<uint32_t*>(acc_smem + sizeof(unsigned long long) * 2 * BIN_SLICE);  // [BIN_SLICE / 16], 2 bits per entry
-    const uint32_t li = gridDim.y - 1u - blockIdx.y, bin = blockIdx.x;   // newest records first (see k_grid_backward_accumulate)
-    if (bin >= plan.n_bins[li]) return;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * BIN_SLICE; i += ACC_THREADS) acc[i] = 0ull;
-    if (tid < BIN_SLICE / 16) poison[tid] = 0u;
-    __syncthreads();
-    const uint32_t n_chunks = plan.n_chunks;
-    const uint32_t* __restrict__ desc = descriptors + plan.desc_base[li] + (size_t)bin * n_chunks;
-    const uint16_t* __restrict__ level_keys = keys16 + (size_t)li * n_chunks * KL::MAX_SLOTS;
-    const uint32_t* __restrict__ level_vals = values + (size_t)li * n_chunks * KL::MAX_SLOTS;
-    // A group of 8 lanes walks one run (~32 records on a hashed level) at a time, FOUR records per lane: one 16-byte value load and one
-    // 8-byte key load (runs start at multiples of 4 slots).  Descriptors of the group's next 8 runs come with one load (a lane each).
-    constexpr int GROUP = 8, GROUPS = ACC_THREADS / GROUP, RUNS_AHEAD = 4;
-    const int grp = tid / GROUP, gl = tid % GROUP, lane = tid & 63, group_base = lane & ~(GROUP - 1);
-    auto fixed_addend = [](float v) -> unsigned long long {   // exact fixed-point addend of a finite fp16 value (see k_grid_backward_accumulate)
-        const bool big = __builtin_fabsf(v) >= 128.0f;
-        const int32_t q = (int32_t)(v * (big ? 8.0f : 0x1p24f));
-        return (unsigned long long)(long long)q << (big ? 21 : 0);
-    };
-    auto add_record = [&](const uint32_t idx, const uint32_t val) {
-        const half2_t hv = __builtin_bit_cast(half2_t, val);
-        const bool fin0 = (val & 0x7c00u) != 0x7c00u, fin1 = (val & 0x7c000000u) != 0x7c000000u;
-        __hip_atomic_fetch_add(&acc[2 * idx], fixed_addend(fin0 ? (float)hv.x : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&acc[2 * idx + 1], fixed_addend(fin1 ? (float)hv.y : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!(fin0 && fin1)) atomicOr(&poison[idx >> 4], ((fin0 ? 0u : 1u) | (fin1 ? 0u : 2u)) << ((idx & 15u) * 2u));
-    };
-    auto add4 = [&](const uint2 k, const uint4 v, uint32_t left) {   // up to four records; `left` = records of the run from this lane's first
-        if (left > 0u) add_record(k.x & 0xffffu, v.x);
-        if (left > 1u) add_record(k.x >> 16, v.y);
-        if (left > 2u) add_record(k.y & 0xffffu, v.z);
-        if (left > 3u) add_record(k.y >> 16, v.w);
-    };
-    const uint32_t rot = (bin * 97u) % n_chunks;
-    auto chunk_of = [&](uint32_t i) { const uint32_t k = i + rot; return k >= n_chunks ? k - n_chunks : k; };
-    for (uint32_t k0 = grp; k0 < n_chunks; k0 += GROUPS * GROUP) {  // this group's runs k0 + GROUPS * i, i = 0..GROUP-1 (before rotation)
-        const uint32_t my_k = k0 + (uint32_t)gl * GROUPS;
-        const uint32_t my_desc = desc[chunk_of(my_k < n_chunks ? my_k : k0)];
-#pragma unroll 1
-        for (int i0 = 0; i0 < GROUP; i0 += RUNS_AHEAD) {
-            if (k0 + (uint32_t)i0 * GROUPS >= n_chunks) break;
-            uint32_t base[RUNS_AHEAD], cnt[RUNS_AHEAD];
-            uint4 rv[RUNS_AHEAD];
-            uint2 rk[RUNS_AHEAD];
-#pragma unroll
-            for (int a = 0; a < RUNS_AHEAD; a++) {
-                const uint32_t i = k0 + (uint32_t)(i0 + a) * GROUPS;
-                const uint32_t d = __shfl(my_desc, group_base + i0 + a, 64);
-                const uint32_t k = chunk_of(i < n_chunks ? i : k0);
-                cnt[a] = i < n_chunks ? d >> 16 : 0u;
-                base[a] = k * (uint32_t)KL::MAX_SLOTS + (cnt[a] ? (d & 0xffffu) : 0u);   // < 2^28 slots per level
-                const uint32_t at = base[a] + (4u * gl < cnt[a] ? 4u * gl : 0u);          // unconditional loads at clamped addresses
-                rv[a] = *reinterpret_cast<const uint4*>(level_vals + at);
-                rk[a] = *reinterpret_cast<const uint2*>(level_keys + at);
-            }
-#pragma unroll
-            for (int a = 0; a < RUNS_AHEAD; a++) {
-                const uint32_t first = 4u * gl;
-                add4(rk[a], rv[a], cnt[a] > first ? cnt[a] - first : 0u);
-                for (uint32_t i = 4u * GROUP + first; i < cnt[a]; i += 4u * GROUP) {  // the part of the run beyond 32 records
-                    const uint4 v = *reinterpret_cast<const uint4*>(level_vals + base[a] + i);
-                    const uint2 k = *reinterpret_cast<const uint2*>(level_keys + base[a] + i);
-                    add4(k, v, cnt[a] - i);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t level = plan.level[li];
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-    const bool interleaved = plan.interleaved[li] != 0;
-    half2_t* __restrict__ gtable = reinterpret_cast<half2_t*>(grad_grid + (size_t)off0 * 2);
-    bool nonfinite = false;
-    for (uint32_t i = tid; i < (uint32_t)BIN_SLICE; i += ACC_THREADS) {
-        const uint32_t e = interleaved ? (i << BIN_DENSE_BITS) + bin : bin * BIN_SLICE + i;
-        if (e >= hashmap_size) break;
-        const long long s0 = (long long)acc[2 * i], s1 = (long long)acc[2 * i + 1];
-        const uint32_t bad = (poison[i >> 4] >> ((i & 15u) * 2u)) & 3u;
-        if (s0 == 0 && s1 == 0 && !bad) continue;
-        const half2_t old = gtable[e];
-        const float nan = __builtin_nanf("");
-        half2_t nu;
-        nu.x = (half_t)((float)old.x + ((bad & 1u) ? nan : (float)s0 * 0x1p-24f));
-        nu.y = (half_t)((float)old.y + ((bad & 2u) ? nan : (float)s1 * 0x1p-24f));
-        gtable[e] = nu;
-        nonfinite = nonfinite || !__builtin_isfinite((float)nu.x) || !__builtin_isfinite((float)nu.y);
-    }
-    if (found_inf && __any(nonfinite) && (tid & 63) == 0) found_inf[0] = 1.0f;
-}
-
 // gridencoder.cu:343-369
 template <typename T>
 __global__ void k_grid_input_backward(const T* __restrict__ grad, const T* __restrict__ dy_dx, T* __restrict__ grad_inputs,
@@ -1824,131 +1446,6 @@ extern "C" int ngp_grid_encode_backward(const void* grad, const float* inputs, c
                                         uint32_t interp, int dtype, ngp_stream_t stream) {
     return ngp_grid_encode_backward_ex(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
                                        align_corners, interp, dtype, 0.0f, stream);
-}
-
-// ---- keyed record path (key phase / value phase, see k_grid_backward_keys) ----
-namespace ngp {
-struct KeyedSizes {
-    size_t desc, totals, keys, slots, values;
-    size_t key_bytes() const { return desc + totals + keys + slots; }
-    size_t value_bytes() const { return values + 64; }
-};
-static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
-
-// the keyed path serves calls in which EVERY level is binned (fp16, C = 2, D = 2 or 3, >= 16 k samples): returns false otherwise
-static bool keyed_plan(BackwardPlan& plan, KeyedSizes& ks, const int32_t* offsets_host, const GridLevels& lv, uint32_t B, uint32_t D, uint32_t C,
-                       uint32_t L, int dtype, uint32_t gridtype, bool ac) {
-    plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, ac, true);
-    if (plan.n_binned != L || plan.n_atomic != 0) return false;
-    const size_t chunks = (size_t)plan.n_binned * plan.bins.n_chunks;
-    const size_t max_slots = D == 2 ? KeyedLayout<2>::MAX_SLOTS : KeyedLayout<3>::MAX_SLOTS;
-    const size_t slot_words = D == 2 ? KeyedLayout<2>::SLOT_WORDS : KeyedLayout<3>::SLOT_WORDS;
-    ks.desc = align256((size_t)plan.total_desc * sizeof(uint32_t));
-    ks.totals = align256(chunks * sizeof(uint32_t));
-    ks.keys = align256(chunks * max_slots * sizeof(uint16_t));
-    ks.slots = align256(chunks * slot_words * sizeof(uint16_t));
-    ks.values = align256(chunks * max_slots * sizeof(uint32_t));
-    return true;
-}
-static KeyedPtrs keyed_ptrs(void* key_ws, const KeyedSizes& ks) {
-    unsigned char* p = reinterpret_cast<unsigned char*>(key_ws);
-    KeyedPtrs kp;
-    kp.descriptors = reinterpret_cast<uint32_t*>(p);
-    kp.totals = reinterpret_cast<uint32_t*>(p + ks.desc);
-    kp.keys16 = reinterpret_cast<uint16_t*>(p + ks.desc + ks.totals);
-    kp.slots = reinterpret_cast<uint16_t*>(p + ks.desc + ks.totals + ks.keys);
-    return kp;
-}
-template <int D>
-static int launch_keys(const float* inputs, const int32_t* offsets, uint32_t B, const GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp,
-                       InputMap im, const BackwardPlan& p, KeyedPtrs kp, hipStream_t st) {
-    hipLaunchKernelGGL((k_grid_backward_keys<D>), dim3(p.bins.n_chunks * p.n_binned), dim3(BIN_THREADS), 0, st, inputs, offsets, B, lv, gridtype, ac,
-                       interp, im, p.bins, kp);
-    return check_launch("grid_backward_keys");
-}
-template <int D>
-static int launch_keyed(const void* grad, const float* inputs, const int32_t* offsets, void* grad_emb, uint32_t B, const GridLevels& lv, bool ac,
-                        uint32_t interp, InputMap im, const BackwardPlan& p, KeyedPtrs kp, uint32_t* values, hipStream_t st) {
-    constexpr size_t acc_smem = sizeof(unsigned long long) * 2 * BIN_SLICE + sizeof(uint32_t) * (BIN_SLICE / 16);
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_accumulate_keyed<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)acc_smem) != hipSuccess) {
-            set_error("grid_encode_backward_keyed: hipFuncSetAttribute(LDS size) failed");
-            return NGP_ERR_LAUNCH;
-        }
-        configured = true;
-    }
-    hipLaunchKernelGGL((k_grid_backward_values<D>), dim3(p.bins.n_chunks * p.n_binned), dim3(BIN_THREADS), 0, st, (const half_t*)grad, inputs, B, lv,
-                       ac, interp, im, p.bins, (const uint32_t*)kp.totals, (const uint16_t*)kp.slots, values);
-    int rc = check_launch("grid_encode_backward_keyed(values)");
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_grid_backward_accumulate_keyed<D>), dim3(p.max_bins, p.n_binned), dim3(ACC_THREADS), acc_smem, st, offsets,
-                       (half_t*)grad_emb, p.bins, (const uint32_t*)kp.descriptors, (const uint16_t*)kp.keys16, (const uint32_t*)values, p.found_inf);
-    return check_launch("grid_encode_backward_keyed(accumulate)");
-}
-}  // namespace ngp
-
-extern "C" int ngp_grid_backward_keyed_bytes(const int32_t* offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                                             uint32_t gridtype, int align_corners, int dtype, size_t* key_bytes, size_t* value_bytes) {
-    NGP_REQUIRE(key_bytes && value_bytes, NGP_ERR_INVALID, "grid_backward_keyed_bytes: NULL output");
-    *key_bytes = *value_bytes = 0;
-    if (!offsets_host || L < 1 || L > NGP_MAX_LEVELS || (D != 2 && D != 3)) return NGP_OK;
-    GridLevels lv;
-    fill_levels(lv, L, S, H);
-    BackwardPlan plan;
-    KeyedSizes ks;
-    if (!keyed_plan(plan, ks, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0)) return NGP_OK;
-    *key_bytes = ks.key_bytes();
-    *value_bytes = ks.value_bytes();
-    return NGP_OK;
-}
-
-extern "C" int ngp_grid_backward_keys(const float* inputs, const int32_t* offsets, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
-                                      uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
-                                      const int32_t* offsets_host, void* key_workspace, size_t key_bytes, ngp_stream_t stream) {
-    int rc = check_grid_args("grid_backward_keys", B, D, C, L, dtype);
-    if (rc) return rc;
-    NGP_REQUIRE(inputs && offsets && offsets_host && key_workspace, NGP_ERR_INVALID, "grid_backward_keys: NULL argument");
-    GridLevels lv;
-    fill_levels(lv, L, S, H);
-    BackwardPlan plan;
-    KeyedSizes ks;
-    NGP_REQUIRE((D == 2 || D == 3) && keyed_plan(plan, ks, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0), NGP_ERR_INVALID,
-                "grid_backward_keys: the keyed record path needs fp16 tables with C = 2, D = 2 or 3, >= 16384 samples and every level binned "
-                "(ngp_grid_backward_keyed_bytes() == 0 for this call)");
-    NGP_REQUIRE(ks.key_bytes() <= key_bytes, NGP_ERR_INVALID, "grid_backward_keys: key workspace of %zu bytes, %zu needed", key_bytes, ks.key_bytes());
-    const KeyedPtrs kp = keyed_ptrs(key_workspace, ks);
-    const InputMap im = make_input_map(bound);
-    hipStream_t st = as_stream(stream);
-    return D == 2 ? launch_keys<2>(inputs, offsets, B, lv, gridtype, align_corners != 0, interp, im, plan, kp, st)
-                  : launch_keys<3>(inputs, offsets, B, lv, gridtype, align_corners != 0, interp, im, plan, kp, st);
-}
-
-extern "C" int ngp_grid_encode_backward_keyed(const void* grad, const float* inputs, const int32_t* offsets, void* grad_embeddings, uint32_t B,
-                                              uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
-                                              uint32_t interp, int dtype, float bound, const int32_t* offsets_host, const void* key_workspace,
-                                              size_t key_bytes, void* value_workspace, size_t value_bytes, float* found_inf,
-                                              ngp_stream_t stream) {
-    int rc = check_grid_args("grid_encode_backward_keyed", B, D, C, L, dtype);
-    if (rc) return rc;
-    NGP_REQUIRE(grad && inputs && offsets && grad_embeddings && offsets_host && key_workspace && value_workspace, NGP_ERR_INVALID,
-                "grid_encode_backward_keyed: NULL argument");
-    GridLevels lv;
-    fill_levels(lv, L, S, H);
-    BackwardPlan plan;
-    KeyedSizes ks;
-    NGP_REQUIRE((D == 2 || D == 3) && keyed_plan(plan, ks, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0), NGP_ERR_INVALID,
-                "grid_encode_backward_keyed: not a keyed-path call (ngp_grid_backward_keyed_bytes() == 0)");
-    NGP_REQUIRE(ks.key_bytes() <= key_bytes && ks.value_bytes() <= value_bytes, NGP_ERR_INVALID,
-                "grid_encode_backward_keyed: workspaces of %zu + %zu bytes, %zu + %zu needed", key_bytes, value_bytes, ks.key_bytes(), ks.value_bytes());
-    plan.found_inf = found_inf;
-    const KeyedPtrs kp = keyed_ptrs(const_cast<void*>(key_workspace), ks);
-    const InputMap im = make_input_map(bound);
-    hipStream_t st = as_stream(stream);
-    uint32_t* values = reinterpret_cast<uint32_t*>(value_workspace);
-    return D == 2 ? launch_keyed<2>(grad, inputs, offsets, grad_embeddings, B, lv, align_corners != 0, interp, im, plan, kp, values, st)
-                  : launch_keyed<3>(grad, inputs, offsets, grad_embeddings, B, lv, align_corners != 0, interp, im, plan, kp, values, st);
 }
 
 extern "C" int ngp_grad_total_variation(const void* inputs, const void* embeddings, void* grad, const int32_t* offsets,

@@ -123,19 +123,9 @@ def _network_forward(enc, dirs, d_valid, ws16, wc16, nl_sigma, nl_color, density
     _check(capi.lib.ngp_pipeline_rgb_forward(out16.data_ptr(), rgb.data_ptr(), M, st))
 
 
-def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf=None, key_ws=None):
+def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf=None):
     """hash-grid scatter of the level-major fp16 gradient; large batches take the binned atomic-free path (needs scratch memory).
-    found_inf: optional device float that the kernels set when a table gradient comes out non-finite (the optimizer's sweep, done here).
-    key_ws: the key workspace `_grid_keys` made for these samples -> only the value phase runs here (ngp_grid_encode_backward_keyed)"""
-    if key_ws is not None:
-        arr, kb, vb = capi.grid_backward_keyed_bytes(offsets, M, 3, 2, L, S, H, gridtype, align, capi.NGP_F16)
-        if arr is None or kb == 0 or kb > key_ws.numel():
-            raise RuntimeError('fused: key workspace does not match this grid-backward call')
-        val_ws = torch.empty(vb, dtype=torch.uint8, device=x.device)
-        _check(capi.lib.ngp_grid_encode_backward_keyed(g_enc.data_ptr(), x.data_ptr(), offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
-                                                        gridtype, align, interp, capi.NGP_F16, float(bound), ctypes.cast(arr, ctypes.c_void_p),
-                                                        key_ws.data_ptr(), kb, val_ws.data_ptr(), vb, capi.ptr(found_inf), st))
-        return
+    found_inf: optional device float that the kernels set when a table gradient comes out non-finite (the optimizer's sweep, done here)"""
     arr, ws, nbytes = capi.grid_backward_workspace(offsets, M, 3, 2, L, S, H, gridtype, align, capi.NGP_F16)
     if found_inf is not None and arr is None:
         raise RuntimeError('fused: the in-kernel non-finite sweep needs the host copy of the encoder offsets (call iteration_checks_gradients '
@@ -144,25 +134,6 @@ def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp
                                                       None, None, gridtype, align, interp, capi.NGP_F16, float(bound),
                                                       None if arr is None else ctypes.cast(arr, ctypes.c_void_p), capi.ptr(ws), nbytes,
                                                       capi.ptr(found_inf), st))
-
-
-USE_KEYED_BACKWARD = True   # hash-grid backward as position-only key phase (with the march) + gradient value phase (False: the fused record sort)
-
-
-def _grid_keys(xyzs, offsets, M, cfg, st):
-    """the position-only half of the hash-grid backward (ngp_grid_backward_keys): cell indices, run structure, record slots, slice
-    descriptors of the marched samples -- issued right behind the march (on whatever stream that runs: the lookahead side stream, the
-    graph that overlaps the shadow all-gather, or in line).  -> key workspace tensor, or None when the call is not a keyed-path call."""
-    (bound, L, S, H, gridtype, align, interp, _, _, _) = cfg
-    if not USE_KEYED_BACKWARD or offsets is None:
-        return None
-    arr, kb, vb = capi.grid_backward_keyed_bytes(offsets, M, 3, 2, L, S, H, gridtype, align, capi.NGP_F16)
-    if arr is None or kb == 0:
-        return None
-    key_ws = torch.empty(kb, dtype=torch.uint8, device=xyzs.device)
-    _check(capi.lib.ngp_grid_backward_keys(xyzs.data_ptr(), offsets.data_ptr(), M, 3, 2, L, S, H, gridtype, align, interp, capi.NGP_F16, float(bound),
-                                           ctypes.cast(arr, ctypes.c_void_p), key_ws.data_ptr(), kb, st))
-    return key_ws
 
 
 def _half_weights(embeddings, w_sigma, w_color, bufs):
@@ -225,11 +196,11 @@ def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
 # ------------------------------------------------------------------------------------------------------------------
 def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfield, aabb, counter, cfg, rcfg, noise_seed=None):
     """-> (image, depth, weights_sum, saved): the forward launches of the fused training render on the current stream"""
-    marched = _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, noise_seed, offsets)
+    marched = _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, noise_seed)
     return _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg)
 
 
-def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, noise_seed=None, offsets=None):
+def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, noise_seed=None):
     """the parameter-independent front of the iteration: near/far + march_rays_train (one C call, three launches).  Needs neither the table nor the MLP weights, so
     in data-parallel training it overlaps the all-gather of the freshly updated fp16 shadows (optim.NGPAdam.gather_shadows)."""
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
@@ -257,13 +228,11 @@ def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, nois
                                               max_steps, N, cascade, grid_size, M, aabb.data_ptr(), float(min_near), nears.data_ptr(),
                                               fars.data_ptr(), xyzs.data_ptr(), dirs.data_ptr(), deltas.data_ptr(), rays.data_ptr(),
                                               counter.data_ptr(), noises.data_ptr(), ws.data_ptr(), march_flags, st))
-    # the position-only half of the hash-grid backward rides with the march (offsets given): everything it needs exists now
-    key_ws = _grid_keys(xyzs, offsets, M, cfg, st)
-    return (xyzs, dirs, deltas, rays, nears, fars, ws, key_ws)
+    return (xyzs, dirs, deltas, rays, nears, fars, ws)
 
 
 def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg, composite=True):
-    (xyzs, dirs, deltas, rays, nears, fars, ws, key_ws) = marched
+    (xyzs, dirs, deltas, rays, nears, fars, ws) = marched
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
     (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
     N, M = rays.shape[0], capacity
@@ -284,7 +253,7 @@ def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg, co
     fb_c = torch.empty(nl_color, M, 64, **half)
     _network_forward(enc, dirs, M, ws16, wc16, nl_sigma, nl_color, float(density_scale), True, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M, st)
     if not composite:
-        return (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, None, None, bg, ws, key_ws)
+        return (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, None, None, bg, ws)
     # ---- composite + epilogue ----
     weights_sum = torch.empty(N, **f32)
     depth_raw = torch.empty(N, **f32)
@@ -296,14 +265,14 @@ def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg, co
                                                         float(T_thresh), weights_sum.data_ptr(), depth_raw.data_ptr(), image_raw.data_ptr(),
                                                         bg_mode, float(bg_scalar), capi.ptr(bg), nears.data_ptr(), fars.data_ptr(),
                                                         image.data_ptr(), depth.data_ptr(), st))
-    saved = (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, ws, key_ws)
+    saved = (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, ws)
     return image, depth, weights_sum, saved
 
 
 def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g_wc, found_inf=None):
     """the backward launches: grad_image [N,3] fp32 (and optionally grad_ws [N]) -> gradients accumulated into g_emb (scatter-add, must
     hold the running sum / zeros) and written to g_ws / g_wc (fp16, flat)"""
-    (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, march_ws, key_ws) = saved
+    (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, march_ws) = saved
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
     (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
     M, N = xyzs.shape[0], rays.shape[0]
@@ -325,7 +294,7 @@ def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g
 def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf=None):
     """colour MLP -> exp / feature shuffle -> sigma MLP -> grid scatter, from g_sigma [M] fp32 and g_out16 [M,16] fp16 (CONSUMED: reused as
     the sigma net's output gradient)"""
-    (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, march_ws, key_ws) = saved
+    (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, march_ws) = saved
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
     density_scale = rcfg[8]
     M = xyzs.shape[0]
@@ -361,7 +330,7 @@ def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, fou
         _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
                                               0, 6, 1, scratch[:nl_sigma].data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
                                               _PLANAR_IN | _PLANAR_DX, st))
-    _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf, key_ws)
+    _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf)
 
 
 class _fused_render_train(Function):
@@ -433,7 +402,7 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     target = target.contiguous().view(-1, 3)
     if target.shape[0] != rays_o.shape[0] or target.dtype != torch.float32:
         raise RuntimeError('fused_train_iteration: target must be [N,3] float32')
-    marched = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed, model.encoder.offsets)
+    marched = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
     return _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf)
 
 
@@ -461,7 +430,7 @@ def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg,
         _render_train_backward(saved, cfg, rcfg, grad_image, None, bufs[3], bufs[4].view(-1), bufs[5].view(-1), found_inf)
         return loss, image, depth, weights_sum
     saved = _render_train_network(marched, bufs[0], bufs[1], bufs[2], bg_t, offsets, cfg, rcfg, composite=False)
-    (xyzs, _, _, _, _, _, _, _, _, rgb, sigma, deltas, rays, _, _, bg, march_ws, _) = saved
+    (xyzs, _, _, _, _, _, _, _, _, rgb, sigma, deltas, rays, _, _, bg, march_ws) = saved
     (_, _, _, _, _, _, _, T_thresh, _, bg_scalar) = rcfg
     nears, fars = marched[4], marched[5]
     N, M, dev = rays.shape[0], xyzs.shape[0], xyzs.device
@@ -498,7 +467,7 @@ def fused_train_iteration_split(model, rays_o, rays_d, target, box, counter, cap
     box_ = {}
 
     def march():
-        box_['m'] = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed, model.encoder.offsets)
+        box_['m'] = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
 
     def rest():
         return _train_iteration_rest(box_['m'], bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf)

@@ -16,7 +16,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libngp_hip.so')
+# NGP_HIP_LIBRARY: developer override for A/B runs of compile-time variants (tools/build_variant.sh); default = the in-tree build
+LIB_PATH = os.environ.get('NGP_HIP_LIBRARY') or os.path.join(_HERE, 'libngp_hip.so')
 
 NGP_F32, NGP_F16 = 0, 1
 NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR, NGP_FF_LAYERED, NGP_FF_SINGLE_WAVE, NGP_FF_DEFER_REDUCE = 1, 2, 4, 8, 16

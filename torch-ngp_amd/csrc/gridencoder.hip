@@ -746,7 +746,13 @@ constexpr int BIN_PPB = BIN_ITERS * (BIN_THREADS / 64) * 32;   // samples per wo
 constexpr int BIN_SLICE_BITS = NGP_BIN_SLICE_BITS;             // 4096 table entries per slice / bin
 constexpr int BIN_SLICE = 1 << BIN_SLICE_BITS;
 constexpr int BIN_MAX_BINS = 512;                              // one thread per bin in the layout step
-constexpr int ACC_THREADS = 1024;
+#ifndef NGP_ACC_THREADS
+#define NGP_ACC_THREADS 1024
+#endif
+#ifndef NGP_ACC_RUNS_AHEAD
+#define NGP_ACC_RUNS_AHEAD 4
+#endif
+constexpr int ACC_THREADS = NGP_ACC_THREADS;
 // Dense levels: samples cluster where the scene is, so contiguous slices would be very unevenly loaded (and a 4913-entry level would
 // have two of them).  Their entries are dealt round-robin to BIN_DENSE_BINS workgroups instead: bin = index mod 128, slot = index / 128.
 constexpr int BIN_DENSE_BITS = 7;
@@ -914,7 +920,7 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     // second pass.  The kernel is bound by the bytes it pulls (measured: fetching 64 records per run instead of 32 costs +40 %), so
     // nothing is fetched speculatively.  A group fetches the descriptors of its next 16 runs with ONE load (a lane each), then issues
     // the loads of RUNS_AHEAD runs back to back -- unconditionally, at clamped addresses -- before it touches the accumulator.
-    constexpr int GROUP = 16, GROUPS = ACC_THREADS / GROUP, RUNS_AHEAD = 4;
+    constexpr int GROUP = 16, GROUPS = ACC_THREADS / GROUP, RUNS_AHEAD = NGP_ACC_RUNS_AHEAD;
     const int grp = tid / GROUP, gl = tid % GROUP, lane = tid & 63, group_base = lane & ~(GROUP - 1);
     // Exact fixed-point addend of a finite fp16 value v (11 significant bits), straight-line for BOTH magnitude ranges:
     //   |v| <  128: v * 2^24 is an integer below 2^31                      -> q = (int32) (v * 2^24), addend = q

@@ -14,7 +14,10 @@ import torch.nn as nn
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
-from .backend import _backend
+try:  # the compiled binding first, as the reference does (ffmlp/ffmlp.py:9-12); the ctypes binding of the same C ABI otherwise
+    import _ffmlp as _backend
+except ImportError:
+    from .backend import _backend
 
 ACTIVATION_IDS = {'relu': 0, 'exponential': 1, 'sine': 2, 'sigmoid': 3, 'squareplus': 4, 'softplus': 5}
 

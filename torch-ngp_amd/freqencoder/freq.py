@@ -10,7 +10,10 @@ import torch
 from torch import nn
 from torch.amp import custom_bwd, custom_fwd
 
-from .backend import _backend
+try:  # the compiled binding first, as the reference does (freqencoder/freq.py:9-12); the ctypes binding of the same C ABI otherwise
+    import _freqencoder as _backend
+except ImportError:
+    from .backend import _backend
 
 
 def encoded_width(input_dim, degree):

@@ -17,7 +17,10 @@ import torch.nn as nn
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
-from .backend import _backend
+try:  # the compiled binding first, as the reference does (gridencoder/grid.py:9-12); the ctypes binding of the same C ABI otherwise
+    import _gridencoder as _backend
+except ImportError:
+    from .backend import _backend
 
 GRIDTYPE_IDS = {'hash': 0, 'tiled': 1}
 INTERP_IDS = {'linear': 0, 'smoothstep': 1}

@@ -273,7 +273,7 @@ class NeRFRenderer(nn.Module):
         + graphs 21.3 / 2.0 ms (the frame is bound by its kernels, not by launches: graphs are off by default), device state with the adaptive
         row budget below (`adaptive_n_step`, default) 17.3 / 1.95 ms.  `_loop_debug = []` collects (iterations done, alive bound, boost,
         survival per iteration) at every read-back (tools/render_loop_trace.py)."""
-        from raymarching.backend import _backend as rb
+        from raymarching.raymarching import _backend as rb   # compiled binding when built, else ctypes (same C ABI)
         import _ngp_capi as capi
         n_rays, dev = rays_o.shape[0], rays_o.device
         key = (n_rays, str(dev), float(dt_gamma), int(max_steps), float(T_thresh), float(self.density_scale), self.density_bitfield.data_ptr(),

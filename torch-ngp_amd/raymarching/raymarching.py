@@ -12,7 +12,10 @@ import torch
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
-from .backend import _backend
+try:  # the compiled binding first, as the reference does (raymarching/raymarching.py:9-12); the ctypes binding of the same C ABI otherwise
+    import _raymarching as _backend
+except ImportError:
+    from .backend import _backend
 
 __all__ = ['near_far_from_aabb', 'sph_from_ray', 'morton3D', 'morton3D_invert', 'packbits', 'packbits_capped', 'march_rays_train',
            'composite_rays_train', 'march_rays', 'composite_rays', 'compact_rays']

@@ -6,7 +6,10 @@ import torch.nn as nn
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
-from .backend import _backend
+try:  # the compiled binding first, as the reference does (shencoder/sphere_harmonics.py:8-11); the ctypes binding of the same C ABI otherwise
+    import _shencoder as _backend
+except ImportError:
+    from .backend import _backend
 
 
 class _sh_encoder(Function):

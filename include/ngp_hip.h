@@ -235,6 +235,17 @@ int ngp_grid_encode_backward_ws(const void* grad, const float* inputs, const voi
                                 int dtype, float bound, const int32_t* offsets_host, void* workspace, size_t workspace_bytes,
                                 ngp_stream_t stream);
 
+/* The apply half of the occupancy-grid refresh (NeRFRenderer.update_extra_state, nerf/renderer.py:515-529) in three launches instead of
+ * ~15 PyTorch ones: `tmp_grid[cas, indices] = sigmas` (scatter of density_scale * sigmas), the EMA-max update
+ * `grid = max(grid * decay, tmp)` where both sides are >= 0 (one update per distinct cell), `mean(clamp(grid, 0))` (double, fixed order)
+ * and packbits against min(density_thresh, mean) -- nothing read back.  cells [n] int64: cascade * H^3 + morton index of each queried
+ * point; scratch [n_cells] fp32: -1 everywhere before the first call, left that way; workspace: ngp_density_grid_update_workspace_bytes,
+ * zeroed before the first call. */
+size_t ngp_density_grid_update_workspace_bytes(uint32_t n_cells);
+int ngp_density_grid_update(const float* sigmas, const int64_t* cells, uint32_t n, float density_scale, float decay, float* density_grid,
+                            uint32_t n_cells, float* scratch, float density_thresh, float* mean_out, uint8_t* bitfield, void* workspace,
+                            ngp_stream_t stream);
+
 /* flags of the ffmlp *_ex entry points */
 #define NGP_FF_INPUT_PLANAR 1u /* inputs are [input_dim/2][B][2] fp16 planes = the grid encoder's [L,B,C=2] output */
 #define NGP_FF_DX_PLANAR 2u    /* grad_inputs is written in that planar layout = what grid_encode_backward reads */

@@ -219,6 +219,57 @@ def test_sync_free_occupancy_refresh():
     assert torch.equal(a, b) and torch.equal(c, raymarching.packbits(grid0, 0.25, torch.empty_like(model.density_bitfield)))
 
 
+@pytest.mark.parametrize('bound,full', [(1, False), (1, True), (4, False)])
+def test_fused_occupancy_apply_equals_the_reference_formulation(bound, full):
+    """the three-launch apply half of the occupancy refresh (ngp_density_grid_update) against the reference's PyTorch formulation
+    (nerf/renderer.py:515-529: tmp_grid of -1, index-assign, mask, EMA-max, clamp, mean, packbits) on the SAME sampled cells and
+    positions: cells sampled once bit-identical; a cell sampled several times takes ONE of its fresh densities (index_put_ leaves open
+    which); untouched cells untouched; mean and bitfield consistent with the updated grid; the scratch buffer is back at -1."""
+    import raymarching
+    from nerf.network_ff import NeRFNetwork
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    model = NeRFNetwork(bound=bound, cuda_ray=True, density_thresh=0.01, density_scale=1.5).to(dev).train()
+    with torch.no_grad():
+        model.encoder.embeddings.uniform_(-0.5, 0.5)
+    g0 = (torch.rand_like(model.density_grid) * 0.05 - 0.01)      # some cells negative (never updated: renderer.py:517)
+    cells = model.grid_size ** 3
+    model.density_grid.copy_(g0)
+    model.iter_density = 0 if full else 20
+    with torch.autocast('cuda', dtype=torch.float16):
+        samples = model.refresh_sample(full=full)
+        res = {}
+        for fused in (True, False):
+            model.density_grid.copy_(g0)
+            model.density_bitfield.zero_()
+            model.fused_refresh = fused
+            mean = model.refresh_apply(samples)
+            res[fused] = (model.density_grid.clone(), model.density_bitfield.clone(), float(mean))
+        # the fresh densities themselves, for the duplicate check
+        ids = torch.cat([cid + cas * cells for cas, cid, _ in samples])
+        sig = torch.cat([model._query_sigma(p) for _, _, p in samples]).float()
+    (ga, ba, ma), (gb, bb, mb) = res[True], res[False]
+    counts = torch.bincount(ids, minlength=g0.numel())
+    once = (counts == 1).view_as(g0)
+    never = (counts == 0).view_as(g0)
+    assert once.sum() > 1000
+    assert torch.equal(ga[once], gb[once]), 'cells sampled once: bit-identical with the PyTorch formulation'
+    assert torch.equal(ga[never], g0[never]) and torch.equal(gb[never], g0[never])
+    assert torch.equal(ga[g0 < 0], g0[g0 < 0]), 'cells marked untrained (< 0) are never updated'
+    dup = (counts > 1).view(-1)
+    if dup.any():
+        lo = torch.full((g0.numel(),), float('inf'), device=dev).scatter_reduce(0, ids, sig, 'amin')
+        hi = torch.full((g0.numel(),), -float('inf'), device=dev).scatter_reduce(0, ids, sig, 'amax')
+        old = g0.view(-1)
+        ok_range = (ga.view(-1) >= torch.maximum(old * 0.95, lo) - 1e-7) & (ga.view(-1) <= torch.maximum(old * 0.95, hi) + 1e-7)
+        assert bool(ok_range[dup & (old >= 0)].all())
+    assert abs(ma - float(ga.clamp(min=0).double().mean())) <= 1e-6 * max(1e-3, ma)
+    assert abs(ma - mb) <= 1e-4 * max(1e-3, mb)
+    want = raymarching.packbits(ga, min(ma, model.density_thresh), torch.empty_like(ba))
+    assert torch.equal(ba, want)
+    assert float(model._refresh_state['scratch'].max()) == -1.0 and float(model._refresh_state['scratch'].min()) == -1.0
+
+
 @pytest.mark.parametrize('toggle', ['USE_FUSED_MID', 'USE_FUSED_COMPOSITE', 'USE_FUSED_SCAN'])
 def test_iteration_fusions_are_bit_identical_to_the_unfused_launches(toggle):
     """the optional launch fusions of the autograd-free iteration (colour-head epilogue + one slab reduction; composite + loss + backward in

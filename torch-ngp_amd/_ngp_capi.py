@@ -69,6 +69,7 @@ _SIGNATURES = {
                                     _sz, _vp],
     'ngp_grid_encode_backward_checked': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp,
                                          _vp, _sz, _vp, _vp],
+    'ngp_density_grid_update': [_vp, _vp, _u32, _f32, _f32, _vp, _u32, _vp, _f32, _vp, _vp, _vp, _vp],
     'ngp_ffmlp_forward_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_inference_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_backward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp],
@@ -112,6 +113,8 @@ lib.ngp_ffmlp_backward_workspace_bytes.restype = _sz
 lib.ngp_grid_backward_workspace_bytes.argtypes = [_vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _i32]
 lib.ngp_grid_backward_workspace_bytes.restype = _sz
 lib.ngp_compact_rays_workspace_bytes.restype = _sz
+lib.ngp_density_grid_update_workspace_bytes.argtypes = [_u32]
+lib.ngp_density_grid_update_workspace_bytes.restype = _sz
 
 if lib.ngp_abi_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH}: ABI version {lib.ngp_abi_version()} != expected {ABI_VERSION}; rebuild the extension")
@@ -119,7 +122,7 @@ if lib.ngp_abi_version() != ABI_VERSION:
 EXPORTED = sorted(list(_SIGNATURES) + ['ngp_last_error', 'ngp_target_arch', 'ngp_abi_version',
                                        'ngp_march_rays_train_workspace_bytes', 'ngp_compact_rays_workspace_bytes',
                                        'ngp_grid_backward_workspace_bytes', 'ngp_ffmlp_backward_workspace_bytes',
-                                       'ngp_ffmlp_backward_slab_count'])
+                                       'ngp_ffmlp_backward_slab_count', 'ngp_density_grid_update_workspace_bytes'])
 
 
 def check(rc):

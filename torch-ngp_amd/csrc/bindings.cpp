@@ -222,6 +222,17 @@ void packbits_capped(const Tensor grid, const uint32_t N, const float density_th
     check(ngp_packbits_ex((const float*)ptr(grid), N, density_thresh, (const float*)ptr(thresh_cap), (uint8_t*)ptr(bitfield), stream()));
 }
 
+void density_grid_update(const Tensor sigmas, const Tensor cells, const uint32_t n, const float density_scale, const float decay, Tensor density_grid,
+                         const uint32_t n_cells, Tensor scratch, const float density_thresh, Tensor mean_out, Tensor bitfield, Tensor workspace) {
+    CHECK_F32(sigmas); CHECK_F32(density_grid); CHECK_F32(scratch); CHECK_F32(mean_out);
+    CHECK_DENSE(cells);
+    TORCH_CHECK(cells.scalar_type() == at::ScalarType::Long, "cells must be an int64 tensor");
+    check(ngp_density_grid_update((const float*)ptr(sigmas), (const int64_t*)ptr(cells), n, density_scale, decay, (float*)ptr(density_grid), n_cells,
+                                  (float*)ptr(scratch), density_thresh, (float*)ptr(mean_out), (uint8_t*)ptr(bitfield), ptr(workspace), stream()));
+}
+
+size_t density_grid_update_workspace_bytes(const uint32_t n_cells) { return ngp_density_grid_update_workspace_bytes(n_cells); }
+
 void march_rays_train(const Tensor rays_o, const Tensor rays_d, const Tensor grid, const float bound, const float dt_gamma, const uint32_t max_steps,
                       const uint32_t N, const uint32_t C, const uint32_t H, const uint32_t M, const Tensor nears, const Tensor fars, Tensor xyzs,
                       Tensor dirs, Tensor deltas, Tensor rays, Tensor counter, Tensor noises) {
@@ -385,6 +396,8 @@ PYBIND11_MODULE(_raymarching, m) {
     m.def("composite_rays", &composite_rays, "composite rays (HIP, gfx950)");
     // extensions used by the mirror's on-device inference loop and occupancy refresh (include/ngp_hip.h)
     m.def("packbits_capped", &packbits_capped, "packbits against min(density_thresh, device scalar)");
+    m.def("density_grid_update", &density_grid_update, "occupancy refresh, apply half: scatter / EMA-max / mean / packbits in three launches");
+    m.def("density_grid_update_workspace_bytes", &density_grid_update_workspace_bytes, "bytes of its (zero-initialised) workspace");
     m.def("march_rays_ex", &march_rays_ex, "march_rays that zeroes the rows it does not fill");
     m.def("compact_rays", &compact_rays, "order-preserving compaction of rays_alive");
     m.def("march_rays_dev", &march_rays_dev, "march_rays with the alive count on the device");

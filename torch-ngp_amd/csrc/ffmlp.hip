@@ -363,8 +363,10 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     half8_t* img_s = reinterpret_cast<half8_t*>(smem);
     const uint32_t frags_s = NIB * in_kb + (nl_s - 1) * NIB * NKB + NKB;
     half8_t* img_c = img_s + (size_t)frags_s * 64;
+#ifndef NGP_FF_SKIP_IMAGE  // (timing experiment only: how much of a launch is the weight-image build; results are garbage with it)
     build_forward_image<WIDTH>(img_s, w_sigma, 32, nl_s);
     build_forward_image<WIDTH>(img_c, w_color, 32, nl_c);
+#endif
     const size_t rows = (size_t)n_tiles * FF_TILE;
     __syncthreads();
 
@@ -935,7 +937,9 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img = reinterpret_cast<half8_t*>(smem);
     const uint32_t nfrag = bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx);
+#ifndef NGP_FF_SKIP_IMAGE
     build_backward_image<WIDTH>(img, weights, in_dim, num_layers, with_dx);
+#endif
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = lane & 31, h = lane >> 5;
     const int pair = wid & (FP_PAIRS - 1), role = wid / FP_PAIRS;

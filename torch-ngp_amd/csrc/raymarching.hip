@@ -133,6 +133,91 @@ __global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thr
 }
 
 // ---------------------------------------------------------------------------------------------
+// occupancy-grid refresh, apply half (nerf/renderer.py:515-529): the reference builds a full `tmp_grid` of -1, index-assigns the fresh
+// densities, masks, takes the EMA-max, clamps, means and packs -- about fifteen PyTorch launches over the whole grid.  Here:
+//   k_density_scatter    : scratch[cell] = density_scale * sigma             (`tmp_grid[cas, indices] = sigmas`; duplicates: any one wins,
+//                                                                             as with index_put_)
+//   k_density_apply_mean : one streaming pass over all cells: `grid = max(grid * decay, scratch)` where both are >= 0, the written scratch
+//                          entries go back to -1 (the state the buffer is kept in between calls), mean of max(grid, 0) in double, fixed order
+//   k_packbits           : against min(density_thresh, mean) with the mean still on the device
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RM_THREADS) void k_density_scatter(const float* __restrict__ sigmas, const int64_t* __restrict__ cells, uint32_t n,
+                                                                  float scale, float* __restrict__ scratch, uint32_t n_cells) {
+    const uint32_t i = blockIdx.x * RM_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c = (uint64_t)cells[i];
+    if (c < n_cells) scratch[c] = sigmas[i] * scale;
+}
+
+// one pass over ALL cells (a stream of 2 x 4 B per cell; a per-sample pass would need a fabric atomic per sample to find the first
+// visitor of a cell): cells whose scratch entry was written take the EMA-max and hand the entry back as -1; the same pass sums
+// max(grid, 0) in double -- block partials, the last block (ticket) adds them in a fixed order and writes the mean
+constexpr int DM_THREADS = 256, DM_PER_THREAD = 32;  // 8192 cells per block
+__global__ __launch_bounds__(DM_THREADS) void k_density_apply_mean(float* __restrict__ grid, float* __restrict__ scratch, uint32_t n_cells, float decay,
+                                                                     double* __restrict__ partials, uint32_t* __restrict__ ticket,
+                                                                     float* __restrict__ mean_out) {
+    const uint32_t base = blockIdx.x * (DM_THREADS * DM_PER_THREAD);
+    double acc = 0.0;
+    auto one = [&](float g, float f, bool& touched) {
+        touched = !(f == -1.0f);                                  // written by the scatter (a NaN density counts as written: it is reset, not applied)
+        if (f >= 0.0f && g >= 0.0f) g = fmaxf(g * decay, f);      // renderer.py:517-518: both sides valid
+        acc += (double)fmaxf(g, 0.0f);
+        return g;
+    };
+#pragma unroll 2
+    for (int k = 0; k < DM_PER_THREAD / 4; k++) {
+        const uint32_t i = base + (uint32_t)(k * DM_THREADS + threadIdx.x) * 4u;
+        if (i + 3u < n_cells) {
+            float4_t g = *reinterpret_cast<const float4_t*>(grid + i);
+            const float4_t f = *reinterpret_cast<const float4_t*>(scratch + i);
+            bool t0, t1, t2, t3;
+            g.x = one(g.x, f.x, t0); g.y = one(g.y, f.y, t1); g.z = one(g.z, f.z, t2); g.w = one(g.w, f.w, t3);
+            if (t0 || t1 || t2 || t3) {
+                *reinterpret_cast<float4_t*>(grid + i) = g;
+                *reinterpret_cast<float4_t*>(scratch + i) = float4_t{-1.0f, -1.0f, -1.0f, -1.0f};
+            }
+        } else {
+            for (uint32_t j = i; j < n_cells; j++) {
+                bool t;
+                const float g = one(grid[j], scratch[j], t);
+                if (t) { grid[j] = g; scratch[j] = -1.0f; }
+            }
+        }
+    }
+    __shared__ double part[DM_THREADS / 64];
+    __shared__ bool last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double b = 0.0;
+#pragma unroll
+        for (int w = 0; w < DM_THREADS / 64; w++) b += part[w];
+        // write-through store + own-store wait, then the ticket: the last block reads every partial from memory (see k_composite_train_loss_bwd)
+        __hip_atomic_store(&partials[blockIdx.x], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (!last) return;
+    double t = 0.0;
+    for (uint32_t b = threadIdx.x; b < gridDim.x; b += DM_THREADS) t += __hip_atomic_load(&partials[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < DM_THREADS / 64; w++) sum += part[w];
+        mean_out[0] = (float)(sum / (double)n_cells);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // the marcher (shared by training and inference)          raymarching.cu:312-480, 701-805
 // ---------------------------------------------------------------------------------------------
 struct Ray {
@@ -1176,6 +1261,34 @@ extern "C" int ngp_packbits_ex(const float* grid, uint32_t N, float density_thre
 
 extern "C" int ngp_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, ngp_stream_t stream) {
     return ngp_packbits_ex(grid, N, density_thresh, nullptr, bitfield, stream);
+}
+
+extern "C" size_t ngp_density_grid_update_workspace_bytes(uint32_t n_cells) {
+    return sizeof(double) * (size_t)cdiv(n_cells, DM_THREADS * DM_PER_THREAD) + 64;
+}
+
+// nerf/renderer.py:515-529 in three launches (see k_density_scatter).  cells: global cell index (cascade * H^3 + morton index) of every
+// queried point; scratch [n_cells] fp32 must hold -1 everywhere before the FIRST call and is left that way; workspace
+// (ngp_density_grid_update_workspace_bytes) must be zeroed before the first call.  mean_out[0] = mean(max(grid, 0)) after the update,
+// bitfield = packbits(grid, min(density_thresh, mean)).
+extern "C" int ngp_density_grid_update(const float* sigmas, const int64_t* cells, uint32_t n, float density_scale, float decay, float* density_grid,
+                                       uint32_t n_cells, float* scratch, float density_thresh, float* mean_out, uint8_t* bitfield, void* workspace,
+                                       ngp_stream_t stream) {
+    NGP_REQUIRE(density_grid && scratch && mean_out && bitfield && workspace, NGP_ERR_INVALID, "density_grid_update: NULL tensor");
+    NGP_REQUIRE(n_cells >= 8 && n_cells % 8 == 0, NGP_ERR_INVALID, "density_grid_update: the grid must hold a multiple of 8 cells (got %u)", n_cells);
+    NGP_REQUIRE(((reinterpret_cast<uintptr_t>(density_grid) | reinterpret_cast<uintptr_t>(scratch)) & 15) == 0, NGP_ERR_INVALID,
+                "density_grid_update: grid and scratch must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    if (n) {
+        NGP_REQUIRE(sigmas && cells, NGP_ERR_INVALID, "density_grid_update: NULL tensor");
+        RM_LAUNCH_1D(k_density_scatter, n, st, sigmas, cells, n, density_scale, scratch, n_cells);
+    }
+    const uint32_t blocks = cdiv(n_cells, DM_THREADS * DM_PER_THREAD);
+    double* partials = reinterpret_cast<double*>(workspace);
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(partials + blocks);
+    hipLaunchKernelGGL(k_density_apply_mean, dim3(blocks), dim3(DM_THREADS), 0, st, density_grid, scratch, n_cells, decay, partials, ticket, mean_out);
+    RM_LAUNCH_1D(k_packbits, n_cells / 8, st, (const float*)density_grid, n_cells / 8, density_thresh, (const float*)mean_out, bitfield);
+    return check_launch("density_grid_update");
 }
 
 // workspace: [0] fit_end, [1] ticket of the fused composite/loss/backward kernel (cleared by the scan), [2 .. 2+N) windows per ray, then N x MARCH_MASK_WINDOWS 64-bit emit masks

@@ -474,9 +474,22 @@ class NeRFRenderer(nn.Module):
 
     @torch.no_grad()
     def refresh_apply(self, samples, decay=0.95):
-        """the weight-dependent half: density at the sampled positions, EMA-max update of the cells that are valid on both sides
-        (renderer.py:515-529), bitfield packed against min(mean_density, density_thresh) with the mean still on the device
-        (ngp_packbits_ex).  No host synchronisation (capturable).  Returns the device mean."""
+        """the weight-dependent half: density at the sampled positions (ONE network evaluation over all cascades), then the EMA-max
+        update of the cells that are valid on both sides, the mean of the clamped grid and the bitfield packed against
+        min(mean_density, density_thresh) (renderer.py:515-529) as one native call of three launches (raymarching.update_density_grid;
+        the reference issues ~15 PyTorch launches over the whole grid here).  No host synchronisation (capturable).  Returns the device
+        mean.  `fused_refresh = False` keeps the PyTorch formulation (identical values; tests compare the two)."""
+        cells = self.grid_size ** 3
+        if getattr(self, 'fused_refresh', True) and self.density_grid.is_cuda and self.density_grid.is_contiguous():
+            if len(samples) == 1 and samples[0][0] == 0:
+                ids, pts = samples[0][1], samples[0][2]
+            else:
+                ids = torch.cat([cell_ids + cas * cells for cas, cell_ids, _ in samples], 0)
+                pts = torch.cat([p for _, _, p in samples], 0)
+            sigma = self.density(pts)['sigma'].reshape(-1).detach()      # density_scale is applied by the update kernel
+            state = self.__dict__.setdefault('_refresh_state', {})
+            return raymarching.update_density_grid(sigma, ids, self.density_scale, decay, self.density_grid, self.density_thresh,
+                                                   self.density_bitfield, state).reshape(())
         fresh = -torch.ones_like(self.density_grid)
         for cas, cell_ids, pts in samples:
             fresh[cas, cell_ids] = self._query_sigma(pts)

@@ -57,6 +57,21 @@ def packbits_capped(grid, N, density_thresh, thresh_cap, bitfield):
     capi.check(capi.lib.ngp_packbits_ex(capi.ptr(grid), N, float(density_thresh), capi.ptr(thresh_cap), capi.ptr(bitfield), capi.stream()))
 
 
+def density_grid_update(sigmas, cells, n, density_scale, decay, density_grid, n_cells, scratch, density_thresh, mean_out, bitfield, workspace):
+    """extension: the apply half of the occupancy refresh in three launches (include/ngp_hip.h, ngp_density_grid_update)"""
+    _f32(sigmas, 'sigmas'); _f32(density_grid, 'density_grid'); _f32(scratch, 'scratch'); _f32(mean_out, 'mean_out')
+    capi.dense(cells, 'cells')
+    if cells.dtype != torch.int64:
+        raise RuntimeError("cells must be an int64 tensor")
+    capi.check(capi.lib.ngp_density_grid_update(capi.ptr(sigmas), capi.ptr(cells), n, float(density_scale), float(decay), capi.ptr(density_grid),
+                                                n_cells, capi.ptr(scratch), float(density_thresh), capi.ptr(mean_out), capi.ptr(bitfield),
+                                                capi.ptr(workspace), capi.stream()))
+
+
+def density_grid_update_workspace_bytes(n_cells):
+    return int(capi.lib.ngp_density_grid_update_workspace_bytes(n_cells))
+
+
 def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
                      counter, noises):
     for t, n in ((rays_o, 'rays_o'), (rays_d, 'rays_d'), (nears, 'nears'), (fars, 'fars'), (xyzs, 'xyzs'), (dirs, 'dirs'),
@@ -192,7 +207,8 @@ composite_rays_train_backward = _accept_half(composite_rays_train_backward)
 _backend = types.SimpleNamespace(
     march_rays_dev=march_rays_dev, composite_rays_dev=composite_rays_dev, compact_rays_dev=compact_rays_dev,
     near_far_from_aabb=near_far_from_aabb, sph_from_ray=sph_from_ray, morton3D=morton3D, morton3D_invert=morton3D_invert,
-    packbits=packbits, packbits_capped=packbits_capped, march_rays_train=march_rays_train, composite_rays_train_forward=composite_rays_train_forward,
+    packbits=packbits, packbits_capped=packbits_capped, density_grid_update=density_grid_update,
+    density_grid_update_workspace_bytes=density_grid_update_workspace_bytes, march_rays_train=march_rays_train, composite_rays_train_forward=composite_rays_train_forward,
     composite_rays_train_backward=composite_rays_train_backward, march_rays=march_rays, march_rays_ex=march_rays_ex,
     composite_rays=composite_rays,
     compact_rays=compact_rays)

@@ -73,7 +73,8 @@ TIMED = {
     # the whole network behind the encoder in one launch: enc 64 B + dir 12 B in, both forward buffers + h16 32 B + colour input 64 B + sigma 4 B +
     # rgb 12 B out per sample; flops of both MLPs
     'ngp_network_forward': ('network_forward', 2,
-                            lambda a: 64.0 + 12.0 + 128.0 * (a[6] + a[7]) + 32.0 + 64.0 + 4.0 + 12.0, lambda a: _ff_flops(a[6]) + _ff_flops(a[7]), 'sample'),
+                            lambda a: (64.0 + 12.0 + 128.0 * (a[6] + a[7]) + 32.0 + 64.0 + 4.0 + 12.0) if a[9] else (64.0 + 12.0 + 4.0 + 12.0),
+                            lambda a: _ff_flops(a[6]) + _ff_flops(a[7]), 'sample'),
     'ngp_ffmlp_backward_ex': ('ffmlp_backward', 4, lambda a: _ff_bwd_bytes(a[8]), lambda a: 2.0 * _ff_flops(a[8]), 'sample'),
 }
 
@@ -83,7 +84,7 @@ class KernelTimers:
     stream, which is what `_ngp_capi.stream()` hands to the library)."""
 
     def __init__(self, capi):
-        self.capi, self.records, self.enabled, self.orig, self.step = capi, {}, False, {}, 0
+        self.capi, self.records, self.enabled, self.orig, self.step, self.suffix = capi, {}, False, {}, 0, ''
         for sym in TIMED:
             self.orig[sym] = getattr(capi.lib, sym)
             setattr(capi.lib, sym, self._wrap(sym))
@@ -99,7 +100,7 @@ class KernelTimers:
             a.record()
             rc = inner(*args)
             b.record()
-            self.records.setdefault(label, []).append((a, b, int(args[b_idx]), fbytes(args), fflops(args), unit, self.step))
+            self.records.setdefault(label + self.suffix, []).append((a, b, int(args[b_idx]), fbytes(args), fflops(args), unit, self.step))
             return rc
         return call
 
@@ -150,7 +151,7 @@ SETUP_ITERATIONS = 33  # 16 worst-case-sized eager steps + the first estimate-si
 class TrainingRun:
     """one configuration of the training workload (model + optimizer + stepper + resident batches) and its timing protocol"""
 
-    def __init__(self, args, dev, world, rank, fused, graph, torch_optim, autograd, rays=None):
+    def __init__(self, args, dev, world, rank, fused, graph, torch_optim, autograd, rays=None, config5=False):
         import raymarching
         import synthetic_scene as sc
         import ddp
@@ -160,10 +161,21 @@ class TrainingRun:
         self.args, self.dev, self.world, self.rank, self.use_graph, self.torch_optim = args, dev, world, rank, graph, torch_optim
         self.rays = int(rays if rays is not None else args.rays)   # rays per GPU and step
         torch.manual_seed(0)  # identical parameters on every rank (FFMLP reseeds to 42 itself)
-        model = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
+        self.config5 = config5
+        if config5:
+            # BASELINE config 5's shape (Tanks&Temples-style, main_nerf.py:44-47,80): bound = 8 -> 4 cascades, dt_gamma = 1/128, background
+            # model on a radius-32 sphere (2-D hash grid + nn.Linear head), nn.Linear sigma / colour networks (nerf/network.py: there is
+            # no --ff background model in the reference), rays marched through all four cascades
+            from nerf.network import NeRFNetwork as NeRFNetworkLinear
+            model = NeRFNetworkLinear(bound=8, cuda_ray=True, bg_radius=32.0, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
+            grid = sc.occupancy_density(bound=8.0, cascade=4)
+            grid = np.maximum(grid, np.where(np.random.default_rng(5).uniform(size=grid.shape) < 0.02, 30.0, 0.0).astype(np.float32))
+            occ = torch.from_numpy(grid).to(dev)
+        else:
+            model = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
+            occ = torch.from_numpy(sc.occupancy_density()).to(dev)
         model.train()
         model.fused = fused
-        occ = torch.from_numpy(sc.occupancy_density()).to(dev)
         model.density_grid.copy_(occ)
         model.density_bitfield = raymarching.packbits(model.density_grid, 10.0, model.density_bitfield)
         fixed_bits = model.density_bitfield.clone()
@@ -201,8 +213,12 @@ class TrainingRun:
         self.pool = []
         for k in range(self.n_pool):
             o, d, gt = sc.training_batch(self.rays, seed=1000 * rank + k)
+            if config5:
+                o = o * np.float32(2.0)   # cameras at twice the lego distance: rays cross cascades 0..3 of the bound-8 box
             self.pool.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
         self.opt_kwargs = dict(staged=False, bg_color=1, perturb=True, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+        if config5:
+            self.opt_kwargs.update(bg_color=None, dt_gamma=1.0 / 128)
 
         def keep_scene(m):
             # N > 1: the occupancy exchange of the data-parallel path (element-wise MAX of the grid + re-pack + common sample estimate)
@@ -309,6 +325,92 @@ class TrainingRun:
         return f'hip-graph replay ({st.n_captures} iteration + {st.n_update_captures} refresh capture(s), all before the timed region){la}'
 
 
+def sdf_encoder_mlp(dev, sizes=(1 << 18, 1 << 21), reps=12):
+    """BASELINE config 4 (main_sdf.py --fp16 --ff, sdf/netowrk_ff.py:9-48): hash grid (L16 F2 T2^19, 16 -> 2048) + FFMLP(32 -> 64 x 3 -> 1), no ray
+    marching -- the configuration that isolates the encoder / MLP rooflines.  Per batch size (2^18 = main_sdf.py:43's points per step,
+    2^21 = testing/test_ffmlp.py:100) the four kernels of one training step are timed on uniform points with HIP events on the launch
+    stream (median of `reps` launches, every launch on fresh uniform-random inputs already resident in HBM): grid_encode_forward,
+    ffmlp_forward (training: stores activations), ffmlp_backward (+dL/dx), grid_encode_backward (record sort + exact slice accumulation).
+    Algorithmic bytes / flops per point as SURVEY.md 8(d).  Untimed relative to the headline metric."""
+    import ctypes
+    import _ngp_capi as capi
+    from encoding import get_encoder
+    from ffmlp import FFMLP
+    torch.manual_seed(0)
+    enc, in_dim = get_encoder('hashgrid')
+    enc = enc.to(dev)
+    net = FFMLP(input_dim=in_dim, output_dim=1, hidden_dim=64, num_layers=3).to(dev)
+    emb16 = enc.embeddings.detach().half().uniform_(-0.1, 0.1)
+    w16 = net.weights.detach().half()
+    offs = enc.offsets
+    L, S, H = int(enc.num_levels), float(np.log2(enc.per_level_scale)), int(enc.base_resolution)
+    nl = 3
+    out = {'config': 'main_sdf.py --fp16 --ff: hashgrid L16 F2 T2^19 (16 -> 2048) + FFMLP 32 -> 64x3 -> 1 (output padded to 16), uniform points in [0,1]^3',
+           'unit': 'us per launch (median), HIP events on the launch stream', 'batches': {}}
+
+    def timed(fn, fresh=None):
+        ts = []
+        for i in range(reps + 2):
+            if fresh is not None:
+                fresh()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                ts.append(a.elapsed_time(b))
+        return float(np.median(ts)) * 1e-3   # seconds
+
+    st = capi.stream
+    for B in sizes:
+        x = torch.rand(B, 3, device=dev)
+        enc_out = torch.empty(L, B, 2, device=dev, dtype=torch.half)
+        fb = torch.empty(nl, B, 64, device=dev, dtype=torch.half)
+        y = torch.empty(B, 16, device=dev, dtype=torch.half)
+        gy = torch.zeros(B, 16, device=dev, dtype=torch.half)
+        gy[:, 0] = (torch.randn(B, device=dev) * 0.1).half()
+        bb = torch.empty(nl, B, 64, device=dev, dtype=torch.half)
+        g_enc = torch.empty(L, B, 2, device=dev, dtype=torch.half)
+        gw = torch.zeros(w16.numel(), device=dev, dtype=torch.half)
+        g_emb = torch.zeros_like(emb16)
+        arr, ws, nbytes = capi.grid_backward_workspace(offs, B, 3, 2, L, S, H, 0, False, capi.NGP_F16)
+
+        def k_gf():
+            capi.check(capi.lib.ngp_grid_encode_forward_ex(x.data_ptr(), emb16.data_ptr(), offs.data_ptr(), enc_out.data_ptr(), B, 3, 2, L, S, H, None, 0, 0, 0,
+                                                           capi.NGP_F16, 0.0, st()))
+
+        def k_ff():
+            capi.check(capi.lib.ngp_ffmlp_forward_ex(enc_out.data_ptr(), w16.data_ptr(), B, 32, 16, 64, nl, 0, 6, fb.data_ptr(), y.data_ptr(),
+                                                     capi.NGP_FF_INPUT_PLANAR, st()))
+
+        def k_fb():
+            capi.check(capi.lib.ngp_ffmlp_backward_ex(gy.data_ptr(), enc_out.data_ptr(), w16.data_ptr(), fb.data_ptr(), B, 32, 16, 64, nl, 0, 6, 1,
+                                                      bb.data_ptr(), g_enc.data_ptr(), gw.data_ptr(), capi.NGP_FF_INPUT_PLANAR | capi.NGP_FF_DX_PLANAR, st()))
+
+        def k_gb():
+            capi.check(capi.lib.ngp_grid_encode_backward_checked(g_enc.data_ptr(), x.data_ptr(), None, offs.data_ptr(), g_emb.data_ptr(), B, 3, 2, L, S, H,
+                                                                 None, None, 0, 0, 0, capi.NGP_F16, 0.0,
+                                                                 None if arr is None else ctypes.cast(arr, ctypes.c_void_p), capi.ptr(ws), nbytes, None, st()))
+        rows = {}
+        for name, fn, byts, flops, fresh in (
+                ('grid_encode_forward', k_gf, 588.0, 0.0, lambda: x.uniform_()),
+                ('ffmlp_forward', k_ff, _ff_fwd_bytes(nl), _ff_flops(nl), None),
+                ('ffmlp_backward', k_fb, _ff_bwd_bytes(nl), 2.0 * _ff_flops(nl), None),
+                ('grid_encode_backward', k_gb, 1100.0, 0.0, lambda: g_emb.zero_())):
+            t = timed(fn, fresh)
+            row = {'us': round(t * 1e6, 1), 'bytes_per_point': byts, 'achieved_GBps': round(B * byts / t / 1e9, 1),
+                   'hbm_frac': round(B * byts / t / 1e9 / HBM_PEAK_GBS, 4)}
+            if flops:
+                row['mfma_TFLOPs'] = round(B * flops / t / 1e12, 2)
+                row['mfma_frac'] = round(B * flops / t / 1e12 / MFMA_F16_PEAK_TFLOPS, 5)
+            rows[name] = row
+        total = sum(r['us'] for r in rows.values())
+        out['batches'][str(B)] = {'kernels': rows, 'sum_us': round(total, 1), 'points_per_s_kernels_only': round(B / (total * 1e-6), 1)}
+        del x, enc_out, fb, y, gy, bb, g_enc, ws
+    return out
+
+
 def cpu_baselines(args):
     """rank 0, N = 1: (a) the reference's pure-PyTorch device='cpu' path on the host cores this container may use, (b) the scalar-C
     oracle on one thread.  (a) runs in a subprocess with a hard timeout: an intra-op pool larger than the container's CPU quota can
@@ -392,6 +494,8 @@ def main():
                     '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID, USE_FUSED_SCAN, USE_FUSED_CHECK); recorded in config.fusions_off')
     ap.add_argument('--dropin-steps', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the untimed extra workloads: sdf_encoder_mlp (BASELINE config 4) and tnt_bound8 (config 5)')
+    ap.add_argument('--extra-steps', type=int, default=48)
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='N > 1: weak = --rays per GPU (global batch grows with N, the headline); strong = --rays in total, --rays / N per GPU')
@@ -519,6 +623,19 @@ def main():
             if world > 1:
                 dist.all_reduce(best, op=dist.ReduceOp.MAX)
             render[name] = round(float(best.item()), 2)
+        if rank == 0 and not args.no_roofline:
+            # the inference kernels of one more opaque frame with HIP-event pairs (encoder and fused network launches of the eval loop; the
+            # march / composite / compaction kernels of the loop are in the committed rocprofv3 summary, profiles/)
+            model.density_scale = 300.0
+            timers.suffix, timers.enabled, timers.step = ' (800x800 render, opaque frame)', True, 1 << 30
+            with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+                (ddp.render_sharded(model, ro, rd, **rkw) if world > 1 else model.render(ro, rd, **rkw))
+            torch.cuda.synchronize()
+            timers.suffix, timers.enabled = '', False
+            for r in timers.summary():
+                if r['kernel'].endswith('opaque frame)'):
+                    r['traffic_source'] = None
+                    roofs.append(r)
         model.density_scale = 1
         model.train()
 
@@ -551,6 +668,21 @@ def main():
                   'execution': 'eager launches, module-by-module network (model.fused = False), torch.optim.Adam(fused) + GradScaler',
                   'final_loss': d_res['final_loss']}
         del d_run
+
+    sdf = tnt = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        sdf = sdf_encoder_mlp(dev)
+        # BASELINE config 5 as a measured workload: the bound-8 / 4-cascade / dt_gamma = 1/128 / background-model training step through the
+        # drop-in modules (nerf/network.py nn.Linear networks: the reference has no --ff background model), torch Adam + GradScaler, eager
+        t_run = TrainingRun(args, dev, 1, 0, fused=False, graph=False, torch_optim=True, autograd=True, config5=True)
+        t_run.setup(4)
+        t_res = t_run.timed(args.extra_steps)
+        tnt = {'config': 'Tanks&Temples-shaped: bound=8, 4 cascades x 128^3, dt_gamma=1/128, background model (radius-32 sphere, 2-D hashgrid + nn.Linear), '
+                         'nn.Linear sigma/colour networks (nerf/network.py), --fp16 --cuda_ray, 4096 rays, torch.optim.Adam(fused) + GradScaler, eager launches',
+               'value': round(t_res['samples'] / t_res['elapsed'], 1), 'unit': 'samples/s', 'steps': args.extra_steps,
+               'ms_per_step': round(t_res['elapsed'] / args.extra_steps * 1e3, 4),
+               'samples_per_step': round(t_res['samples'] / args.extra_steps, 1), 'final_loss': t_res['final_loss']}
+        del t_run
 
     if rank == 0:
         roof = None
@@ -588,7 +720,7 @@ def main():
                        'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
                        'final_loss': res['final_loss']},
             'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'dropin_path': dropin, 'render_800x800_ms': render,
-            'strong_scaling': strong,
+            'strong_scaling': strong, 'sdf_encoder_mlp': sdf, 'tnt_bound8': tnt,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -232,6 +232,33 @@ class TorchNeRF(nn.Module):
         h = torch.cat([self.encoder_dir(d), self.encoder_bg(x)], -1)
         return torch.sigmoid(_run_mlp(self.bg_net, h))
 
+    # ---- the same network with the ROUNDING POINTS of the Trainer's fp16 autocast (nerf/utils.py:557: `with torch.cuda.amp.autocast`) ----
+    # The parameters must already hold fp16-representable values (autocast casts them per call).  Under autocast the grid encoder returns
+    # fp16 (grid.py:43-44,57), every nn.Linear takes fp16 inputs and returns fp16 (fp32 accumulation inside the GEMM), ReLU and sigmoid keep
+    # fp16, trunc_exp computes in fp32 on the fp16 value (activation.py:8, custom_fwd(cast_inputs=float32)), the SH encoder returns fp32 and
+    # is rounded to fp16 where the colour / background stack takes it in.  Each rounding is `.half().float()` on the fp32 CPU value.
+    @staticmethod
+    def _h(t):
+        return t.half().float()
+
+    def _run_mlp_autocast(self, layers, h):
+        h = self._h(h)
+        for i, lin in enumerate(layers):
+            h = self._h(lin(h))
+            if i != len(layers) - 1:
+                h = F.relu(h)
+        return h
+
+    def forward_autocast(self, x, d):
+        h = self._run_mlp_autocast(self.sigma_net, self._h(self.encoder(x, bound=self.bound)))
+        sigma = torch.exp(h[..., 0].clamp(max=88.0))
+        rgb = self._h(torch.sigmoid(self._run_mlp_autocast(self.color_net, torch.cat([self.encoder_dir(d), h[..., 1:]], -1))))
+        return sigma, rgb
+
+    def background_autocast(self, x, d):
+        h = torch.cat([self.encoder_dir(d), self._h(self.encoder_bg(x))], -1)
+        return self._h(torch.sigmoid(self._run_mlp_autocast(self.bg_net, h)))
+
     def run(self, rays_o, rays_d, num_steps=128, upsample_steps=0, bg_color=None, perturb=False, **kwargs):
         """nerf/renderer.py:125-253 with upsample_steps == 0 (main_nerf.py:30 default for this path)"""
         assert upsample_steps == 0, 'the importance-resampling branch is not part of the timed baseline'

@@ -124,10 +124,19 @@ def test_cuda_ray_training_step_with_background_model_vs_oracle():
     sd = {k: v.detach().cpu().half().float() for k, v in m.state_dict().items() if 'embeddings' in k or 'weight' in k}
     ref.load_state_dict(sd, strict=False)
     with torch.no_grad():
-        sigma, rgb = ref(torch.from_numpy(xyzs[:mm]), torch.from_numpy(dirs[:mm]))
-        bgc = ref.background(tc.sph_from_ray(torch.from_numpy(o), torch.from_numpy(d), bg_radius), torch.from_numpy(d)).numpy()
+        # the oracle applies the rounding points of the autocast run (fp16 encoder output, fp16 output of every Linear / sigmoid; fp32
+        # accumulation inside each GEMM): what is left is fp32 summation order inside the GEMMs and exp / sigmoid implementations
+        sigma, rgb = ref.forward_autocast(torch.from_numpy(xyzs[:mm]), torch.from_numpy(dirs[:mm]))
+        bgc = ref.background_autocast(tc.sph_from_ray(torch.from_numpy(o), torch.from_numpy(d), bg_radius), torch.from_numpy(d)).numpy()
+        sigma32, rgb32 = ref(torch.from_numpy(xyzs[:mm]), torch.from_numpy(dirs[:mm]))
     ws, dep, img = oracle.composite_rays_train_forward(sigma.numpy(), rgb.numpy(), deltas[:mm], rays)
     want = img + (1 - ws)[:, None] * bgc
     got = out['image'][0].detach().float().cpu().numpy()
-    assert np.abs(got - want).max() < 5e-3, np.abs(got - want).max()
-    np.testing.assert_allclose(out['weights_sum'].detach().cpu().numpy(), ws, rtol=0, atol=5e-3)
+    err_img = np.abs(got - want).max()
+    err_ws = np.abs(out['weights_sum'].detach().cpu().numpy() - ws).max()
+    # bar: 1e-3 of the colour range (north-star); the fp32-activation oracle (no rounding points) sits at ~4e-3, which is the fp16 Linear
+    # outputs of the reference's own autocast path, not this implementation
+    assert err_img < 1e-3, err_img
+    assert err_ws < 1e-3, err_ws
+    ws32, _, img32 = oracle.composite_rays_train_forward(sigma32.numpy(), rgb32.numpy(), deltas[:mm], rays)
+    assert np.abs(img - img32).max() < 2e-2      # the two oracles bracket the fp16 effect

@@ -73,7 +73,11 @@ def test_render_eval_image_matches_oracle_loop():
                            dt_gamma=0, max_steps=1024, T_thresh=1e-4)
     # the training-style oracle composite visits the same samples as the chunked inference loop (tests/test_oracle_kat.py)
     ref = orc.train_step(o, d, np.zeros((2048, 3), np.float32), bits, np.zeros(2048, np.float32), with_backward=False)
-    np.testing.assert_allclose(out['image'][0].float().cpu().numpy(), ref['image'], rtol=0, atol=4e-3)
+    # the eval loop composites through `T = 1 - weights_sum` (raymarching.cu:866) where the training compositor carries a running product
+    # (:543): same samples, same rounding points in the network, a different fp32 recurrence -- measured 3e-5 on MI355X; bar = 1e-3 of the
+    # colour range (the north-star's tolerance)
+    err = np.abs(out['image'][0].float().cpu().numpy() - ref['image']).max()
+    assert err < 1e-3, err
 
 
 @pytest.mark.parametrize('density_scale,perturb', [(1.0, False), (40.0, False), (300.0, True)])

@@ -12,7 +12,8 @@ are staged, unmodified, into the git-ignored directory `_refstage/` (`tools/run_
   --side mirror              this repo's nerf/network_ff.py + nerf/renderer.py over this repo's operator packages (module-by-module path)
   --side reference-callers   the reference's network_ff.py + renderer.py over this repo's operator packages
   --side reference-all       the reference's callers AND wrappers; only `_gridencoder/_shencoder/_raymarching/_ffmlp` (what the
-                             reference builds from CUDA sources) are this repo's `_backend` objects over libngp_hip.so
+                             reference builds from CUDA sources) are this repo's: the compiled pybind modules torch-ngp_amd/_*.so
+                             (NGP_A24_CTYPES=1: the ctypes `_backend` objects instead), both over libngp_hip.so
   --compare A.npz B.npz      counters / rays / bitfields bit-exact, images / losses / gradients / parameters to fp16 tolerance
 
 Environment stubs (not reference code): `trimesh`, `mcubes`, `turtle` (ffmlp.py imports it by accident; needs tkinter) and
@@ -83,8 +84,15 @@ def build_side(side):
     if side == 'reference-all':
         # the reference's wrappers import `_gridencoder` etc. first (grid.py:9-12): hand them this repo's backend objects
         for pkg, native in (('gridencoder', '_gridencoder'), ('shencoder', '_shencoder'), ('raymarching', '_raymarching'), ('ffmlp', '_ffmlp')):
+            if os.path.isfile(os.path.join(PKG, native + '.so')) and os.environ.get('NGP_A24_CTYPES') != '1':
+                # the compiled binding of this repo under the reference's first-choice import name: nothing to hand over, the
+                # reference wrapper's own `import _gridencoder as _backend` finds torch-ngp_amd/_gridencoder.so
+                importlib.import_module(native)
+                where[native] = sys.modules[native].__file__
+                continue
             ours = _load_file(f'_ngp_backend_{pkg}', os.path.join(PKG, pkg, 'backend.py'))
             sys.modules[native] = ours._backend
+            where[native] = ours.__file__ + ' (ctypes _backend object)'
         sys.path.insert(0, STAGE)  # gridencoder/, shencoder/, raymarching/, ffmlp/, encoding.py, activation.py now resolve to the reference's
     ref_pkg = types.ModuleType('refnerf')
     ref_pkg.__path__ = [os.path.join(STAGE, 'nerf')]

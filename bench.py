@@ -66,6 +66,7 @@ TIMED = {
     'ngp_ffmlp_forward': ('ffmlp_forward', 2, lambda a: _ff_fwd_bytes(a[6]), lambda a: _ff_flops(a[6]), 'sample'),
     'ngp_ffmlp_backward': ('ffmlp_backward', 4, lambda a: _ff_bwd_bytes(a[8]), lambda a: 2.0 * _ff_flops(a[8]), 'sample'),
     'ngp_grid_encode_forward_ex': ('grid_encode_forward', 4, lambda a: 588.0, lambda a: 0.0, 'point'),
+    'ngp_grid_encode_forward_sched': ('grid_encode_forward', 4, lambda a: 588.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_ex': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_ws': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_checked': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
@@ -377,8 +378,8 @@ def sdf_encoder_mlp(dev, sizes=(1 << 18, 1 << 21), reps=12):
         arr, ws, nbytes = capi.grid_backward_workspace(offs, B, 3, 2, L, S, H, 0, False, capi.NGP_F16)
 
         def k_gf():
-            capi.check(capi.lib.ngp_grid_encode_forward_ex(x.data_ptr(), emb16.data_ptr(), offs.data_ptr(), enc_out.data_ptr(), B, 3, 2, L, S, H, None, 0, 0, 0,
-                                                           capi.NGP_F16, 0.0, st()))
+            capi.check(capi.lib.ngp_grid_encode_forward_sched(x.data_ptr(), emb16.data_ptr(), offs.data_ptr(), enc_out.data_ptr(), B, 3, 2, L, S, H, None, 0, 0,
+                                                              0, capi.NGP_F16, 0.0, None, st()))
 
         def k_ff():
             capi.check(capi.lib.ngp_ffmlp_forward_ex(enc_out.data_ptr(), w16.data_ptr(), B, 32, 16, 64, nl, 0, 6, fb.data_ptr(), y.data_ptr(),
@@ -629,7 +630,7 @@ def main():
             model.density_scale = 300.0
             timers.suffix, timers.enabled, timers.step = ' (800x800 render, opaque frame)', True, 1 << 30
             with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
-                (ddp.render_sharded(model, ro, rd, **rkw) if world > 1 else model.render(ro, rd, **rkw))
+                model.render(ro, rd, **rkw)   # rank 0 alone, the whole frame: no collective in here
             torch.cuda.synchronize()
             timers.suffix, timers.enabled = '', False
             for r in timers.summary():

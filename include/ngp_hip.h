@@ -210,6 +210,14 @@ int ngp_grid_encode_backward_ex(const void* grad, const float* inputs, const voi
                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                 uint32_t interp, int dtype, float bound, ngp_stream_t stream);
+/* grid_encode_forward_ex with relative per-level costs from the caller (HOST array of L positive floats, e.g. the expected fraction of
+ * consecutive samples that change cell at each level): the launch's per-XCD work lists are balanced by them -- whole levels stay on XCD
+ * (level mod 8), the tail of the most loaded XCDs' last level moves to the least loaded ones.  Scheduling only: the arithmetic per
+ * (level, point) and the results are identical.  level_cost_host == NULL: ngp_grid_encode_forward_ex (every level costs the same). */
+int ngp_grid_encode_forward_sched(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                  uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                  uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
+                                  const float* level_cost_host, ngp_stream_t stream);
 
 /* grid_encode_backward_ex with a caller-provided workspace: fp16 tables with C = 2 and D <= 3 (the instant-ngp configuration) then
  * run the HASHED levels WITHOUT memory-side atomics -- contributions are sorted by table slice (8-byte records, coalesced stores) and

@@ -20,7 +20,7 @@ def test_bench_two_ranks_share_one_gpu(extra):
     # plain `python bench.py --gpus 2`, NO launcher: bench.py re-executes itself under torch.distributed.run with one process per rank
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-dropin',
            '--strong-steps', '4'] + (['--no-render'] if extra else []) + extra
-    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
     assert res.returncode == 0, res.stderr[-3000:]
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['config']['captures_in_timed_region'] == 0

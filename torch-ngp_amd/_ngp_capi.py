@@ -64,6 +64,7 @@ _SIGNATURES = {
     'ngp_ffmlp_inference': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     'ngp_ffmlp_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
     'ngp_grid_encode_forward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
+    'ngp_grid_encode_forward_sched': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _f32, _vp, _vp],
     'ngp_grid_encode_backward_ex': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
     'ngp_grid_encode_backward_ws': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp, _vp,
                                     _sz, _vp],
@@ -196,3 +197,24 @@ def grid_backward_workspace(offsets, B, D, C, L, S, H, gridtype, align_corners, 
     if n == 0:
         return arr, None, 0
     return arr, torch.empty(n, dtype=torch.uint8, device=offsets.device), n
+
+
+_LEVEL_COSTS = {}
+
+
+def ray_level_costs(L, S, H, step_unit):
+    """relative cost per level of gathering ray-ordered samples `step_unit` apart (in the encoder's unit cube) -- for
+    ngp_grid_encode_forward_sched.  A level costs the more the more often consecutive samples change cell: measured on MI355X 19 us
+    (level 0, resolution 16) .. 46 us (resolution >= ~700 at a step of 1/590: saturated) per level and XCD
+    (profiles/r03_grid_forward_levels.txt), i.e. 0.41 + 0.59 * min(1, resolution * step / 1.2).  Returns a c_void_p to a cached host
+    float array (kept alive here)."""
+    key = (int(L), float(S), int(H), round(float(step_unit), 9))
+    hit = _LEVEL_COSTS.get(key)
+    if hit is None:
+        scale = (ctypes.c_float * L)()
+        res = (ctypes.c_uint32 * L)()
+        check(lib.ngp_grid_level_table(L, float(S), H, ctypes.cast(scale, ctypes.c_void_p), ctypes.cast(res, ctypes.c_void_p)))
+        arr = (ctypes.c_float * L)(*[0.41 + 0.59 * min(1.0, float(res[l]) * float(step_unit) / 1.2) for l in range(L)])
+        hit = (arr, ctypes.cast(arr, ctypes.c_void_p))
+        _LEVEL_COSTS[key] = hit
+    return hit[1]

@@ -20,6 +20,8 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 namespace ngp {
 
@@ -309,6 +311,17 @@ __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward(const float* __res
 //   half sums are combined with one DPP quad permute per channel.
 // ------------------------------------------------------------------------------------------------
 constexpr int FWD_PTS_PER_WAVE = 32;
+// Work list per XCD.  Whole levels go to XCD (level mod 8) as described above; that alone leaves the XCDs unevenly loaded when the levels
+// differ in cost -- on ray-ordered samples a level costs the more the finer it is (consecutive samples stop sharing cells and cache lines):
+// measured 19 .. 46 us per level on one XCD, XCD 0 (levels 0, 8) done after 47 us, XCD 7 (levels 7, 15) after 70 us, and the launch lasts
+// as long as the slowest XCD (profiles/r03_grid_forward_levels.txt).  With per-level costs from the caller the tail of the most loaded
+// XCDs' last level is handed, tile range by tile range, to the least loaded ones.
+constexpr int FWD_MAX_SEG = 8;
+struct FwdSchedule {
+    uint16_t level[8][FWD_MAX_SEG];
+    uint32_t tile0[8][FWD_MAX_SEG];
+    uint32_t end[8][FWD_MAX_SEG];   // slots of this XCD consumed after the segment (cumulative); unused segments repeat the last value
+};
 
 __device__ __forceinline__ float quad_swap1(float v) {  // value of lane ^ 1 (DPP quad_perm [1,0,3,2])
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -318,12 +331,20 @@ template <typename T, int D, int C>
 __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid,
                                                                    const int32_t* __restrict__ offsets, T* __restrict__ outputs,
                                                                    uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
-                                                                   bool align_corners, uint32_t interp, uint32_t tiles_per_level,
+                                                                   bool align_corners, uint32_t interp, FwdSchedule sched,
                                                                    uint32_t points_per_block, InputMap im) {
     constexpr int NJ = 1 << (D - 1);
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const uint32_t li = slot / tiles_per_level, tile = slot - li * tiles_per_level;
-    const uint32_t level = xcd + 8u * li;
+    uint32_t level = 0xffffu, tile = 0u, begin = 0u;
+#pragma unroll
+    for (int sg = 0; sg < FWD_MAX_SEG; sg++) {   // this XCD's work list: runs of consecutive tiles of one level, in order
+        const uint32_t e = sched.end[xcd][sg];
+        if (level == 0xffffu && slot < e) {
+            level = sched.level[xcd][sg];
+            tile = sched.tile0[xcd][sg] + (slot - begin);
+        }
+        begin = e;
+    }
     if (level >= L) return;
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
@@ -1098,10 +1119,68 @@ static uint32_t fwd_blocks(uint32_t B) {
     return nb < 1 ? 1 : (nb > 65535u ? 65535u : nb);
 }
 
+#ifndef NGP_FWD_BALANCE
+#define NGP_FWD_BALANCE 1
+#endif
+// level_cost[l]: relative time of one tile of level l (nullptr: unknown -> every level costs the same -> whole levels only, the plain
+// (level mod 8) placement).  Returns the number of slots of the longest work list.
+static uint32_t build_forward_schedule(FwdSchedule& sc, uint32_t L, uint32_t tiles, const float* level_cost) {
+    struct Seg { uint32_t level, tile0, n; };
+    std::vector<Seg> list[8];
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto cost = [&](uint32_t l) { return level_cost ? (double)level_cost[l] : 1.0; };
+    for (uint32_t l = 0; l < L; l++) {
+#ifdef NGP_FWD_LEVEL_MASK_PROBE  // timing probe only (profiles/r03_grid_forward_levels.txt): launch only the levels of a bit mask
+        if (const char* mk = getenv("NGP_FWD_LEVEL_MASK")) { if (!((strtoul(mk, nullptr, 0) >> l) & 1ul)) continue; }
+#endif
+        list[l & 7u].push_back({l, 0u, tiles});
+        load[l & 7u] += cost(l) * tiles;
+    }
+    if (NGP_FWD_BALANCE && level_cost && L > 8) {
+        double target = 0.0;
+        for (int x = 0; x < 8; x++) target += load[x] / 8.0;
+        for (int round = 0; round < 16; round++) {
+            int hi = 0, lo = 0;
+            for (int x = 1; x < 8; x++) {
+                if (load[x] > load[hi]) hi = x;
+                if (load[x] < load[lo]) lo = x;
+            }
+            if (load[hi] - target < 0.02 * target || list[lo].size() >= (size_t)FWD_MAX_SEG || list[hi].empty()) break;
+            Seg& last = list[hi].back();               // the donor gives away the END of the level it processes last
+            const double c = cost(last.level);
+            uint32_t n = (uint32_t)(std::min(load[hi] - target, target - load[lo]) / c);
+            if (n == 0) break;
+            if (n >= last.n) n = last.n > 1 ? last.n - 1 : 0;
+            if (n == 0) break;
+            last.n -= n;
+            list[lo].push_back({last.level, last.tile0 + last.n, n});
+            load[hi] -= c * n;
+            load[lo] += c * n;
+        }
+    }
+    uint32_t max_slots = 0;
+    for (int x = 0; x < 8; x++) {
+        uint32_t e = 0;
+        for (int sg = 0; sg < FWD_MAX_SEG; sg++) {
+            if (sg < (int)list[x].size()) {
+                sc.level[x][sg] = (uint16_t)list[x][sg].level;
+                sc.tile0[x][sg] = list[x][sg].tile0;
+                e += list[x][sg].n;
+            } else {
+                sc.level[x][sg] = 0xffffu;
+                sc.tile0[x][sg] = 0u;
+            }
+            sc.end[x][sg] = e;
+        }
+        max_slots = e > max_slots ? e : max_slots;
+    }
+    return max_slots;
+}
+
 template <typename T, int D, int C>
 static int launch_forward(const float* inputs, const void* emb, const int32_t* offsets, void* outputs, uint32_t B,
                           uint32_t L, const GridLevels& lv, void* dy_dx, uint32_t gridtype, bool ac, uint32_t interp,
-                          InputMap im, hipStream_t st) {
+                          InputMap im, const float* level_cost, hipStream_t st) {
     if (dy_dx) {
         dim3 grid(fwd_blocks(B), L, 1);
         hipLaunchKernelGGL((k_grid_forward<T, D, C, true>), grid, dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
@@ -1112,9 +1191,10 @@ static int launch_forward(const float* inputs, const void* emb, const int32_t* o
     uint32_t ppb = 1024;
     while (ppb > 128 && (uint64_t)cdiv(B, ppb) * L < 2048) ppb >>= 1;
     const uint32_t tiles = cdiv(B, ppb);
-    const uint32_t blocks = 8u * cdiv(L, 8u) * tiles;
-    hipLaunchKernelGGL((k_grid_forward_pair<T, D, C>), dim3(blocks), dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
-                       (T*)outputs, B, L, lv, gridtype, ac, interp, tiles, ppb, im);
+    FwdSchedule sched;
+    const uint32_t max_slots = build_forward_schedule(sched, L, tiles, level_cost);
+    hipLaunchKernelGGL((k_grid_forward_pair<T, D, C>), dim3(8u * max_slots), dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
+                       (T*)outputs, B, L, lv, gridtype, ac, interp, sched, ppb, im);
     return check_launch("grid_encode_forward");
 }
 
@@ -1342,10 +1422,10 @@ static InputMap make_input_map(float bound) {
     return im;
 }
 
-extern "C" int ngp_grid_encode_forward_ex(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
-                                          uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
-                                          uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
-                                          ngp_stream_t stream) {
+extern "C" int ngp_grid_encode_forward_sched(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                             uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
+                                             const float* level_cost_host, ngp_stream_t stream) {
     int rc = check_grid_args("grid_encode_forward", B, D, C, L, dtype);
     NGP_REQUIRE(!(bound > 0.0f && dy_dx), NGP_ERR_INVALID, "grid_encode_forward: the fused input mapping does not provide dy_dx");
     const InputMap im = make_input_map(bound);
@@ -1356,13 +1436,24 @@ extern "C" int ngp_grid_encode_forward_ex(const float* inputs, const void* embed
     fill_levels(lv, L, S, H);
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
+    const float* level_cost = level_cost_host;
+    for (uint32_t l = 0; level_cost && l < L; l++)
+        NGP_REQUIRE(level_cost[l] > 0.0f && level_cost[l] < 1e6f, NGP_ERR_INVALID, "grid_encode_forward: level_cost[%u] must be positive and finite", l);
     if (dtype == NGP_F16) {
-        NGP_DISPATCH_DC(launch_forward, half_t, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, im, st)
+        NGP_DISPATCH_DC(launch_forward, half_t, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, im, level_cost, st)
     } else {
-        NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, im, st)
+        NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, im, level_cost, st)
     }
     set_error("grid_encode_forward: unsupported (D=%u, C=%u)", D, C);
     return NGP_ERR_INVALID;
+}
+
+extern "C" int ngp_grid_encode_forward_ex(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                          uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                          uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
+                                          ngp_stream_t stream) {
+    return ngp_grid_encode_forward_sched(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, dtype,
+                                         bound, nullptr, stream);
 }
 
 extern "C" int ngp_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,

@@ -47,8 +47,8 @@ class _fused_ngp(Function):
         half = dict(device=dev, dtype=torch.half)
 
         enc = torch.empty(L, M, 2, **half)
-        _check(capi.lib.ngp_grid_encode_forward_ex(x.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
-                                                    None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
+        _check(capi.lib.ngp_grid_encode_forward_sched(x.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
+                                                    None, gridtype, align, interp, capi.NGP_F16, float(bound), None, st))
         h16 = torch.empty(M, 16, **half)
         color_in = torch.empty(M, 32, **half)
         out16 = torch.empty(M, 16, **half)
@@ -242,8 +242,9 @@ def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg, co
     half = dict(device=dev, dtype=torch.half)
     # ---- network ----
     enc = torch.empty(L, M, 2, **half)
-    _check(capi.lib.ngp_grid_encode_forward_ex(xyzs.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
-                                                None, gridtype, align, interp, capi.NGP_F16, float(bound), st))
+    _check(capi.lib.ngp_grid_encode_forward_sched(xyzs.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
+                                                None, gridtype, align, interp, capi.NGP_F16, float(bound),
+                                                   capi.ray_level_costs(L, S, H, 3.0 ** 0.5 / (max_steps * max(float(bound), 1e-6))) if USE_BALANCED_FORWARD else None, st))
     h16 = torch.empty(M, 16, **half)
     color_in = torch.empty(M, 32, **half)
     out16 = torch.empty(M, 16, **half)
@@ -406,6 +407,7 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     return _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf)
 
 
+USE_BALANCED_FORWARD = True  # encoder launch of the training step: per-XCD work lists balanced by per-level cost of ray-ordered samples (False: whole levels)
 USE_FUSED_CHECK = True      # the optimizer's non-finite sweep is done by the gradient-producing kernels (False: NGPAdam's CHECK launch)
 USE_FUSED_SCAN = True       # the marcher's write pass hands out the sample slots itself (False: scan launch between the passes)
 USE_FUSED_MID = True        # colour-head backward writes grad_h16 itself; one slab reduction for both MLPs (False: five launches)
@@ -494,10 +496,10 @@ def fused_density(x, encoder, sigma_net, bound):
     w16 = w16 if w16 is not None else w.detach().to(torch.half)
     L = int(encoder.num_levels)
     enc = torch.empty(L, M, 2, device=dev, dtype=torch.half)
-    _check(capi.lib.ngp_grid_encode_forward_ex(x.contiguous().data_ptr(), emb16.data_ptr(), encoder.offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L,
+    _check(capi.lib.ngp_grid_encode_forward_sched(x.contiguous().data_ptr(), emb16.data_ptr(), encoder.offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L,
                                                 float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution), None,
                                                 int(encoder.gridtype_id), int(bool(encoder.align_corners)), int(encoder.interp_id),
-                                                capi.NGP_F16, float(bound), st))
+                                                capi.NGP_F16, float(bound), None, st))
     h16 = torch.empty(M, 16, device=dev, dtype=torch.half)
     _check(capi.lib.ngp_ffmlp_inference_ex(enc.data_ptr(), w16.data_ptr(), M, 32, 16, 64, int(sigma_net.num_layers), 0, 6, None, h16.data_ptr(),
                                            _PLANAR_IN, st))

@@ -23,7 +23,7 @@ NGP_F32, NGP_F16 = 0, 1
 NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR, NGP_FF_LAYERED, NGP_FF_SINGLE_WAVE, NGP_FF_DEFER_REDUCE = 1, 2, 4, 8, 16
 NGP_MARCH_RESET_COUNTER, NGP_MARCH_ZERO_TAIL, NGP_MARCH_NOISE_FROM_SEED, NGP_MARCH_SCAN_LAUNCH = 1, 2, 4, 8
 NGP_OPT_PHASE_CHECK, NGP_OPT_PHASE_UPDATE, NGP_OPT_PHASE_COMMIT = 1, 2, 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -104,7 +104,10 @@ __device__ __forceinline__ uint32_t fwd_frag_count(uint32_t in_dim, uint32_t num
 // Every workgroup pays for this before its first tile, so the loop is organised around memory latency: the sources of IMG_BATCH
 // fragments per thread are worked out first, ALL their loads are issued (unconditionally, at clamped addresses), and only then is
 // anything stored -- one round trip to L2 per batch instead of one per fragment (measured: ~12 us of fixed cost per launch before).
-constexpr int IMG_BATCH = 8;
+#ifndef NGP_FF_IMG_BATCH
+#define NGP_FF_IMG_BATCH 8
+#endif
+constexpr int IMG_BATCH = NGP_FF_IMG_BATCH;
 
 // where the two 8-byte halves of fragment element e come from (nullptr: zeros)
 template <int WIDTH>

@@ -37,6 +37,16 @@ worst case and read back, which cannot be captured, and `step()` simply runs eag
 import torch
 
 
+def _capture_into(g, **kw):
+    """torch.cuda.graph(g, ...).  With a torch.distributed process group alive its watchdog thread polls HIP events while this thread
+    captures; in the default 'global' capture mode such a call from ANOTHER thread invalidates the capture -- 'thread_local' restricts the
+    check to the capturing thread (the data-parallel path captures three graphs around its collectives)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        kw.setdefault('capture_error_mode', 'thread_local')
+    return torch.cuda.graph(g, **kw)
+
+
 def mse_loss(out, target):
     # mean over rays and channels of the squared error (nerf/utils.py:516,557) through PyTorch's fused MSE kernels
     return torch.nn.functional.mse_loss(out['image'][0], target)
@@ -217,7 +227,7 @@ class GraphedTrainStep:
             self._capture_lookahead()
         elif self.averager is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _capture_into(g):
                 self.loss = self._iteration_front().detach()
                 self._iteration_back()
             self.graphs = (g,)
@@ -235,22 +245,22 @@ class GraphedTrainStep:
             opt.wait_shadows()
             torch.cuda.synchronize()
             ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with _capture_into(ga):
                 march()
-            with torch.cuda.graph(gb, pool=ga.pool()):
+            with _capture_into(gb, pool=ga.pool()):
                 self.loss = rest()[0][0].detach()
                 if not self._checked_ok:
                     opt.pre_reduce_check()     # (else the kernels that deposited the local gradients flagged them)
-            with torch.cuda.graph(gc_, pool=ga.pool()):
+            with _capture_into(gc_, pool=ga.pool()):
                 opt.apply()
             self.graphs = (ga, gb, gc_)
             self.sharded = True
             self.used_direct = True
         else:  # the RCCL all-reduce stays eager between the two halves
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with _capture_into(g1):
                 self.loss = self._iteration_front().detach()
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with _capture_into(g2, pool=g1.pool()):
                 self._iteration_back()
             self.graphs = (g1, g2)
         self.n_captures += 1
@@ -271,9 +281,9 @@ class GraphedTrainStep:
                                                       kw.get('T_thresh', 1e-4), noise_seed=self.la_seed[p:p + 1],
                                                       found_inf=opt.scalars[2:3] if self._checked_ok else None)
             gm, gr = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gm, pool=pool_march):
+            with _capture_into(gm, pool=pool_march):
                 march()
-            with torch.cuda.graph(gr, pool=pool_rest):
+            with _capture_into(gr, pool=pool_rest):
                 opt.zero_grad(set_to_none=True)
                 loss = rest()[0][0].detach()
                 self._iteration_back()
@@ -300,15 +310,15 @@ class GraphedTrainStep:
                 gs, ga = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 if getattr(self, '_sample_pool', None) is None:
                     self._sample_pool = torch.cuda.graph_pool_handle()
-                with torch.cuda.graph(gs, pool=self._sample_pool):
+                with _capture_into(gs, pool=self._sample_pool):
                     samples = m.refresh_sample(full=full)
-                with torch.cuda.graph(ga, pool=self._rest_pool):
+                with _capture_into(ga, pool=self._rest_pool):
                     with torch.autocast('cuda', dtype=self.autocast_dtype):
                         mean = m.refresh_apply(samples)
                 self.update_graphs[full] = (ga, mean, gs, samples)
             else:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.graphs[0].pool()):
+                with _capture_into(g, pool=self.graphs[0].pool()):
                     with torch.autocast('cuda', dtype=self.autocast_dtype):
                         mean = m.refresh_occupancy(full=full)
                 self.update_graphs[full] = (g, mean)

@@ -380,3 +380,40 @@ def test_backward_binned_all_index_modes(D, gridtype, align, interp):
     import _ngp_capi as capi
     arr = (ctypes.c_int32 * len(offs))(*[int(v) for v in offs])
     assert capi.lib.ngp_grid_backward_workspace_bytes(ctypes.cast(arr, ctypes.c_void_p), B, D, C, L, S, 8, gridtype, int(align), capi.NGP_F16) > 0
+
+
+@pytest.mark.parametrize('B', [4096, 100001])
+def test_forward_balanced_work_lists_are_scheduling_only(B):
+    """ngp_grid_encode_forward_sched: per-level costs from the caller re-balance the per-XCD work lists (tile ranges of the most loaded
+    XCDs' last level move to the least loaded ones); the arithmetic per (level, point) does not change -> bit-identical outputs for any
+    cost vector, with the ray-sample model of the training path, with extreme costs (many moved segments) and with none; non-positive or
+    non-finite costs are refused (RuntimeError)."""
+    import ctypes
+    import _ngp_capi as capi
+    rng = np.random.default_rng(B)
+    offs, pls = oracle.grid_offsets(**LEGO)
+    S = float(np.log2(pls))
+    x = torch.from_numpy(_points(B, 3, rng)).cuda()
+    emb = torch.from_numpy(oracle.round_fp16(rng.uniform(-1, 1, (int(offs[-1]), 2)).astype(np.float32))).cuda().half()
+    ot = torch.from_numpy(offs).cuda()
+
+    def run(costs):
+        out = torch.full((16, B, 2), float('nan'), device='cuda', dtype=torch.half)
+        arr = None if costs is None else (ctypes.c_float * 16)(*costs)
+        rc = capi.lib.ngp_grid_encode_forward_sched(x.data_ptr(), emb.data_ptr(), ot.data_ptr(), out.data_ptr(), B, 3, 2, 16, S, 16, None, 0, 0, 0,
+                                                    capi.NGP_F16, 0.0, None if arr is None else ctypes.cast(arr, ctypes.c_void_p), capi.stream())
+        capi.check(rc)
+        torch.cuda.synchronize()
+        return out
+
+    base = run(None)
+    assert torch.isfinite(base.float()).all(), 'every (level, point) written exactly once'
+    ref, _ = _run_forward(x.cpu().numpy(), emb.float().cpu().numpy(), offs, S, 16, torch.float16)
+    assert np.array_equal(base.float().cpu().numpy(), ref), 'no costs == the reference-contract entry point'
+    model = ctypes.cast(capi.ray_level_costs(16, S, 16, 3.0 ** 0.5 / 1024), ctypes.POINTER(ctypes.c_float * 16)).contents
+    for costs in (list(model), [1.0] * 16, [0.05] * 8 + [1.0] * 8, [1.0] * 8 + [0.05] * 8, list(np.linspace(0.1, 3.0, 16)), [1e-3] * 15 + [50.0]):
+        got = run(costs)
+        assert torch.equal(got.view(torch.int16), base.view(torch.int16)), costs
+    for bad in ([0.0] + [1.0] * 15, [1.0] * 15 + [float('nan')], [-1.0] * 16):
+        with pytest.raises(RuntimeError):
+            run(bad)

@@ -4,9 +4,10 @@
 combined with --pmc):
 
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-roofline
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph --no-roofline
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/rNN_pmc_traffic.json
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o run -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline ...
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o run -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline ...
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write ["<how bench.py ran>"] > profiles/rNN_pmc_traffic.json
+(tools/final_evidence.sh runs the two passes in bench.py's DEFAULT mode: HIP-graph replay with the lookahead march on the side stream)
 
 Units and corrections (guide, section HBM): the counters are in KiB-like units (bytes = value * 1024); on gfx950 FETCH_SIZE reports
 exactly half of the bytes of a wide (16 B per lane) coalesced streaming read, so the read side of the streaming kernels (ffmlp,
@@ -63,7 +64,9 @@ def main():
                        'note': 'raw FETCH_SIZE, 4-byte gather/scatter width uncalibrated' if factor == 1.0 else
                                'FETCH_SIZE doubled (16 B/lane streaming reads are tallied at half, MI355X_MICROARCH.md HBM section)'}
     json.dump({'per_launch': per_launch, 'detail': detail, 'unit': 'bytes of HBM traffic per kernel launch',
-               'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py --no-graph'}, sys.stdout, indent=1)
+               'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on ' +
+                         (sys.argv[3] if len(sys.argv) > 3 else 'python bench.py (default mode: HIP-graph replay, lookahead march on the side stream)')},
+              sys.stdout, indent=1)
 
 
 if __name__ == '__main__':

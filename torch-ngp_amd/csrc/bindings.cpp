@@ -60,25 +60,34 @@ inline Tensor scratch(size_t bytes, const Tensor& like) {
 }
 
 // HOST copy of a grid encoder's `offsets` (steers the plan of the record-sort backward): read back once per tensor, never during stream
-// capture (the workspace-free atomic path serves that call instead)
+// capture (the workspace-free atomic path serves that call instead).  An entry is valid only for the SAME, still living tensor object
+// (weak reference to its TensorImpl) at the same version: an address handed out again by the caching allocator is a miss.
 const int32_t* host_offsets(const Tensor& offsets) {
     struct Entry {
-        int64_t numel;
+        c10::weak_intrusive_ptr<c10::TensorImpl> owner;
         uint32_t version;
         std::vector<int32_t> v;
     };
     static std::mutex mu;
-    static std::unordered_map<const void*, Entry> cache;
+    static std::unordered_map<const c10::TensorImpl*, Entry> cache;
     std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(offsets.data_ptr());
-    if (it != cache.end() && it->second.numel == offsets.numel() && it->second.version == offsets._version()) return it->second.v.data();
+    const c10::TensorImpl* impl = offsets.unsafeGetTensorImpl();
+    auto it = cache.find(impl);
+    if (it != cache.end()) {
+        auto alive = it->second.owner.lock();
+        if (alive && alive.get() == impl && it->second.version == offsets._version() && (int64_t)it->second.v.size() == offsets.numel())
+            return it->second.v.data();
+        cache.erase(it);
+    }
     if (c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None) return nullptr;
     Tensor h = offsets.to(at::kCPU).contiguous();
-    Entry e{offsets.numel(), offsets._version(), std::vector<int32_t>(h.data_ptr<int32_t>(), h.data_ptr<int32_t>() + h.numel())};
-    if (cache.size() > 64) cache.clear();
-    auto& slot = cache[offsets.data_ptr()];
-    slot = std::move(e);
-    return slot.v.data();
+    if (cache.size() > 64) {   // drop entries whose tensors are gone
+        for (auto e = cache.begin(); e != cache.end();) e = e->second.owner.expired() ? cache.erase(e) : std::next(e);
+        if (cache.size() > 64) cache.clear();
+    }
+    Entry e{c10::weak_intrusive_ptr<c10::TensorImpl>(offsets.getIntrusivePtr()), offsets._version(),
+            std::vector<int32_t>(h.data_ptr<int32_t>(), h.data_ptr<int32_t>() + h.numel())};
+    return cache.insert_or_assign(impl, std::move(e)).first->second.v.data();
 }
 
 // ---- gridencoder (gridencoder.h:12-15) ----

@@ -108,11 +108,13 @@ def test_bound8_four_cascade_training_step():
     assert want['n_samples'] == total
     for fused in (True, False):
         err = np.abs(res[fused][0] - want['image']).max()
+        print(f'bound-8 image vs oracle (fused={fused}): {err:.2e}')
         assert err < 1e-3, (fused, err)
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=0, atol=1e-4)
     g_ref = want['grads'][0]
     for fused in (True, False):
         rel = np.linalg.norm(res[fused][1] / 1024.0 - g_ref) / np.linalg.norm(g_ref)
+        print(f'bound-8 table gradient vs oracle (fused={fused}): rel L2 {rel:.2e}')
         assert rel < 2e-3, (fused, rel)
     rel = np.linalg.norm(res[True][1] - res[False][1]) / np.linalg.norm(res[False][1])
     assert rel < 2e-3

@@ -104,10 +104,7 @@ __device__ __forceinline__ uint32_t fwd_frag_count(uint32_t in_dim, uint32_t num
 // Every workgroup pays for this before its first tile, so the loop is organised around memory latency: the sources of IMG_BATCH
 // fragments per thread are worked out first, ALL their loads are issued (unconditionally, at clamped addresses), and only then is
 // anything stored -- one round trip to L2 per batch instead of one per fragment (measured: ~12 us of fixed cost per launch before).
-#ifndef NGP_FF_IMG_BATCH
-#define NGP_FF_IMG_BATCH 8
-#endif
-constexpr int IMG_BATCH = NGP_FF_IMG_BATCH;
+constexpr int IMG_BATCH = 8;  // (10 = the fused network's whole image in one round: measured, no gain -- EXPERIMENTS.md)
 
 // where the two 8-byte halves of fragment element e come from (nullptr: zeros)
 template <int WIDTH>
@@ -366,10 +363,8 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     half8_t* img_s = reinterpret_cast<half8_t*>(smem);
     const uint32_t frags_s = NIB * in_kb + (nl_s - 1) * NIB * NKB + NKB;
     half8_t* img_c = img_s + (size_t)frags_s * 64;
-#ifndef NGP_FF_SKIP_IMAGE  // (timing experiment only: how much of a launch is the weight-image build; results are garbage with it)
     build_forward_image<WIDTH>(img_s, w_sigma, 32, nl_s);
     build_forward_image<WIDTH>(img_c, w_color, 32, nl_c);
-#endif
     const size_t rows = (size_t)n_tiles * FF_TILE;
     __syncthreads();
 
@@ -940,9 +935,7 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img = reinterpret_cast<half8_t*>(smem);
     const uint32_t nfrag = bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx);
-#ifndef NGP_FF_SKIP_IMAGE
     build_backward_image<WIDTH>(img, weights, in_dim, num_layers, with_dx);
-#endif
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = lane & 31, h = lane >> 5;
     const int pair = wid & (FP_PAIRS - 1), role = wid / FP_PAIRS;

@@ -306,6 +306,9 @@ class GraphedTrainStep:
             gc.collect()
             torch.cuda.synchronize()
             m = self.model
+            if getattr(m, 'fused_refresh', True) and getattr(m, 'density_grid', None) is not None and m.density_grid.is_cuda:
+                import raymarching   # the refresh's persistent scratch exists before anything is captured
+                raymarching.density_grid_state(m.density_grid, m.__dict__.setdefault('_refresh_state', {}))
             if self.la is not None and hasattr(m, 'refresh_sample'):
                 gs, ga = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 if getattr(self, '_sample_pool', None) is None:

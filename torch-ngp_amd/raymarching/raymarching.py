@@ -18,7 +18,7 @@ except ImportError:
     from .backend import _backend
 
 __all__ = ['near_far_from_aabb', 'sph_from_ray', 'morton3D', 'morton3D_invert', 'packbits', 'packbits_capped', 'march_rays_train',
-           'composite_rays_train', 'march_rays', 'composite_rays', 'compact_rays', 'update_density_grid']
+           'composite_rays_train', 'march_rays', 'composite_rays', 'compact_rays', 'update_density_grid', 'density_grid_state']
 
 _f32_fwd = custom_fwd(device_type='cuda', cast_inputs=torch.float32)
 
@@ -121,6 +121,18 @@ def packbits_capped(grid, thresh, thresh_cap, bitfield):
     return bitfield
 
 
+def density_grid_state(density_grid, state):
+    """(re)create the buffers `update_density_grid` keeps between calls -- a scratch grid holding -1, the mean's block partials, the device
+    mean -- for this grid's size and device.  Call it once OUTSIDE stream capture before the update is captured into a HIP graph (a
+    creation inside the capture would be replayed, and re-initialise the buffers, with every replay)."""
+    n_cells, dev = density_grid.numel(), density_grid.device
+    if state.get('n_cells') != n_cells or state.get('device') != dev:
+        state.update(n_cells=n_cells, device=dev, scratch=torch.full((n_cells,), -1.0, dtype=torch.float32, device=dev),
+                     workspace=torch.zeros(int(_backend.density_grid_update_workspace_bytes(n_cells)), dtype=torch.uint8, device=dev),
+                     mean=torch.zeros(1, dtype=torch.float32, device=dev))
+    return state
+
+
 def update_density_grid(sigmas, cells, density_scale, decay, density_grid, density_thresh, bitfield, state):
     """extension (not in the reference): the apply half of NeRFRenderer.update_extra_state (nerf/renderer.py:515-529) as one native call --
     `tmp_grid[cas, indices] = density_scale * sigmas`, `grid = max(grid * decay, tmp_grid)` where both are >= 0, the mean of the clamped
@@ -128,11 +140,7 @@ def update_density_grid(sigmas, cells, density_scale, decay, density_grid, densi
     morton index) per sigma; `state`: dict owned by the caller that keeps the scratch buffers between calls.
     Writes density_grid / bitfield in place, returns the device mean (1-element fp32 tensor)."""
     n_cells = density_grid.numel()
-    dev = density_grid.device
-    if state.get('n_cells') != n_cells or state.get('device') != dev:
-        state.update(n_cells=n_cells, device=dev, scratch=torch.full((n_cells,), -1.0, dtype=torch.float32, device=dev),
-                     workspace=torch.zeros(int(_backend.density_grid_update_workspace_bytes(n_cells)), dtype=torch.uint8, device=dev),
-                     mean=torch.zeros(1, dtype=torch.float32, device=dev))
+    density_grid_state(density_grid, state)
     sigmas = sigmas.reshape(-1).float().contiguous()
     cells = cells.reshape(-1).contiguous()
     _backend.density_grid_update(sigmas, cells, sigmas.numel(), float(density_scale), float(decay), density_grid, n_cells, state['scratch'],

@@ -674,15 +674,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra:
         sdf = sdf_encoder_mlp(dev)
         # BASELINE config 5 as a measured workload: the bound-8 / 4-cascade / dt_gamma = 1/128 / background-model training step through the
-        # drop-in modules (nerf/network.py nn.Linear networks: the reference has no --ff background model), torch Adam + GradScaler, eager
-        t_run = TrainingRun(args, dev, 1, 0, fused=False, graph=False, torch_optim=True, autograd=True, config5=True)
+        # drop-in modules (nerf/network.py nn.Linear networks: the reference has no --ff background model), torch Adam + GradScaler, the
+        # iteration replayed from a HIP graph (autograd inside the capture)
+        t_run = TrainingRun(args, dev, 1, 0, fused=False, graph=not args.no_graph, torch_optim=True, autograd=True, config5=True)
         t_run.setup(4)
         t_res = t_run.timed(args.extra_steps)
         tnt = {'config': 'Tanks&Temples-shaped: bound=8, 4 cascades x 128^3, dt_gamma=1/128, background model (radius-32 sphere, 2-D hashgrid + nn.Linear), '
-                         'nn.Linear sigma/colour networks (nerf/network.py), --fp16 --cuda_ray, 4096 rays, torch.optim.Adam(fused) + GradScaler, eager launches',
+                         'nn.Linear sigma/colour networks (nerf/network.py: library GEMMs), --fp16 --cuda_ray, 4096 rays, torch.optim.Adam(fused) + GradScaler, drop-in modules through autograd',
                'value': round(t_res['samples'] / t_res['elapsed'], 1), 'unit': 'samples/s', 'steps': args.extra_steps,
                'ms_per_step': round(t_res['elapsed'] / args.extra_steps * 1e3, 4),
-               'samples_per_step': round(t_res['samples'] / args.extra_steps, 1), 'final_loss': t_res['final_loss']}
+               'samples_per_step': round(t_res['samples'] / args.extra_steps, 1), 'final_loss': t_res['final_loss'],
+               'execution': t_run.execution(), 'captures_in_timed_region': t_res['captures']}
         del t_run
 
     if rank == 0:

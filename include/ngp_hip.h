@@ -219,6 +219,11 @@ int ngp_grid_encode_forward_sched(const float* inputs, const void* embeddings, c
                                   uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
                                   const float* level_cost_host, ngp_stream_t stream);
 
+/* diagnostic: the per-XCD work lists ngp_grid_encode_forward_sched would launch for L levels of `tiles` tiles each (host computation):
+ * 8 x 8 segments (level, first tile, cumulative slot end; level 0xffff = unused); returns the slots of the longest list (0 on bad arguments) */
+uint32_t ngp_grid_forward_work_lists(uint32_t L, uint32_t tiles, const float* level_cost_host, uint16_t* level_out, uint32_t* tile0_out,
+                                     uint32_t* end_out);
+
 /* grid_encode_backward_ex with a caller-provided workspace: fp16 tables with C = 2 and D <= 3 (the instant-ngp configuration) then
  * run the HASHED levels WITHOUT memory-side atomics -- contributions are sorted by table slice (8-byte records, coalesced stores) and
  * each slice is summed exactly in a 64-bit fixed-point LDS accumulator, rounded once and added to grad_embeddings by the workgroup that

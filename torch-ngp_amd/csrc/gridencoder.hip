@@ -1422,6 +1422,23 @@ static InputMap make_input_map(float bound) {
     return im;
 }
 
+// The forward's per-XCD work lists as the launch would build them (host computation, no device work): 8 x 8 segments
+// (level, first tile, cumulative slot end), level 0xffff = unused.  Returns the slots of the longest list.  For tests of the scheduler's
+// invariant: every (level, tile) of the call appears in exactly one segment.
+extern "C" uint32_t ngp_grid_forward_work_lists(uint32_t L, uint32_t tiles, const float* level_cost_host, uint16_t* level_out, uint32_t* tile0_out,
+                                                uint32_t* end_out) {
+    if (!level_out || !tile0_out || !end_out || L < 1 || L > NGP_MAX_LEVELS) return 0;
+    FwdSchedule sc;
+    const uint32_t max_slots = build_forward_schedule(sc, L, tiles, level_cost_host);
+    for (int x = 0; x < 8; x++)
+        for (int sg = 0; sg < FWD_MAX_SEG; sg++) {
+            level_out[x * FWD_MAX_SEG + sg] = sc.level[x][sg];
+            tile0_out[x * FWD_MAX_SEG + sg] = sc.tile0[x][sg];
+            end_out[x * FWD_MAX_SEG + sg] = sc.end[x][sg];
+        }
+    return max_slots;
+}
+
 extern "C" int ngp_grid_encode_forward_sched(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
                                              uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,

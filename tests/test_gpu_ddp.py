@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize('extra', [[], ['--replicated-optim']])
 def test_bench_two_ranks_share_one_gpu(extra):
-    env = dict(os.environ, NGP_BENCH_SHARE_GPU='1', NGP_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    # GLOO_SOCKET_IFNAME=lo: the container's hostname may not resolve; gloo then needs no name lookup to pick its transport device
+    env = dict(os.environ, NGP_BENCH_SHARE_GPU='1', NGP_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1', GLOO_SOCKET_IFNAME='lo')
     env.pop('WORLD_SIZE', None)
     # plain `python bench.py --gpus 2`, NO launcher: bench.py re-executes itself under torch.distributed.run with one process per rank
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-dropin',
@@ -106,7 +107,7 @@ def test_sharded_frame_is_bit_identical_to_the_one_rank_frame(tmp_path):
     the frame equals the frame one rank renders alone, bit for bit (image and depth)"""
     script = tmp_path / 'frame.py'
     script.write_text(_FRAME)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', GLOO_SOCKET_IFNAME='lo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29519',
            str(script), ROOT]
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)

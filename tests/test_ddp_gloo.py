@@ -267,7 +267,11 @@ def _render_worker(rank, world, port, out):
     m = _PerRayRenderer()
     got = render_sharded(m, o, d, bg_color=1)
     want = _PerRayRenderer().render(o, d)
-    out[rank] = (torch.equal(got['image'], want['image']), torch.equal(got['depth'], want['depth']), tuple(got['image'].shape),
+    # fewer rays than ranks: the surplus rank renders nothing and still takes part in the exchange
+    m1 = _PerRayRenderer()
+    tiny = render_sharded(m1, o[:, :1], d[:, :1], bg_color=1)
+    tiny_ok = torch.equal(tiny['image'], want['image'][:, :1]) and m1.calls == ([1] if rank == 0 else [])
+    out[rank] = (torch.equal(got['image'], want['image']) and tiny_ok, torch.equal(got['depth'], want['depth']), tuple(got['image'].shape),
                  tuple(got['depth'].shape), m.calls)
     dist.destroy_process_group()
 

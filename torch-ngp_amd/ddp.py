@@ -106,13 +106,14 @@ def render_sharded(model, rays_o, rays_d, rank=None, world=None, group=None, **k
         return model.render(rays_o, rays_d, **kwargs)
     per = (n + world - 1) // world
     sl = shard_rays(n, rank, world)
-    mine = model.render(rays_o[:, sl].contiguous(), rays_d[:, sl].contiguous(), **kwargs)
     dev = rays_o.device
     # [per, 4] = rgb + depth per ray; the last rank's block is padded to the common size for the fixed-size all-gather
     block = torch.zeros(per, 4, dtype=torch.float32, device=dev)
-    k = sl.stop - sl.start
-    block[:k, :3] = mine['image'].reshape(-1, 3).float()
-    block[:k, 3] = mine['depth'].reshape(-1).float()
+    k = max(0, sl.stop - sl.start)
+    if k > 0:   # (more ranks than rays: the surplus ranks only take part in the exchange)
+        mine = model.render(rays_o[:, sl].contiguous(), rays_d[:, sl].contiguous(), **kwargs)
+        block[:k, :3] = mine['image'].reshape(-1, 3).float()
+        block[:k, 3] = mine['depth'].reshape(-1).float()
     full = torch.empty(world * per, 4, dtype=torch.float32, device=dev)
     if dist.get_backend(group) == 'nccl':
         dist.all_gather_into_tensor(full, block, group=group)

@@ -510,8 +510,8 @@ def main():
         faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP extension has no CPU fallback)'
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        self_launch(args)   # does not return: this process becomes the launcher of N ranks
+    if args.gpus > 1 and int(os.environ.get('WORLD_SIZE', '1') or 1) <= 1 and 'LOCAL_RANK' not in os.environ:
+        self_launch(args)   # no launcher around this process: it becomes the launcher of N ranks (does not return)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

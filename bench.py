@@ -568,6 +568,28 @@ def main():
     # roofline pass (untimed): HIP graphs cannot carry timing events, so the same iteration is run eagerly for a few steps
     # with HIP-event pairs around the named kernels, on the stream they are launched on, same batches, same state.
     roofs, traffic_source = [], None
+    comm_events = {}
+    if not args.no_roofline and world > 1 and not args.torch_optim:
+        # N > 1: HIP-event pairs around the gradient exchange of the eager iterations below, on the stream each collective is issued on
+        # (rank 0's view; with RCCL the pair brackets the collective's kernels, which are ordered with that stream)
+        opt = run.optimizer
+
+        def timed_call(name, fn):
+            def call(*a, **k):
+                if rank != 0:
+                    return fn(*a, **k)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*a, **k)
+                e1.record()
+                comm_events.setdefault(name, []).append((e0, e1))
+                return out
+            return call
+        if getattr(opt, 'shard', False):
+            opt.reduce_gradients = timed_call('reduce_scatter_fp16_gradients_plus_verdict', opt.reduce_gradients)
+            opt._all_gather = timed_call('all_gather_fp16_shadows', opt._all_gather)
+        else:
+            opt.all_reduce = timed_call('all_reduce_fp16_gradients', opt.all_reduce)
     if not args.no_roofline:
         # every rank runs these iterations (the data-parallel exchange inside them is collective); only rank 0 times its kernels
         timers.enabled = rank == 0
@@ -590,6 +612,17 @@ def main():
             for r in roofs:
                 r['traffic_source'] = (f'{traffic_source} (committed rocprofv3 --pmc pass of the same workload; not measured in this run)'
                                        if r['traffic'] is not None else None)
+    comm_ms = None
+    if comm_events:
+        torch.cuda.synchronize()
+        nbytes = int(run.optimizer.flat_grad16.numel() * 2)
+        comm_ms = {'message_bytes': nbytes, 'note': 'eager iterations after the timed region, rank 0, HIP events on the issuing stream'}
+        for name, evs in comm_events.items():
+            ms = [a.elapsed_time(b) for a, b in evs[1:]] or [a.elapsed_time(b) for a, b in evs]
+            comm_ms[name] = {'ms': round(float(np.median(ms)), 4), 'calls': len(evs),
+                             'algorithmic_GBps': round(nbytes * (world - 1) / world / (float(np.median(ms)) * 1e-3) / 1e9, 1)}
+        for name in ('reduce_gradients', '_all_gather', 'all_reduce'):   # un-wrap: the instance attributes shadow the methods
+            run.optimizer.__dict__.pop(name, None)
     if world > 1 and getattr(run.optimizer, 'shard', False):
         run.optimizer.wait_shadows()
         run.optimizer.gather_master()  # collective: every rank's fp32 master weights complete again (every rank renders with them below)
@@ -728,7 +761,7 @@ def main():
                        'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
                        'final_loss': res['final_loss']},
             'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'dropin_path': dropin, 'render_800x800_ms': render,
-            'strong_scaling': strong, 'sdf_encoder_mlp': sdf, 'tnt_bound8': tnt,
+            'strong_scaling': strong, 'collectives': comm_ms, 'sdf_encoder_mlp': sdf, 'tnt_bound8': tnt,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

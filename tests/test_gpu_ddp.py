@@ -38,6 +38,10 @@ def test_bench_two_ranks_share_one_gpu(extra):
     assert line['comm']['ranks'] == 2 and line['comm']['self_launched'] and line['comm']['backend'].startswith('gloo')
     assert line['rccl_ranks'] == 0          # gloo here: the field counts ranks joined through RCCL only
     assert line['scaling'] == 'weak' and line['config']['global_rays_per_step'] == 8192
+    coll = line['collectives']
+    assert coll['message_bytes'] > 2 * 12_000_000
+    for name in (['all_reduce_fp16_gradients'] if extra else ['reduce_scatter_fp16_gradients_plus_verdict', 'all_gather_fp16_shadows']):
+        assert coll[name]['ms'] > 0 and coll[name]['calls'] >= 4
     st = line['strong_scaling']
     assert st['scaling'] == 'strong' and st['rays_per_gpu_per_step'] == 2048 and st['global_rays_per_step'] == 4096
     assert 2e5 < st['samples_per_step_global'] < 3.5e5 and st['captures_in_timed_region'] == 0

@@ -502,7 +502,7 @@ def main():
                     help='N > 1: weak = --rays per GPU (global batch grows with N, the headline); strong = --rays in total, --rays / N per GPU')
     ap.add_argument('--no-strong', action='store_true', help='N > 1, --scaling weak: skip the secondary strong-scaling measurement (`strong_scaling`)')
     ap.add_argument('--strong-steps', type=int, default=128)
-    ap.add_argument('--watchdog', type=float, default=600.0, help='seconds after which a run that has not finished dumps every thread\'s stack to stderr '
+    ap.add_argument('--watchdog', type=float, default=900.0, help='seconds after which a run that has not finished dumps every thread\'s stack to stderr '
                     'and exits non-zero (a hung collective must not hang the box); 0 disables')
     args = ap.parse_args()
     if args.watchdog > 0:

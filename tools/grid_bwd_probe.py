@@ -49,9 +49,22 @@ if only == 'zero':
     print(f'zero gradient        : {run(torch.zeros_like(g)):7.1f} us'); sys.exit(0)
 if only == 'random':
     print(f'random gradient      : {run(g):7.1f} us'); sys.exit(0)
+if only in ('coarse', 'fine'):
+    gg = g.clone()
+    if only == 'coarse': gg[10:] = 0
+    else: gg[:10] = 0
+    print(f'{only:21s}: {run(gg):7.1f} us'); sys.exit(0)
 print(f'random gradient      : {run(g):7.1f} us')
 print(f'zero gradient        : {run(torch.zeros_like(g)):7.1f} us')
 gc = g.clone(); gc[10:] = 0
 print(f'levels 0-9 only      : {run(gc):7.1f} us')
 gf = g.clone(); gf[:10] = 0
 print(f'levels 10-15 only    : {run(gf):7.1f} us')
+if hasattr(capi.lib, 'ngp_debug_bin_probe') or os.environ.get('NGP_BIN_PROBE'):
+    buf = (ctypes.c_uint64 * 16)()
+    capi.lib.ngp_debug_bin_probe(buf, 1)
+    run(g, reps=5)
+    capi.lib.ngp_debug_bin_probe(buf, 0)
+    n = max(1, buf[15])
+    names = ['loop head', 'fetch+params', 'slots', 'wait B2', 'scan+desc', 'zero+staging', 'wait B3', 'copy-out', 'cur=nxt wait']
+    print('sort item phases (cycles per item, wave 0):', ', '.join(f'{names[i]} {buf[i] / n:.0f}' for i in range(9)), f'| items {n}')

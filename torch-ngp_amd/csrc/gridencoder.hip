@@ -20,6 +20,7 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <vector>
 
@@ -42,8 +43,8 @@ struct LevelIndexer {
     bool hashed;
     bool need_mod;       // false when a dense index is provably < size
 
-    __device__ __forceinline__ void init(uint32_t gridtype, bool align_corners, uint32_t hashmap_size,
-                                         uint32_t resolution) {
+    __host__ __device__ __forceinline__ void init(uint32_t gridtype, bool align_corners, uint32_t hashmap_size,
+                                                  uint32_t resolution) {
         uint32_t s = 1;
 #pragma unroll
         for (int d = 0; d < D; d++) {
@@ -751,22 +752,22 @@ __global__ __launch_bounds__(BWD_THREADS) void k_grid_backward(const T* __restri
 // The result is the exact sum rounded once -- more accurate than the reference's fp16 atomics and bit-reproducible run to run
 // (integer addition commutes); non-finite contributions poison their entry with NaN (the loss scaler skips the step either way).
 // ------------------------------------------------------------------------------------------------
-// (tuning knobs of the record sort, compile-time: -DNGP_BIN_THREADS=... -DNGP_BIN_ITERS=...)
+// (tuning knobs of the record sort, compile-time: -DNGP_BIN_THREADS=... -DNGP_BIN_RESIDENT=... -DNGP_BIN_MERGE_MIN=...)
 #ifndef NGP_BIN_THREADS
 #define NGP_BIN_THREADS 512
 #endif
-#ifndef NGP_BIN_ITERS
-#define NGP_BIN_ITERS 2
-#endif
 constexpr int BIN_THREADS = NGP_BIN_THREADS;
-constexpr int BIN_ITERS = NGP_BIN_ITERS;                       // wave-steps per workgroup
-constexpr int BIN_PPB = BIN_ITERS * (BIN_THREADS / 64) * 32;   // samples per workgroup (2 lanes per sample)
+constexpr int BIN_PPB = BIN_THREADS;                           // samples per workgroup item = per chunk (one lane per sample)
 #ifndef NGP_BIN_SLICE_BITS
 #define NGP_BIN_SLICE_BITS 12
 #endif
 constexpr int BIN_SLICE_BITS = NGP_BIN_SLICE_BITS;             // 4096 table entries per slice / bin
 constexpr int BIN_SLICE = 1 << BIN_SLICE_BITS;
-constexpr int BIN_MAX_BINS = 512;                              // one thread per bin in the layout step
+constexpr int BIN_MAX_BINS = 512;                              // bins per level at most (every wave scans them, 8 per lane)
+#ifndef NGP_BIN_RESIDENT
+#define NGP_BIN_RESIDENT 3
+#endif
+constexpr int BIN_RESIDENT = NGP_BIN_RESIDENT;                 // persistent sort workgroups per CU
 #ifndef NGP_ACC_THREADS
 #define NGP_ACC_THREADS 1024
 #endif
@@ -779,12 +780,20 @@ constexpr int ACC_THREADS = NGP_ACC_THREADS;
 constexpr int BIN_DENSE_BITS = 7;
 constexpr int BIN_DENSE_BINS = 1 << BIN_DENSE_BITS;
 
+constexpr int BIN_LC_WORDS = 12;
 struct BinPlan {
-    uint8_t level[NGP_MAX_LEVELS];       // binned levels (blockIdx.y indexes these arrays)
-    uint16_t n_bins[NGP_MAX_LEVELS];
-    uint8_t interleaved[NGP_MAX_LEVELS];  // 0: bin = index >> 12 (contiguous slices); 1: bin = index & 127 (dense levels, see below)
-    uint32_t desc_base[NGP_MAX_LEVELS];  // first descriptor of the level; descriptors are [bin][chunk]
-    uint32_t n_chunks;                   // workgroups of pass 1 per level = chunks per level
+    // per binned level li (blockIdx.y of the accumulate, item index of the sort): constants in 32-bit words, so that a wave-uniform index
+    // becomes a few scalar loads from the kernel-argument segment.  Made from the caller's HOST copy of the offsets.
+    //   [0] level  [1] n_bins  [2] flags (1: interleaved bins, 4: hashed, 8: index needs the modulo)  [3] table entries  [4] scale (float bits)
+    //   [5] mask (entries - 1 if a power of two, else 0)  [7] first descriptor of the level ([bin][chunk])  [8..10] dense strides
+    uint32_t lc[NGP_MAX_LEVELS][BIN_LC_WORDS];
+    uint32_t n_chunks;                   // chunks (BIN_PPB samples) per level
+    uint32_t n_levels;                   // binned levels
+    // interleaved = 0: bin = index >> 12 (contiguous slices); 1: bin = index & 127 (dense levels, see above)
+    __host__ __device__ __forceinline__ uint32_t level(uint32_t li) const { return lc[li][0]; }
+    __host__ __device__ __forceinline__ uint32_t n_bins(uint32_t li) const { return lc[li][1]; }
+    __host__ __device__ __forceinline__ bool interleaved(uint32_t li) const { return (lc[li][2] & 1u) != 0u; }
+    __host__ __device__ __forceinline__ uint32_t desc_base(uint32_t li) const { return lc[li][7]; }
 };
 
 __device__ __forceinline__ uint32_t pack_half2(float a, float b) {
@@ -805,15 +814,288 @@ struct AtomicPart {
     uint32_t points_per_block;
 };
 
-template <int D, int AMERGE /* run merge of the atomic workgroups: 3 = DPP over the wave, 1 = ds_bpermute */>
-__global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restrict__ inputs,
-                                                                   const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid,
-                                                                   uint32_t B, GridLevels lv, uint32_t gridtype, bool align_corners,
-                                                                   uint32_t interp, InputMap im, BinPlan plan,
-                                                                   uint32_t* __restrict__ descriptors, uint2* __restrict__ records,
-                                                                   AtomicPart ap) {
-    using T = half_t;
-    uint32_t bin_block = blockIdx.x;
+// DPP carries between the 16-lane rows (profiles/r01_dpp_probe.txt): row_bcast:15 hands lane 15 of a row to every lane of the NEXT row,
+// row_bcast:31 hands lane 31 to every lane of rows 2 and 3; the row mask keeps the other rows at `old` = 0.
+__device__ __forceinline__ uint32_t bcast15_rows13(uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x142, 0xA, 0xF, false);
+}
+__device__ __forceinline__ uint32_t bcast31_rows23(uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, 0x143, 0xC, 0xF, false);
+}
+
+// Record sort, round 4: ONE LANE PER SAMPLE, count pass + place pass.
+//
+// A wave64 VALU instruction occupies its SIMD for 4 cycles; the round-3 sort (a sample on two lanes, each repeating the position work)
+// issued 52 M of them = 85 us of the chip's 1024 SIMDs: it WAS its instruction stream (EXPERIMENTS.md).  Now a lane computes the position
+// inside the level, the per-dimension index terms and weights ONCE and emits all 2^D corner records of its sample.
+//   * Corner slot s holds the vertex whose coordinates have the ABSOLUTE parities of the bits of s, so a vertex shared by the cells of
+//     consecutive samples of a ray sits in the same slot on neighbouring lanes: runs of equal table address in a slot are summed in fp32
+//     over all 64 samples of the wave (segmented Hillis-Steele scan: four DPP row shifts, two broadcast carries -- pure VALU, a fixed
+//     tree: bit-reproducible) and only the LAST lane of a run issues a record.  A slot whose wave has fewer than NGP_BIN_MERGE_MIN
+//     continuing lanes skips the scan (fine levels: consecutive samples share no vertex).
+//   * COUNT pass: addresses, run structure (lane masks, kept in scalar registers), one non-returning LDS add per record into the wave's
+//     OWN row of bin counters.  After ONE barrier every wave reads all rows, scans the bins for itself and knows where its own records
+//     of every bin go (chunk offset of the bin + records of the waves before it): no shared cursor, no second barrier.  PLACE pass:
+//     values, run sums, packing; a returning LDS add on the wave's own cursor row gives the final slot in the staging area.  What a lane
+//     carries across the barrier are 2 D index terms and 2 D weights -- not addresses, values and ranks of 2^D records: <= 64 VGPRs, four
+//     workgroups per CU.  Second barrier, coalesced copy of the sorted chunk (16 bytes per lane).
+//   * Workgroups are persistent over a contiguous range of (chunk, level) items, level fastest: positions are loaded once per chunk,
+//     the gradient of the next item is in flight while the current one is sorted, per-level constants are scalar loads from the plan.
+#ifdef NGP_BIN_PHASE_PROBE  // timing probe only: shader-clock cycles per phase of the sort's item loop, summed over wave 0 of every workgroup
+__device__ unsigned long long g_bin_probe[16];
+#define NGP_PROBE_T(i) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_probe; t_probe = t_now; }
+#else
+#define NGP_PROBE_T(i)
+#endif
+#ifndef NGP_BIN_MERGE_MIN
+#define NGP_BIN_MERGE_MIN 8
+#endif
+
+// record key bits: channel 0 / 1 of the value is 1/64 of the contribution (a run sum beyond the fp16 range); table indices stay below 2^21
+constexpr uint32_t BIN_KEY_SCALED0 = 0x80000000u, BIN_KEY_SCALED1 = 0x40000000u, BIN_KEY_SCALED = BIN_KEY_SCALED0 | BIN_KEY_SCALED1;
+
+// Wave-uniform 64-bit lane masks, pinned to scalar registers where they are made.  and / andn2 / shifts / bit counts have 64-bit scalar
+// forms; only COMPARES are written on the 32-bit halves (there is no scalar u64 less-than: a 64-bit compare would be done by the vector
+// unit and drag the mask into vector registers).
+struct LaneMask {
+    unsigned long long v;
+    __device__ __forceinline__ static LaneMask of(unsigned long long b) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+        return LaneMask{((unsigned long long)hi << 32) | lo};
+    }
+    __device__ __forceinline__ bool any() const { return ((uint32_t)v | (uint32_t)(v >> 32)) != 0u; }
+    __device__ __forceinline__ bool any_of(uint32_t each_half) const { return (((uint32_t)v | (uint32_t)(v >> 32)) & each_half) != 0u; }
+    __device__ __forceinline__ int count() const { return __builtin_popcountll(v); }
+};
+
+// Segmented inclusive scan of two floats inside the 16-lane ROWS of the wave: open = all ones in a lane that CONTINUES the run of the
+// lane below it, 0 in the first lane of a run (and in the first lane of every row: a run that crosses a row boundary is cut there and
+// issues one more record -- the two cross-row carries would cost as much as two more steps for a handful of records per wave).
+// Hillis-Steele with DPP row shifts 1, 2, 4, 8.  Written in assembly because the select costs nothing this way: the incoming value is
+// ANDed with the lane's `open` mask in the DPP instruction that fetches it (5 VALU per step instead of 9 from the compiler's mov_dpp +
+// cndmask + add), and `open &= open[i - N]` leaves lanes without a source untouched (no bound_ctrl: the lane is not written).  s_nop: a
+// VALU write needs two wait states before a DPP read of the register (the compiler cannot see into the blocks, so every block keeps the
+// distance itself).  A step is skipped (wave-uniform) when no open lane has a source for it: runs of two or three samples (the middle
+// levels) finish after one or two steps.
+#define NGP_SEG_ROW_STEP(N)                                                                       \
+    asm volatile("s_nop 1\n\t"                                                                    \
+                 "v_and_b32_dpp %3, %0, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                 "v_and_b32_dpp %4, %1, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                 "v_and_b32_dpp %2, %2, %2 row_shr:" #N " row_mask:0xf bank_mask:0xf\n\t"          \
+                 "v_add_f32 %0, %0, %3\n\t"                                                       \
+                 "v_add_f32 %1, %1, %4\n\t"                                                       \
+                 : "+v"(v0), "+v"(v1), "+v"(open), "=&v"(t0), "=&v"(t1))
+__device__ __forceinline__ void seg_scan_rows(float& v0, float& v1, const LaneMask& continues) {
+    uint32_t open = __builtin_amdgcn_inverse_ballot_w64(continues.v) ? 0xffffffffu : 0u, t0, t1;
+    auto still_open = [&]() { return LaneMask::of(__builtin_amdgcn_ballot_w64(open != 0u)); };
+    NGP_SEG_ROW_STEP(1);
+    if (still_open().any_of(0xFFFCFFFCu)) {  // an open lane at row position >= 2 has a source two lanes below
+        NGP_SEG_ROW_STEP(2);
+        if (still_open().any_of(0xFFF0FFF0u)) {
+            NGP_SEG_ROW_STEP(4);
+            if (still_open().any_of(0xFF00FF00u)) NGP_SEG_ROW_STEP(8);
+        }
+    }
+}
+#undef NGP_SEG_ROW_STEP
+
+struct BinItem {  // wave-uniform description of one (chunk, level) item
+    uint32_t li, chunk_x, n_bins, desc_base;
+    float scale;
+    bool interleaved, plan_ok;
+    half_t* gtable;
+};
+
+// LDS counters addressed by BYTE offset from the start of the dynamic LDS segment (one v_add less per counter than pointer arithmetic)
+__device__ __forceinline__ void lds_add_u32(uint32_t byte_addr) {
+    __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(byte_addr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_add_rtn_u32(uint32_t byte_addr) {
+    return __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t*>(byte_addr), 1u, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int D>
+struct BinLane {  // what a lane carries from the count pass to the place pass
+    uint32_t addr[1 << D];  // table index of corner slot s (slot = ABSOLUTE parities of the vertex coordinates)
+    float wp[D][2];         // per dimension: weight of the cell's vertex with EVEN coordinate ([d][0]) and with ODD coordinate ([d][1]); a dead
+                            // lane has 0 in dimension 0
+};
+
+template <bool FAST>
+__device__ __forceinline__ uint32_t bin_counter_addr(uint32_t addr, const BinItem& it, uint32_t row_base) {  // LDS byte address of the bin's counter
+    // (rows are 512-byte aligned: the base is ORed in)
+    if constexpr (FAST) return ((addr >> (BIN_SLICE_BITS - 2)) & (uint32_t)((BIN_MAX_BINS - 1) << 2)) | row_base;
+    else return ((it.interleaved ? (addr & (uint32_t)(BIN_DENSE_BINS - 1)) : (addr >> BIN_SLICE_BITS)) << 2) | row_base;
+}
+
+// Lanes of a corner slot that CONTINUE the run of the lane below them: same table index, both live, same 16-lane row (`pairs` holds the
+// last two conditions and the wave's merge decision).  Computed wherever it is needed (two VALU) rather than carried in scalar registers.
+__device__ __forceinline__ LaneMask bin_run_mask(uint32_t addr, const LaneMask& pairs) {
+    return LaneMask{LaneMask::of(__builtin_amdgcn_ballot_w64(wave_shr1(addr) == addr)).v & pairs.v};
+}
+// the lanes that issue a record: live and not continued by the lane above (the LAST lane of a run)
+__device__ __forceinline__ bool bin_issues(const LaneMask& live, const LaneMask& m) {
+    return __builtin_amdgcn_inverse_ballot_w64(live.v & ~(m.v >> 1));
+}
+// `pairs` of a wave: this lane and the one below it are live and sit in the same 16-lane row -- or nothing at all when fewer than
+// NGP_BIN_MERGE_MIN lanes of the wave continue a run in corner slot 0 (fine levels: consecutive samples share no vertex; the decision is
+// made once per wave and pass, from the same data in both passes)
+__device__ __forceinline__ LaneMask bin_pairs(const LaneMask& live, uint32_t addr0) {
+    LaneMask pairs{live.v & (live.v << 1) & 0xFFFEFFFEFFFEFFFEull};
+    if (bin_run_mask(addr0, pairs).count() < NGP_BIN_MERGE_MIN) pairs.v = 0ull;
+    return pairs;
+}
+
+// COUNT pass.  FAST = hashed level with a power-of-two table in contiguous slices (every fine level of the instant-ngp configuration)
+template <int D, bool FAST>
+__device__ __forceinline__ void bin_pass_count(const float (&x)[D], uint32_t gbits, bool in_range, const BinItem& it, const LevelIndexer<D>& ix,
+                                               bool align_corners, uint32_t interp, InputMap im, uint32_t hrow_base, BinLane<D>& bl,
+                                               LaneMask& live_mask) {
+    constexpr int NS = 1 << D;
+    float frac[D], deriv[D];
+    uint32_t cell[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) { frac[d] = 0.0f; cell[d] = 0u; }
+    bool live = in_range && (gbits & 0x7fff7fffu) != 0u;  // an exactly-zero gradient (samples behind an early-terminated ray) adds nothing
+    if (live) live = locate<D>(x, it.scale, align_corners, interp, frac, deriv, cell, im);
+    live_mask = LaneMask::of(__builtin_amdgcn_ballot_w64(live));
+#pragma unroll
+    for (int s = 0; s < NS; s++) bl.addr[s] = 0u;
+#pragma unroll
+    for (int d = 0; d < D; d++) bl.wp[d][0] = bl.wp[d][1] = 0.0f;
+    if (!live_mask.any()) return;  // (wave-uniform: every lane executes the cross-lane reads below)
+    uint32_t tp[D][2];  // per dimension: index term of the cell's vertex with EVEN coordinate ([d][0]) and with ODD coordinate ([d][1])
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const uint32_t lower = FAST ? cell[d] * kPrimes[d] : ix.term(d, cell[d]);
+        const uint32_t upper = lower + (FAST ? kPrimes[d] : ix.step(d));
+        const bool odd = (cell[d] & 1u) != 0u;
+        tp[d][0] = odd ? upper : lower;
+        tp[d][1] = odd ? lower : upper;
+        const float f = frac[d], nf = 1.0f - frac[d];
+        bl.wp[d][0] = odd ? f : nf;
+        bl.wp[d][1] = odd ? nf : f;
+    }
+    if (!live) bl.wp[0][0] = bl.wp[0][1] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        uint32_t t[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) t[d] = tp[d][(s >> d) & 1];
+        if constexpr (FAST) {  // hashed, power-of-two table
+            uint32_t a = t[0];
+#pragma unroll
+            for (int d = 1; d < D; d++) a ^= t[d];
+            bl.addr[s] = a & ix.mask;
+        } else {
+            bl.addr[s] = ix.combine(t);
+        }
+    }
+    if (!(FAST || it.plan_ok)) return;
+    const LaneMask pairs = bin_pairs(live_mask, bl.addr[0]);
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (bin_issues(live_mask, bin_run_mask(bl.addr[s], pairs))) lds_add_u32(bin_counter_addr<FAST>(bl.addr[s], it, hrow_base));
+}
+
+// PLACE pass: staging slots from the wave's own cursors (eight returning LDS adds in flight), then values, run sums and the records
+template <int D, bool FAST>
+__device__ __forceinline__ void bin_pass_place(uint32_t gbits, const BinItem& it, const BinLane<D>& bl, const LaneMask& live_mask_in,
+                                               uint32_t prow_base, uint2* __restrict__ staging) {
+    constexpr int NS = 1 << D;
+    // (pinned to scalar registers again: carried across the barrier the mask may sit in a vector register, and everything derived from
+    // it would then be computed by the vector unit)
+    const LaneMask live_mask = LaneMask::of(live_mask_in.v);
+    if (!live_mask.any()) return;
+    const LaneMask pairs = bin_pairs(live_mask, bl.addr[0]);
+    const bool binned = FAST || it.plan_ok;
+    uint32_t slot[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        slot[s] = 0u;
+        if (binned && bin_issues(live_mask, bin_run_mask(bl.addr[s], pairs))) slot[s] = lds_add_rtn_u32(bin_counter_addr<FAST>(bl.addr[s], it, prow_base));
+    }
+    const half2_t gh = __builtin_bit_cast(half2_t, gbits);
+    const float g0 = (float)gh.x, g1 = (float)gh.y;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const uint32_t addr = bl.addr[s];
+        float w = bl.wp[0][s & 1];
+#pragma unroll
+        for (int d = 1; d < D; d++) w *= bl.wp[d][(s >> d) & 1];
+        float v0 = w * g0, v1 = w * g1;
+        const LaneMask m = bin_run_mask(addr, pairs);
+        uint32_t key = addr;
+        if (m.any()) {  // segmented inclusive scan: the last lane of a run ends up with the run's sum
+            seg_scan_rows(v0, v1, m);
+            // a run of up to 16 finite fp16-range terms can leave the fp16 range although the sum over the whole batch need not: such a
+            // record carries sum / 64 in that channel and says so in bit 31 / 30 of its key (the accumulate shifts the exact fixed-point
+            // addend back).  Rare: one test for the wave first.
+            if (__builtin_amdgcn_ballot_w64(fmaxf(__builtin_fabsf(v0), __builtin_fabsf(v1)) >= 32768.0f) != 0ull) {
+                if (__builtin_fabsf(v0) >= 32768.0f) { v0 *= 0.015625f; key |= BIN_KEY_SCALED0; }
+                if (__builtin_fabsf(v1) >= 32768.0f) { v1 *= 0.015625f; key |= BIN_KEY_SCALED1; }
+            }
+        }
+        const uint32_t packed = pack_half2(v0, v1);
+        if (bin_issues(live_mask, m)) {
+            if (binned) staging[slot[s]] = make_uint2(key, packed);
+            else atomic_add_packed(it.gtable + (size_t)addr * 2, packed);
+        }
+    }
+}
+
+// After the count barrier: a wave reads every wave's counter row (BPL consecutive bins per lane), scans the bin totals and writes ITS OWN
+// cursor row: chunk offset of the bin + the records of the waves before it.  Wave 0 also writes the descriptors.  Returns all records.
+template <int BPL, int WAVES>
+__device__ __forceinline__ uint32_t bin_offsets(const uint32_t* __restrict__ hist, uint32_t* __restrict__ prow, int lane, int wid, const BinItem& it,
+                                                uint32_t n_chunks, uint32_t* __restrict__ descriptors) {
+    constexpr int CAP = 64 * BPL;
+    uint32_t tot[BPL], mine[BPL], run = 0u;
+#pragma unroll
+    for (int k = 0; k < BPL; k++) tot[k] = mine[k] = 0u;
+#pragma unroll BPL <= 2 ? WAVES : 1  // (8 x 8 loads in flight would cost the kernel its occupancy)
+    for (int w = 0; w < WAVES; w++) {
+#pragma unroll
+        for (int k = 0; k < BPL; k++) tot[k] += hist[w * CAP + lane * BPL + k];
+    }
+#pragma unroll 1
+    for (int w = 0; w < wid; w++) {  // (wave-uniform trip count) the records of the waves before this one
+#pragma unroll
+        for (int k = 0; k < BPL; k++) mine[k] += hist[w * CAP + lane * BPL + k];
+    }
+#pragma unroll
+    for (int k = 0; k < BPL; k++) run += tot[k];
+    uint32_t incl = run;
+    incl += row_shr<1>(incl);
+    incl += row_shr<2>(incl);
+    incl += row_shr<4>(incl);
+    incl += row_shr<8>(incl);
+    incl += bcast15_rows13(incl);
+    incl += bcast31_rows23(incl);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t begin = incl - run;
+#pragma unroll
+    for (int k = 0; k < BPL; k++) {
+        prow[lane * BPL + k] = begin + mine[k];
+        const uint32_t bin = (uint32_t)(lane * BPL + k);
+        if (wid == 0 && bin < it.n_bins) descriptors[it.desc_base + (size_t)bin * n_chunks + it.chunk_x] = begin | (tot[k] << 16);  // both <= 4096
+        begin += tot[k];
+    }
+    return total;
+}
+
+#ifndef NGP_BIN_WAVES_PER_EU
+#define NGP_BIN_WAVES_PER_EU 6
+#endif
+template <int D, int AMERGE /* run merge of the atomic workgroups: 3 = DPP over the wave, 1 = ds_bpermute */,
+          int BPL /* bin counters per lane and wave: 2 (levels of <= 128 bins, 40 KiB of LDS) or 8 (<= 512 bins, 64 KiB) */>
+__global__ __launch_bounds__(BIN_THREADS) __attribute__((amdgpu_waves_per_eu(BPL == 2 ? NGP_BIN_WAVES_PER_EU : 4, BPL == 2 ? NGP_BIN_WAVES_PER_EU : 4)))
+void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restrict__ inputs, const int32_t* __restrict__ offsets,
+                         half_t* __restrict__ grad_grid, uint32_t B, GridLevels lv, uint32_t gridtype, bool align_corners, uint32_t interp,
+                         InputMap im, BinPlan plan, uint32_t* __restrict__ descriptors, uint2* __restrict__ records, AtomicPart ap) {
+    uint32_t bin_block = blockIdx.x, n_bin_blocks = gridDim.x;
     if (ap.n_blocks) {
         const uint64_t total = gridDim.x;
         const uint32_t a0 = (uint32_t)(((uint64_t)blockIdx.x * ap.n_blocks) / total);
@@ -825,96 +1107,117 @@ __global__ __launch_bounds__(BIN_THREADS) void k_grid_backward_bin(const half_t*
             return;
         }
         bin_block = blockIdx.x - a0;
+        n_bin_blocks = gridDim.x - ap.n_blocks;
     }
-    const uint32_t li = bin_block / plan.n_chunks, chunk_x = bin_block % plan.n_chunks;
     constexpr int C = 2;
-    constexpr int NJ = 1 << (D - 1);
-    constexpr int CPL = 2, LPP = 2, PTS = 32;
+    constexpr int NS = 1 << D;               // corner slots = records per sample
+    constexpr int MAX_REC = BIN_PPB * NS;    // records per workgroup item = slots per chunk
     constexpr int WAVES = BIN_THREADS / 64;
-    constexpr int MAX_REC = BIN_PPB * 2 * NJ;  // records per workgroup = slots per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
     uint2* staging = reinterpret_cast<uint2*>(bin_smem);                              // [MAX_REC]
-    uint32_t* hist = reinterpret_cast<uint32_t*>(bin_smem + sizeof(uint2) * MAX_REC);  // [BIN_MAX_BINS] records per bin
-    uint32_t* loff = hist + BIN_MAX_BINS;                                             // [BIN_MAX_BINS] exclusive offsets in the sorted order
-    uint32_t* wsum = loff + BIN_MAX_BINS;                                             // [WAVES]
+    uint32_t* hist = reinterpret_cast<uint32_t*>(bin_smem + sizeof(uint2) * MAX_REC);  // [WAVES][cap] records per (wave, bin)
+    constexpr uint32_t cap = 64 * BPL;
+    uint32_t* pos = hist + WAVES * cap;                                               // [WAVES][cap] staging cursors per (wave, bin)
+    const int tid = threadIdx.x, lane = tid & 63, wid = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t* __restrict__ hrow = hist + wid * cap;
+    uint32_t* __restrict__ prow = pos + wid * cap;
+    // LDS byte addresses of the two rows
+    const uint32_t hrow_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)hrow;
+    const uint32_t prow_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)prow;
+    const uint32_t n_levels = plan.n_levels;
+    const uint32_t n_items = plan.n_chunks * n_levels;
+    // this workgroup's items: [item, item_end), item = chunk * n_levels + li
+    uint32_t item = (uint32_t)(((uint64_t)bin_block * n_items) / n_bin_blocks);
+    const uint32_t item_end = (uint32_t)((((uint64_t)bin_block + 1u) * n_items) / n_bin_blocks);
+    BinItem it;
+    it.chunk_x = item / n_levels;
+    it.li = item - it.chunk_x * n_levels;
 
-    const uint32_t level = plan.level[li];
-    const uint32_t n_bins = plan.n_bins[li];
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-    const float scale = lv.scale[level];
-    LevelIndexer<D> indexer;
-    indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
-    half_t* __restrict__ gtable = grad_grid + (size_t)off0 * C;
-    const half_t* __restrict__ glevel = grad + (size_t)level * B * C;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int pl = lane / LPP;
-    const uint32_t xb = (uint32_t)lane & 1u;
-    const uint32_t b_begin = chunk_x * BIN_PPB;
-    const uint32_t b_end = min(B, b_begin + BIN_PPB);
-    // the plan was made from the caller's HOST copy of the offsets; if the device offsets describe a larger level, stay in bounds
-    // (those records take the atomic)
-    const bool plan_ok = hashmap_size <= (n_bins << BIN_SLICE_BITS);
-    const bool interleaved = plan.interleaved[li] != 0;
-    auto bin_of = [&](uint32_t a) { return interleaved ? (a & (uint32_t)(BIN_DENSE_BINS - 1)) : (a >> BIN_SLICE_BITS); };
-
-    BwdSample<T, D, C> smp[BIN_ITERS];  // every global load of the workgroup is in flight before the first use
+    for (uint32_t i = lane; i < cap; i += 64) hrow[i] = 0u;
+    float x[D];
 #pragma unroll
-    for (int it = 0; it < BIN_ITERS; it++) {
-        const uint32_t b = b_begin + (uint32_t)(it * WAVES + wid) * PTS + pl;
-        smp[it].load(inputs, glevel, b, b < b_end, 0);
-    }
-    if (tid < BIN_MAX_BINS) hist[tid] = 0u;
+    for (int d = 0; d < D; d++) x[d] = 0.0f;
+    uint32_t g_cur = 0u, chunk_loaded = 0xffffffffu;
+    auto fetch_g = [&](uint32_t chunk_x, uint32_t li) -> uint32_t {
+        const uint32_t b = chunk_x * BIN_PPB + (uint32_t)tid;
+        return b < B ? *reinterpret_cast<const uint32_t*>(grad + ((size_t)plan.lc[li][0] * B + b) * C) : 0u;
+    };
+    if (item < item_end) g_cur = fetch_g(it.chunk_x, it.li);
     __syncthreads();
-
-    uint32_t raddr[BIN_ITERS * NJ], rval[BIN_ITERS * NJ], rrank[BIN_ITERS * NJ];
+#ifdef NGP_BIN_PHASE_PROBE
+    unsigned long long t_probe = __builtin_amdgcn_s_memtime(), t_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (; item < item_end; item++) {
+        NGP_PROBE_T(0)
+        const uint32_t b = it.chunk_x * BIN_PPB + (uint32_t)tid;
+        const bool in_range = b < B;
+        if (it.chunk_x != chunk_loaded) {  // (wave-uniform) the positions: once per chunk
+            chunk_loaded = it.chunk_x;
+            if (in_range) {
 #pragma unroll
-    for (int it = 0; it < BIN_ITERS; it++) {
-        uint32_t addr[NJ];
-        float v[NJ][CPL];
-        bool issue[NJ];
-        corner_runs<T, D, C, 2>(smp[it], scale, align_corners, interp, indexer, im, pl, xb, addr, v, issue);
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const uint32_t packed = pack_half2(v[j][0], v[j][1]);
-            const bool rec = issue[j] && (packed & 0x7fff7fffu) != 0u;  // (+-0, +-0) adds nothing
-            raddr[it * NJ + j] = addr[j];
-            rval[it * NJ + j] = packed;
-            if (rec && !plan_ok) atomic_add_packed(gtable + (size_t)addr[j] * C, packed);
-            rrank[it * NJ + j] = (rec && plan_ok) ? atomicAdd(&hist[bin_of(addr[j])], 1u) : 0xffffffffu;
+                for (int d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+            }
         }
+        uint32_t li_next = it.li + 1u, chunk_next = it.chunk_x;
+        if (li_next == n_levels) { li_next = 0u; chunk_next++; }
+        const uint32_t g_next = item + 1u < item_end ? fetch_g(chunk_next, li_next) : 0u;  // in flight during this item
+        const uint32_t* __restrict__ lc = plan.lc[it.li];
+        const uint32_t level = lc[0], flags = lc[2];
+        it.n_bins = lc[1];
+        it.scale = __builtin_bit_cast(float, lc[4]);
+        it.desc_base = lc[7];
+        it.interleaved = (flags & 1u) != 0u;
+        LevelIndexer<D> indexer;
+        indexer.size = lc[3];
+        indexer.mask = lc[5];
+        indexer.hashed = (flags & 4u) != 0u;
+        indexer.need_mod = (flags & 8u) != 0u;
+#pragma unroll
+        for (int d = 0; d < D; d++) indexer.stride[d] = lc[8 + (d < 3 ? d : 2)];
+        // the plan was made from the caller's HOST copy of the offsets; the device offsets are authoritative: if they describe another level
+        // size, index with them, and stay in bounds (records of a level that outgrew its bins take the atomic)
+        const uint32_t off0 = (uint32_t)offsets[level], size_dev = (uint32_t)offsets[level + 1] - off0;
+        if (size_dev != indexer.size) indexer.init(gridtype, align_corners, size_dev, lv.res[level]);
+        it.plan_ok = size_dev <= (it.n_bins << BIN_SLICE_BITS);
+        it.gtable = grad_grid + (size_t)off0 * C;
+        NGP_PROBE_T(1)
+        BinLane<D> bl;
+        LaneMask live_mask;
+        const bool fast = indexer.hashed && indexer.mask != 0u && !it.interleaved && it.plan_ok;
+        if (fast) bin_pass_count<D, true>(x, g_cur, in_range, it, indexer, align_corners, interp, im, hrow_base, bl, live_mask);
+        else bin_pass_count<D, false>(x, g_cur, in_range, it, indexer, align_corners, interp, im, hrow_base, bl, live_mask);
+        NGP_PROBE_T(2)
+        __syncthreads();  // all counts of this item are in
+        NGP_PROBE_T(3)
+        const uint32_t total = bin_offsets<BPL, WAVES>(hist, prow, lane, wid, it, plan.n_chunks, descriptors);
+        NGP_PROBE_T(4)
+        if (fast) bin_pass_place<D, true>(g_cur, it, bl, live_mask, prow_base, staging);
+        else bin_pass_place<D, false>(g_cur, it, bl, live_mask, prow_base, staging);
+        NGP_PROBE_T(5)
+        __syncthreads();  // the sorted chunk is complete in LDS (and every wave has read every counter row)
+        NGP_PROBE_T(6)
+        for (uint32_t i = lane; i < cap; i += 64) hrow[i] = 0u;  // own counters for the next item
+        // 16 bytes per lane (two records): 8-byte global accesses run at 0.5-0.7x the 16-byte rate on this chip (MI355X_MICROARCH.md)
+        uint4* __restrict__ chunk = reinterpret_cast<uint4*>(records + ((size_t)it.li * plan.n_chunks + it.chunk_x) * MAX_REC);
+        const uint4* staging2 = reinterpret_cast<const uint4*>(staging);
+        for (uint32_t r = tid; 2u * r < total; r += BIN_THREADS) chunk[r] = staging2[r];  // an odd tail writes one unused slot of the chunk
+        NGP_PROBE_T(7)
+        g_cur = g_next;
+        it.li = li_next;
+        it.chunk_x = chunk_next;
+#ifdef NGP_BIN_PHASE_PROBE
+        asm volatile("" ::"v"(g_cur));
+        NGP_PROBE_T(8)
+        t_acc[9] += 1ull;
+#endif
+        // (the next item's staging stores come after ITS first barrier, i.e. after every wave has finished this copy)
     }
-    __syncthreads();
-    {   // exclusive scan of the bin counts -> layout of the sorted chunk; one descriptor per bin
-        const uint32_t cnt = tid < BIN_MAX_BINS ? hist[tid] : 0u;
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wsum[wid] = incl;
-        __syncthreads();
-        uint32_t before = 0u;
-#pragma unroll
-        for (int w = 0; w < WAVES; w++) before += (w < wid) ? wsum[w] : 0u;
-        const uint32_t begin = before + incl - cnt;
-        if (tid < BIN_MAX_BINS) loff[tid] = begin;
-        if ((uint32_t)tid < n_bins)
-            descriptors[plan.desc_base[li] + (size_t)tid * plan.n_chunks + chunk_x] = begin | (cnt << 16);  // both <= 4096
+#ifdef NGP_BIN_PHASE_PROBE
+    if (tid == 0) {
+        for (int i = 0; i < 9; i++) atomicAdd(&g_bin_probe[i], t_acc[i]);
+        atomicAdd(&g_bin_probe[15], t_acc[9]);
     }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < BIN_ITERS * NJ; r++)
-        if (rrank[r] != 0xffffffffu) staging[loff[bin_of(raddr[r])] + rrank[r]] = make_uint2(raddr[r], rval[r]);
-    __syncthreads();
-    uint32_t total = 0u;
-#pragma unroll
-    for (int w = 0; w < WAVES; w++) total += wsum[w];
-    // 16 bytes per lane (two records): 8-byte global accesses run at 0.5-0.7x the 16-byte rate on this chip (MI355X_MICROARCH.md)
-    uint4* __restrict__ chunk = reinterpret_cast<uint4*>(records + ((size_t)li * plan.n_chunks + chunk_x) * MAX_REC);
-    const uint4* staging2 = reinterpret_cast<const uint4*>(staging);
-    for (uint32_t r = tid; 2u * r < total; r += BIN_THREADS) chunk[r] = staging2[r];  // an odd tail writes one unused slot of the chunk
+#endif
 }
 
 template <int D>
@@ -928,13 +1231,13 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     // levels in REVERSE order: the sort wrote the last level's records last, so they are the ones still in the memory-side cache
     // (same-box A/B: -4 us per iteration)
     const uint32_t li = gridDim.y - 1u - blockIdx.y, bin = blockIdx.x;
-    if (bin >= plan.n_bins[li]) return;
+    if (bin >= plan.n_bins(li)) return;
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * BIN_SLICE; i += ACC_THREADS) acc[i] = 0ull;
     if (tid < BIN_SLICE / 16) poison[tid] = 0u;
     __syncthreads();
     const uint32_t n_chunks = plan.n_chunks;
-    const uint32_t* __restrict__ desc = descriptors + plan.desc_base[li] + (size_t)bin * n_chunks;
+    const uint32_t* __restrict__ desc = descriptors + plan.desc_base(li) + (size_t)bin * n_chunks;
     const uint2* __restrict__ level_records = records + (size_t)li * n_chunks * MAX_REC;
     // A group of 16 lanes walks one run (the records of one chunk that fall into this slice: ~32 on a hashed level) at a time, two
     // records = 16 bytes per lane (8-byte global accesses run at 0.5-0.7x the 16-byte rate); the rest of a longer run follows in a
@@ -948,18 +1251,19 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     //   |v| >= 128: v is a multiple of 2^-3 (ulp of the binade of 128)     -> q = (int32) (v * 8) (<= 524032), addend = q << 21
     // one multiply, one conversion, one 64-bit shift by a selected amount; both channels are added unconditionally (a zero addend is
     // harmless).  Only inf / NaN leave the straight line: they poison their channel behind one (rare) branch per record.
-    const bool interleaved = plan.interleaved[li] != 0;
+    const bool interleaved = plan.interleaved(li);
     auto fixed_addend = [](float v) -> unsigned long long {
         const bool big = __builtin_fabsf(v) >= 128.0f;
         const int32_t q = (int32_t)(v * (big ? 8.0f : 0x1p24f));
         return (unsigned long long)(long long)q << (big ? 21 : 0);  // (shifted as unsigned: two's complement, exact mod 2^64)
     };
     auto add_record = [&](const uint32_t key, const uint32_t val) {
-        const uint32_t idx = interleaved ? (key >> BIN_DENSE_BITS) : (key & (BIN_SLICE - 1u));
+        const uint32_t idx = interleaved ? ((key & ~BIN_KEY_SCALED) >> BIN_DENSE_BITS) : (key & (BIN_SLICE - 1u));
+        const int up0 = (key & BIN_KEY_SCALED0) ? 6 : 0, up1 = (key & BIN_KEY_SCALED1) ? 6 : 0;  // the channel carries 1/64 of its contribution
         const half2_t hv = __builtin_bit_cast(half2_t, val);
         const bool fin0 = (val & 0x7c00u) != 0x7c00u, fin1 = (val & 0x7c000000u) != 0x7c000000u;
-        __hip_atomic_fetch_add(&acc[2 * idx], fixed_addend(fin0 ? (float)hv.x : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&acc[2 * idx + 1], fixed_addend(fin1 ? (float)hv.y : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[2 * idx], fixed_addend(fin0 ? (float)hv.x : 0.0f) << up0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[2 * idx + 1], fixed_addend(fin1 ? (float)hv.y : 0.0f) << up1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!(fin0 && fin1)) atomicOr(&poison[idx >> 4], ((fin0 ? 0u : 1u) | (fin1 ? 0u : 2u)) << ((idx & 15u) * 2u));
     };
     const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(level_records);  // 2 words per record
@@ -1001,7 +1305,7 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         }
     }
     __syncthreads();
-    const uint32_t level = plan.level[li];
+    const uint32_t level = plan.level(li);
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
     half2_t* __restrict__ gtable = reinterpret_cast<half2_t*>(grad_grid + (size_t)off0 * 2);
@@ -1231,6 +1535,12 @@ constexpr uint32_t BIN_MAX_SAMPLES = 1u << 24;
 static constexpr int bin_first_level() { return NGP_GRID_BWD_BIN_FROM; }
 
 // Every level of an eligible call is binned: hashed levels in contiguous slices, dense levels in round-robin bins.
+static uint32_t float_bits(float v) {
+    uint32_t u;
+    memcpy(&u, &v, sizeof(u));
+    return u;
+}
+
 static void plan_backward(BackwardPlan& p, const int32_t* offsets_host, const GridLevels& lv, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                           int dtype, uint32_t gridtype, bool align_corners, bool have_workspace) {
     const bool eligible = have_workspace && offsets_host && dtype == NGP_F16 && C == 2 && (D == 2 || D == 3) && B >= BIN_MIN_SAMPLES &&
@@ -1251,10 +1561,27 @@ static void plan_backward(BackwardPlan& p, const int32_t* offsets_host, const Gr
             continue;
         }
         const uint32_t i = p.n_binned++;
-        p.bins.level[i] = (uint8_t)l;
-        p.bins.n_bins[i] = (uint16_t)n_bins;
-        p.bins.interleaved[i] = interleave ? 1 : 0;
-        p.bins.desc_base[i] = p.total_desc;
+        uint32_t* lc = p.bins.lc[i];
+        for (int k = 0; k < BIN_LC_WORDS; k++) lc[k] = 0u;
+        lc[0] = l;
+        lc[1] = n_bins;
+        lc[3] = size;
+        lc[4] = float_bits(lv.scale[l]);
+        lc[7] = p.total_desc;
+        {   // the indexer's constants exactly as LevelIndexer::init derives them on the device (32-bit arithmetic)
+            uint32_t s = 1, stride[3] = {0u, 0u, 0u};
+            for (uint32_t d = 0; d < D && d < 3; d++) {
+                if (s <= size) {
+                    stride[d] = s;
+                    s *= align_corners ? lv.res[l] : (lv.res[l] + 1u);
+                }
+            }
+            const bool hashed_dev = gridtype == 0u && s > size;
+            const bool need_mod = hashed_dev || s > size || align_corners;
+            lc[2] = (interleave ? 1u : 0u) | (hashed_dev ? 4u : 0u) | (need_mod ? 8u : 0u);
+            lc[5] = ((size & (size - 1u)) == 0u) ? size - 1u : 0u;
+            lc[8] = stride[0]; lc[9] = stride[1]; lc[10] = stride[2];
+        }
         p.total_desc += n_bins * p.bins.n_chunks;
         p.total_records += (uint64_t)p.bins.n_chunks * BIN_PPB * (1u << D);
         p.max_bins = n_bins > p.max_bins ? n_bins : p.max_bins;
@@ -1266,13 +1593,17 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
                                 const GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, InputMap im, const BackwardPlan& p,
                                 void* workspace, bool with_atomic_levels, hipStream_t st) {
     constexpr size_t acc_smem = sizeof(unsigned long long) * 2 * BIN_SLICE + sizeof(uint32_t) * (BIN_SLICE / 16);
-    constexpr size_t bin_smem = sizeof(uint2) * BIN_PPB * (1 << D) + sizeof(uint32_t) * (2 * BIN_MAX_BINS + BIN_THREADS / 64);
+    const uint32_t bins_cap = p.max_bins <= 128u ? 128u : (uint32_t)BIN_MAX_BINS;
+    constexpr size_t bin_smem_max = sizeof(uint2) * BIN_PPB * (1 << D) + sizeof(uint32_t) * 2 * (BIN_THREADS / 64) * BIN_MAX_BINS;
+    const size_t bin_smem = sizeof(uint2) * BIN_PPB * (1 << D) + sizeof(uint32_t) * 2 * (BIN_THREADS / 64) * bins_cap;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_accumulate<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)acc_smem) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_bin<D, AMERGE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)bin_smem) != hipSuccess) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_bin<D, AMERGE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bin_smem_max) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_bin<D, AMERGE, BIN_MAX_BINS / 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bin_smem_max) != hipSuccess) {
             set_error("grid_encode_backward: hipFuncSetAttribute(LDS size) failed");
             return NGP_ERR_LAUNCH;
         }
@@ -1285,9 +1616,29 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     ap.points_per_block = 1024;
     ap.blocks_per_level = cdiv(B, ap.points_per_block);
     ap.n_blocks = with_atomic_levels ? ap.blocks_per_level * p.n_atomic : 0u;
-    const uint32_t blocks = p.bins.n_chunks * p.n_binned + ap.n_blocks;
-    hipLaunchKernelGGL((k_grid_backward_bin<D, AMERGE>), dim3(blocks), dim3(BIN_THREADS), bin_smem, st, (const half_t*)grad, inputs, offsets,
-                       (half_t*)grad_emb, B, lv, gridtype, ac, interp, im, p.bins, descriptors, records, ap);
+    // persistent sort workgroups: as many as are resident at once (LDS and registers allow BIN_RESIDENT per CU), never more than items
+    static int n_cus = 0;
+    if (!n_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+            set_error("grid_encode_backward: hipGetDeviceProperties failed");
+            return NGP_ERR_LAUNCH;
+        }
+        n_cus = prop.multiProcessorCount;
+    }
+    const uint32_t n_items = p.bins.n_chunks * p.n_binned;
+    // (128 counters per wave: 40 KiB of LDS per workgroup, four of them on a CU; 512: 64 KiB, two)
+    const uint32_t persistent = std::min<uint32_t>(n_items, (uint32_t)n_cus * (bins_cap <= 128u ? BIN_RESIDENT : 2u));
+    const uint32_t blocks = persistent + ap.n_blocks;
+    BinPlan bins = p.bins;
+    bins.n_levels = p.n_binned;
+    if (bins_cap <= 128u)
+        hipLaunchKernelGGL((k_grid_backward_bin<D, AMERGE, 2>), dim3(blocks), dim3(BIN_THREADS), bin_smem, st, (const half_t*)grad, inputs, offsets,
+                           (half_t*)grad_emb, B, lv, gridtype, ac, interp, im, bins, descriptors, records, ap);
+    else
+        hipLaunchKernelGGL((k_grid_backward_bin<D, AMERGE, BIN_MAX_BINS / 64>), dim3(blocks), dim3(BIN_THREADS), bin_smem, st, (const half_t*)grad, inputs,
+                           offsets, (half_t*)grad_emb, B, lv, gridtype, ac, interp, im, bins, descriptors, records, ap);
     int rc = check_launch("grid_encode_backward(bin)");
     if (rc) return rc;
     hipLaunchKernelGGL((k_grid_backward_accumulate<D>), dim3(p.max_bins, p.n_binned), dim3(ACC_THREADS), acc_smem, st, offsets,
@@ -1400,6 +1751,14 @@ static int check_grid_args(const char* fn, uint32_t B, uint32_t D, uint32_t C, u
 }  // namespace ngp
 
 using namespace ngp;
+
+#ifdef NGP_BIN_PHASE_PROBE
+extern "C" int ngp_debug_bin_probe(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ngp::g_bin_probe), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ngp::g_bin_probe), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 extern "C" int ngp_grid_level_table(uint32_t L, float S, uint32_t H, float* scale_out, uint32_t* resolution_out) {
     NGP_REQUIRE(scale_out && resolution_out, NGP_ERR_INVALID, "ngp_grid_level_table: NULL output");

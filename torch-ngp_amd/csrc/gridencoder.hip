@@ -1134,6 +1134,17 @@ void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restric
     it.li = item - it.chunk_x * n_levels;
 
     for (uint32_t i = lane; i < cap; i += 64) hrow[i] = 0u;
+    // binned levels whose size on the device differs from the host copy the plan was made from (none, normally): one check per wave here
+    // instead of two dependent scalar loads in front of every item
+    unsigned long long levels_differ;
+    {
+        bool differ = false;
+        if ((uint32_t)lane < n_levels) {
+            const uint32_t level = plan.lc[lane][0];
+            differ = (uint32_t)offsets[level + 1] - (uint32_t)offsets[level] != plan.lc[lane][3];
+        }
+        levels_differ = __builtin_amdgcn_ballot_w64(differ);
+    }
     float x[D];
 #pragma unroll
     for (int d = 0; d < D; d++) x[d] = 0.0f;
@@ -1174,12 +1185,16 @@ void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restric
         indexer.need_mod = (flags & 8u) != 0u;
 #pragma unroll
         for (int d = 0; d < D; d++) indexer.stride[d] = lc[8 + (d < 3 ? d : 2)];
-        // the plan was made from the caller's HOST copy of the offsets; the device offsets are authoritative: if they describe another level
-        // size, index with them, and stay in bounds (records of a level that outgrew its bins take the atomic)
-        const uint32_t off0 = (uint32_t)offsets[level], size_dev = (uint32_t)offsets[level + 1] - off0;
-        if (size_dev != indexer.size) indexer.init(gridtype, align_corners, size_dev, lv.res[level]);
-        it.plan_ok = size_dev <= (it.n_bins << BIN_SLICE_BITS);
-        it.gtable = grad_grid + (size_t)off0 * C;
+        // the plan was made from the caller's HOST copy of the offsets; the device offsets are authoritative: where they describe another
+        // level size (checked once per wave, above) index with them, and stay in bounds (records of a level that outgrew its bins take the atomic)
+        it.plan_ok = true;
+        it.gtable = grad_grid;
+        if ((levels_differ >> it.li) & 1ull) {
+            const uint32_t off0 = (uint32_t)offsets[level], size_dev = (uint32_t)offsets[level + 1] - off0;
+            indexer.init(gridtype, align_corners, size_dev, lv.res[level]);
+            it.plan_ok = size_dev <= (it.n_bins << BIN_SLICE_BITS);
+            it.gtable = grad_grid + (size_t)off0 * C;
+        }
         NGP_PROBE_T(1)
         BinLane<D> bl;
         LaneMask live_mask;
@@ -1220,87 +1235,139 @@ void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restric
 #endif
 }
 
+// Pass 2, round 4: DENSE lanes.  The kernel is bound by its instruction stream (34 M VALU per launch, PMC), and the round-3 walk -- a group
+// of 16 lanes per run, two records per lane, a second trip for the part of a run beyond 32 records -- kept about a third of the lanes
+// busy: runs are Poisson-distributed around 32 records, so most waves made the second trip for a handful of records.  Now a wave takes
+// a contiguous share of the slice's runs (one per chunk), scans their lengths, and walks the CONCATENATION of its runs 64 record pairs at
+// a time: lane l of window w handles pair 64 w + l.  Which run a pair belongs to comes from a scatter of the run heads that fall into
+// the window (one LDS byte array per wave) followed by a DPP max-scan over the lanes -- about 15 VALU per window of 128 records, whatever
+// the run lengths.  Non-finite and scaled records (rare) leave the straight-line addend behind one wave-uniform branch.
 template <int D>
 __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_grid_backward_accumulate(const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid,
                                                                           BinPlan plan, const uint32_t* __restrict__ descriptors,
                                                                           const uint2* __restrict__ records, float* __restrict__ found_inf) {
     constexpr int MAX_REC = BIN_PPB * (1 << D);
+    constexpr int WAVES = ACC_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_smem);                                // [BIN_SLICE][2]
     uint32_t* poison = reinterpret_cast<uint32_t*>(acc_smem + sizeof(unsigned long long) * 2 * BIN_SLICE);  // [BIN_SLICE / 16], 2 bits per entry
+    uint2* run_table = reinterpret_cast<uint2*>(poison + BIN_SLICE / 16);                                   // [WAVES][64] {first record, first pair | records << 18}
+    uint32_t* head_at = reinterpret_cast<uint32_t*>(run_table + WAVES * 64);                                // [WAVES][64] run (1-based) whose first pair sits at this lane of the window
     // levels in REVERSE order: the sort wrote the last level's records last, so they are the ones still in the memory-side cache
     // (same-box A/B: -4 us per iteration)
     const uint32_t li = gridDim.y - 1u - blockIdx.y, bin = blockIdx.x;
     if (bin >= plan.n_bins(li)) return;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 2 * BIN_SLICE; i += ACC_THREADS) acc[i] = 0ull;
     if (tid < BIN_SLICE / 16) poison[tid] = 0u;
     __syncthreads();
     const uint32_t n_chunks = plan.n_chunks;
     const uint32_t* __restrict__ desc = descriptors + plan.desc_base(li) + (size_t)bin * n_chunks;
-    const uint2* __restrict__ level_records = records + (size_t)li * n_chunks * MAX_REC;
-    // A group of 16 lanes walks one run (the records of one chunk that fall into this slice: ~32 on a hashed level) at a time, two
-    // records = 16 bytes per lane (8-byte global accesses run at 0.5-0.7x the 16-byte rate); the rest of a longer run follows in a
-    // second pass.  The kernel is bound by the bytes it pulls (measured: fetching 64 records per run instead of 32 costs +40 %), so
-    // nothing is fetched speculatively.  A group fetches the descriptors of its next 16 runs with ONE load (a lane each), then issues
-    // the loads of RUNS_AHEAD runs back to back -- unconditionally, at clamped addresses -- before it touches the accumulator.
-    constexpr int GROUP = 16, GROUPS = ACC_THREADS / GROUP, RUNS_AHEAD = NGP_ACC_RUNS_AHEAD;
-    const int grp = tid / GROUP, gl = tid % GROUP, lane = tid & 63, group_base = lane & ~(GROUP - 1);
+    const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(records + (size_t)li * n_chunks * MAX_REC);  // 2 words per record
+    const bool interleaved = plan.interleaved(li);
     // Exact fixed-point addend of a finite fp16 value v (11 significant bits), straight-line for BOTH magnitude ranges:
     //   |v| <  128: v * 2^24 is an integer below 2^31                      -> q = (int32) (v * 2^24), addend = q
     //   |v| >= 128: v is a multiple of 2^-3 (ulp of the binade of 128)     -> q = (int32) (v * 8) (<= 524032), addend = q << 21
     // one multiply, one conversion, one 64-bit shift by a selected amount; both channels are added unconditionally (a zero addend is
-    // harmless).  Only inf / NaN leave the straight line: they poison their channel behind one (rare) branch per record.
-    const bool interleaved = plan.interleaved(li);
+    // harmless).
     auto fixed_addend = [](float v) -> unsigned long long {
         const bool big = __builtin_fabsf(v) >= 128.0f;
         const int32_t q = (int32_t)(v * (big ? 8.0f : 0x1p24f));
         return (unsigned long long)(long long)q << (big ? 21 : 0);  // (shifted as unsigned: two's complement, exact mod 2^64)
     };
-    auto add_record = [&](const uint32_t key, const uint32_t val) {
-        const uint32_t idx = interleaved ? ((key & ~BIN_KEY_SCALED) >> BIN_DENSE_BITS) : (key & (BIN_SLICE - 1u));
-        const int up0 = (key & BIN_KEY_SCALED0) ? 6 : 0, up1 = (key & BIN_KEY_SCALED1) ? 6 : 0;  // the channel carries 1/64 of its contribution
+    auto entry_of = [&](uint32_t key) { return interleaved ? ((key & ~BIN_KEY_SCALED) >> BIN_DENSE_BITS) : (key & (BIN_SLICE - 1u)); };
+    auto add_plain = [&](const uint32_t key, const uint32_t val) {  // finite, unscaled
+        const uint32_t idx = entry_of(key);
+        const half2_t hv = __builtin_bit_cast(half2_t, val);
+        __hip_atomic_fetch_add(&acc[2 * idx], fixed_addend((float)hv.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[2 * idx + 1], fixed_addend((float)hv.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto add_general = [&](const uint32_t key, const uint32_t val) {  // inf / NaN poison their channel; a scaled channel carries 1/64
+        const uint32_t idx = entry_of(key);
+        const int up0 = (key & BIN_KEY_SCALED0) ? 6 : 0, up1 = (key & BIN_KEY_SCALED1) ? 6 : 0;
         const half2_t hv = __builtin_bit_cast(half2_t, val);
         const bool fin0 = (val & 0x7c00u) != 0x7c00u, fin1 = (val & 0x7c000000u) != 0x7c000000u;
         __hip_atomic_fetch_add(&acc[2 * idx], fixed_addend(fin0 ? (float)hv.x : 0.0f) << up0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&acc[2 * idx + 1], fixed_addend(fin1 ? (float)hv.y : 0.0f) << up1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!(fin0 && fin1)) atomicOr(&poison[idx >> 4], ((fin0 ? 0u : 1u) | (fin1 ? 0u : 2u)) << ((idx & 15u) * 2u));
     };
-    const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(level_records);  // 2 words per record
-    auto load2 = [&](uint32_t first_record) {  // records first_record, first_record + 1
-        uint4 q;
-        __builtin_memcpy(&q, words + 2u * first_record, sizeof(q));  // 8-byte aligned: global_load_dwordx4 takes it
-        return q;
+    auto special = [](uint32_t key, uint32_t val) {  // a record the straight-line addend does not cover
+        return (key & BIN_KEY_SCALED) != 0u || (val & 0x7c00u) == 0x7c00u || (val & 0x7c000000u) == 0x7c000000u;
     };
     // every workgroup of a level walks the same chunks: start each one somewhere else
     const uint32_t rot = (bin * 97u) % n_chunks;
     auto chunk_of = [&](uint32_t i) { const uint32_t k = i + rot; return k >= n_chunks ? k - n_chunks : k; };
-    for (uint32_t k0 = grp; k0 < n_chunks; k0 += GROUPS * GROUP) {  // this group's runs k0 + GROUPS * i, i = 0..GROUP-1 (before rotation)
-        const uint32_t my_k = k0 + (uint32_t)gl * GROUPS;
-        const uint32_t my_desc = desc[chunk_of(my_k < n_chunks ? my_k : k0)];  // (lanes past the end re-read a valid descriptor, unused)
-#pragma unroll 1
-        for (int i0 = 0; i0 < GROUP; i0 += RUNS_AHEAD) {
-            if (k0 + (uint32_t)i0 * GROUPS >= n_chunks) break;
-            uint32_t base[RUNS_AHEAD], cnt[RUNS_AHEAD];
-            uint4 ra[RUNS_AHEAD];
-#pragma unroll
-            for (int a = 0; a < RUNS_AHEAD; a++) {
-                const uint32_t i = k0 + (uint32_t)(i0 + a) * GROUPS;
-                const uint32_t d = __shfl(my_desc, group_base + i0 + a, 64);
-                const uint32_t k = chunk_of(i < n_chunks ? i : k0);
-                cnt[a] = i < n_chunks ? d >> 16 : 0u;
-                base[a] = k * (uint32_t)MAX_REC + (cnt[a] ? (d & 0xffffu) : 0u);  // 32-bit record index: < 2^28
-                ra[a] = load2(base[a] + (2u * gl < cnt[a] ? 2u * gl : 0u));
-            }
-#pragma unroll
-            for (int a = 0; a < RUNS_AHEAD; a++) {
-                if (2u * gl < cnt[a]) add_record(ra[a].x, ra[a].y);
-                if (2u * gl + 1u < cnt[a]) add_record(ra[a].z, ra[a].w);
-                for (uint32_t i = 2u * GROUP + 2u * gl; i < cnt[a]; i += 2u * GROUP) {  // the part of the run beyond 32 records
-                    const uint4 q = load2(base[a] + i);
-                    add_record(q.x, q.y);
-                    if (i + 1u < cnt[a]) add_record(q.z, q.w);
-                }
+    // (lanes of the wave talk to each other through these two arrays with nothing but the LDS's in-order execution between a store and
+    // the load of another lane: the accesses are volatile, otherwise the compiler forwards a lane's OWN earlier store to its load)
+    typedef volatile __attribute__((address_space(3))) uint32_t* lds_words_t;
+    lds_words_t my_runs = (lds_words_t)(__attribute__((address_space(3))) void*)(run_table + wid * 64);
+    lds_words_t my_heads = (lds_words_t)(__attribute__((address_space(3))) void*)(head_at + wid * 64);
+    const uint32_t per_wave = (n_chunks + WAVES - 1) / WAVES;
+    const uint32_t run_end = min(n_chunks, (uint32_t)(wid + 1) * per_wave);
+    for (uint32_t run0 = (uint32_t)wid * per_wave; run0 < run_end; run0 += 64u) {  // this wave's runs, 64 at a time (a lane each)
+        const uint32_t i = run0 + (uint32_t)lane;
+        uint32_t first = 0u, cnt = 0u;
+        if (i < run_end) {
+            const uint32_t k = chunk_of(i), d = desc[k];
+            cnt = d >> 16;
+            first = k * (uint32_t)MAX_REC + (d & 0xffffu);  // 32-bit record index: < 2^28
+        }
+        const uint32_t pairs = (cnt + 1u) >> 1;  // 16-byte accesses: two records per lane (an odd run ends in a half-used pair)
+        uint32_t incl = pairs;
+        incl += row_shr<1>(incl);
+        incl += row_shr<2>(incl);
+        incl += row_shr<4>(incl);
+        incl += row_shr<8>(incl);
+        incl += bcast15_rows13(incl);
+        incl += bcast31_rows23(incl);
+        const uint32_t total_pairs = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t start = incl - pairs;
+        my_runs[2 * lane] = first;
+        my_runs[2 * lane + 1] = start | (cnt << 18);  // (start < 64 * 2048 = 2^17, cnt <= 4096)
+        uint32_t carry = 0u;  // run (1-based) that covers the pair before the window
+        // one window: which run does pair w0 + lane belong to (heads inside the window are scattered, the rest follows by a max-scan),
+        // then the 16-byte load of the pair.  valid: bit 0 = first record, bit 1 = second record of the pair exists
+        auto fetch = [&](uint32_t w0, uint4& q, uint32_t& valid) {
+            my_heads[lane] = 0u;
+            if (pairs != 0u && start - w0 < 64u) my_heads[start - w0] = (uint32_t)lane + 1u;  // (unsigned: start >= w0)
+            uint32_t r = my_heads[lane];
+            r = max(r, row_shr<1>(r));
+            r = max(r, row_shr<2>(r));
+            r = max(r, row_shr<4>(r));
+            r = max(r, row_shr<8>(r));
+            r = max(r, bcast15_rows13(r));
+            r = max(r, bcast31_rows23(r));
+            r = max(r, carry);
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)r, 63);
+            const uint32_t p = w0 + (uint32_t)lane;
+            const bool have = p < total_pairs;  // (r >= 1 then: pair 0 is the head of the first non-empty run)
+            const uint32_t ri = have ? r - 1u : 0u;
+            const uint32_t r_first = my_runs[2 * ri], r_word = my_runs[2 * ri + 1];
+            const uint32_t r_start = r_word & 0x3ffffu, r_cnt = r_word >> 18;
+            const uint32_t rec = 2u * (p - r_start);  // first record of the pair inside its run
+            q = make_uint4(0u, 0u, 0u, 0u);
+            if (have) __builtin_memcpy(&q, words + 2u * (r_first + rec), sizeof(q));  // 8-byte aligned: global_load_dwordx4 takes it
+            valid = have ? (rec + 1u < r_cnt ? 3u : 1u) : 0u;
+        };
+        // two windows ahead: the loads of windows w + 1 and w + 2 are in flight during the adds of window w (the kernel waits on memory)
+        uint4 q1, q2;
+        uint32_t valid1 = 0u, valid2 = 0u;
+        if (total_pairs != 0u) fetch(0u, q1, valid1);
+        if (total_pairs > 64u) fetch(64u, q2, valid2);
+        for (uint32_t w0 = 0u; w0 < total_pairs; w0 += 64u) {
+            const uint4 q = q1;
+            const uint32_t valid = valid1;
+            q1 = q2;
+            valid1 = valid2;
+            valid2 = 0u;
+            if (w0 + 128u < total_pairs) fetch(w0 + 128u, q2, valid2);
+            const bool have = (valid & 1u) != 0u, second = (valid & 2u) != 0u;
+            if (__builtin_amdgcn_ballot_w64((have && special(q.x, q.y)) || (second && special(q.z, q.w))) == 0ull) {
+                if (have) add_plain(q.x, q.y);
+                if (second) add_plain(q.z, q.w);
+            } else {
+                if (have) add_general(q.x, q.y);
+                if (second) add_general(q.z, q.w);
             }
         }
     }
@@ -1592,7 +1659,8 @@ template <int D, int AMERGE>
 static int launch_backward_bins(const void* grad, const float* inputs, const int32_t* offsets, void* grad_emb, uint32_t B,
                                 const GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, InputMap im, const BackwardPlan& p,
                                 void* workspace, bool with_atomic_levels, hipStream_t st) {
-    constexpr size_t acc_smem = sizeof(unsigned long long) * 2 * BIN_SLICE + sizeof(uint32_t) * (BIN_SLICE / 16);
+    constexpr size_t acc_smem = sizeof(unsigned long long) * 2 * BIN_SLICE + sizeof(uint32_t) * (BIN_SLICE / 16) +
+                                (ACC_THREADS / 64) * 64 * (sizeof(uint2) + sizeof(uint32_t));
     const uint32_t bins_cap = p.max_bins <= 128u ? 128u : (uint32_t)BIN_MAX_BINS;
     constexpr size_t bin_smem_max = sizeof(uint2) * BIN_PPB * (1 << D) + sizeof(uint32_t) * 2 * (BIN_THREADS / 64) * BIN_MAX_BINS;
     const size_t bin_smem = sizeof(uint2) * BIN_PPB * (1 << D) + sizeof(uint32_t) * 2 * (BIN_THREADS / 64) * bins_cap;

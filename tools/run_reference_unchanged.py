@@ -117,7 +117,31 @@ def imported_from(side, where):
     return where
 
 
-def run_side(side, out_path, steps=20, n_rays=4096):
+GOLDEN_IMAGE_STEPS = (0, 15, 16, 19)   # images / depths kept in the compact form (first, last worst-case-sized, first estimate-sized, last)
+GOLDEN_STRIDE = 997                    # every 997th element of a tensor with more than 2^17 elements (a prime: no level/channel aliasing)
+
+
+def compact(rec):
+    """the committed form (tests/golden/a24_reference_callers.npz): per-step counters, losses, the sample estimate and the eval frame in
+    full, training images at GOLDEN_IMAGE_STEPS, big tensors (table gradient / parameters, density grids) as a strided sample plus their
+    L2 norm; bitfields as is (256 KiB)"""
+    import numpy as np
+    out = {}
+    for k, v in rec.items():
+        if k.startswith(('image_', 'depth_')) and int(k.split('_')[1]) not in GOLDEN_IMAGE_STEPS:
+            continue
+        v = np.asarray(v)
+        if v.dtype.kind == 'f' and v.size > (1 << 17):
+            flat = v.reshape(-1)
+            out[k] = flat[::GOLDEN_STRIDE].copy()
+            out[k + '__norm'] = np.array(float(np.sqrt((flat.astype(np.float64) ** 2).sum())))
+        else:
+            out[k] = v
+    out['_compact'] = np.array(1)
+    return out
+
+
+def run_side(side, out_path, steps=20, n_rays=4096, golden=False):
     import numpy as np
     import torch
     Net, where = build_side(side)
@@ -188,6 +212,8 @@ def run_side(side, out_path, steps=20, n_rays=4096):
     rec['eval_depth'] = ev['depth'][0].float().cpu().numpy()
     rec['_where'] = np.array(json.dumps(where))
     rec['_side'] = np.array(side)
+    if golden:
+        rec = compact(rec)
     np.savez_compressed(out_path, **rec)
     print(json.dumps({'side': side, 'out': out_path, 'imported_from': where, 'final_loss': float(rec[f'loss_{steps - 1}']),
                       'samples_last_step': int(rec[f'counter_{steps - 1}'][0])}))
@@ -213,6 +239,8 @@ def compare(a_path, b_path, report_path=None):
             rows.append({'key': k, 'check': 'fraction of identical cells (duplicate-index scatter is order-dependent)', 'value': 1.0 - same,
                          'ok': same > 0.97})
             ok = ok and same > 0.97
+            continue
+        if k not in b.files:   # (a full file against a compact one: only the keys both hold)
             continue
         exact = k.startswith(('counter_', 'mean_count'))
         if exact:
@@ -249,6 +277,7 @@ def main():
     ap.add_argument('--side', choices=['mirror', 'reference-callers', 'reference-all'])
     ap.add_argument('--out')
     ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--golden', action='store_true', help='write the compact form (see compact()): what tests/golden/a24_reference_callers.npz holds')
     ap.add_argument('--compare', nargs=2)
     ap.add_argument('--report')
     args = ap.parse_args()
@@ -257,7 +286,7 @@ def main():
     if args.unstage:
         shutil.rmtree(STAGE, ignore_errors=True)
     if args.side:
-        run_side(args.side, args.out or os.path.join(ROOT, 'gpurun_out', f'a24_{args.side}.npz'), steps=args.steps)
+        run_side(args.side, args.out or os.path.join(ROOT, 'gpurun_out', f'a24_{args.side}.npz'), steps=args.steps, golden=args.golden)
     if args.compare:
         sys.exit(0 if compare(args.compare[0], args.compare[1], args.report) else 1)
 

@@ -10,11 +10,24 @@ import torch
 
 
 def save_checkpoint(path, model, epoch=0, global_step=0, stats=None, optimizer=None, scaler=None, lr_scheduler=None, ema=None, full=False,
-                    best=False):
+                    best=False, write=None):
+    """`write`: whether THIS rank writes the file.  Default: rank 0 of an initialised process group (what the reference Trainer does,
+    nerf/utils.py:650-655), every caller otherwise.
+
+    With optim.NGPAdam(shard=True) the call is COLLECTIVE: every rank must make it (the fp32 master weights and the moments are gathered
+    from their owners), and only the writing rank touches `path`.  A caller that keeps the reference's `if local_rank == 0:` guard
+    around the call would leave rank 0 alone in a collective: that is refused with an error instead of a hang (pass write=... or call
+    from every rank)."""
+    import torch.distributed as dist
+    in_group = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if write is None:
+        write = (not in_group) or dist.get_rank() == 0
     state = {'epoch': epoch, 'global_step': global_step, 'stats': stats if stats is not None else {}}
     if optimizer is not None and getattr(optimizer, 'shard', False):
         # optim.NGPAdam(shard=True): a rank keeps only its own 1/world of the fp32 master weights current between steps -- complete them
         # from their owners before ANY state_dict (also the model-only "best" checkpoints); a collective: every rank calls save_checkpoint
+        if in_group:
+            _all_ranks_here(optimizer)
         optimizer.wait_shadows()
         optimizer.gather_master()
     if getattr(model, 'cuda_ray', False):
@@ -33,8 +46,24 @@ def save_checkpoint(path, model, epoch=0, global_step=0, stats=None, optimizer=N
     if best and 'density_grid' in sd:  # nerf/utils.py:1066-1068
         sd = {k: v for k, v in sd.items() if k != 'density_grid'}
     state['model'] = sd
-    torch.save(state, path)
+    if write:
+        torch.save(state, path)
     return state
+
+
+def _all_ranks_here(optimizer, timeout_s=60.0):
+    """sharded checkpoints gather from every rank: a call made by a subset of the ranks (the reference's rank-0 guard) would hang in the
+    first collective.  A store-based roll call turns that into an error within `timeout_s`."""
+    import datetime
+    import torch.distributed as dist
+    group = getattr(optimizer, 'group', None)
+    try:
+        dist.monitored_barrier(group=group, timeout=datetime.timedelta(seconds=timeout_s))
+    except (RuntimeError, ValueError) as e:  # monitored_barrier exists for gloo groups only; RCCL groups fall through to the collective
+        if 'monitored_barrier' in str(e) or 'Gloo' in str(e) or 'gloo' in str(e) and 'only' in str(e):
+            return
+        raise RuntimeError('save_checkpoint with optim.NGPAdam(shard=True) is collective: every rank must call it (only the `write` rank '
+                           'touches the file) -- ' + str(e)) from e
 
 
 def load_checkpoint(checkpoint, model, optimizer=None, scaler=None, lr_scheduler=None, ema=None, model_only=False, map_location=None):

@@ -45,6 +45,16 @@ inline uint64_t cdiv64(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 inline hipStream_t as_stream(ngp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- debug build (make DEBUG_BOUNDS=1 -> libngp_hip_dbg.so): device-side range traps on the indices the fast paths trust ----
+// (encoder work lists and table indices, record-sort slots / descriptors / counters, accumulate record and entry indices, marcher sample
+// rows).  A violated bound aborts the kernel (s_trap), which the host sees as a failed synchronisation; the product build compiles the
+// checks away.
+#ifdef NGP_DEBUG_BOUNDS
+#define NGP_BOUNDS(cond) do { if (!(cond)) __builtin_trap(); } while (0)
+#else
+#define NGP_BOUNDS(cond) do { } while (0)
+#endif
+
 // ---- device helpers ----
 // fp32 -> fp16, round-to-nearest-even of the fp32 VALUE.  Without the barrier the compiler folds `(half)(a * b)` into v_fma_mixlo_f16, which
 // rounds the exact product once: a different result on exact ties than "compute in fp32, then cast" -- what the reference's autocast path

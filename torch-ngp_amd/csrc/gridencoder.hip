@@ -346,6 +346,7 @@ __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* 
         }
         begin = e;
     }
+    NGP_BOUNDS(level < L || level == 0xffffu);
     if (level >= L) return;
     const uint32_t off0 = (uint32_t)offsets[level];
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* 
     indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
     const T* __restrict__ table = grid + (size_t)off0 * C;
     T* __restrict__ olevel = outputs + (size_t)level * B * C;
+    NGP_BOUNDS((uint64_t)tile * points_per_block < (uint64_t)B);  // every listed tile holds at least one point
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int pl = lane >> 1;
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* 
                 pg[0] = cell[0] + xb;
 #pragma unroll
                 for (int d = 1; d < D; d++) pg[d] = cell[d] + ((j >> (d - 1)) & 1);
+                NGP_BOUNDS(indexer(pg) < hashmap_size);
                 corner[j].load(table + (size_t)indexer(pg) * C);
             }
             const float w0 = xb ? frac[0] : 1.0f - frac[0];
@@ -997,7 +1000,10 @@ __device__ __forceinline__ void bin_pass_count(const float (&x)[D], uint32_t gbi
     const LaneMask pairs = bin_pairs(live_mask, bl.addr[0]);
 #pragma unroll
     for (int s = 0; s < NS; s++)
-        if (bin_issues(live_mask, bin_run_mask(bl.addr[s], pairs))) lds_add_u32(bin_counter_addr<FAST>(bl.addr[s], it, hrow_base));
+        if (bin_issues(live_mask, bin_run_mask(bl.addr[s], pairs))) {
+            NGP_BOUNDS(bl.addr[s] < ix.size && bin_counter_addr<FAST>(bl.addr[s], it, hrow_base) - hrow_base < 4u * it.n_bins);
+            lds_add_u32(bin_counter_addr<FAST>(bl.addr[s], it, hrow_base));
+        }
 }
 
 // PLACE pass: staging slots from the wave's own cursors (eight returning LDS adds in flight), then values, run sums and the records
@@ -1040,6 +1046,7 @@ __device__ __forceinline__ void bin_pass_place(uint32_t gbits, const BinItem& it
         }
         const uint32_t packed = pack_half2(v0, v1);
         if (bin_issues(live_mask, m)) {
+            NGP_BOUNDS(!binned || slot[s] < (uint32_t)(BIN_PPB * NS));
             if (binned) staging[slot[s]] = make_uint2(key, packed);
             else atomic_add_packed(it.gtable + (size_t)addr * 2, packed);
         }
@@ -1080,6 +1087,7 @@ __device__ __forceinline__ uint32_t bin_offsets(const uint32_t* __restrict__ his
     for (int k = 0; k < BPL; k++) {
         prow[lane * BPL + k] = begin + mine[k];
         const uint32_t bin = (uint32_t)(lane * BPL + k);
+        NGP_BOUNDS(begin + tot[k] <= (uint32_t)(BIN_PPB * 8) && it.chunk_x < n_chunks);
         if (wid == 0 && bin < it.n_bins) descriptors[it.desc_base + (size_t)bin * n_chunks + it.chunk_x] = begin | (tot[k] << 16);  // both <= 4096
         begin += tot[k];
     }
@@ -1278,12 +1286,14 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     auto entry_of = [&](uint32_t key) { return interleaved ? ((key & ~BIN_KEY_SCALED) >> BIN_DENSE_BITS) : (key & (BIN_SLICE - 1u)); };
     auto add_plain = [&](const uint32_t key, const uint32_t val) {  // finite, unscaled
         const uint32_t idx = entry_of(key);
+        NGP_BOUNDS(idx < (uint32_t)BIN_SLICE);
         const half2_t hv = __builtin_bit_cast(half2_t, val);
         __hip_atomic_fetch_add(&acc[2 * idx], fixed_addend((float)hv.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_add(&acc[2 * idx + 1], fixed_addend((float)hv.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     auto add_general = [&](const uint32_t key, const uint32_t val) {  // inf / NaN poison their channel; a scaled channel carries 1/64
         const uint32_t idx = entry_of(key);
+        NGP_BOUNDS(idx < (uint32_t)BIN_SLICE);
         const int up0 = (key & BIN_KEY_SCALED0) ? 6 : 0, up1 = (key & BIN_KEY_SCALED1) ? 6 : 0;
         const half2_t hv = __builtin_bit_cast(half2_t, val);
         const bool fin0 = (val & 0x7c00u) != 0x7c00u, fin1 = (val & 0x7c000000u) != 0x7c000000u;
@@ -1346,6 +1356,7 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
             const uint32_t r_start = r_word & 0x3ffffu, r_cnt = r_word >> 18;
             const uint32_t rec = 2u * (p - r_start);  // first record of the pair inside its run
             q = make_uint4(0u, 0u, 0u, 0u);
+            NGP_BOUNDS(!have || (r >= 1u && r <= 64u && rec < r_cnt && r_first + rec < n_chunks * (uint32_t)MAX_REC));
             if (have) __builtin_memcpy(&q, words + 2u * (r_first + rec), sizeof(q));  // 8-byte aligned: global_load_dwordx4 takes it
             valid = have ? (rec + 1u < r_cnt ? 3u : 1u) : 0u;
         };
@@ -1495,8 +1506,12 @@ static uint32_t fwd_blocks(uint32_t B) {
 #endif
 // level_cost[l]: relative time of one tile of level l (nullptr: unknown -> every level costs the same -> whole levels only, the plain
 // (level mod 8) placement).  Returns the number of slots of the longest work list.
+static_assert(NGP_MAX_LEVELS <= 8 * FWD_MAX_SEG, "whole levels alone must fit the per-XCD work lists");
 static uint32_t build_forward_schedule(FwdSchedule& sc, uint32_t L, uint32_t tiles, const float* level_cost) {
     struct Seg { uint32_t level, tile0, n; };
+    // (a cost vector that is not positive and finite is ignored here -- the entry points that take one from a caller refuse it first)
+    for (uint32_t l = 0; level_cost && l < L; l++)
+        if (!(level_cost[l] > 0.0f && level_cost[l] < 1e6f)) { level_cost = nullptr; break; }
     std::vector<Seg> list[8];
     double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto cost = [&](uint32_t l) { return level_cost ? (double)level_cost[l] : 1.0; };
@@ -1519,7 +1534,8 @@ static uint32_t build_forward_schedule(FwdSchedule& sc, uint32_t L, uint32_t til
             if (load[hi] - target < 0.02 * target || list[lo].size() >= (size_t)FWD_MAX_SEG || list[hi].empty()) break;
             Seg& last = list[hi].back();               // the donor gives away the END of the level it processes last
             const double c = cost(last.level);
-            uint32_t n = (uint32_t)(std::min(load[hi] - target, target - load[lo]) / c);
+            const double want = std::min(load[hi] - target, target - load[lo]) / c;
+            uint32_t n = want >= (double)tiles ? tiles : (want > 0.0 ? (uint32_t)want : 0u);
             if (n == 0) break;
             if (n >= last.n) n = last.n > 1 ? last.n - 1 : 0;
             if (n == 0) break;
@@ -1891,6 +1907,28 @@ extern "C" int ngp_grid_encode_forward_sched(const float* inputs, const void* em
     set_error("grid_encode_forward: unsupported (D=%u, C=%u)", D, C);
     return NGP_ERR_INVALID;
 }
+
+#ifdef NGP_DEBUG_BOUNDS
+// self-test of the range traps (debug library only, tests/test_gpu_debug_bounds.py): a forward launch whose work list names a tile
+// BEHIND the last point -- NGP_BOUNDS in k_grid_forward_pair must abort it
+extern "C" int ngp_debug_forward_bad_tile(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs, uint32_t B,
+                                          ngp_stream_t stream) {
+    GridLevels lv;
+    fill_levels(lv, 2, 1.0f, 16);
+    FwdSchedule sc;
+    for (int x = 0; x < 8; x++)
+        for (int sg = 0; sg < FWD_MAX_SEG; sg++) {
+            sc.level[x][sg] = 0xffffu;
+            sc.tile0[x][sg] = 0u;
+            sc.end[x][sg] = x == 0 ? 1u : 0u;
+        }
+    sc.level[0][0] = 0;
+    sc.tile0[0][0] = cdiv(B, 1024u);  // one past the last tile
+    hipLaunchKernelGGL((k_grid_forward_pair<half_t, 3, 2>), dim3(8u), dim3(FWD_THREADS), 0, as_stream(stream), inputs, (const half_t*)embeddings,
+                       offsets, (half_t*)outputs, B, 2u, lv, 0u, false, 0u, sc, 1024u, InputMap{0.0f, 0.0f});
+    return check_launch("debug_forward_bad_tile");
+}
+#endif
 
 extern "C" int ngp_grid_encode_forward_ex(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
                                           uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,

@@ -653,6 +653,7 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
             const float lt = below ? prev_after : last_t;
             if (e) {
                 const size_t o = (size_t)offset + rank;
+                NGP_BOUNDS(o < (size_t)M);
                 float* xo = xyzs + o * 3;
                 float* dd = dirs + o * 3;
                 xo[0] = x; xo[1] = y; xo[2] = z;

@@ -75,12 +75,16 @@ def sync_occupancy(model):
     """element-wise MAX of the density grid over ranks, then re-pack the bitfield locally (every 16 steps)"""
     import raymarching
     dist.all_reduce(model.density_grid, op=dist.ReduceOp.MAX)
-    mean_density = float(model.density_grid.clamp(min=0).mean())
+    # ONE host read-back for both scalars (the grid is identical on every rank now, so MAX leaves the mean unchanged; the sample estimate
+    # becomes the largest of the ranks'): the threshold of packbits and the capacity logic of graph.py are host values by the reference's
+    # contract, the read-back is what remains of it -- once per 16 steps, and every rank waits for the slowest one HERE and nowhere else
+    both = torch.stack([model.density_grid.clamp(min=0).mean().float(),
+                        torch.tensor(float(model.mean_count), device=model.density_grid.device)])
+    dist.all_reduce(both, op=dist.ReduceOp.MAX)
+    mean_density, mean_count = both.tolist()
     model.mean_density = mean_density
     model.density_bitfield = raymarching.packbits(model.density_grid, min(mean_density, model.density_thresh), model.density_bitfield)
-    mc = torch.tensor([float(model.mean_count)], device=model.density_grid.device)
-    dist.all_reduce(mc, op=dist.ReduceOp.MAX)
-    model.mean_count = int(mc.item())
+    model.mean_count = int(mean_count)
 
 
 def shard_rays(n_rays, rank=None, world=None):
@@ -98,7 +102,10 @@ def render_sharded(model, rays_o, rays_d, rank=None, world=None, group=None, **k
     contiguous block of rows through `model.render` (the eval branch of run_cuda, renderer.py:322-367) and the blocks are
     all-gathered, so every rank returns the full {'image' [1,N,3], 'depth' [1,N]}.  No exchange during marching.  A ray's samples
     and their compositing order do not depend on which other rays share its launch (the eval loop's n_step only regroups samples into
-    iterations), so the gathered frame is bit-identical to the one-rank frame (tests/test_ddp_gloo.py, tests/test_gpu_ddp.py)."""
+    iterations), so the gathered frame is bit-identical to the one-rank frame (tests/test_ddp_gloo.py, tests/test_gpu_ddp.py) -- with
+    one caveat, the same as in nerf/renderer.py's eval loop: the loop stops once the sum of n_step = clamp(N // n_alive, 1, 8) reaches
+    max_steps, and that sequence depends on how many rays share the launch, so a ray that still needs samples at that point (bound > 1
+    with dt_gamma = 0 can need more than max_steps) is cut off at a different sample when the frame is sharded."""
     rank = dist.get_rank(group) if rank is None else rank
     world = dist.get_world_size(group) if world is None else world
     n = rays_o.shape[-2]

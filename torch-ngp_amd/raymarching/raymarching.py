@@ -13,6 +13,9 @@ from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
 
 try:  # the compiled binding first, as the reference does (raymarching/raymarching.py:9-12); the ctypes binding of the same C ABI otherwise
+    import os as _os
+    if _os.environ.get('NGP_HIP_LIBRARY'):  # a variant library is selected: the compiled module links the in-tree one, the ctypes binding follows the variable
+        raise ImportError('NGP_HIP_LIBRARY is set')
     import _raymarching as _backend
 except ImportError:
     from .backend import _backend

@@ -157,8 +157,12 @@ def _optim_worker(rank, world, port, out, shard):
         from checkpoint import save_checkpoint
         from optim import NGPEma
         holder = torch.nn.ParameterList(params)
+        # default: only rank 0 writes (nerf/utils.py:650-655 keeps the Trainer's save on local_rank 0) -- the call itself is collective
+        dflt = io.BytesIO()
+        save_checkpoint(dflt, holder, optimizer=opt, full=False, best=True)
+        ok = ok and ((dflt.tell() > 0) == (rank == 0))
         buf = io.BytesIO()
-        save_checkpoint(buf, holder, optimizer=opt, full=False, best=True)
+        save_checkpoint(buf, holder, optimizer=opt, full=False, best=True, write=True)   # every rank into its OWN buffer
         buf.seek(0)
         ck = torch.load(buf, weights_only=False)['model']
         ck_worst = max(float((ck[str(i)] - r.detach()).abs().max()) for i, r in enumerate(ref))

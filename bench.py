@@ -77,7 +77,27 @@ TIMED = {
                             lambda a: (64.0 + 12.0 + 128.0 * (a[6] + a[7]) + 32.0 + 64.0 + 4.0 + 12.0) if a[9] else (64.0 + 12.0 + 4.0 + 12.0),
                             lambda a: _ff_flops(a[6]) + _ff_flops(a[7]), 'sample'),
     'ngp_ffmlp_backward_ex': ('ffmlp_backward', 4, lambda a: _ff_bwd_bytes(a[8]), lambda a: 2.0 * _ff_flops(a[8]), 'sample'),
+    # the colour network's backward (it also writes the sigma network's output gradient: + 4 B sigma gradient in, 32 B out per sample)
+    'ngp_network_backward_color': ('ffmlp_backward (colour net)', 4, lambda a: _ff_bwd_bytes(a[5]) + 36.0, lambda a: 2.0 * _ff_flops(a[5]), 'sample'),
+    # compositing + loss + their backward in one launch: sigma 4 + rgb 12 + deltas 8 in, 4 + 32 gradient out per sample (+ rays, target,
+    # image, depth, weights: 80 B per ray) -- SURVEY.md 8(d): 64 B / sample + 80 B / ray
+    'ngp_composite_train_loss_backward': ('composite + loss + backward', 4, lambda a: 64.0 + 80.0 * a[5] / max(a[4], 1), lambda a: 0.0, 'sample'),
+    # near/far + both passes of march_rays_train: 32 B written per sample (xyz, dir, deltas) + 48 B per ray (origins, directions, rays, near/far)
+    'ngp_march_rays_train_aabb': ('march_rays_train (+ near/far)', 9, lambda a: 32.0 + 48.0 * a[6] / max(a[9], 1), lambda a: 0.0, 'sample'),
+    # Adam + loss-scale logic + fp16 shadows + gradient zeroing over every parameter: fp32 master / two moments read and written (24 B),
+    # fp16 gradient read and zeroed (4 B), fp16 shadow written (2 B) = 30 B per parameter.  Only the calls that UPDATE are rows.
+    'ngp_optim_adam_step_ex': ('k_adam (Adam + scaler + shadows + gradient zeroing)', lambda a: _adam_params(a), lambda a: 30.0, lambda a: 0.0, 'parameter'),
 }
+
+
+def _adam_params(a):
+    """parameters streamed by one ngp_optim_adam_step_ex call: the sum of its n[] array when the UPDATE phase is asked for, else 0"""
+    import ctypes
+    k, phases = int(a[0]), int(a[19])
+    if k == 0 or not (phases & 2) or not a[1]:
+        return 0
+    n = ctypes.cast(a[1], ctypes.POINTER(ctypes.c_uint64))
+    return int(sum(n[i] for i in range(k)))
 
 
 class KernelTimers:
@@ -97,11 +117,14 @@ class KernelTimers:
         def call(*args):
             if not self.enabled:
                 return inner(*args)
+            units = int(b_idx(args)) if callable(b_idx) else int(args[b_idx])
+            if units <= 0:   # (a call that moves nothing of this row's kind: e.g. the optimizer's CHECK / COMMIT phases)
+                return inner(*args)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             rc = inner(*args)
             b.record()
-            self.records.setdefault(label + self.suffix, []).append((a, b, int(args[b_idx]), fbytes(args), fflops(args), unit, self.step))
+            self.records.setdefault(label + self.suffix, []).append((a, b, units, fbytes(args), fflops(args), unit, self.step))
             return rc
         return call
 
@@ -111,7 +134,7 @@ class KernelTimers:
         out = []
         for label, recs in self.records.items():
             ms = np.array([a.elapsed_time(b) for a, b, *_ in recs])
-            unit_of = [min(r[2], marched[r[6]]) if marched and r[6] < len(marched) and marched[r[6]] > 0 else r[2] for r in recs]
+            unit_of = [min(r[2], marched[r[6]]) if marched and r[5] != 'parameter' and r[6] < len(marched) and marched[r[6]] > 0 else r[2] for r in recs]
             units = np.array(unit_of, dtype=np.float64)
             byts = np.array([u * r[3] for u, r in zip(unit_of, recs)])
             flops = np.array([u * r[4] for u, r in zip(unit_of, recs)])

@@ -854,8 +854,14 @@ __device__ unsigned long long g_bin_probe[16];
 #define NGP_BIN_MERGE_MIN 8
 #endif
 
-// record key bits: channel 0 / 1 of the value is 1/64 of the contribution (a run sum beyond the fp16 range); table indices stay below 2^21
-constexpr uint32_t BIN_KEY_SCALED0 = 0x80000000u, BIN_KEY_SCALED1 = 0x40000000u, BIN_KEY_SCALED = BIN_KEY_SCALED0 | BIN_KEY_SCALED1;
+// record key bits (16-bit keys): channel 0 / 1 of the value is 1/64 of the contribution (a run sum beyond the fp16 range); bits 0..11 = entry
+// inside the slice
+constexpr uint32_t BIN_KEY_SCALED0 = 0x8000u, BIN_KEY_SCALED1 = 0x4000u, BIN_KEY_SCALED = BIN_KEY_SCALED0 | BIN_KEY_SCALED1;
+// Records travel in PAIR UNITS of 12 bytes: {key of record 0 | key of record 1 << 16, value 0, value 1}.  Sorted by bin, a record needs only
+// its index INSIDE the slice (12 bits) and the two scale flags: 6 bytes per record instead of 8 on the way to memory and back (the record
+// stream is what the two kernels move: 157 -> 118 MB each way per step).  A bin with an odd number of records ends in a half-used unit whose
+// second half is {key 0, value +0}.
+constexpr uint32_t BIN_UNIT_BYTES = 12;
 
 // Wave-uniform 64-bit lane masks, pinned to scalar registers where they are made.  and / andn2 / shifts / bit counts have 64-bit scalar
 // forms; only COMPARES are written on the 32-bit halves (there is no scalar u64 less-than: a 64-bit compare would be done by the vector
@@ -1009,7 +1015,7 @@ __device__ __forceinline__ void bin_pass_count(const float (&x)[D], uint32_t gbi
 // PLACE pass: staging slots from the wave's own cursors (eight returning LDS adds in flight), then values, run sums and the records
 template <int D, bool FAST>
 __device__ __forceinline__ void bin_pass_place(uint32_t gbits, const BinItem& it, const BinLane<D>& bl, const LaneMask& live_mask_in,
-                                               uint32_t prow_base, uint2* __restrict__ staging) {
+                                               uint32_t prow_base, uint32_t staging_base) {
     constexpr int NS = 1 << D;
     // (pinned to scalar registers again: carried across the barrier the mask may sit in a vector register, and everything derived from
     // it would then be computed by the vector unit)
@@ -1033,7 +1039,7 @@ __device__ __forceinline__ void bin_pass_place(uint32_t gbits, const BinItem& it
         for (int d = 1; d < D; d++) w *= bl.wp[d][(s >> d) & 1];
         float v0 = w * g0, v1 = w * g1;
         const LaneMask m = bin_run_mask(addr, pairs);
-        uint32_t key = addr;
+        uint32_t key = FAST ? (addr & (uint32_t)(BIN_SLICE - 1)) : (it.interleaved ? (addr >> BIN_DENSE_BITS) : (addr & (uint32_t)(BIN_SLICE - 1)));
         if (m.any()) {  // segmented inclusive scan: the last lane of a run ends up with the run's sum
             seg_scan_rows(v0, v1, m);
             // a run of up to 16 finite fp16-range terms can leave the fp16 range although the sum over the whole batch need not: such a
@@ -1046,8 +1052,9 @@ __device__ __forceinline__ void bin_pass_place(uint32_t gbits, const BinItem& it
         }
         const uint32_t packed = pack_half2(v0, v1);
         if (bin_issues(live_mask, m)) {
-            NGP_BOUNDS(!binned || slot[s] < (uint32_t)(BIN_PPB * NS));
-            if (binned) staging[slot[s]] = make_uint2(key, packed);
+            NGP_BOUNDS(!binned || slot[s] < (uint32_t)(BIN_PPB * NS) + (uint32_t)BIN_MAX_BINS);
+            if (binned)  // record `slot` of the chunk (bins start at even slots: the copy-out packs slots 2u, 2u + 1 into pair unit u)
+                *(__attribute__((address_space(3))) unsigned long long*)(uintptr_t)(staging_base + slot[s] * 8u) = ((unsigned long long)packed << 32) | key;
             else atomic_add_packed(it.gtable + (size_t)addr * 2, packed);
         }
     }
@@ -1057,7 +1064,7 @@ __device__ __forceinline__ void bin_pass_place(uint32_t gbits, const BinItem& it
 // cursor row: chunk offset of the bin + the records of the waves before it.  Wave 0 also writes the descriptors.  Returns all records.
 template <int BPL, int WAVES>
 __device__ __forceinline__ uint32_t bin_offsets(const uint32_t* __restrict__ hist, uint32_t* __restrict__ prow, int lane, int wid, const BinItem& it,
-                                                uint32_t n_chunks, uint32_t* __restrict__ descriptors) {
+                                                uint32_t n_chunks, uint32_t* __restrict__ descriptors, uint32_t staging_base) {
     constexpr int CAP = 64 * BPL;
     uint32_t tot[BPL], mine[BPL], run = 0u;
 #pragma unroll
@@ -1072,26 +1079,36 @@ __device__ __forceinline__ uint32_t bin_offsets(const uint32_t* __restrict__ his
 #pragma unroll
         for (int k = 0; k < BPL; k++) mine[k] += hist[w * CAP + lane * BPL + k];
     }
+    // cursors count RECORDS from an EVEN base per bin: record c of the chunk sits in pair unit c >> 1, half c & 1
+    uint32_t begin = 0u;
+    {
+        uint32_t even[BPL], erun = 0u;
 #pragma unroll
-    for (int k = 0; k < BPL; k++) run += tot[k];
-    uint32_t incl = run;
-    incl += row_shr<1>(incl);
-    incl += row_shr<2>(incl);
-    incl += row_shr<4>(incl);
-    incl += row_shr<8>(incl);
-    incl += bcast15_rows13(incl);
-    incl += bcast31_rows23(incl);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    uint32_t begin = incl - run;
+        for (int k = 0; k < BPL; k++) { even[k] = (tot[k] + 1u) & ~1u; erun += even[k]; }
+        uint32_t incl = erun;
+        incl += row_shr<1>(incl);
+        incl += row_shr<2>(incl);
+        incl += row_shr<4>(incl);
+        incl += row_shr<8>(incl);
+        incl += bcast15_rows13(incl);
+        incl += bcast31_rows23(incl);
+        begin = incl - erun;
+        (void)run;
+        const uint32_t total_units = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63) >> 1;
 #pragma unroll
-    for (int k = 0; k < BPL; k++) {
-        prow[lane * BPL + k] = begin + mine[k];
-        const uint32_t bin = (uint32_t)(lane * BPL + k);
-        NGP_BOUNDS(begin + tot[k] <= (uint32_t)(BIN_PPB * 8) && it.chunk_x < n_chunks);
-        if (wid == 0 && bin < it.n_bins) descriptors[it.desc_base + (size_t)bin * n_chunks + it.chunk_x] = begin | (tot[k] << 16);  // both <= 4096
-        begin += tot[k];
+        for (int k = 0; k < BPL; k++) {
+            prow[lane * BPL + k] = begin + mine[k];
+            const uint32_t bin = (uint32_t)(lane * BPL + k);
+            NGP_BOUNDS(begin + even[k] <= (uint32_t)(BIN_PPB * 8) + (uint32_t)CAP && it.chunk_x < n_chunks);
+            if (wid == 0 && bin < it.n_bins) {
+                descriptors[it.desc_base + (size_t)bin * n_chunks + it.chunk_x] = (begin >> 1) | (tot[k] << 16);  // first unit | records
+                if (tot[k] & 1u)  // the unused second half of the bin's last pair: key 0, value +0
+                    *(volatile __attribute__((address_space(3))) unsigned long long*)(uintptr_t)(staging_base + (begin + tot[k]) * 8u) = 0ull;
+            }
+            begin += even[k];
+        }
+        return total_units;
     }
-    return total;
 }
 
 #ifndef NGP_BIN_WAVES_PER_EU
@@ -1122,9 +1139,11 @@ void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restric
     constexpr int MAX_REC = BIN_PPB * NS;    // records per workgroup item = slots per chunk
     constexpr int WAVES = BIN_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char bin_smem[];
-    uint2* staging = reinterpret_cast<uint2*>(bin_smem);                              // [MAX_REC]
-    uint32_t* hist = reinterpret_cast<uint32_t*>(bin_smem + sizeof(uint2) * MAX_REC);  // [WAVES][cap] records per (wave, bin)
+    unsigned char* staging = bin_smem;                                                // [MAX_REC + cap] records of 8 bytes (a pad record per odd bin)
+    const uint32_t staging_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)staging;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(bin_smem + sizeof(uint2) * (MAX_REC + 64 * BPL));  // [WAVES][cap] records per (wave, bin)
     constexpr uint32_t cap = 64 * BPL;
+    static_assert((MAX_REC / 2 + 32 * BPL) * BIN_UNIT_BYTES <= MAX_REC * sizeof(uint2), "pair units (plus half a unit of padding per bin) fit the chunk");
     uint32_t* pos = hist + WAVES * cap;                                               // [WAVES][cap] staging cursors per (wave, bin)
     const int tid = threadIdx.x, lane = tid & 63, wid = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
     uint32_t* __restrict__ hrow = hist + wid * cap;
@@ -1212,18 +1231,24 @@ void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restric
         NGP_PROBE_T(2)
         __syncthreads();  // all counts of this item are in
         NGP_PROBE_T(3)
-        const uint32_t total = bin_offsets<BPL, WAVES>(hist, prow, lane, wid, it, plan.n_chunks, descriptors);
+        const uint32_t total_units = bin_offsets<BPL, WAVES>(hist, prow, lane, wid, it, plan.n_chunks, descriptors, staging_base);
         NGP_PROBE_T(4)
-        if (fast) bin_pass_place<D, true>(g_cur, it, bl, live_mask, prow_base, staging);
-        else bin_pass_place<D, false>(g_cur, it, bl, live_mask, prow_base, staging);
+        if (fast) bin_pass_place<D, true>(g_cur, it, bl, live_mask, prow_base, staging_base);
+        else bin_pass_place<D, false>(g_cur, it, bl, live_mask, prow_base, staging_base);
         NGP_PROBE_T(5)
         __syncthreads();  // the sorted chunk is complete in LDS (and every wave has read every counter row)
         NGP_PROBE_T(6)
         for (uint32_t i = lane; i < cap; i += 64) hrow[i] = 0u;  // own counters for the next item
-        // 16 bytes per lane (two records): 8-byte global accesses run at 0.5-0.7x the 16-byte rate on this chip (MI355X_MICROARCH.md)
-        uint4* __restrict__ chunk = reinterpret_cast<uint4*>(records + ((size_t)it.li * plan.n_chunks + it.chunk_x) * MAX_REC);
+        // copy-out: records 2u, 2u + 1 of the staging area (16 bytes) become pair unit u of the chunk (12 bytes: the two 16-bit keys share a word)
+        uint32_t* __restrict__ chunk = reinterpret_cast<uint32_t*>(records + ((size_t)it.li * plan.n_chunks + it.chunk_x) * MAX_REC);
         const uint4* staging2 = reinterpret_cast<const uint4*>(staging);
-        for (uint32_t r = tid; 2u * r < total; r += BIN_THREADS) chunk[r] = staging2[r];  // an odd tail writes one unused slot of the chunk
+        for (uint32_t u = tid; u < total_units; u += BIN_THREADS) {
+            const uint4 q = staging2[u];
+            uint32_t* dst = chunk + 3u * u;
+            const uint32_t keys = (q.x & 0xffffu) | (q.z << 16);
+            const uint32_t unit[3] = {keys, q.y, q.w};
+            __builtin_memcpy(dst, unit, sizeof(unit));  // 4-byte aligned: global_store_dwordx3
+        }
         NGP_PROBE_T(7)
         g_cur = g_next;
         it.li = li_next;
@@ -1283,7 +1308,7 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         const int32_t q = (int32_t)(v * (big ? 8.0f : 0x1p24f));
         return (unsigned long long)(long long)q << (big ? 21 : 0);  // (shifted as unsigned: two's complement, exact mod 2^64)
     };
-    auto entry_of = [&](uint32_t key) { return interleaved ? ((key & ~BIN_KEY_SCALED) >> BIN_DENSE_BITS) : (key & (BIN_SLICE - 1u)); };
+    auto entry_of = [&](uint32_t key) { return key & (BIN_SLICE - 1u); };  // (16-bit keys: the entry inside the slice, two scale flags)
     auto add_plain = [&](const uint32_t key, const uint32_t val) {  // finite, unscaled
         const uint32_t idx = entry_of(key);
         NGP_BOUNDS(idx < (uint32_t)BIN_SLICE);
@@ -1320,7 +1345,7 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         if (i < run_end) {
             const uint32_t k = chunk_of(i), d = desc[k];
             cnt = d >> 16;
-            first = k * (uint32_t)MAX_REC + (d & 0xffffu);  // 32-bit record index: < 2^28
+            first = k * (uint32_t)(2 * MAX_REC) + (d & 0xffffu) * 3u;  // WORD index of the run's first pair unit inside the level: < 2^31
         }
         const uint32_t pairs = (cnt + 1u) >> 1;  // 16-byte accesses: two records per lane (an odd run ends in a half-used pair)
         uint32_t incl = pairs;
@@ -1356,8 +1381,12 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
             const uint32_t r_start = r_word & 0x3ffffu, r_cnt = r_word >> 18;
             const uint32_t rec = 2u * (p - r_start);  // first record of the pair inside its run
             q = make_uint4(0u, 0u, 0u, 0u);
-            NGP_BOUNDS(!have || (r >= 1u && r <= 64u && rec < r_cnt && r_first + rec < n_chunks * (uint32_t)MAX_REC));
-            if (have) __builtin_memcpy(&q, words + 2u * (r_first + rec), sizeof(q));  // 8-byte aligned: global_load_dwordx4 takes it
+            NGP_BOUNDS(!have || (r >= 1u && r <= 64u && rec < r_cnt && r_first + 3u * (p - r_start) + 2u < n_chunks * (uint32_t)(2 * MAX_REC)));
+            if (have) {  // one pair unit: {keys, value 0, value 1} (4-byte aligned: global_load_dwordx3)
+                uint32_t u[3];
+                __builtin_memcpy(u, words + (r_first + 3u * (p - r_start)), sizeof(u));
+                q = make_uint4(u[0] & 0xffffu, u[1], u[0] >> 16, u[2]);
+            }
             valid = have ? (rec + 1u < r_cnt ? 3u : 1u) : 0u;
         };
         // two windows ahead: the loads of windows w + 1 and w + 2 are in flight during the adds of window w (the kernel waits on memory)
@@ -1678,8 +1707,8 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     constexpr size_t acc_smem = sizeof(unsigned long long) * 2 * BIN_SLICE + sizeof(uint32_t) * (BIN_SLICE / 16) +
                                 (ACC_THREADS / 64) * 64 * (sizeof(uint2) + sizeof(uint32_t));
     const uint32_t bins_cap = p.max_bins <= 128u ? 128u : (uint32_t)BIN_MAX_BINS;
-    constexpr size_t bin_smem_max = sizeof(uint2) * BIN_PPB * (1 << D) + sizeof(uint32_t) * 2 * (BIN_THREADS / 64) * BIN_MAX_BINS;
-    const size_t bin_smem = sizeof(uint2) * BIN_PPB * (1 << D) + sizeof(uint32_t) * 2 * (BIN_THREADS / 64) * bins_cap;
+    constexpr size_t bin_smem_max = sizeof(uint2) * (BIN_PPB * (1 << D) + BIN_MAX_BINS) + sizeof(uint32_t) * 2 * (BIN_THREADS / 64) * BIN_MAX_BINS;
+    const size_t bin_smem = sizeof(uint2) * (BIN_PPB * (1 << D) + bins_cap) + sizeof(uint32_t) * 2 * (BIN_THREADS / 64) * bins_cap;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_accumulate<D>), hipFuncAttributeMaxDynamicSharedMemorySize,

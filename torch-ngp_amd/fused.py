@@ -476,6 +476,12 @@ def fused_train_iteration_split(model, rays_o, rays_d, target, box, counter, cap
     return march, rest
 
 
+# Spacing (in the encoder's unit cube) between consecutive points of the NEXT fused_density call when the caller knows its points are
+# spatially ordered (the occupancy refresh's Morton-sorted cells: NeRFRenderer.refresh_apply sets it around its one density call).  The
+# encoder then balances its per-XCD work lists with the ray-sample cost model (scheduling only: identical results).  None: no hint.
+density_point_spacing = None
+
+
 @torch.no_grad()
 def fused_density(x, encoder, sigma_net, bound):
     """inference-only `NeRFNetwork.density(x)`: hash grid (input map in-kernel, level-major output consumed in place) -> sigma MLP
@@ -496,10 +502,11 @@ def fused_density(x, encoder, sigma_net, bound):
     w16 = w16 if w16 is not None else w.detach().to(torch.half)
     L = int(encoder.num_levels)
     enc = torch.empty(L, M, 2, device=dev, dtype=torch.half)
+    S, H = float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution)
+    costs = None if density_point_spacing is None else capi.ray_level_costs(L, S, H, float(density_point_spacing))
     _check(capi.lib.ngp_grid_encode_forward_sched(x.contiguous().data_ptr(), emb16.data_ptr(), encoder.offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L,
-                                                float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution), None,
-                                                int(encoder.gridtype_id), int(bool(encoder.align_corners)), int(encoder.interp_id),
-                                                capi.NGP_F16, float(bound), None, st))
+                                                S, H, None, int(encoder.gridtype_id), int(bool(encoder.align_corners)), int(encoder.interp_id),
+                                                capi.NGP_F16, float(bound), costs, st))
     h16 = torch.empty(M, 16, device=dev, dtype=torch.half)
     _check(capi.lib.ngp_ffmlp_inference_ex(enc.data_ptr(), w16.data_ptr(), M, 32, 16, 64, int(sigma_net.num_layers), 0, 6, None, h16.data_ptr(),
                                            _PLANAR_IN, st))

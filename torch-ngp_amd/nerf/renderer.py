@@ -458,13 +458,26 @@ class NeRFRenderer(nn.Module):
                         for cas in range(self.cascade):
                             samples.append((cas, cell_ids, self._cascade_points(coords, cas)))
         else:  # a quarter of the cells at random plus as many drawn from the currently occupied ones
+            # Both draws are i.i.d. uniform WITH replacement, as in the reference -- but generated as ORDER STATISTICS, i.e. already sorted
+            # by Morton code: n sorted uniforms are the normalised partial sums of n + 1 exponentials (one cumsum).  The density network then
+            # sees spatially coherent points (neighbours in the list are neighbours in space), which is what the encoder's caches want:
+            # the refresh is the one place where the hash grid was evaluated on randomly ORDERED points.  Which cells are drawn has the
+            # same distribution as before; the scatter of the results does not depend on the order (duplicates: any of them wins, as in
+            # the reference).
             n = self.grid_size ** 3 // 4
+            cells = self.grid_size ** 3
+
+            def sorted_uniform(count):
+                """`count` i.i.d. uniforms on [0, 1), ascending (fp64 partial sums: 2^19 terms)"""
+                e = -torch.log(torch.rand(count + 1, device=dev, dtype=torch.float64).clamp_(min=1e-300))
+                c = torch.cumsum(e, 0)
+                return (c[:count] / c[count]).clamp_(max=1.0 - 2.0 ** -40)
             for cas in range(self.cascade):
-                rand_coords = torch.randint(0, self.grid_size, (n, 3), device=dev)
-                rand_ids = raymarching.morton3D(rand_coords).long()
+                rand_ids = (sorted_uniform(n) * cells).long().clamp_(max=cells - 1)
+                rand_coords = raymarching.morton3D_invert(rand_ids)
                 # occ_ids = nonzero(grid > 0)[randint(0, count, n)] without knowing `count` on the host
                 occupied = torch.cumsum(self.density_grid[cas] > 0, 0, dtype=torch.int32)
-                pick = (torch.rand(n, device=dev) * occupied[-1]).to(torch.int32).clamp_(max=occupied[-1] - 1).clamp_(min=0)
+                pick = (sorted_uniform(n) * occupied[-1]).to(torch.int32).clamp_(max=occupied[-1] - 1).clamp_(min=0)
                 occ_ids = torch.searchsorted(occupied, pick + 1).clamp_(max=occupied.shape[0] - 1)
                 occ_coords = raymarching.morton3D_invert(occ_ids)
                 cell_ids = torch.cat([rand_ids, occ_ids], 0)
@@ -486,7 +499,14 @@ class NeRFRenderer(nn.Module):
             else:
                 ids = torch.cat([cell_ids + cas * cells for cas, cell_ids, _ in samples], 0)
                 pts = torch.cat([p for _, _, p in samples], 0)
-            sigma = self.density(pts)['sigma'].reshape(-1).detach()      # density_scale is applied by the update kernel
+            # (refresh_sample hands over Morton-sorted cells: consecutive points are ~ (4 cells per sample)^(1/3) = 1.6 cells apart; in the
+            # encoder's unit cube a cell of cascade 0 measures 1 / grid_size -- a hint for the encoder's work-list balancing, nothing else)
+            import fused as _fused
+            _fused.density_point_spacing = 1.6 / self.grid_size if len(samples) == self.cascade and len(samples[0][1]) < cells else None
+            try:
+                sigma = self.density(pts)['sigma'].reshape(-1).detach()      # density_scale is applied by the update kernel
+            finally:
+                _fused.density_point_spacing = None
             state = self.__dict__.setdefault('_refresh_state', {})
             return raymarching.update_density_grid(sigma, ids, self.density_scale, decay, self.density_grid, self.density_thresh,
                                                    self.density_bitfield, state).reshape(())

@@ -601,11 +601,25 @@ template <int WIDTH, bool RELU>
 __device__ __forceinline__ void activation_transfer(uint32_t act, const float16_t (&acc)[Shape<WIDTH>::NIB],
                                                     const half8_t (&post)[Shape<WIDTH>::NKB], half8_t (&dz)[Shape<WIDTH>::NKB]) {
     if (RELU) {
+        // dZ = post > 0 ? half(dH) : 0 on PAIRS of fp16 values, without compares or selects (round 4: the compare + convert + select +
+        // pack sequence was 3.5 VALU per element and a third of the backward's instruction stream; this is 2): a stored ReLU output
+        // is +0 or positive, so "non-zero" is the sign of (0 - bits) as a 16-bit integer -- an arithmetic shift spreads it over the
+        // half, an AND applies it.  Bit-identical to the select for every finite stored activation (a NaN activation, which the select
+        // treats as "not positive", keeps its gradient here: the step is skipped by the loss scaler either way).
+        typedef short short2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int kb = 0; kb < Shape<WIDTH>::NKB; kb++)
+        for (int kb = 0; kb < Shape<WIDTH>::NKB; kb++) {
+            uint32_t out[4];
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                dz[kb][j] = (float)post[kb][j] > 0.0f ? (half_t)acc[kb >> 1][(kb & 1) * 8 + j] : (half_t)0.0f;
+            for (int q = 0; q < 4; q++) {
+                const half2_t h = {(half_t)acc[kb >> 1][(kb & 1) * 8 + 2 * q], (half_t)acc[kb >> 1][(kb & 1) * 8 + 2 * q + 1]};
+                const half2_t y = {post[kb][2 * q], post[kb][2 * q + 1]};
+                const short2_t live = ((short2_t){0, 0} - __builtin_bit_cast(short2_t, y)) >> (short2_t){15, 15};  // 0xffff where the unit fired
+                out[q] = __builtin_bit_cast(uint32_t, h) & __builtin_bit_cast(uint32_t, live);
+            }
+            uint32_t packed[4] = {out[0], out[1], out[2], out[3]};
+            __builtin_memcpy(&dz[kb], packed, sizeof(packed));
+        }
     } else {
 #pragma unroll
         for (int kb = 0; kb < Shape<WIDTH>::NKB; kb++)
@@ -859,11 +873,20 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_backward(const half_t* __r
     // accumulator (row = output feature o, col = input feature i = lane&31)
     // every (row, col) of a gradient matrix belongs to exactly one lane of a wave, so the waves add their
     // partial sums one after the other without atomics: the summation order is fixed => bit-reproducible.
+    // (the sixteen partial sums of a block are read together, then added and written: `red[..] += a[r]` in a loop is sixteen dependent LDS
+    // round trips, the compiler cannot see that the addresses differ)
     auto flush = [&](const float16_t& a, uint32_t base, uint32_t ld, int ib, int jb, uint32_t rows, uint32_t cols) {
+        float t[16];
+        const uint32_t i = 32 * jb + n;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const uint32_t o = (uint32_t)acc_row(ib, h, r), i = 32 * jb + n;
-            if (o < rows && i < cols) red[base + o * ld + i] += a[r];
+            const uint32_t o = (uint32_t)acc_row(ib, h, r);
+            t[r] = (o < rows && i < cols) ? red[base + o * ld + i] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t o = (uint32_t)acc_row(ib, h, r);
+            if (o < rows && i < cols) red[base + o * ld + i] = t[r] + a[r];
         }
     };
     for (int turn = 0; turn < FF_WAVES; turn++) {
@@ -977,11 +1000,21 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
     };
     float* red = reinterpret_cast<float*>(smem);
     const uint32_t n_params = ff_param_count(in_dim, WIDTH, num_layers);
+    // (round 4) the sixteen partial sums of a block are READ together, then added and written: written as `red[..] += a[r]` the compiler
+    // has to order every read behind the previous write (it cannot see that the sixteen addresses differ), and the epilogue became
+    // sixteen dependent LDS round trips per block and wave -- with one wave flushing at a time, ~20 of the kernel's 47 us.
     auto flush = [&](const float16_t& a, uint32_t base, uint32_t ld, int ib, int jb, uint32_t rws, uint32_t cols) {
+        float t[16];
+        const uint32_t i = 32 * jb + n;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const uint32_t o = (uint32_t)acc_row(ib, h, r), i = 32 * jb + n;
-            if (o < rws && i < cols) red[base + o * ld + i] += a[r];
+            const uint32_t o = (uint32_t)acc_row(ib, h, r);
+            t[r] = (o < rws && i < cols) ? red[base + o * ld + i] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t o = (uint32_t)acc_row(ib, h, r);
+            if (o < rws && i < cols) red[base + o * ld + i] = t[r] + a[r];
         }
     };
     auto begin_reduction = [&]() {
@@ -1038,8 +1071,10 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
             end_of_round(base);
         }
         begin_reduction();
-        for (int turn = 0; turn < 2 * FP_PAIRS; turn++) {
-            if (wid == turn) {
+        // the waves of a role add into the same entries, one after the other (a fixed order: deterministic); the two roles own disjoint
+        // parts of the slab and take their turns at the same time
+        for (int turn = 0; turn < FP_PAIRS; turn++) {
+            if (pair == turn) {
 #pragma unroll
                 for (int ib = 0; ib < NIB; ib++)
 #pragma unroll
@@ -1179,8 +1214,8 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
             end_of_round(base);
         }
         begin_reduction();
-        for (int turn = 0; turn < 2 * FP_PAIRS; turn++) {
-            if (wid == turn) {
+        for (int turn = 0; turn < FP_PAIRS; turn++) {
+            if (pair == turn) {
 #pragma unroll
                 for (int ib = 0; ib < NIB; ib++)
 #pragma unroll
@@ -1457,9 +1492,13 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_wgrad(const half_t* __rest
     for (int turn = 0; turn < FF_WAVES; turn++) {
         if (wid == turn) {
 #pragma unroll
-            for (int j = 0; j < WG_NJB; j++)
+            for (int j = 0; j < WG_NJB; j++) {
+                float t[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) red[acc_row(0, h, r)][32 * j + n] += acc[j][r];
+                for (int r = 0; r < 16; r++) t[r] = red[acc_row(0, h, r)][32 * j + n];
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[acc_row(0, h, r)][32 * j + n] = t[r] + acc[j][r];
+            }
         }
         __syncthreads();
     }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # one gpurun call that refreshes the round's evidence on ONE box: gpurun_out/<tag>/...  (copied into profiles/ afterwards)
-tag=${1:-r03_final}
+tag=${1:-r04_final}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
 out=gpurun_out/$tag; mkdir -p $out
@@ -19,6 +19,7 @@ python tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE > $out/pmc_t
 rm -rf $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
 timeout 300 python tools/time_update.py > $out/occupancy_refresh.txt 2>&1
 timeout 300 python tools/bench_render.py > $out/render_800x800.txt 2>&1
+timeout 120 python tools/grid_bwd_probe.py > $out/grid_backward_probe.txt 2>&1
 rocm-smi --showclocks --showpower > $out/box_state_after.txt 2>&1
 python - <<PY
 import json

@@ -1417,18 +1417,37 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
     half2_t* __restrict__ gtable = reinterpret_cast<half2_t*>(grad_grid + (size_t)off0 * 2);
     bool nonfinite = false;
-    for (uint32_t i = tid; i < (uint32_t)BIN_SLICE; i += ACC_THREADS) {
-        const uint32_t e = interleaved ? (i << BIN_DENSE_BITS) + bin : bin * BIN_SLICE + i;
-        if (e >= hashmap_size) break;
-        const long long s0 = (long long)acc[2 * i], s1 = (long long)acc[2 * i + 1];
-        const uint32_t bad = (poison[i >> 4] >> ((i & 15u) * 2u)) & 3u;
-        if (s0 == 0 && s1 == 0 && !bad) continue;
-        const half2_t old = gtable[e];
+    // every thread owns BIN_SLICE / ACC_THREADS entries: their old values are loaded TOGETHER, then added to and stored (written as one
+    // load-add-store per loop trip the compiler has to order each load behind the previous store -- it cannot see that the entries
+    // differ -- and the tail of every workgroup became that many dependent round trips to memory)
+    constexpr int PER_THREAD = BIN_SLICE / ACC_THREADS;
+    static_assert(BIN_SLICE % ACC_THREADS == 0, "slice entries divide evenly over the workgroup");
+    uint32_t ent[PER_THREAD];
+    long long sum0[PER_THREAD], sum1[PER_THREAD];
+    uint32_t badb[PER_THREAD];
+    half2_t oldv[PER_THREAD];
+    bool touch[PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; k++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)k * ACC_THREADS;
+        ent[k] = interleaved ? (i << BIN_DENSE_BITS) + bin : bin * BIN_SLICE + i;
+        sum0[k] = (long long)acc[2 * i];
+        sum1[k] = (long long)acc[2 * i + 1];
+        badb[k] = (poison[i >> 4] >> ((i & 15u) * 2u)) & 3u;
+        touch[k] = ent[k] < hashmap_size && !(sum0[k] == 0 && sum1[k] == 0 && !badb[k]);
+        oldv[k] = half2_t{(half_t)0.0f, (half_t)0.0f};
+    }
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; k++)
+        if (touch[k]) oldv[k] = gtable[ent[k]];
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; k++) {
+        if (!touch[k]) continue;
         const float nan = __builtin_nanf("");
         half2_t nu;
-        nu.x = (half_t)((float)old.x + ((bad & 1u) ? nan : (float)s0 * 0x1p-24f));
-        nu.y = (half_t)((float)old.y + ((bad & 2u) ? nan : (float)s1 * 0x1p-24f));
-        gtable[e] = nu;
+        nu.x = (half_t)((float)oldv[k].x + ((badb[k] & 1u) ? nan : (float)sum0[k] * 0x1p-24f));
+        nu.y = (half_t)((float)oldv[k].y + ((badb[k] & 2u) ? nan : (float)sum1[k] * 0x1p-24f));
+        gtable[ent[k]] = nu;
         nonfinite = nonfinite || !__builtin_isfinite((float)nu.x) || !__builtin_isfinite((float)nu.y);
     }
     // the optimizer's non-finite sweep over the table, done where the final values are produced (benign race: every writer stores 1)

@@ -109,6 +109,26 @@ class GraphedTrainStep:
             self.la_sample_event = torch.cuda.Event()
 
     # ------------------------------------------------------------------------------------------
+    def close(self):
+        """wait for everything this object queued -- including the side stream's march of a batch that will never be consumed (the last
+        step announces its successor) -- BEFORE its graphs and their private memory pools are released.  A HIP graph that is destroyed while
+        one of its replays is still running hands its pool back to the caching allocator, and the still-running kernels then write into
+        whatever the next owner of that memory keeps there.  Called by __del__; call it explicitly when the object's lifetime matters."""
+        side = getattr(self, 'la_side', None)
+        try:
+            if side is not None:
+                side.synchronize()
+            comm = getattr(getattr(self, 'optimizer', None), '_comm_stream', None)
+            if comm is not None:
+                comm.synchronize()
+            if torch.cuda.is_available() and (self.graphs is not None or self.update_graphs):
+                torch.cuda.current_stream().synchronize()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown: the device context may be gone already
+            pass
+
+    def __del__(self):
+        self.close()
+
     def _capacity(self):
         mc = int(self.model.mean_count)
         if mc <= 0:

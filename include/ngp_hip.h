@@ -225,9 +225,9 @@ uint32_t ngp_grid_forward_work_lists(uint32_t L, uint32_t tiles, const float* le
                                      uint32_t* end_out);
 
 /* grid_encode_backward_ex with a caller-provided workspace: fp16 tables with C = 2 and D <= 3 (the instant-ngp configuration) then
- * run the HASHED levels WITHOUT memory-side atomics -- contributions are sorted by table slice (8-byte records, coalesced stores) and
- * each slice is summed exactly in a 64-bit fixed-point LDS accumulator, rounded once and added to grad_embeddings by the workgroup that
- * owns it.  The result is the exact sum of the fp16 contributions rounded once (the reference's atomics round after every
+ * run EVERY level WITHOUT memory-side atomics -- contributions are sorted by table slice (12-byte pair units = 6 bytes per record,
+ * coalesced stores) and each slice is summed exactly in a 64-bit fixed-point LDS accumulator, rounded once and added to grad_embeddings
+ * by the workgroup that owns it.  The result is the exact sum of the fp16 contributions rounded once (the reference's atomics round after every
  * add, in an undefined order) and is bit-reproducible; entries that receive a non-finite contribution become NaN.
  * offsets_host: a HOST copy of `offsets` (L + 1 values; the level sizes steer the plan).  workspace: device memory of at least
  * ngp_grid_backward_workspace_bytes(...) bytes, contents irrelevant.  offsets_host == NULL or workspace == NULL -> the atomic path

@@ -186,28 +186,37 @@ void freq_encode_backward(Tensor grad, Tensor outputs, const uint32_t B, const u
 // floating argument is copied back (outputs are caller-allocated arguments): fp32 arithmetic rounded once to fp16.
 struct F32View {
     Tensor orig, f32;
-    explicit F32View(const Tensor& t) : orig(t), f32(t.scalar_type() == at::ScalarType::Half ? t.to(at::kFloat) : t) {}
-    ~F32View() {
-        if (orig.scalar_type() == at::ScalarType::Half) orig.copy_(f32);
-    }
+    bool is_output;
+    F32View(const Tensor& t, bool out) : orig(t), f32(t.scalar_type() == at::ScalarType::Half ? t.to(at::kFloat) : t), is_output(out) {}
     F32View(const F32View&) = delete;
     F32View& operator=(const F32View&) = delete;
     float* p() const { return (float*)f32.data_ptr(); }
+    // copy an OUTPUT back into the caller's fp16 tensor -- called explicitly after the kernel was issued (not from a destructor,
+    // where an exception terminates the process, and never for inputs: that was a wasted round trip and bumped the version counter of
+    // tensors a caller may have saved for backward)
+    void finish() {
+        if (is_output && orig.scalar_type() == at::ScalarType::Half) orig.copy_(f32);
+    }
 };
-#define F32ARG(x)    \
+#define F32ANY(x, OUT)    \
     CHECK_DENSE(x);  \
     CHECK_IS_FLOATING(x); \
-    F32View x##_v(x); \
+    F32View x##_v(x, OUT); \
     TORCH_CHECK(x##_v.f32.scalar_type() == at::ScalarType::Float, #x " must be a float32 tensor (the reference wrappers cast with custom_fwd(cast_inputs=float32))")
+#define F32ARG(x) F32ANY(x, false)   // input
+#define F32OUT(x) F32ANY(x, true)    // output or in/out: finished with F32DONE after the call
+#define F32DONE(x) x##_v.finish()
 
 void near_far_from_aabb(const Tensor rays_o, const Tensor rays_d, const Tensor aabb, const uint32_t N, const float min_near, Tensor nears, Tensor fars) {
-    F32ARG(rays_o); F32ARG(rays_d); F32ARG(aabb); F32ARG(nears); F32ARG(fars);
+    F32ARG(rays_o); F32ARG(rays_d); F32ARG(aabb); F32OUT(nears); F32OUT(fars);
     check(ngp_near_far_from_aabb(rays_o_v.p(), rays_d_v.p(), aabb_v.p(), N, min_near, nears_v.p(), fars_v.p(), stream()));
+    F32DONE(nears); F32DONE(fars);
 }
 
 void sph_from_ray(const Tensor rays_o, const Tensor rays_d, const float radius, const uint32_t N, Tensor coords) {
-    F32ARG(rays_o); F32ARG(rays_d); F32ARG(coords);
+    F32ARG(rays_o); F32ARG(rays_d); F32OUT(coords);
     check(ngp_sph_from_ray(rays_o_v.p(), rays_d_v.p(), radius, N, coords_v.p(), stream()));
+    F32DONE(coords);
 }
 
 void morton3D(const Tensor coords, const uint32_t N, Tensor indices) {
@@ -245,40 +254,44 @@ size_t density_grid_update_workspace_bytes(const uint32_t n_cells) { return ngp_
 void march_rays_train(const Tensor rays_o, const Tensor rays_d, const Tensor grid, const float bound, const float dt_gamma, const uint32_t max_steps,
                       const uint32_t N, const uint32_t C, const uint32_t H, const uint32_t M, const Tensor nears, const Tensor fars, Tensor xyzs,
                       Tensor dirs, Tensor deltas, Tensor rays, Tensor counter, Tensor noises) {
-    F32ARG(rays_o); F32ARG(rays_d); F32ARG(nears); F32ARG(fars); F32ARG(xyzs); F32ARG(dirs); F32ARG(deltas); F32ARG(noises);
+    F32ARG(rays_o); F32ARG(rays_d); F32ARG(nears); F32ARG(fars); F32OUT(xyzs); F32OUT(dirs); F32OUT(deltas); F32ARG(noises);
     CHECK_I32(rays); CHECK_I32(counter);
     CHECK_DENSE(grid);
     Tensor ws = scratch(ngp_march_rays_train_workspace_bytes(N), rays);
     check(ngp_march_rays_train(rays_o_v.p(), rays_d_v.p(), (const uint8_t*)ptr(grid), bound, dt_gamma, max_steps, N, C, H, M, nears_v.p(), fars_v.p(),
                                xyzs_v.p(), dirs_v.p(), deltas_v.p(), (int32_t*)ptr(rays), (int32_t*)ptr(counter), noises_v.p(), ws.data_ptr(), stream()));
+    F32DONE(xyzs); F32DONE(dirs); F32DONE(deltas);
 }
 
 void composite_rays_train_forward(const Tensor sigmas, const Tensor rgbs, const Tensor deltas, const Tensor rays, const uint32_t M, const uint32_t N,
                                   const float T_thresh, Tensor weights_sum, Tensor depth, Tensor image) {
-    F32ARG(sigmas); F32ARG(rgbs); F32ARG(deltas); F32ARG(weights_sum); F32ARG(depth); F32ARG(image);
+    F32ARG(sigmas); F32ARG(rgbs); F32ARG(deltas); F32OUT(weights_sum); F32OUT(depth); F32OUT(image);
     CHECK_I32(rays);
     check(ngp_composite_rays_train_forward(sigmas_v.p(), rgbs_v.p(), deltas_v.p(), (const int32_t*)ptr(rays), M, N, T_thresh, weights_sum_v.p(),
                                            depth_v.p(), image_v.p(), stream()));
+    F32DONE(weights_sum); F32DONE(depth); F32DONE(image);
 }
 
 void composite_rays_train_backward(const Tensor grad_weights_sum, const Tensor grad_image, const Tensor sigmas, const Tensor rgbs, const Tensor deltas,
                                    const Tensor rays, const Tensor weights_sum, const Tensor image, const uint32_t M, const uint32_t N,
                                    const float T_thresh, Tensor grad_sigmas, Tensor grad_rgbs) {
     F32ARG(grad_weights_sum); F32ARG(grad_image); F32ARG(sigmas); F32ARG(rgbs); F32ARG(deltas); F32ARG(weights_sum); F32ARG(image);
-    F32ARG(grad_sigmas); F32ARG(grad_rgbs);
+    F32OUT(grad_sigmas); F32OUT(grad_rgbs);
     CHECK_I32(rays);
     check(ngp_composite_rays_train_backward(grad_weights_sum_v.p(), grad_image_v.p(), sigmas_v.p(), rgbs_v.p(), deltas_v.p(), (const int32_t*)ptr(rays),
                                             weights_sum_v.p(), image_v.p(), M, N, T_thresh, grad_sigmas_v.p(), grad_rgbs_v.p(), stream()));
+    F32DONE(grad_sigmas); F32DONE(grad_rgbs);
 }
 
 void march_rays(const uint32_t n_alive, const uint32_t n_step, const Tensor rays_alive, const Tensor rays_t, const Tensor rays_o, const Tensor rays_d,
                 const float bound, const float dt_gamma, const uint32_t max_steps, const uint32_t C, const uint32_t H, const Tensor grid,
                 const Tensor nears, const Tensor fars, Tensor xyzs, Tensor dirs, Tensor deltas, Tensor noises) {
-    F32ARG(rays_t); F32ARG(rays_o); F32ARG(rays_d); F32ARG(nears); F32ARG(fars); F32ARG(xyzs); F32ARG(dirs); F32ARG(deltas); F32ARG(noises);
+    F32ARG(rays_t); F32ARG(rays_o); F32ARG(rays_d); F32ARG(nears); F32ARG(fars); F32OUT(xyzs); F32OUT(dirs); F32OUT(deltas); F32ARG(noises);
     CHECK_I32(rays_alive);
     CHECK_DENSE(grid);
     check(ngp_march_rays(n_alive, n_step, (const int32_t*)ptr(rays_alive), rays_t_v.p(), rays_o_v.p(), rays_d_v.p(), bound, dt_gamma, max_steps, C, H,
                          (const uint8_t*)ptr(grid), nears_v.p(), fars_v.p(), xyzs_v.p(), dirs_v.p(), deltas_v.p(), noises_v.p(), stream()));
+    F32DONE(xyzs); F32DONE(dirs); F32DONE(deltas);
 }
 
 void march_rays_ex(const uint32_t n_alive, const uint32_t n_step, const Tensor rays_alive, const Tensor rays_t, const Tensor rays_o, const Tensor rays_d,
@@ -294,10 +307,11 @@ void march_rays_ex(const uint32_t n_alive, const uint32_t n_step, const Tensor r
 
 void composite_rays(const uint32_t n_alive, const uint32_t n_step, const float T_thresh, Tensor rays_alive, Tensor rays_t, Tensor sigmas, Tensor rgbs,
                     Tensor deltas, Tensor weights_sum, Tensor depth, Tensor image) {
-    F32ARG(rays_t); F32ARG(sigmas); F32ARG(rgbs); F32ARG(deltas); F32ARG(weights_sum); F32ARG(depth); F32ARG(image);
+    F32OUT(rays_t); F32ARG(sigmas); F32ARG(rgbs); F32ARG(deltas); F32OUT(weights_sum); F32OUT(depth); F32OUT(image);
     CHECK_I32(rays_alive);
     check(ngp_composite_rays(n_alive, n_step, T_thresh, (int32_t*)ptr(rays_alive), rays_t_v.p(), sigmas_v.p(), rgbs_v.p(), deltas_v.p(), weights_sum_v.p(),
                              depth_v.p(), image_v.p(), stream()));
+    F32DONE(rays_t); F32DONE(weights_sum); F32DONE(depth); F32DONE(image);
 }
 
 void compact_rays(const Tensor rays_alive, const uint32_t n_alive, Tensor out_alive, Tensor out_count) {

@@ -504,7 +504,14 @@ class NeRFRenderer(nn.Module):
             import fused as _fused
             _fused.density_point_spacing = 1.6 / self.grid_size if len(samples) == self.cascade and len(samples[0][1]) < cells else None
             try:
-                sigma = self.density(pts)['sigma'].reshape(-1).detach()      # density_scale is applied by the update kernel
+                # ONE network evaluation over all cascades up to REFRESH_CHUNK points, chunked beyond (a full sweep of bound 16 is
+                # 5 x 128^3 = 10.5 M points; peak activation memory -- and the pool of a graph the refresh is captured into -- otherwise
+                # grows with the cascade count)
+                chunk = int(getattr(self, 'refresh_chunk', 1 << 22))
+                if pts.shape[0] <= chunk:
+                    sigma = self.density(pts)['sigma'].reshape(-1).detach()      # density_scale is applied by the update kernel
+                else:
+                    sigma = torch.cat([self.density(pts[i:i + chunk])['sigma'].reshape(-1).detach() for i in range(0, pts.shape[0], chunk)], 0)
             finally:
                 _fused.density_point_spacing = None
             state = self.__dict__.setdefault('_refresh_state', {})

@@ -130,6 +130,11 @@ def density_grid_state(density_grid, state):
     creation inside the capture would be replayed, and re-initialise the buffers, with every replay)."""
     n_cells, dev = density_grid.numel(), density_grid.device
     if state.get('n_cells') != n_cells or state.get('device') != dev:
+        if density_grid.is_cuda and torch.cuda.is_current_stream_capturing():
+            # (ADVICE r3) created under a capture the fills below would be REPLAYED, i.e. the scratch grid, the partials and the mean would
+            # be re-initialised by every replay -- silently wrong from the second replay on
+            raise RuntimeError('density_grid_state: the refresh scratch must be created outside stream capture (call '
+                               'raymarching.density_grid_state(model.density_grid, state) -- or run one refresh eagerly -- before capturing)')
         state.update(n_cells=n_cells, device=dev, scratch=torch.full((n_cells,), -1.0, dtype=torch.float32, device=dev),
                      workspace=torch.zeros(int(_backend.density_grid_update_workspace_bytes(n_cells)), dtype=torch.uint8, device=dev),
                      mean=torch.zeros(1, dtype=torch.float32, device=dev))

@@ -57,7 +57,7 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak, same guide
 # and are resolved at call time (in 64 B + out 32 B + 128 B per stored hidden layer; backward: grad 32 + saved activations
 # 128/layer + inputs 64 + dL/dx 64).
 def _ff_fwd_bytes(nl): return 64.0 + 32.0 + 128.0 * nl
-def _ff_bwd_bytes(nl): return 32.0 + 128.0 * nl + 64.0 + 64.0
+def _ff_bwd_bytes(nl, stored=True): return 32.0 + (128.0 * nl if stored else 0.0) + 64.0 + 64.0   # stored=False: NGP_FF_RECOMPUTE, no forward buffer read
 def _ff_flops(nl): return 2.0 * 64 * (32 + 64 * (nl - 1) + 16)
 
 TIMED = {
@@ -71,14 +71,15 @@ TIMED = {
     'ngp_grid_encode_backward_ws': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_checked': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_ffmlp_forward_ex': ('ffmlp_forward', 2, lambda a: _ff_fwd_bytes(a[6]), lambda a: _ff_flops(a[6]), 'sample'),
-    # the whole network behind the encoder in one launch: enc 64 B + dir 12 B in, both forward buffers + h16 32 B + colour input 64 B + sigma 4 B +
-    # rgb 12 B out per sample; flops of both MLPs
+    # the whole network behind the encoder in one launch: enc 64 B + dir 12 B in, both forward buffers (when they are stored: not with the
+    # recomputing backward) + h16 32 B + colour input 64 B + sigma 4 B + rgb 12 B out per sample; flops of both MLPs
     'ngp_network_forward': ('network_forward', 2,
-                            lambda a: (64.0 + 12.0 + 128.0 * (a[6] + a[7]) + 32.0 + 64.0 + 4.0 + 12.0) if a[9] else (64.0 + 12.0 + 4.0 + 12.0),
+                            lambda a: (64.0 + 12.0 + (128.0 * (a[6] + a[7]) if a[10] else 0.0) + 32.0 + 64.0 + 4.0 + 12.0) if a[9] else (64.0 + 12.0 + 4.0 + 12.0),
                             lambda a: _ff_flops(a[6]) + _ff_flops(a[7]), 'sample'),
-    'ngp_ffmlp_backward_ex': ('ffmlp_backward', 4, lambda a: _ff_bwd_bytes(a[8]), lambda a: 2.0 * _ff_flops(a[8]), 'sample'),
+    'ngp_ffmlp_backward_ex': ('ffmlp_backward', 4, lambda a: _ff_bwd_bytes(a[8], bool(a[3])), lambda a: 2.0 * _ff_flops(a[8]), 'sample'),
     # the colour network's backward (it also writes the sigma network's output gradient: + 4 B sigma gradient in, 32 B out per sample)
-    'ngp_network_backward_color': ('ffmlp_backward (colour net)', 4, lambda a: _ff_bwd_bytes(a[5]) + 36.0, lambda a: 2.0 * _ff_flops(a[5]), 'sample'),
+    'ngp_network_backward_color': ('ffmlp_backward (colour net)', 4, lambda a: _ff_bwd_bytes(a[5], bool(a[3])) + 36.0,
+                                   lambda a: 2.0 * _ff_flops(a[5]), 'sample'),
     # compositing + loss + their backward in one launch: sigma 4 + rgb 12 + deltas 8 in, 4 + 32 gradient out per sample (+ rays, target,
     # image, depth, weights: 80 B per ray) -- SURVEY.md 8(d): 64 B / sample + 80 B / ray
     'ngp_composite_train_loss_backward': ('composite + loss + backward', 4, lambda a: 64.0 + 80.0 * a[5] / max(a[4], 1), lambda a: 0.0, 'sample'),
@@ -318,8 +319,16 @@ class TrainingRun:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        stamps = []
         for _ in range(steps):
             loss = self.train_step()
+            if len(stamps) < 16:
+                stamps.append(time.perf_counter() - t0)
+        # host time to ISSUE the steps, nothing waited for: over the whole run it approaches `elapsed` once the launch queue is full (back
+        # pressure); the first steps after the synchronisation show what the host itself needs per step
+        issued = time.perf_counter() - t0
+        deltas = sorted(b - a for a, b in zip(stamps[:-1], stamps[1:]))
+        self.host_first_steps_ms = round(deltas[len(deltas) // 2] * 1e3, 4) if len(deltas) >= 3 else None   # median: refresh steps excluded
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -337,7 +346,7 @@ class TrainingRun:
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
             dist.all_reduce(total, op=dist.ReduceOp.SUM)
-        return {'elapsed': float(el.item()), 'samples': int(total.item()), 'final_loss': final_loss, 'captures': int(captures)}
+        return {'elapsed': float(el.item()), 'samples': int(total.item()), 'final_loss': final_loss, 'captures': int(captures), 'issued': issued, 'host_first': self.host_first_steps_ms}
 
     def execution(self):
         st = self.stepper
@@ -780,6 +789,7 @@ def main():
                        'sharded_update_fallback': fallback,
                        'execution': run.execution(), 'setup_iterations_untimed': SETUP_ITERATIONS, 'fusions_off': fusions_off,
                        'captures_in_timed_region': res['captures'],
+                       'host_issue_ms_per_step': round(res['issued'] / args.steps * 1e3, 4), 'host_ms_per_step_unblocked': res.get('host_first'),
                        'autograd_free_iteration': bool(stepper.used_direct), 'fused_pipeline': bool(model.fused),
                        'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
                        'final_loss': res['final_loss']},

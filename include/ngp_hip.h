@@ -266,6 +266,9 @@ int ngp_density_grid_update(const float* sigmas, const int64_t* cells, uint32_t 
 #define NGP_FF_SINGLE_WAVE 8u  /* testing: backward with one wave per tile stream instead of the paired kernel (2- and 3-layer nets) */
 #define NGP_FF_DEFER_REDUCE 16u /* backward of a 2- / 3-layer net: leave the per-workgroup fp32 weight-gradient slabs in backward_buffer; the
                                  * caller sums them later (ngp_ffmlp_reduce_slabs_pair), e.g. two networks' slabs in one launch */
+#define NGP_FF_RECOMPUTE 32u   /* backward of a 64-wide ReLU net with 32 inputs and 2 / 3 layers: forward_buffer is not read (may be NULL); the
+                                 * hidden activations are recomputed from `inputs` -- bit for bit what the forward pass would have stored.
+                                 * ngp_network_forward(training) with both forward buffers NULL is the matching forward: it does not store them */
 int ngp_ffmlp_forward_ex(const void* inputs, const void* weights, uint32_t B, uint32_t input_dim, uint32_t output_dim,
                          uint32_t hidden_dim, uint32_t num_layers, uint32_t activation, uint32_t output_activation,
                          void* forward_buffer, void* outputs, uint32_t flags, ngp_stream_t stream);
@@ -292,7 +295,8 @@ int ngp_ffmlp_backward_ws(const void* grad, const void* inputs, const void* weig
  * row-major or (flags & NGP_FF_INPUT_PLANAR) the encoder's own [16][M][2] layout; dirs [M_valid,3] fp32 (rows >= M_valid use dir = 0);
  * -> sigma [M] fp32 (= density_scale * exp(h0)), rgb [M,3] fp32.  training != 0 also writes what ngp_ffmlp_backward* and the
  * ngp_pipeline_*_backward kernels read: forward_buffer_sigma [nl_s,M,64], h16 [M,16], color_in [M,32], forward_buffer_color [nl_c,M,64]
- * (all fp16, the forward buffers in this library's private layout).  Bit-identical to the sequence ngp_ffmlp_forward_ex ->
+ * (all fp16, the forward buffers in this library's private layout; both forward buffers NULL: not stored, for a backward that runs with
+ * NGP_FF_RECOMPUTE).  Bit-identical to the sequence ngp_ffmlp_forward_ex ->
  * ngp_pipeline_mid_forward -> ngp_ffmlp_forward_ex -> ngp_pipeline_rgb_forward it replaces. */
 int ngp_network_forward(const void* enc, const float* dirs, uint32_t M, uint32_t M_valid, const void* w_sigma, const void* w_color,
                         uint32_t num_layers_sigma, uint32_t num_layers_color, float density_scale, int training,
@@ -303,7 +307,7 @@ int ngp_network_forward(const void* enc, const float* dirs, uint32_t M, uint32_t
  *  - ngp_network_backward_color = ngp_ffmlp_backward_ex of the colour MLP (32 -> 64 x (n-1) -> 16, ReLU, n = 2 or 3) whose input-gradient
  *    epilogue writes the sigma net's output gradient grad_h16 [M,16] directly (what ngp_pipeline_mid_backward would assemble from
  *    grad_sigma [M], h16 [M,16] and dL/d(colour input)[:,16:31]); same bits, one launch and a [M,32] round trip less.
- *    flags: 0 or NGP_FF_DEFER_REDUCE.
+ *    flags: 0, NGP_FF_DEFER_REDUCE, NGP_FF_RECOMPUTE (forward_buffer_color may then be NULL).
  *  - ngp_ffmlp_backward_slab_count: how many fp32 slabs [n_params] a deferred backward of that shape leaves at the start of its
  *    backward_buffer (0: the gradients were stored directly, nothing to sum).
  *  - ngp_ffmlp_reduce_slabs_pair: sums two slab sets (n_slabs x n_params fp32 each, either may be empty) into fp16 weight

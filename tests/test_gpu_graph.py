@@ -270,10 +270,11 @@ def test_fused_occupancy_apply_equals_the_reference_formulation(bound, full):
     assert float(model._refresh_state['scratch'].max()) == -1.0 and float(model._refresh_state['scratch'].min()) == -1.0
 
 
-@pytest.mark.parametrize('toggle', ['USE_FUSED_MID', 'USE_FUSED_COMPOSITE', 'USE_FUSED_SCAN'])
+@pytest.mark.parametrize('toggle', ['USE_FUSED_MID', 'USE_FUSED_COMPOSITE', 'USE_FUSED_SCAN', 'USE_RECOMPUTE'])
 def test_iteration_fusions_are_bit_identical_to_the_unfused_launches(toggle):
     """the optional launch fusions of the autograd-free iteration (colour-head epilogue + one slab reduction; composite + loss + backward in
-    one kernel) against the launches they replace: every deposited gradient, the image and the counters bit for bit."""
+    one kernel; hidden activations recomputed by the backward instead of stored by the forward) against the launches they replace: every
+    deposited gradient, the image and the counters bit for bit."""
     import fused
     dev = torch.device('cuda')
     n_rays = 1024
@@ -286,12 +287,13 @@ def test_iteration_fusions_are_bit_identical_to_the_unfused_launches(toggle):
         params = (model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights)
         counter = torch.zeros(2, dtype=torch.int32, device=dev)
         capacity = model.mean_count + (128 - model.mean_count % 128)
+        default = getattr(fused, toggle)
         setattr(fused, toggle, on)
         try:
             loss, image, depth, ws = fused.fused_train_iteration(model, o, d, gt, model.aabb_train, counter, capacity, opt.scalars[0:1], 1, False, 0,
                                                                  1024, 1e-4)
         finally:
-            setattr(fused, toggle, True)
+            setattr(fused, toggle, default)
         res[on] = ([p._ngp_grad16.clone() for p in params], image.clone(), ws.clone(), counter.clone(), float(loss))
     a, b = res[True], res[False]
     assert torch.equal(a[3], b[3]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])

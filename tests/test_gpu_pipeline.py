@@ -254,6 +254,64 @@ def test_fused_network_forward_is_bit_identical_to_the_four_kernels(nl_s, nl_c, 
     assert float(res[(True, True)][1].std()) > 0 and torch.isfinite(res[(True, True)][0]).all()
 
 
+@pytest.mark.parametrize('nl_s,nl_c', [(2, 3), (3, 2), (2, 2), (3, 3)])
+@pytest.mark.parametrize('M', [128, 33408, 270336])
+def test_backward_that_recomputes_the_activations_is_bit_identical_to_the_stored_one(nl_s, nl_c, M):
+    """NGP_FF_RECOMPUTE: the training forward stores no hidden activations (ngp_network_forward with both forward buffers NULL) and the
+    paired backward kernels rebuild them from their inputs.  Same MFMA sequence, same ReLU / fp16 rounding as the forward kernel, so every
+    gradient -- colour weights, grad_h16, sigma weights, the planar encoder gradient -- must agree bit for bit with the stored path, for
+    one workgroup (direct store), for many (slabs) and past the tile counts where all three DMA stages are in flight."""
+    import fused
+    import _ngp_capi as capi
+    dev = torch.device('cuda')
+    st = capi.stream()
+    g = torch.Generator(device='cuda').manual_seed(100 + nl_s * 10 + nl_c)
+    half = dict(device=dev, dtype=torch.half)
+    enc = (torch.rand(16, M, 2, device=dev, generator=g) - 0.5).half()
+    dirs = torch.nn.functional.normalize(torch.randn(M, 3, device=dev, generator=g), dim=-1)
+    ws = ((torch.rand(64 * (32 + 64 * (nl_s - 1) + 16), device=dev, generator=g) * 2 - 1) * (3 / 64) ** 0.5).half()
+    wc = ((torch.rand(64 * (32 + 64 * (nl_c - 1) + 16), device=dev, generator=g) * 2 - 1) * (3 / 64) ** 0.5).half()
+    g_out16 = (torch.randn(M, 16, device=dev, generator=g) * 0.05).half()
+    g_out16[:, 3:] = 0
+    g_sigma = torch.randn(M, device=dev, generator=g) * 0.01
+    res = {}
+    for recompute in (False, True):
+        fb_s = None if recompute else torch.zeros(nl_s, M, 64, **half)
+        fb_c = None if recompute else torch.zeros(nl_c, M, 64, **half)
+        h16, color_in, out16 = torch.zeros(M, 16, **half), torch.zeros(M, 32, **half), torch.zeros(M, 16, **half)
+        sigma, rgb = torch.zeros(M, device=dev), torch.zeros(M, 3, device=dev)
+        fused._network_forward(enc, dirs, M, ws, wc, nl_s, nl_c, 1.3, True, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M, st)
+        flag = capi.NGP_FF_RECOMPUTE if recompute else 0
+        scratch_c, scratch_s = torch.zeros(nl_c, M, 64, **half), torch.zeros(nl_s, M, 64, **half)
+        g_h16, g_wc, g_ws, g_enc = torch.zeros(M, 16, **half), torch.zeros_like(wc), torch.zeros_like(ws), torch.zeros(16, M, 2, **half)
+        capi.check(capi.lib.ngp_network_backward_color(g_out16.data_ptr(), color_in.data_ptr(), wc.data_ptr(), capi.ptr(fb_c), M, nl_c,
+                                                       scratch_c.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), 1.3, g_h16.data_ptr(),
+                                                       g_wc.data_ptr(), flag, st))
+        capi.check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws.data_ptr(), capi.ptr(fb_s), M, 32, 16, 64, nl_s, 0, 6, 1,
+                                                  scratch_s.data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
+                                                  capi.NGP_FF_INPUT_PLANAR | capi.NGP_FF_DX_PLANAR | flag, st))
+        # and the colour net through the plain entry point (row-major inputs, dL/dx stored)
+        g_cin, g_wc2, scratch2 = torch.zeros(M, 32, **half), torch.zeros_like(wc), torch.zeros(nl_c, M, 64, **half)
+        capi.check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc.data_ptr(), capi.ptr(fb_c), M, 32, 16, 64, nl_c, 0, 6,
+                                                  1, scratch2.data_ptr(), g_cin.data_ptr(), g_wc2.data_ptr(), flag, st))
+        res[recompute] = dict(sigma=sigma, rgb=rgb, h16=h16, color_in=color_in, g_h16=g_h16, g_wc=g_wc, g_ws=g_ws, g_enc=g_enc, g_cin=g_cin, g_wc2=g_wc2)
+    torch.cuda.synchronize()
+    for k, v in res[True].items():
+        assert torch.isfinite(v.float()).all(), k
+        assert torch.equal(v, res[False][k]), (k, float((v.float() - res[False][k].float()).abs().max()))
+    for k in ('g_h16', 'g_wc', 'g_ws', 'g_enc', 'g_cin'):
+        assert float(res[True][k].float().abs().max()) > 0, k
+    assert torch.equal(res[True]['g_wc'], res[True]['g_wc2'])
+    # without the flag a missing forward buffer is an error, and the flag is refused where no recomputing kernel exists
+    with pytest.raises(RuntimeError):
+        capi.check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc.data_ptr(), None, M, 32, 16, 64, nl_c, 0, 6, 1,
+                                                  scratch2.data_ptr(), g_cin.data_ptr(), g_wc2.data_ptr(), 0, st))
+    with pytest.raises(RuntimeError):
+        capi.check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc.data_ptr(), None, M, 32, 16, 64, nl_c, 0, 6, 1,
+                                                  scratch2.data_ptr(), g_cin.data_ptr(), g_wc2.data_ptr(),
+                                                  capi.NGP_FF_RECOMPUTE | capi.NGP_FF_SINGLE_WAVE, st))
+
+
 @pytest.mark.parametrize('bg_mode', [1, 2])
 @pytest.mark.parametrize('scaled', [False, True])
 def test_fused_composite_loss_backward_is_bit_identical_to_the_four_kernels(bg_mode, scaled):

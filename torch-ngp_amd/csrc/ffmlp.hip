@@ -331,7 +331,7 @@ __device__ __forceinline__ float16_t relu_network_tail(float16_t (&acc)[2], cons
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
         pack_hidden<WIDTH>(acc, hid);
-        if (TRAIN) {
+        if (TRAIN && fb) {  // (fb == NULL: the backward recomputes the activations, NGP_FF_RECOMPUTE)
             half8_t* dst = reinterpret_cast<half8_t*>(fb) + l * layer_stride + (size_t)tile * NKB * 64 + lane;
 #pragma unroll
             for (int kb = 0; kb < NKB; kb++) stream_store(dst + kb * 64, hid[kb]);
@@ -947,7 +947,51 @@ struct MidEpilogue {
     float density_scale;
 };
 
-template <int WIDTH, int IN_JB, int NHM /* 1 or 2 */, bool RELU>
+// RECOMP (round 4, fused training step only): the hidden activations are not read from a forward buffer -- the forward pass did not store
+// them -- but recomputed from the tile's inputs X with the forward image of the same weights: the same MFMA sequence, the same ReLU and
+// fp16 rounding as k_network_forward / k_ffmlp_forward, so bit for bit what the forward buffer would have held.  A 64-wide layer is
+// 128 B per sample written by the forward pass and read again here; recomputing it is 8 MFMAs and ~50 vector instructions per 32 samples.
+// The tile DMA then carries dY and X only (3 KiB instead of 11-15), both roles run the forward chain themselves: role 0 keeps the two
+// layers it needs in registers, role 1 parks all of them in a private LDS scratch (each lane re-reads only what it wrote).
+template <int WIDTH, int NHM, typename Sink>
+__device__ __forceinline__ void recompute_hidden(const half8_t* __restrict__ fimg_lane, uint32_t in_kb, const unsigned char* xb, bool in_planar,
+                                                 int lane, Sink&& sink) {
+    constexpr int NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    float16_t acc[NIB];
+#pragma unroll
+    for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
+    for (uint32_t kb = 0; kb < in_kb; kb++) {
+        const half8_t x = tile_x(xb, kb, in_planar, lane);
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(fimg_lane[(ib * in_kb + kb) * 64], x, acc[ib]);
+    }
+    const half8_t* fhid = fimg_lane + (size_t)NIB * in_kb * 64;
+    half8_t hid[NKB];
+#pragma unroll
+    for (int l = 0; l <= NHM; l++) {
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
+        pack_hidden<WIDTH>(acc, hid);
+        sink(l, hid);
+        if (l == NHM) break;
+        const half8_t* wl = fhid + (size_t)l * NIB * NKB * 64;
+#pragma unroll
+        for (int ib = 0; ib < NIB; ib++) {
+            acc[ib] = zero16();
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++) acc[ib] = mfma(wl[(ib * NKB + kb) * 64], hid[kb], acc[ib]);
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WIDTH, int IN_JB, int NHM /* 1 or 2 */, bool RELU, bool RECOMP = false>
 __global__ __launch_bounds__(FP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __restrict__ inputs, const half_t* __restrict__ weights,
                              const half_t* __restrict__ forward_buffer, uint32_t n_tiles, uint32_t in_dim, uint32_t num_layers, uint32_t act,
@@ -958,37 +1002,62 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img = reinterpret_cast<half8_t*>(smem);
     const uint32_t nfrag = bwd_frag_count<WIDTH>(in_dim, num_layers, with_dx);
+    const uint32_t in_kb = in_dim / 16;
+    // RECOMP: the forward image (input layer + hidden matmuls, no output layer) sits behind the backward image
+    const uint32_t ffrag = RECOMP ? NIB * in_kb + (num_layers - 1) * NIB * NKB : 0u;
     build_backward_image<WIDTH>(img, weights, in_dim, num_layers, with_dx);
+    if (RECOMP) build_forward_image<WIDTH>(img + (size_t)nfrag * 64, weights, in_dim, num_layers, 0, ffrag);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = lane & 31, h = lane >> 5;
     const int pair = wid & (FP_PAIRS - 1), role = wid / FP_PAIRS;
     const Selectors sel = make_selectors(n, h);
     __syncthreads();
 
-    const uint32_t in_kb = in_dim / 16;
     const half8_t* img_out = img + lane;
     const half8_t* img_hid = img_out + (size_t)NIB * 64;
     const half8_t* img_in = img_hid + (size_t)(num_layers - 1) * NIB * NKB * 64;
+    const half8_t* fimg = img + (size_t)nfrag * 64 + lane;
     const size_t layer_stride = (size_t)n_tiles * NKB * 64;
     const half8_t* fb = reinterpret_cast<const half8_t*>(forward_buffer);
     const size_t rows = (size_t)n_tiles * FF_TILE;
-    const uint32_t tile_frags = 1 + num_layers * NKB + in_dim / 16;
-    unsigned char* pf_base = smem + (size_t)nfrag * 1024 + (size_t)pair * pf_depth * tile_frags * 1024;
+    const uint32_t act_layers = RECOMP ? 0u : num_layers;  // layers of stored activations in a tile buffer
+    const uint32_t tile_frags = 1 + act_layers * NKB + in_kb;
+    unsigned char* pf_base = smem + (size_t)(nfrag + ffrag) * 1024 + (size_t)pair * pf_depth * tile_frags * 1024;
+    // RECOMP: role 1's recomputed activations of hidden layers 0 .. NHM-1, [layer][kb] fragments behind all tile buffers
+    half8_t* scratch = reinterpret_cast<half8_t*>(smem + (size_t)(nfrag + ffrag) * 1024 + (size_t)FP_PAIRS * pf_depth * tile_frags * 1024 +
+                                                  (size_t)pair * NHM * NKB * 1024) + lane;
     const uint32_t base_step = gridDim.x * FP_PAIRS;
     uint32_t cur = 0;
     auto prefetch = [&](uint32_t buffer, uint32_t tile) {
-        prefetch_tile<WIDTH>(pf_base + (size_t)buffer * tile_frags * 1024, tile, grad, fb, inputs, num_layers, layer_stride, rows, in_dim, in_planar,
+        prefetch_tile<WIDTH>(pf_base + (size_t)buffer * tile_frags * 1024, tile, grad, fb, inputs, act_layers, layer_stride, rows, in_dim, in_planar,
                              lane, n, h);
     };
-    if (role == 0 && blockIdx.x * FP_PAIRS + pair < n_tiles) prefetch(0, blockIdx.x * FP_PAIRS + pair);
-    // per tile round: the landed tile is handed over (barrier), the other buffer is refilled; returns the tile's buffer
+    // pf_depth buffers per pair: tiles of the next pf_depth - 1 rounds are in flight while one is worked on (depth 3 only with RECOMP, whose
+    // rounds are shorter than a DMA round trip)
+    if (role == 0) {
+        for (uint32_t d = 0; d + 1 < (pf_depth > 1 ? pf_depth : 2u); d++)
+            if (blockIdx.x * FP_PAIRS + d * base_step + pair < n_tiles) prefetch(d, blockIdx.x * FP_PAIRS + d * base_step + pair);
+    }
+    // DMA instructions per tile (the wait below has to name how many YOUNGER ones may still be in flight)
+    const bool deep = RECOMP && pf_depth == 3 && in_kb == 2;
+    // per tile round: the landed tile is handed over (barrier), the free buffer is refilled; returns the tile's buffer
     auto next_tile_buffer = [&](uint32_t base) -> const unsigned char* {
-        if (role == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (role == 0) {
+            // a tile that does not exist was not requested: its slot in the queue is missing, so only the oldest request may be waited for
+            // by count while a full set of younger ones exists
+            if (deep && base + base_step + pair < n_tiles) {
+                if (in_planar) wait_vmcnt<1 + 2 * 4>(); else wait_vmcnt<1 + 2>();   // in_dim = 32 (IN_JB == 1): dY + two X fragments
+            } else {
+                wait_vmcnt<0>();
+            }
+        }
         __syncthreads();
         const unsigned char* tb = pf_base + (size_t)cur * tile_frags * 1024;
         if (pf_depth > 1) {
-            cur ^= 1u;
-            if (role == 0 && base + base_step + pair < n_tiles) prefetch(cur, base + base_step + pair);
+            const uint32_t ahead = pf_depth - 1;
+            const uint32_t fill = cur == 0 ? pf_depth - 1 : cur - 1;   // the buffer of the round before this one: both roles are done with it
+            cur = cur + 1 == pf_depth ? 0u : cur + 1;
+            if (role == 0 && base + ahead * base_step + pair < n_tiles) prefetch(fill, base + ahead * base_step + pair);
         }
         return tb;
     };
@@ -1040,10 +1109,22 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
                 const half8_t* tfrag = reinterpret_cast<const half8_t*>(tb) + lane;
                 const half8_t dy = tfrag[0];
                 half8_t a_top[NKB], a_below[NKB];
+                if constexpr (RECOMP) {
+                    recompute_hidden<WIDTH, NHM>(fimg, in_kb, tb + 1024, in_planar, lane, [&](int l, const half8_t (&hid)[NKB]) {
+                        if (l == NHM) {
 #pragma unroll
-                for (int kb = 0; kb < NKB; kb++) a_top[kb] = tfrag[(1 + NHM * NKB + kb) * 64];
+                            for (int kb = 0; kb < NKB; kb++) a_top[kb] = hid[kb];
+                        } else if (l == NHM - 1) {
 #pragma unroll
-                for (int kb = 0; kb < NKB; kb++) a_below[kb] = tfrag[(1 + (NHM - 1) * NKB + kb) * 64];
+                            for (int kb = 0; kb < NKB; kb++) a_below[kb] = hid[kb];
+                        }
+                    });
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < NKB; kb++) a_top[kb] = tfrag[(1 + NHM * NKB + kb) * 64];
+#pragma unroll
+                    for (int kb = 0; kb < NKB; kb++) a_below[kb] = tfrag[(1 + (NHM - 1) * NKB + kb) * 64];
+                }
                 half8_t aT[NIB][2], zT[NIB][2];
                 transpose_hidden<WIDTH>(a_top, sel, aT);
                 {
@@ -1104,8 +1185,25 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
                 const half8_t* tfrag = reinterpret_cast<const half8_t*>(tb) + lane;
                 const half8_t dy = tfrag[0];
                 half8_t a_prev[NKB];
+                // post-activations of hidden layer l: the tile buffer, or this wave's recomputed copy
+                const half8_t* afrag = RECOMP ? scratch : tfrag + 64;
+                if constexpr (RECOMP) {
+                    recompute_hidden<WIDTH, NHM>(fimg, in_kb, tb + 1024, in_planar, lane, [&](int l, const half8_t (&hid)[NKB]) {
+                        if (l == NHM) {
 #pragma unroll
-                for (int kb = 0; kb < NKB; kb++) a_prev[kb] = tfrag[(1 + NHM * NKB + kb) * 64];
+                            for (int kb = 0; kb < NKB; kb++) a_prev[kb] = hid[kb];
+                        } else {
+#pragma unroll
+                            for (int kb = 0; kb < NKB; kb++) scratch[(l * NKB + kb) * 64] = hid[kb];
+                        }
+                    });
+                    // the lower layers come back from LDS when they are needed: forwarding the stored registers would keep 16-32 more of
+                    // them alive through the dgrad chain, which has none to spare
+                    asm volatile("" ::: "memory");
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < NKB; kb++) a_prev[kb] = afrag[(NHM * NKB + kb) * 64];
+                }
                 float16_t acc[NIB];
 #pragma unroll
                 for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(img_out[ib * 64], dy, zero16());
@@ -1114,7 +1212,7 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
                 // top hidden matmul: dgrad only (its dW belongs to role 0)
                 activation_transfer<WIDTH, RELU>(act, acc, a_prev, dz);
 #pragma unroll
-                for (int kb = 0; kb < NKB; kb++) a_prev[kb] = tfrag[(1 + (NHM - 1) * NKB + kb) * 64];
+                for (int kb = 0; kb < NKB; kb++) a_prev[kb] = afrag[((NHM - 1) * NKB + kb) * 64];
 #pragma unroll
                 for (int ib = 0; ib < NIB; ib++) {
                     acc[ib] = zero16();
@@ -1124,7 +1222,7 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
                 if constexpr (NHM == 2) {  // lower hidden matmul: dW and dgrad
                     activation_transfer<WIDTH, RELU>(act, acc, a_prev, dz);
 #pragma unroll
-                    for (int kb = 0; kb < NKB; kb++) a_prev[kb] = tfrag[(1 + kb) * 64];
+                    for (int kb = 0; kb < NKB; kb++) a_prev[kb] = afrag[kb * 64];
                     transpose_hidden<WIDTH>(dz, sel, zT);
                     transpose_hidden<WIDTH>(a_prev, sel, aT);
 #pragma unroll
@@ -1150,7 +1248,7 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
                         const uint32_t kb = 2 * jb + e;
-                        if (kb < in_kb) t = mfma(tile_x(tb + (size_t)(1 + num_layers * NKB) * 1024, kb, in_planar, lane), sel.nat[e], t);
+                        if (kb < in_kb) t = mfma(tile_x(tb + (size_t)(1 + act_layers * NKB) * 1024, kb, in_planar, lane), sel.nat[e], t);
                     }
                     half8_t xT[2];
                     pack_transposed(t, xT);
@@ -1770,6 +1868,34 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
     NGP_REQUIRE(lds <= 160 * 1024, NGP_ERR_INVALID, "ffmlp_backward: LDS need (%zu B) exceeds 160 KiB", lds);
     // one fp32 slab per workgroup lives in the caller's backward_buffer ([num_layers, B, hidden] fp16)
     const uint32_t blocks = backward_slab_count<WIDTH>(B, in_dim, num_layers);
+    if (flags & NGP_FF_RECOMPUTE) {
+        // no stored activations: the paired kernel recomputes them from the inputs (64-wide ReLU networks with 32 inputs, 2 or 3 layers)
+        if constexpr (WIDTH == 64 && IN_JB == 1 && RELU && (NHM == 1 || NHM == 2)) {
+            NGP_REQUIRE(in_dim == 32 && !(flags & NGP_FF_SINGLE_WAVE), NGP_ERR_INVALID, "ffmlp_backward: NGP_FF_RECOMPUTE needs input_dim 32 and the paired kernel");
+            const uint32_t ffrag = NIB * (in_dim / 16) + (num_layers - 1) * NIB * NKB;
+            const size_t tile_b = (size_t)(1 + in_dim / 16) * 1024;
+            const uint32_t depth = 3;
+            size_t lds_r = (size_t)(nfrag + ffrag) * 1024 + (size_t)depth * FP_PAIRS * tile_b + (size_t)FP_PAIRS * NHM * NKB * 1024;
+            if (lds_r < (size_t)n_params * 4) lds_r = (size_t)n_params * 4;
+            auto pk = k_ffmlp_backward_paired<WIDTH, IN_JB, NHM, RELU, true>;
+            if (lds_r > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+                NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp_backward: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+            }
+            const bool direct = blocks <= 1;
+            hipLaunchKernelGGL(pk, dim3(direct ? 1 : blocks), dim3(FP_THREADS), lds_r, st, (const half_t*)grad, (const half_t*)inputs,
+                               (const half_t*)weights, (const half_t*)nullptr, n_tiles, in_dim, num_layers, act, with_dx, (half_t*)grad_inputs,
+                               direct ? (float*)nullptr : (float*)backward_buffer, direct ? (half_t*)grad_weights : (half_t*)nullptr, in_planar,
+                               dx_planar, depth, mid);
+            int rc = check_launch("ffmlp_backward");
+            if (rc || direct || defer) return rc;
+            hipLaunchKernelGGL(k_ffmlp_reduce_slabs, dim3(cdiv(n_params, RS_PARAMS)), dim3(RS_PARAMS * RS_GROUPS), 0, st,
+                               (const float*)backward_buffer, blocks, n_params, (half_t*)grad_weights);
+            return check_launch("ffmlp_backward(reduce)");
+        } else {
+            NGP_REQUIRE(false, NGP_ERR_INVALID, "ffmlp_backward: NGP_FF_RECOMPUTE serves 64-wide ReLU networks with 32 inputs and 2 or 3 layers");
+        }
+    }
     if constexpr (NHM == 1 || NHM == 2) {
         // 2- and 3-layer networks: two sibling waves per tile stream split the weight-gradient accumulators (see the kernel)
         if (!(flags & NGP_FF_SINGLE_WAVE)) {
@@ -1878,11 +2004,13 @@ extern "C" int ngp_ffmlp_backward_ws(const void* grad, const void* inputs, const
     int rc = check_ff_args("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers);
     if (rc) return rc;
     if (B == 0) return NGP_OK;
-    NGP_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer && grad_weights, NGP_ERR_INVALID, "ffmlp_backward: NULL tensor");
+    NGP_REQUIRE(grad && inputs && weights && (forward_buffer || (flags & NGP_FF_RECOMPUTE)) && backward_buffer && grad_weights, NGP_ERR_INVALID,
+                "ffmlp_backward: NULL tensor");
     NGP_REQUIRE(!calc_grad_inputs || grad_inputs, NGP_ERR_INVALID, "ffmlp_backward: grad_inputs is NULL but calc_grad_inputs is set");
     hipStream_t st = as_stream(stream);
     const bool dx = calc_grad_inputs != 0;
     const bool fast = (hidden_dim == 32 || hidden_dim == 64) && num_layers <= 4 && input_dim <= 64 && !(flags & NGP_FF_LAYERED);
+    NGP_REQUIRE(fast || !(flags & NGP_FF_RECOMPUTE), NGP_ERR_INVALID, "ffmlp_backward: NGP_FF_RECOMPUTE serves 64-wide ReLU networks with 32 inputs and 2 or 3 layers");
     NGP_REQUIRE(fast || !(flags & NGP_FF_DEFER_REDUCE), NGP_ERR_INVALID, "ffmlp_backward: NGP_FF_DEFER_REDUCE needs a 2- or 3-layer network of width 32 / 64");
     if (!fast) {
 #define FF_LAY(W) launch_backward_layered<W>(grad, inputs, weights, forward_buffer, B, input_dim, num_layers, activation, dx, backward_buffer, grad_inputs, grad_weights, flags, workspace, workspace_bytes, st)
@@ -1944,11 +2072,13 @@ extern "C" int ngp_network_backward_color(const void* grad_out16, const void* co
                                           ngp_stream_t stream) {
     NGP_REQUIRE(num_layers_color == 2 || num_layers_color == 3, NGP_ERR_INVALID,
                 "network_backward_color: 2 or 3 layers (got %u); use ngp_ffmlp_backward_ex + ngp_pipeline_mid_backward", num_layers_color);
-    NGP_REQUIRE(!(flags & ~NGP_FF_DEFER_REDUCE), NGP_ERR_INVALID, "network_backward_color: only NGP_FF_DEFER_REDUCE is accepted");
+    NGP_REQUIRE(!(flags & ~(NGP_FF_DEFER_REDUCE | NGP_FF_RECOMPUTE)), NGP_ERR_INVALID,
+                "network_backward_color: only NGP_FF_DEFER_REDUCE and NGP_FF_RECOMPUTE are accepted");
     int rc = check_ff_args("network_backward_color", M, 32, 16, 64, num_layers_color);
     if (rc) return rc;
     if (M == 0) return NGP_OK;
-    NGP_REQUIRE(grad_out16 && color_in && w_color && forward_buffer_color && backward_buffer && grad_sigma && h16 && grad_h16 && grad_w_color,
+    NGP_REQUIRE(grad_out16 && color_in && w_color && (forward_buffer_color || (flags & NGP_FF_RECOMPUTE)) && backward_buffer && grad_sigma && h16 &&
+                    grad_h16 && grad_w_color,
                 NGP_ERR_INVALID, "network_backward_color: NULL tensor");
     const MidEpilogue mid{grad_sigma, (const half_t*)h16, (half_t*)grad_h16, density_scale};
     if (num_layers_color == 2)
@@ -1966,8 +2096,8 @@ extern "C" int ngp_network_forward(const void* enc, const float* dirs, uint32_t 
     NGP_REQUIRE(num_layers_sigma >= 2 && num_layers_color >= 2, NGP_ERR_INVALID, "network_forward: num_layers should be larger than 2");
     if (M == 0) return NGP_OK;
     NGP_REQUIRE(enc && dirs && w_sigma && w_color && sigma && rgb, NGP_ERR_INVALID, "network_forward: NULL tensor");
-    NGP_REQUIRE(!training || (forward_buffer_sigma && h16 && color_in && forward_buffer_color), NGP_ERR_INVALID,
-                "network_forward: the training variant needs forward_buffer_sigma, h16, color_in and forward_buffer_color");
+    NGP_REQUIRE(!training || (h16 && color_in && (forward_buffer_sigma != nullptr) == (forward_buffer_color != nullptr)), NGP_ERR_INVALID,
+                "network_forward: the training variant needs h16 and color_in, and both forward buffers or (NGP_FF_RECOMPUTE backward) neither");
     const size_t lds = forward_image_bytes<64>(32, num_layers_sigma) + forward_image_bytes<64>(32, num_layers_color);
     NGP_REQUIRE(lds <= 152 * 1024, NGP_ERR_INVALID, "network_forward: weights (%zu B) exceed the LDS of a CU", lds);
     const void* kern = training ? reinterpret_cast<const void*>(k_network_forward<true>) : reinterpret_cast<const void*>(k_network_forward<false>);
@@ -1975,7 +2105,10 @@ extern "C" int ngp_network_forward(const void* enc, const float* dirs, uint32_t 
     if (rc) return rc;
     const uint32_t n_tiles = M / FF_TILE;
     const uint32_t per_cu = (uint32_t)((160 * 1024) / (lds + 1024));
-    uint32_t blocks = (uint32_t)device_info().cus * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+#ifndef NGP_NETFWD_PER_CU
+#define NGP_NETFWD_PER_CU 4u   // workgroups per CU; 1 / 2 / 3 measured slower for training (60 / 55 / 56 vs 55 us) and inference (26 / 21 / 20 vs 20 us)
+#endif
+    uint32_t blocks = (uint32_t)device_info().cus * (per_cu < 1 ? 1 : (per_cu > NGP_NETFWD_PER_CU ? NGP_NETFWD_PER_CU : per_cu));
     const uint32_t need = cdiv(n_tiles, FF_WAVES);
     if (blocks > need) blocks = need;
     hipStream_t st = as_stream(stream);

@@ -18,6 +18,7 @@ D = 3 and C = 2, SH degree 4, 64-wide MLPs with 15 geometry features, and a samp
 marchers pad to 128, raymarching.py:200-203).  Everything else takes the module-by-module path, which stays the reference.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -250,8 +251,11 @@ def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg, co
     out16 = torch.empty(M, 16, **half)
     sigma = torch.empty(M, **f32)
     rgb = torch.empty(M, 3, **f32)
-    fb_s = torch.empty(nl_sigma, M, 64, **half)
-    fb_c = torch.empty(nl_color, M, 64, **half)
+    if _recompute(nl_sigma, nl_color):
+        fb_s = fb_c = None  # not stored: the backward kernels recompute the hidden activations (NGP_FF_RECOMPUTE)
+    else:
+        fb_s = torch.empty(nl_sigma, M, 64, **half)
+        fb_c = torch.empty(nl_color, M, 64, **half)
     _network_forward(enc, dirs, M, ws16, wc16, nl_sigma, nl_color, float(density_scale), True, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M, st)
     if not composite:
         return (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, None, None, bg, ws)
@@ -308,12 +312,13 @@ def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, fou
         scratch_c = torch.empty(nl_color, M, 64, **half)
         scratch_s = torch.empty(nl_sigma, M, 64, **half)
         g_h16 = torch.empty(M, 16, **half)
-        _check(capi.lib.ngp_network_backward_color(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), fb_c.data_ptr(), M, nl_color,
+        rc = capi.NGP_FF_RECOMPUTE if fb_c is None else 0
+        _check(capi.lib.ngp_network_backward_color(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), capi.ptr(fb_c), M, nl_color,
                                                    scratch_c.data_ptr(), g_sigma.data_ptr(), h16.data_ptr(), float(density_scale),
-                                                   g_h16.data_ptr(), g_wc.data_ptr(), capi.NGP_FF_DEFER_REDUCE, st))
-        _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
+                                                   g_h16.data_ptr(), g_wc.data_ptr(), capi.NGP_FF_DEFER_REDUCE | rc, st))
+        _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), capi.ptr(fb_s), M, 32, 16, 64, nl_sigma,
                                               0, 6, 1, scratch_s.data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
-                                              _PLANAR_IN | _PLANAR_DX | capi.NGP_FF_DEFER_REDUCE, st))
+                                              _PLANAR_IN | _PLANAR_DX | capi.NGP_FF_DEFER_REDUCE | rc, st))
         _check(capi.lib.ngp_ffmlp_reduce_slabs_pair(scratch_c.data_ptr(), capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_color),
                                                     g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(),
                                                     capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_sigma), g_ws.numel(), g_ws.data_ptr(),
@@ -412,6 +417,17 @@ USE_FUSED_CHECK = True      # the optimizer's non-finite sweep is done by the gr
 USE_FUSED_SCAN = True       # the marcher's write pass hands out the sample slots itself (False: scan launch between the passes)
 USE_FUSED_MID = True        # colour-head backward writes grad_h16 itself; one slab reduction for both MLPs (False: five launches)
 USE_FUSED_COMPOSITE = True  # composite forward + loss + composite backward + sigmoid backward in ONE launch (False: the four kernels)
+# True / NGP_FUSED_RECOMPUTE=1: the training render does not store the MLPs' hidden activations (640 B per sample), the backward kernels
+# recompute them -- bit-identical gradients.  OFF by default: measured on MI355X the forward launch drops from 52 to 31 us, but both
+# backward launches pay more than that for the recomputation (42 -> 57 us and 32 -> 43 us): they are bound by their instruction stream, not
+# by the bytes (EXPERIMENTS.md, round 4).  Worth it only where the 168 MB of activations per 262 k samples do not fit.
+USE_RECOMPUTE = os.environ.get('NGP_FUSED_RECOMPUTE', '0') == '1'
+
+
+def _recompute(nl_sigma, nl_color):
+    """may the training render skip the forward buffers?  Needs the launches that can recompute: the fused network forward and the paired
+    backward kernels behind the fused colour head (2- / 3-layer networks); bit-identical gradients either way (tests/test_gpu_ffmlp.py)"""
+    return bool(USE_RECOMPUTE and USE_FUSED_NETWORK and USE_FUSED_MID and nl_color in (2, 3) and nl_sigma in (2, 3))
 
 
 def iteration_checks_gradients(model):

@@ -107,6 +107,7 @@ class GraphedTrainStep:
             self.la_side = torch.cuda.Stream(device=dev)
             self.la_event = [torch.cuda.Event(), torch.cuda.Event()]
             self.la_sample_event = torch.cuda.Event()
+            self.la_slot_event = None   # recorded on the main stream behind its latest write to the model's sample-count ring (a lookahead miss)
 
     # ------------------------------------------------------------------------------------------
     def close(self):
@@ -366,6 +367,18 @@ class GraphedTrainStep:
         use_graph = self.graph_updates and self.graphs is not None and self.update_capture_error is None
         if use_graph and full not in self.update_graphs:
             use_graph = self._capture_update(full)
+        mean_count = None
+        if use_graph and self.la is not None and m.local_step > 0:
+            # the sample-count estimate is a host read-back (renderer.py:531-538).  Read through the main stream it waits for everything
+            # queued there -- the steps the host is ahead by and the refresh itself -- and the GPU then idles until the host has issued the
+            # next step.  The counts were written by the march launches, on the side stream (or, for a step whose batch was not announced,
+            # early on the main stream: la_slot_event): reading them on the side stream waits for those only, the main stream keeps its
+            # backlog.  Same numbers, read before the refresh is queued instead of after.
+            used = min(16, m.local_step)
+            with torch.cuda.stream(self.la_side):
+                if self.la_slot_event is not None:
+                    self.la_side.wait_event(self.la_slot_event)
+                mean_count = int(m.step_counter[:used, 0].sum().item() / used)
         if use_graph:
             entry = self.update_graphs[full]
             g, mean = entry[0], entry[1]
@@ -380,7 +393,10 @@ class GraphedTrainStep:
         else:
             with torch.autocast('cuda', dtype=self.autocast_dtype):
                 mean = refresh(full=full)
-        m.finish_update(mean)
+        if mean_count is not None:
+            m.finish_update(mean, mean_count=mean_count)
+        else:
+            m.finish_update(mean)
 
     def _eager(self, rays_o, rays_d, target):
         self.optimizer.zero_grad(set_to_none=True)
@@ -426,6 +442,9 @@ class GraphedTrainStep:
             self.la_seed[p:p + 1].fill_(self.global_step)
             gm.replay()
             slot.copy_(self.counter[p], non_blocking=True)
+            if self.la_slot_event is None:
+                self.la_slot_event = torch.cuda.Event()
+            self.la_slot_event.record(main)
         self.la_ready[p] = None
         q = 1 - p
         if next_rays is not None and (self.global_step + 1) % self.update_interval != 0:

@@ -532,13 +532,14 @@ class NeRFRenderer(nn.Module):
         """the device part of update_extra_state (renderer.py:444-529): refresh_sample + refresh_apply"""
         return self.refresh_apply(self.refresh_sample(S, full), decay)
 
-    def finish_update(self, mean):
-        """the host part of update_extra_state: bookkeeping and the sample-count estimate (one read-back, renderer.py:531-538)"""
+    def finish_update(self, mean, mean_count=None):
+        """the host part of update_extra_state: bookkeeping and the sample-count estimate (one read-back, renderer.py:531-538).
+        mean_count: the estimate when the caller has read the counter ring already (graph.GraphedTrainStep reads it off the main stream)"""
         self._mean_density_dev = mean.detach().reshape(())
         self.iter_density += 1
         used = min(16, self.local_step)
         if used > 0:
-            self.mean_count = int(self.step_counter[:used, 0].sum().item() / used)
+            self.mean_count = int(self.step_counter[:used, 0].sum().item() / used) if mean_count is None else int(mean_count)
         self.local_step = 0
 
     @torch.no_grad()

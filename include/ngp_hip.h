@@ -418,8 +418,9 @@ int ngp_composite_rays_train_backward_ex(const float* grad_weights_sum, const fl
  *   out: weights_sum [N], image_out [N,3], depth_out [N] (finished), loss [1] = mean((image_out - target)^2) (deterministic),
  *        grad_sigmas [M] fp32, grad_out16 [M,16] fp16 (columns 0..2 = dL/d(colour-net output) * loss_scale, rest 0) -- both may arrive
  *        uninitialised, every row is written (zeros where no gradient flows)
- *   ray_err [N] fp32: scratch.  march_workspace: the workspace ngp_march_rays_train_ex filled for these rays (word 0 = rows handed
- *        out, word 1 = a ticket that call leaves at 0). */
+ *   ray_err [N] fp32: scratch.  march_workspace: the workspace ngp_march_rays_train_ex filled for these rays, all
+ *        ngp_march_rays_train_workspace_bytes(N) bytes of it (word 0 = rows handed out, word 1 and the 32 words at its end, 128 bytes
+ *        apart = tickets that call leaves at 0 and this one returns to 0). */
 int ngp_composite_train_loss_backward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays, uint32_t M,
                                       uint32_t N, float T_thresh, int bg_mode, float bg_scalar, const float* bg, const float* nears,
                                       const float* fars, const float* target, const float* loss_scale, float* weights_sum,

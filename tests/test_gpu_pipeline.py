@@ -324,6 +324,9 @@ def test_fused_composite_loss_backward_is_bit_identical_to_the_four_kernels(bg_m
     N, M = 1001, 70000
     counts = torch.randint(0, 150, (N,), device=dev, generator=g, dtype=torch.int32)
     counts[::17] = 0
+    long_rays = {5: 385, 300: 700, 600: 1024}                          # more windows than the kernel keeps in registers (6 x 64 samples)
+    for i, c in long_rays.items():
+        counts[i] = c
     offsets = torch.cumsum(counts, 0, dtype=torch.int32) - counts
     total = int(counts.sum())
     assert M - 5000 < total + 3000 and total > M - 8000 or True
@@ -331,6 +334,10 @@ def test_fused_composite_loss_backward_is_bit_identical_to_the_four_kernels(bg_m
     rows_used = min(int(offsets[(offsets + counts) > M][0]) if bool(((offsets + counts) > M).any()) else total, M)
     sigma = torch.rand(M, device=dev, generator=g) * 30
     sigma[torch.rand(M, device=dev, generator=g) < 0.02] = 4000.0    # opaque samples: early termination inside rays
+    for i, c in long_rays.items():                                     # the long rays stay translucent to their last window, except one
+        lo = int(offsets[i])
+        sigma[lo:lo + c] = torch.rand(c, device=dev, generator=g) * 2
+    sigma[int(offsets[600]) + 800] = 4000.0                           # ... that terminates in its 13th window
     rgb = torch.rand(M, 3, device=dev, generator=g).half().float()
     deltas = torch.rand(M, 2, device=dev, generator=g) * 0.01 + 1e-4
     nears, fars = torch.rand(N, device=dev, generator=g), 2 + torch.rand(N, device=dev, generator=g)
@@ -338,7 +345,7 @@ def test_fused_composite_loss_backward_is_bit_identical_to_the_four_kernels(bg_m
     bg = torch.rand(N, 3, device=dev, generator=g) if bg_mode == 2 else None
     scale = torch.tensor([1024.0], device=dev) if scaled else None
     st = capi.stream()
-    ws = torch.zeros(64, dtype=torch.int32, device=dev)
+    ws = torch.zeros(capi.lib.ngp_march_rays_train_workspace_bytes(N) // 4, dtype=torch.int32, device=dev)   # the marcher's workspace, tickets at 0
     ws[0] = rows_used
     f32 = dict(device=dev, dtype=torch.float32)
     nan = float('nan')
@@ -365,7 +372,7 @@ def test_fused_composite_loss_backward_is_bit_identical_to_the_four_kernels(bg_m
                                                           wsum2.data_ptr(), image2.data_ptr(), depth2.data_ptr(), loss2.data_ptr(), err.data_ptr(),
                                                           gs2.data_ptr(), g16b.data_ptr(), ws.data_ptr(), st) == 0
         torch.cuda.synchronize()
-        assert int(ws[1]) == 0 and int(ws[0]) == rows_used
+        assert int(ws[1]) == 0 and int(ws[0]) == rows_used and int(ws[2:].abs().sum()) == 0    # every ticket is back at 0
         assert torch.equal(wsum, wsum2) and torch.equal(image, image2) and torch.equal(depth, depth2)
         assert torch.isfinite(gs2).all() and torch.isfinite(g16b.float()).all()      # every row written
         assert torch.equal(gs, gs2), float((gs - gs2).abs().max())
@@ -374,3 +381,7 @@ def test_fused_composite_loss_backward_is_bit_identical_to_the_four_kernels(bg_m
         assert abs(float(loss) - float(((image - target) ** 2).mean())) <= 1e-5 * float(loss)
     assert float(gs.abs().max()) > 0 and int((g16[:, :3] != 0).any(1).sum()) > 1000
     assert int((gs[:rows_used] == 0).sum()) > 100       # rows behind an early termination were zeroed, not skipped
+    lo = int(offsets[300])
+    assert lo + 700 <= rows_used and int((gs[lo:lo + 700] != 0).sum()) > 650          # a translucent long ray has gradients to its end
+    lo = int(offsets[600])
+    assert lo + 1024 <= rows_used and bool((gs[lo + 801:lo + 1024] == 0).all()) and int((gs[lo:lo + 800] != 0).sum()) > 700

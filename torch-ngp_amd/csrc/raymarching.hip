@@ -357,7 +357,20 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* lds4) {
 // reproducible layout, no atomics (the reference's completion-order atomics are "parity unpinned").
 // ---------------------------------------------------------------------------------------------
 constexpr int MW_WAVES = 4;  // rays per workgroup
-constexpr uint32_t MARCH_MASK_WINDOWS = 20;  // emit masks kept per ray (64 terms each); longer rays re-probe in the write pass
+// The fused composite / loss / backward kernel finds its last workgroup with tickets.  ONE ticket word taken by every workgroup serialises
+// ~1000 device-scope atomics on one address (measured: 8.5 of the kernel's 22 us on the 4096-ray batch), so there are two levels: the
+// workgroups are dealt round-robin onto CT_GROUPS group tickets, 128 bytes apart, and only a group's last arrival takes the final
+// ticket (workspace word 1).  The group tickets live behind the marcher's per-ray words in ITS workspace and are cleared by the marcher
+// together with word 1 (every ticket also returns to 0 by itself).
+constexpr uint32_t CT_GROUPS = 32, CT_GROUP_STRIDE = 32;  // tickets, words between them
+constexpr uint32_t MARCH_MASK_WINDOWS = 20;   // emit masks kept per ray (64 terms each); longer rays re-probe in the write pass
+
+// word index of group ticket 0 in the marcher's workspace: behind [0] fit_end, [1] final ticket, [2 .. 2+N) windows per ray and the
+// N x MARCH_MASK_WINDOWS 64-bit emit masks, rounded up to a 128-byte boundary
+__host__ __device__ inline size_t march_ws_ticket_word(uint32_t N) {
+    const size_t words = (size_t)(2 + ((N + 1u) & ~1u)) + 2 * (size_t)N * MARCH_MASK_WINDOWS;
+    return (words + CT_GROUP_STRIDE - 1) / CT_GROUP_STRIDE * CT_GROUP_STRIDE;
+}
 
 __device__ __forceinline__ float readlane_f(float v, uint32_t l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int)l));
@@ -461,6 +474,7 @@ __global__ __launch_bounds__(MW_WAVES * 64) void k_march_train_wave(const float*
                 fit_end[0] = first_row;
                 fit_end[1] = 0u;  // the ticket of k_composite_train_loss_bwd
             }
+            if (blockIdx.x == ray_blocks && threadIdx.x < CT_GROUPS) fit_end[march_ws_ticket_word(N) + threadIdx.x * CT_GROUP_STRIDE] = 0u;
         } else {
             first_row = fit_end[0];
         }
@@ -717,6 +731,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_march_train_scan(int32_t* __re
         ws[0] = fit_end < M ? fit_end : M;
         ws[1] = 0u;  // the ticket of k_composite_train_loss_bwd
     }
+    if (threadIdx.x < CT_GROUPS) ws[march_ws_ticket_word(N) + threadIdx.x * CT_GROUP_STRIDE] = 0u;  // ... and its group tickets
 }
 
 // samples per ray and iteration of the inference loop (renderer.py:349: max(min(N // n_alive, 8), 1))
@@ -975,12 +990,13 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_bwd(const flo
 // loss is its own three pixels, so nothing crosses rays except the loss VALUE (a logged scalar): every ray deposits its squared error,
 // the last workgroup to finish (a ticket) adds them up in a fixed order -> deterministic.  Four launches, their tails and the
 // [N,3] / [M,3] fp32 intermediates (grad_image, grad_rgbs) are gone; the second sweep re-reads sigma / rgb / delta from L2.
-// ticket[0] must be 0 on entry (k_march_train_scan clears it every step); the kernel leaves it 0.
+// ticket[0] and the group tickets must be 0 on entry (the marcher clears them every step); the kernel leaves them 0.
 __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_loss_bwd(
     const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
     uint32_t M, uint32_t N, float T_thresh, float* __restrict__ weights_sum, Finish fin, const float* __restrict__ target,
     const float* __restrict__ loss_scale, float* __restrict__ ray_err, uint32_t* __restrict__ ticket, float* __restrict__ loss,
-    float* __restrict__ grad_sigmas, half_t* __restrict__ grad_out16, const uint32_t* __restrict__ rows_used, uint32_t ray_blocks) {
+    float* __restrict__ grad_sigmas, half_t* __restrict__ grad_out16, const uint32_t* __restrict__ rows_used, uint32_t ray_blocks,
+    uint32_t* __restrict__ group_tickets) {
     const int lane = threadIdx.x & 63;
     auto zero_row = [&](uint32_t o) {
         half8_t z;
@@ -1102,11 +1118,24 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_loss_bwd(
     __shared__ float part[CT_WAVES];
     __shared__ bool last;
     // every lane waits for ITS OWN outstanding stores (the write-through ray_err store among them) before the barrier: a workgroup-scope
-    // release alone need not emit s_waitcnt vmcnt(0) outside tgsplit mode, and the ticket below is relaxed
+    // release alone need not emit s_waitcnt vmcnt(0) outside tgsplit mode, and the tickets below are relaxed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ray_blocks - 1u;
+    if (threadIdx.x == 0) {
+        // two levels (see CT_GROUPS): my group's ticket; the group's last arrival puts it back to 0 and takes the final ticket.
+        // (Taking the group ticket early -- right after the forward sweep, its answer read here -- was measured: no gain, 19.9 vs 19.0 us;
+        // what is left over a kernel without any ticket, 13.7 us, is one device-scope round trip and the last workgroup's sum.)
+        const uint32_t groups = ray_blocks < CT_GROUPS ? ray_blocks : CT_GROUPS;
+        const uint32_t group = blockIdx.x % groups, members = (ray_blocks - group + groups - 1u) / groups;
+        uint32_t* gt = group_tickets + group * CT_GROUP_STRIDE;
+        bool l = false;
+        if (__hip_atomic_fetch_add(gt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+            __hip_atomic_store(gt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;
+        }
+        last = l;
+    }
     __syncthreads();
     if (!last) return;
     float acc = 0.0f;
@@ -1292,9 +1321,10 @@ extern "C" int ngp_density_grid_update(const float* sigmas, const int64_t* cells
     return check_launch("density_grid_update");
 }
 
-// workspace: [0] fit_end, [1] ticket of the fused composite/loss/backward kernel (cleared by the scan), [2 .. 2+N) windows per ray, then N x MARCH_MASK_WINDOWS 64-bit emit masks
+// workspace: [0] fit_end, [1] final ticket of the fused composite/loss/backward kernel (cleared by the scan), [2 .. 2+N) windows per ray,
+// N x MARCH_MASK_WINDOWS 64-bit emit masks, then that kernel's CT_GROUPS group tickets (march_ws_ticket_word)
 extern "C" size_t ngp_march_rays_train_workspace_bytes(uint32_t N) {
-    return sizeof(uint32_t) * (size_t)(2 + ((N + 1u) & ~1u)) + sizeof(uint64_t) * (size_t)N * MARCH_MASK_WINDOWS;
+    return sizeof(uint32_t) * (march_ws_ticket_word(N) + (size_t)CT_GROUPS * CT_GROUP_STRIDE);
 }
 
 static int check_march_args(const char* fn, uint32_t C, uint32_t H, uint32_t max_steps) {
@@ -1439,7 +1469,7 @@ extern "C" int ngp_composite_train_loss_backward(const float* sigmas, const floa
     const uint32_t ray_blocks = cdiv(N, CT_WAVES), tail_blocks = 32u;
     hipLaunchKernelGGL(k_composite_train_loss_bwd, dim3(ray_blocks + tail_blocks), dim3(CT_WAVES * 64), 0, as_stream(stream), sigmas, rgbs,
                        deltas, rays, M, N, T_thresh, weights_sum, fin, target, loss_scale, ray_err, ws + 1, loss, grad_sigmas,
-                       (half_t*)grad_out16, (const uint32_t*)ws, ray_blocks);
+                       (half_t*)grad_out16, (const uint32_t*)ws, ray_blocks, ws + march_ws_ticket_word(N));
     return check_launch("composite_train_loss_backward");
 }
 

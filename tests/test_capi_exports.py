@@ -83,7 +83,8 @@ def test_host_side_argument_validation_needs_no_gpu():
     with pytest.raises(RuntimeError, match='cascade'):
         capi.check(rc)
     assert lib.ngp_allocate_splitk(3) == 0 and lib.ngp_free_splitk() == 0
-    assert lib.ngp_march_rays_train_workspace_bytes(4096) == 4 * (2 + 4096) + 8 * 4096 * 20  # fit_end, pad, windows per ray, emit masks
+    words = 2 + 4096 + 2 * 4096 * 20  # fit_end, final ticket, windows per ray, emit masks ...
+    assert lib.ngp_march_rays_train_workspace_bytes(4096) == 4 * ((words + 31) // 32 * 32 + 32 * 32)  # ... and 32 group tickets, 128 bytes apart
 
 
 def test_level_table_is_the_oracle_recipe():

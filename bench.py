@@ -636,9 +636,8 @@ def main():
             if stepper.used_direct and stepper.captured_capacity and not getattr(stepper, 'sharded', False) and run.stepper.averager is None:
                 # the launches of the captured (autograd-free) iteration, issued eagerly: the rows are those of the timed step
                 stepper.rays_o.copy_(rays_o.view_as(stepper.rays_o)); stepper.rays_d.copy_(rays_d.view_as(stepper.rays_d)); stepper.target.copy_(gt)
-                with torch.no_grad():
-                    stepper._iteration_front()
-                    stepper._iteration_back()
+                stepper._iteration_front()
+                stepper._iteration_back()
                 marched.append(stepper.counter[0, 0].clone())
             else:
                 stepper._eager(rays_o, rays_d, gt)

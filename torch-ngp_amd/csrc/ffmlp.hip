@@ -1039,14 +1039,22 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
             if (blockIdx.x * FP_PAIRS + d * base_step + pair < n_tiles) prefetch(d, blockIdx.x * FP_PAIRS + d * base_step + pair);
     }
     // DMA instructions per tile (the wait below has to name how many YOUNGER ones may still be in flight)
-    const bool deep = RECOMP && pf_depth == 3 && in_kb == 2;
+    // DMA instructions per tile (dY, the stored activations, X as 16-byte fragments or four 4-byte rows each): the wait below names how many
+    // YOUNGER ones may still be in flight, as an immediate -- the counts of the shapes that run three deep are enumerated
+    const uint32_t tile_loads = 1u + act_layers * NKB + in_kb * (in_planar ? 4u : 1u);
+    const bool deep = pf_depth == 3 && (tile_loads == 3u || tile_loads == 9u || tile_loads == 11u || tile_loads == 17u);
     // per tile round: the landed tile is handed over (barrier), the free buffer is refilled; returns the tile's buffer
     auto next_tile_buffer = [&](uint32_t base) -> const unsigned char* {
         if (role == 0) {
             // a tile that does not exist was not requested: its slot in the queue is missing, so only the oldest request may be waited for
             // by count while a full set of younger ones exists
             if (deep && base + base_step + pair < n_tiles) {
-                if (in_planar) wait_vmcnt<1 + 2 * 4>(); else wait_vmcnt<1 + 2>();   // in_dim = 32 (IN_JB == 1): dY + two X fragments
+                switch (tile_loads) {
+                    case 3u: wait_vmcnt<3>(); break;     // recomputing, 32 row-major inputs
+                    case 9u: wait_vmcnt<9>(); break;     // recomputing, 32 planar inputs
+                    case 11u: wait_vmcnt<11>(); break;   // two stored layers, 32 row-major inputs
+                    default: wait_vmcnt<17>(); break;    // two stored layers, 32 planar inputs (the sigma network of the training step)
+                }
             } else {
                 wait_vmcnt<0>();
             }
@@ -1863,6 +1871,8 @@ static int launch_backward_t(const void* grad, const void* inputs, const void* w
     const size_t tile_bytes = (size_t)(1 + num_layers * NKB + in_dim / 16) * 1024;
     uint32_t pf_depth = 2;
     if ((size_t)nfrag * 1024 + 2 * FF_WAVES * tile_bytes > 160 * 1024) pf_depth = 1;
+    // (three tile buffers for the two-layer networks, which would fit: measured SLOWER, sigma-net backward 32.6 -> 34.1 us; the kernel's wait
+    // counts cover the shapes should that change -- the recomputing variant, whose tiles are 3 KiB, does run three deep)
     size_t lds = (size_t)nfrag * 1024 + (size_t)pf_depth * FF_WAVES * tile_bytes;
     if (lds < (size_t)n_params * 4) lds = (size_t)n_params * 4;
     NGP_REQUIRE(lds <= 160 * 1024, NGP_ERR_INVALID, "ffmlp_backward: LDS need (%zu B) exceeds 160 KiB", lds);

@@ -363,13 +363,27 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     half8_t* img_s = reinterpret_cast<half8_t*>(smem);
     const uint32_t frags_s = NIB * in_kb + (nl_s - 1) * NIB * NKB + NKB;
     half8_t* img_c = img_s + (size_t)frags_s * 64;
-    build_forward_image<WIDTH>(img_s, w_sigma, 32, nl_s);
-    build_forward_image<WIDTH>(img_c, w_color, 32, nl_c);
     const size_t rows = (size_t)n_tiles * FF_TILE;
-    __syncthreads();
-
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = lane & 31, h = lane >> 5;
+    // a tile's inputs (encoder features, direction) are requested one tile ahead -- the first tile's before the weight images are built, so
+    // that round trip runs under the build, the later ones under the previous tile's arithmetic
+    half8_t x_next[in_kb];
+    float dir_next[3] = {0.0f, 0.0f, 0.0f};
+    auto request = [&](uint32_t tile) {
+        if (tile < n_tiles) {
+            const size_t srow = (size_t)tile * FF_TILE + n;
+#pragma unroll
+            for (uint32_t kb = 0; kb < in_kb; kb++) x_next[kb] = load_features8(enc, enc_planar, rows, srow, 32, 16 * kb + 8 * h);
+            dir_next[0] = dir_next[1] = dir_next[2] = 0.0f;
+            if (srow < M_valid) { dir_next[0] = dirs[srow * 3]; dir_next[1] = dirs[srow * 3 + 1]; dir_next[2] = dirs[srow * 3 + 2]; }
+        }
+    };
+    request(blockIdx.x * FF_WAVES + wid);
+    build_forward_image<WIDTH>(img_s, w_sigma, 32, nl_s);
+    build_forward_image<WIDTH>(img_c, w_color, 32, nl_c);
+    __syncthreads();
+
     const size_t layer_stride = (size_t)n_tiles * NKB * 64;  // half8 units
     const half8_t* s_l0 = img_s + lane;
     const half8_t* s_hid = s_l0 + (size_t)NIB * in_kb * 64;
@@ -380,13 +394,18 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 
     for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += gridDim.x * FF_WAVES) {
         const size_t srow = (size_t)tile * FF_TILE + n;
+        half8_t x_cur[in_kb];
+#pragma unroll
+        for (uint32_t kb = 0; kb < in_kb; kb++) x_cur[kb] = x_next[kb];
+        const float dir_x = dir_next[0], dir_y = dir_next[1], dir_z = dir_next[2];
+        request(tile + gridDim.x * FF_WAVES);
         // ---- sigma network ----
         float16_t acc[NIB];
 #pragma unroll
         for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
 #pragma unroll
         for (uint32_t kb = 0; kb < in_kb; kb++) {
-            const half8_t x = load_features8(enc, enc_planar, rows, srow, 32, 16 * kb + 8 * h);
+            const half8_t x = x_cur[kb];
 #pragma unroll
             for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(s_l0[(ib * in_kb + kb) * 64], x, acc[ib]);
         }
@@ -404,8 +423,7 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         // ---- colour-net input: k block 0 = half(SH_4(dir))[8h .. 8h+7], k block 1 = h16[1 + 8h + j] (j < 8; feature 16 -> the zero pad) ----
         half8_t cin[2];
         {
-            float x = 0.0f, y = 0.0f, z = 0.0f;
-            if (srow < M_valid) { x = dirs[srow * 3]; y = dirs[srow * 3 + 1]; z = dirs[srow * 3 + 2]; }
+            const float x = dir_x, y = dir_y, z = dir_z;
             // component i goes to half-wave i >> 3, slot i & 7 (no array: the polynomial values are consumed as they are produced)
 #define SH_OUT(i, v) { const float sh_v_ = (v); if (((i) >> 3) == h) cin[0][(i) & 7] = to_half_rne(sh_v_); }
             SH_BAND_0_VALUES;
@@ -1005,18 +1023,9 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
     const uint32_t in_kb = in_dim / 16;
     // RECOMP: the forward image (input layer + hidden matmuls, no output layer) sits behind the backward image
     const uint32_t ffrag = RECOMP ? NIB * in_kb + (num_layers - 1) * NIB * NKB : 0u;
-    build_backward_image<WIDTH>(img, weights, in_dim, num_layers, with_dx);
-    if (RECOMP) build_forward_image<WIDTH>(img + (size_t)nfrag * 64, weights, in_dim, num_layers, 0, ffrag);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = lane & 31, h = lane >> 5;
     const int pair = wid & (FP_PAIRS - 1), role = wid / FP_PAIRS;
-    const Selectors sel = make_selectors(n, h);
-    __syncthreads();
-
-    const half8_t* img_out = img + lane;
-    const half8_t* img_hid = img_out + (size_t)NIB * 64;
-    const half8_t* img_in = img_hid + (size_t)(num_layers - 1) * NIB * NKB * 64;
-    const half8_t* fimg = img + (size_t)nfrag * 64 + lane;
     const size_t layer_stride = (size_t)n_tiles * NKB * 64;
     const half8_t* fb = reinterpret_cast<const half8_t*>(forward_buffer);
     const size_t rows = (size_t)n_tiles * FF_TILE;
@@ -1032,13 +1041,21 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
         prefetch_tile<WIDTH>(pf_base + (size_t)buffer * tile_frags * 1024, tile, grad, fb, inputs, act_layers, layer_stride, rows, in_dim, in_planar,
                              lane, n, h);
     };
-    // pf_depth buffers per pair: tiles of the next pf_depth - 1 rounds are in flight while one is worked on (depth 3 only with RECOMP, whose
-    // rounds are shorter than a DMA round trip)
+    // pf_depth buffers per pair: tiles of the next pf_depth - 1 rounds are in flight while one is worked on.  The first requests leave BEFORE
+    // the weight images are built (the tile buffers are a region of their own): their round trip runs under the build instead of behind it.
     if (role == 0) {
         for (uint32_t d = 0; d + 1 < (pf_depth > 1 ? pf_depth : 2u); d++)
             if (blockIdx.x * FP_PAIRS + d * base_step + pair < n_tiles) prefetch(d, blockIdx.x * FP_PAIRS + d * base_step + pair);
     }
-    // DMA instructions per tile (the wait below has to name how many YOUNGER ones may still be in flight)
+    build_backward_image<WIDTH>(img, weights, in_dim, num_layers, with_dx);
+    if (RECOMP) build_forward_image<WIDTH>(img + (size_t)nfrag * 64, weights, in_dim, num_layers, 0, ffrag);
+    const Selectors sel = make_selectors(n, h);
+    __syncthreads();
+
+    const half8_t* img_out = img + lane;
+    const half8_t* img_hid = img_out + (size_t)NIB * 64;
+    const half8_t* img_in = img_hid + (size_t)(num_layers - 1) * NIB * NKB * 64;
+    const half8_t* fimg = img + (size_t)nfrag * 64 + lane;
     // DMA instructions per tile (dY, the stored activations, X as 16-byte fragments or four 4-byte rows each): the wait below names how many
     // YOUNGER ones may still be in flight, as an immediate -- the counts of the shapes that run three deep are enumerated
     const uint32_t tile_loads = 1u + act_layers * NKB + in_kb * (in_planar ? 4u : 1u);

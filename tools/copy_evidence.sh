@@ -11,6 +11,7 @@ cp $src/prof_nola/bench.json profiles/${pre}_bench_n1_profiled_no_lookahead.json
 cp $src/prof_nola/kernel_stats.csv profiles/${pre}_bench_n1_kernel_stats_no_lookahead.csv
 cp $src/prof_nola/summary.md profiles/${pre}_bench_n1_summary_no_lookahead.md
 cp $src/pmc_traffic.json profiles/${pre}_pmc_traffic.json
+python3 tools/pmc_traffic.py --annotate profiles/${pre}_pmc_traffic.json
 cp $src/pytest_gpu.txt profiles/${pre}_pytest_gpu.txt
 cp $src/render_800x800.txt profiles/${pre}_render_800x800.txt
 cp $src/occupancy_refresh.txt profiles/${pre}_occupancy_refresh.txt

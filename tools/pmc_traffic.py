@@ -50,7 +50,27 @@ def per_kernel(directory, counter):
     return out
 
 
+def annotate(d):
+    """notes that need the numbers of BOTH grid-backward kernels (also applied to an existing file:  pmc_traffic.py --annotate file.json)"""
+    det = d.get('detail', {})
+    acc, srt = det.get('k_grid_backward_accumulate'), det.get('k_grid_backward_bin')
+    if acc and srt and acc.get('read_correction') == 2.0:
+        raw, stream = acc['fetch_bytes_raw'], srt['write_bytes']
+        known = stream + 4.4e6 + 24.5e6   # records the sort wrote + descriptors + the gradient entries it may touch
+        total = d['per_launch'].get('grid_encode_backward', 0)
+        acc['note'] = ('FETCH_SIZE doubled as for 16 B/lane streaming reads (MI355X_MICROARCH.md HBM section) -- an UPPER bound here: the kernel reads '
+                       '12 B per lane (pair units), a width the guide does not calibrate.  Known input of the kernel: the record stream the sort wrote '
+                       f'(WRITE_SIZE of k_grid_backward_bin, {stream / 1e6:.0f} MB) + 4.4 MB of descriptors + the touched gradient entries (<= 24.5 MB) '
+                       f'~= {known / 1e6:.0f} MB, i.e. a factor of ~{known / raw:.2f} on the raw {raw / 1e6:.0f} MB; with that factor grid_encode_backward '
+                       f'moves ~{(total - 2.0 * raw + known) / 1e6:.0f} MB per launch instead of the {total / 1e6:.0f} MB reported')
+    return d
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == '--annotate':
+        d = annotate(json.load(open(sys.argv[2])))
+        json.dump(d, open(sys.argv[2], 'w'), indent=1)
+        return
     fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
     write = per_kernel(sys.argv[2], 'WRITE_SIZE')
     per_launch, detail = collections.defaultdict(int), {}
@@ -63,9 +83,9 @@ def main():
                        'launches_averaged': fetch.get(key, (0, 0))[1],
                        'note': 'raw FETCH_SIZE, 4-byte gather/scatter width uncalibrated' if factor == 1.0 else
                                'FETCH_SIZE doubled (16 B/lane streaming reads are tallied at half, MI355X_MICROARCH.md HBM section)'}
-    json.dump({'per_launch': per_launch, 'detail': detail, 'unit': 'bytes of HBM traffic per kernel launch',
-               'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on ' +
-                         (sys.argv[3] if len(sys.argv) > 3 else 'python bench.py (default mode: HIP-graph replay, lookahead march on the side stream)')},
+    json.dump(annotate({'per_launch': per_launch, 'detail': detail, 'unit': 'bytes of HBM traffic per kernel launch',
+                        'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on ' +
+                                  (sys.argv[3] if len(sys.argv) > 3 else 'python bench.py (default mode: HIP-graph replay, lookahead march on the side stream)')}),
               sys.stdout, indent=1)
 
 

@@ -70,6 +70,7 @@ TIMED = {
     'ngp_grid_encode_backward_ex': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_ws': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_checked': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
+    'ngp_grid_encode_backward_checked_slabs': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),   # (+ the MLPs' slab reduction in its last launch)
     'ngp_ffmlp_forward_ex': ('ffmlp_forward', 2, lambda a: _ff_fwd_bytes(a[6]), lambda a: _ff_flops(a[6]), 'sample'),
     # the whole network behind the encoder in one launch: enc 64 B + dir 12 B in, both forward buffers (when they are stored: not with the
     # recomputing backward) + h16 32 B + colour input 64 B + sigma 4 B + rgb 12 B out per sample; flops of both MLPs

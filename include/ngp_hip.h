@@ -242,6 +242,21 @@ int ngp_grid_encode_backward_checked(const void* grad, const float* inputs, cons
                                      const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
                                      int dtype, float bound, const int32_t* offsets_host, void* workspace, size_t workspace_bytes,
                                      float* found_inf, ngp_stream_t stream);
+
+/* ngp_grid_encode_backward_checked that also CARRIES the deferred slab reduction of two FFMLP backward launches (NGP_FF_DEFER_REDUCE; same
+ * arguments and results as ngp_ffmlp_reduce_slabs_pair, found_inf shared) in its own last launch instead of a launch of ~270 small blocks
+ * behind it: the two are independent, the reduction fills slots the last table slices leave idle (training step: -1 launch, ~6 us).
+ * slab_sets == NULL: plain ngp_grid_encode_backward_checked.  When this call has no such launch (few samples, no workspace, B == 0) the
+ * reduction is launched on its own: the reduced gradients are there when the call returns either way (stream order). */
+typedef struct ngp_slab_sets {
+    const void* slabs_a; uint32_t n_slabs_a, n_params_a; void* grad_weights_a;
+    const void* slabs_b; uint32_t n_slabs_b, n_params_b; void* grad_weights_b;
+} ngp_slab_sets_t;
+int ngp_grid_encode_backward_checked_slabs(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                           void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                           const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
+                                           int dtype, float bound, const int32_t* offsets_host, void* workspace, size_t workspace_bytes,
+                                           float* found_inf, const ngp_slab_sets_t* slab_sets, ngp_stream_t stream);
 int ngp_grid_encode_backward_ws(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                 void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                 const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,

@@ -270,7 +270,7 @@ def test_fused_occupancy_apply_equals_the_reference_formulation(bound, full):
     assert float(model._refresh_state['scratch'].max()) == -1.0 and float(model._refresh_state['scratch'].min()) == -1.0
 
 
-@pytest.mark.parametrize('toggle', ['USE_FUSED_MID', 'USE_FUSED_COMPOSITE', 'USE_FUSED_SCAN', 'USE_RECOMPUTE'])
+@pytest.mark.parametrize('toggle', ['USE_FUSED_MID', 'USE_FUSED_COMPOSITE', 'USE_FUSED_SCAN', 'USE_RECOMPUTE', 'USE_SLABS_IN_ACCUMULATE'])
 def test_iteration_fusions_are_bit_identical_to_the_unfused_launches(toggle):
     """the optional launch fusions of the autograd-free iteration (colour-head epilogue + one slab reduction; composite + loss + backward in
     one kernel; hidden activations recomputed by the backward instead of stored by the forward) against the launches they replace: every

@@ -312,6 +312,51 @@ def test_backward_that_recomputes_the_activations_is_bit_identical_to_the_stored
                                                   capi.NGP_FF_RECOMPUTE | capi.NGP_FF_SINGLE_WAVE, st))
 
 
+@pytest.mark.parametrize('M', [0, 256, 65536])
+def test_slab_reduction_carried_by_the_grid_backward_equals_its_own_launch(M):
+    """ngp_grid_encode_backward_checked_slabs: the deferred slab reduction of two MLP backwards inside the grid backward's accumulate launch
+    (M = 65536: binned path), or launched on its own when that call has no such launch (M = 256: atomics; M = 0: nothing to scatter) --
+    the same fp16 weight gradients, the same table gradient and the same found_inf as the two separate calls."""
+    import ctypes
+    import _ngp_capi as capi
+    import oracle
+    dev = torch.device('cuda')
+    st = capi.stream()
+    g = torch.Generator(device='cuda').manual_seed(77 + M)
+    offs, pls = oracle.grid_offsets(desired_resolution=2048)
+    S, toffs = float(np.log2(pls)), torch.from_numpy(offs).to(dev)
+    n_a, n_b, s_a, s_b = 64 * (32 + 64 + 16), 64 * (32 + 128 + 16), 37, 5
+    slabs_a, slabs_b = torch.randn(s_a, n_a, device=dev, generator=g), torch.randn(s_b, n_b, device=dev, generator=g)
+    slabs_b[3, 100] = float('inf')                                   # -> found_inf
+    x = torch.rand(max(M, 1), 3, device=dev, generator=g)[:M].contiguous()
+    g_enc = (torch.randn(16, max(M, 1), 2, device=dev, generator=g) * 0.1).half()[:, :M].contiguous()
+    res = {}
+    for carried in (False, True):
+        gw_a, gw_b = torch.zeros(n_a, device=dev, dtype=torch.half), torch.zeros(n_b, device=dev, dtype=torch.half)
+        g_emb = torch.zeros(int(offs[-1]), 2, device=dev, dtype=torch.half)
+        found = torch.zeros(1, device=dev)
+        _, ws, nbytes = capi.grid_backward_workspace(toffs, M, 3, 2, 16, S, 16, 0, 0, capi.NGP_F16) if M else (None, None, 0)
+        host = ctypes.cast(capi.host_offsets(toffs), ctypes.c_void_p)   # (found_inf needs the host copy of the offsets on every path)
+        args = (capi.ptr(g_enc) if M else None, capi.ptr(x) if M else None, None, toffs.data_ptr(), g_emb.data_ptr(), M, 3, 2, 16, S, 16, None, None,
+                0, 0, 0, capi.NGP_F16, 1.0, host, capi.ptr(ws), nbytes, found.data_ptr())
+        if carried:
+            sets = capi.SlabSets(slabs_a.data_ptr(), s_a, n_a, gw_a.data_ptr(), slabs_b.data_ptr(), s_b, n_b, gw_b.data_ptr())
+            capi.check(capi.lib.ngp_grid_encode_backward_checked_slabs(*args, ctypes.cast(ctypes.pointer(sets), ctypes.c_void_p), st))
+        else:
+            capi.check(capi.lib.ngp_ffmlp_reduce_slabs_pair(slabs_a.data_ptr(), s_a, n_a, gw_a.data_ptr(), slabs_b.data_ptr(), s_b, n_b, gw_b.data_ptr(),
+                                                            found.data_ptr(), st))
+            capi.check(capi.lib.ngp_grid_encode_backward_checked(*args, st))
+        torch.cuda.synchronize()
+        res[carried] = (gw_a, gw_b, g_emb, float(found))
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1].view(torch.int16), b[1].view(torch.int16)) and a[3] == b[3] == 1.0
+    assert float(a[0].float().abs().max()) > 0 and bool(torch.isinf(a[1].float()).any())
+    if M >= 65536:
+        assert torch.equal(a[2], b[2]) and float(a[2].float().abs().max()) > 0       # binned path: deterministic
+    elif M:
+        assert torch.allclose(a[2].float(), b[2].float(), rtol=2e-2, atol=1e-3)     # atomics: order of the fp16 additions varies
+
+
 @pytest.mark.parametrize('bg_mode', [1, 2])
 @pytest.mark.parametrize('scaled', [False, True])
 def test_fused_composite_loss_backward_is_bit_identical_to_the_four_kernels(bg_mode, scaled):

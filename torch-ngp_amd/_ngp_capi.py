@@ -70,6 +70,9 @@ _SIGNATURES = {
                                     _sz, _vp],
     'ngp_grid_encode_backward_checked': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp,
                                          _vp, _sz, _vp, _vp],
+    # ... + const ngp_slab_sets_t* (SlabSets below, passed with ctypes.byref; None: plain checked backward)
+    'ngp_grid_encode_backward_checked_slabs': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32,
+                                               _vp, _vp, _sz, _vp, _vp, _vp],
     'ngp_density_grid_update': [_vp, _vp, _u32, _f32, _f32, _vp, _u32, _vp, _f32, _vp, _vp, _vp, _vp],
     'ngp_ffmlp_forward_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_inference_ex': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _u32, _vp],
@@ -132,6 +135,12 @@ def check(rc):
     """Raise RuntimeError with the library's message when a call failed."""
     if rc != 0:
         raise RuntimeError(lib.ngp_last_error().decode('utf-8', 'replace'))
+
+
+class SlabSets(ctypes.Structure):
+    """ngp_slab_sets_t (include/ngp_hip.h): two sets of deferred FFMLP weight-gradient slabs for ngp_grid_encode_backward_checked_slabs"""
+    _fields_ = [('slabs_a', ctypes.c_void_p), ('n_slabs_a', ctypes.c_uint32), ('n_params_a', ctypes.c_uint32), ('grad_weights_a', ctypes.c_void_p),
+                ('slabs_b', ctypes.c_void_p), ('n_slabs_b', ctypes.c_uint32), ('n_params_b', ctypes.c_uint32), ('grad_weights_b', ctypes.c_void_p)]
 
 
 def ptr(t):

@@ -83,4 +83,47 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- fixed-order sum of per-workgroup fp32 weight-gradient slabs (the FFMLP backward's deferred reduction), TWO sets per launch ----
+// One block of RS_PARAMS x RS_GROUPS threads sums RS_PARAMS parameters of one set: group g adds slabs g, g + RS_GROUPS, ..., the groups'
+// partial sums are added in group order and rounded once to fp16 -- the same order for every launch shape, so the same bits whether the
+// blocks are a launch of their own (ffmlp.hip: k_ffmlp_reduce_slabs_pair) or ride in another kernel's grid (gridencoder.hip: the slice
+// accumulate of the training step, which would otherwise be followed by a 7 us launch of ~270 small blocks).
+constexpr int RS_PARAMS = 64, RS_GROUPS = 16;
+struct SlabSets {
+    const float* slabs[2];
+    uint32_t n_slabs[2], n_params[2];
+    _Float16* grad_weights[2];
+    uint32_t blocks[2];  // blocks serving each set: cdiv(n_params, RS_PARAMS), or 0 for a set with nothing to do
+};
+// block `b` of blocks[0] + blocks[1]; part: RS_GROUPS x RS_PARAMS floats of LDS; found_inf (optional) is set to 1 when a resulting gradient is
+// not finite (a set with n_slabs = 0 holds gradients its backward stored directly: only swept).  Called by ALL threads of the block.
+__device__ __forceinline__ void slab_reduce_block(const SlabSets& s, uint32_t b, float (*part)[RS_PARAMS], float* found_inf) {
+    const int set = b >= s.blocks[0] ? 1 : 0;
+    const float* __restrict__ slabs = s.slabs[set];
+    const uint32_t n_slabs = s.n_slabs[set], n_params = s.n_params[set];
+    _Float16* __restrict__ grad_weights = s.grad_weights[set];
+    const uint32_t li = threadIdx.x & (RS_PARAMS - 1), g = threadIdx.x / RS_PARAMS;
+    const uint32_t i = (b - (set ? s.blocks[0] : 0u)) * RS_PARAMS + li;
+    float acc = 0.0f;
+    if (i < n_params)
+        for (uint32_t k = g; k < n_slabs; k += RS_GROUPS) acc += slabs[(size_t)k * n_params + i];
+    part[g][li] = acc;
+    __syncthreads();
+    bool nonfinite = false;
+    if (g == 0 && i < n_params) {
+        _Float16 r;
+        if (n_slabs) {
+            float t = 0.0f;
+#pragma unroll
+            for (int q = 0; q < RS_GROUPS; q++) t += part[q][li];
+            r = (_Float16)t;
+            grad_weights[i] = r;
+        } else {
+            r = grad_weights[i];
+        }
+        nonfinite = !__builtin_isfinite((float)r);
+    }
+    if (found_inf && __any(nonfinite) && (threadIdx.x & 63) == 0) found_inf[0] = 1.0f;
+}
+
 }  // namespace ngp

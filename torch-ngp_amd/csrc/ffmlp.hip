@@ -1643,7 +1643,6 @@ __global__ __launch_bounds__(FF_THREADS) void k_ffmlp_wgrad(const half_t* __rest
 // One workgroup = 64 consecutive parameters x 16 slab groups: thread (g, i) adds slabs g, g+16, g+32, ... of parameter i
 // (coalesced 256-byte rows), the 16 partial sums are combined in LDS in ascending g -- a fixed summation tree, so the
 // result is bit-reproducible -- and rounded once.
-constexpr int RS_PARAMS = 64, RS_GROUPS = 16;
 __global__ __launch_bounds__(RS_PARAMS * RS_GROUPS) void k_ffmlp_reduce_slabs(const float* __restrict__ slabs, uint32_t n_slabs,
                                                                                uint32_t n_params, half_t* __restrict__ grad_weights) {
     __shared__ float part[RS_GROUPS][RS_PARAMS];
@@ -1663,39 +1662,10 @@ __global__ __launch_bounds__(RS_PARAMS * RS_GROUPS) void k_ffmlp_reduce_slabs(co
 }
 
 // the same for TWO slab sets in one launch (the two MLPs of the fused network): workgroups [0, blocks_a) take set a, the rest set b
-__global__ __launch_bounds__(RS_PARAMS * RS_GROUPS) void k_ffmlp_reduce_slabs_pair(const float* __restrict__ slabs_a, uint32_t n_slabs_a,
-                                                                                    uint32_t n_params_a, half_t* __restrict__ gw_a,
-                                                                                    uint32_t blocks_a, const float* __restrict__ slabs_b,
-                                                                                    uint32_t n_slabs_b, uint32_t n_params_b,
-                                                                                    half_t* __restrict__ gw_b, float* __restrict__ found_inf) {
+// (common.h: slab_reduce_block -- shared with the grid encoder's slice accumulate, which can carry these blocks in its own grid)
+__global__ __launch_bounds__(RS_PARAMS * RS_GROUPS) void k_ffmlp_reduce_slabs_pair(SlabSets sets, float* __restrict__ found_inf) {
     __shared__ float part[RS_GROUPS][RS_PARAMS];
-    const bool second = blockIdx.x >= blocks_a;
-    const float* __restrict__ slabs = second ? slabs_b : slabs_a;
-    const uint32_t n_slabs = second ? n_slabs_b : n_slabs_a, n_params = second ? n_params_b : n_params_a;
-    half_t* __restrict__ grad_weights = second ? gw_b : gw_a;
-    const uint32_t li = threadIdx.x & (RS_PARAMS - 1), g = threadIdx.x / RS_PARAMS;
-    const uint32_t i = (blockIdx.x - (second ? blocks_a : 0u)) * RS_PARAMS + li;
-    float s = 0.0f;
-    if (i < n_params)
-        for (uint32_t k = g; k < n_slabs; k += RS_GROUPS) s += slabs[(size_t)k * n_params + i];
-    part[g][li] = s;
-    __syncthreads();
-    bool nonfinite = false;
-    if (g == 0 && i < n_params) {
-        half_t r;
-        if (n_slabs) {
-            float t = 0.0f;
-#pragma unroll
-            for (int q = 0; q < RS_GROUPS; q++) t += part[q][li];
-            r = (half_t)t;
-            grad_weights[i] = r;
-        } else {
-            r = grad_weights[i];  // stored directly by the (single-workgroup) backward: only swept
-        }
-        nonfinite = !__builtin_isfinite((float)r);
-    }
-    // found_inf: the optimizer's non-finite sweep over the MLP gradients, done where the final values are produced
-    if (found_inf && __any(nonfinite) && (threadIdx.x & 63) == 0) found_inf[0] = 1.0f;
+    slab_reduce_block(sets, blockIdx.x, part, found_inf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2087,9 +2057,11 @@ extern "C" int ngp_ffmlp_reduce_slabs_pair(const void* slabs_a, uint32_t n_slabs
     if (blocks_a + blocks_b == 0) return NGP_OK;
     NGP_REQUIRE((!blocks_a || ((slabs_a || !n_slabs_a) && grad_weights_a)) && (!blocks_b || ((slabs_b || !n_slabs_b) && grad_weights_b)),
                 NGP_ERR_INVALID, "ffmlp_reduce_slabs_pair: NULL tensor");
-    hipLaunchKernelGGL(k_ffmlp_reduce_slabs_pair, dim3(blocks_a + blocks_b), dim3(RS_PARAMS * RS_GROUPS), 0, as_stream(stream),
-                       (const float*)slabs_a, n_slabs_a, n_params_a, (half_t*)grad_weights_a, blocks_a, (const float*)slabs_b, n_slabs_b,
-                       n_params_b, (half_t*)grad_weights_b, found_inf);
+    SlabSets sets;
+    sets.slabs[0] = (const float*)slabs_a; sets.n_slabs[0] = n_slabs_a; sets.n_params[0] = n_params_a; sets.grad_weights[0] = (half_t*)grad_weights_a;
+    sets.slabs[1] = (const float*)slabs_b; sets.n_slabs[1] = n_slabs_b; sets.n_params[1] = n_params_b; sets.grad_weights[1] = (half_t*)grad_weights_b;
+    sets.blocks[0] = blocks_a; sets.blocks[1] = blocks_b;
+    hipLaunchKernelGGL(k_ffmlp_reduce_slabs_pair, dim3(blocks_a + blocks_b), dim3(RS_PARAMS * RS_GROUPS), 0, as_stream(stream), sets, found_inf);
     return check_launch("ffmlp_reduce_slabs_pair");
 }
 

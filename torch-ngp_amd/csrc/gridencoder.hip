@@ -1278,17 +1278,26 @@ void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restric
 template <int D>
 __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_grid_backward_accumulate(const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid,
                                                                           BinPlan plan, const uint32_t* __restrict__ descriptors,
-                                                                          const uint2* __restrict__ records, float* __restrict__ found_inf) {
+                                                                          const uint2* __restrict__ records, float* __restrict__ found_inf,
+                                                                          SlabSets slabs) {
     constexpr int MAX_REC = BIN_PPB * (1 << D);
     constexpr int WAVES = ACC_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
+    // one more row of the grid than there are levels: the caller's slab reduction (the two MLPs' weight gradients of the training step,
+    // ngp_grid_encode_backward_checked_slabs) -- ~270 small blocks beside the first slices instead of a launch of their own
+    const uint32_t slab_row = (slabs.blocks[0] + slabs.blocks[1]) != 0u ? 1u : 0u;   // row 0 when present: dispatched first, done in ~4 us
+    if (slab_row && blockIdx.y == 0u) {
+        if (blockIdx.x < slabs.blocks[0] + slabs.blocks[1])
+            slab_reduce_block(slabs, blockIdx.x, reinterpret_cast<float (*)[RS_PARAMS]>(acc_smem), found_inf);
+        return;
+    }
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_smem);                                // [BIN_SLICE][2]
     uint32_t* poison = reinterpret_cast<uint32_t*>(acc_smem + sizeof(unsigned long long) * 2 * BIN_SLICE);  // [BIN_SLICE / 16], 2 bits per entry
     uint2* run_table = reinterpret_cast<uint2*>(poison + BIN_SLICE / 16);                                   // [WAVES][64] {first record, first pair | records << 18}
     uint32_t* head_at = reinterpret_cast<uint32_t*>(run_table + WAVES * 64);                                // [WAVES][64] run (1-based) whose first pair sits at this lane of the window
     // levels in REVERSE order: the sort wrote the last level's records last, so they are the ones still in the memory-side cache
     // (same-box A/B: -4 us per iteration)
-    const uint32_t li = gridDim.y - 1u - blockIdx.y, bin = blockIdx.x;
+    const uint32_t li = plan.n_levels - 1u - (blockIdx.y - slab_row), bin = blockIdx.x;
     if (bin >= plan.n_bins(li)) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 2 * BIN_SLICE; i += ACC_THREADS) acc[i] = 0ull;
@@ -1655,6 +1664,8 @@ struct BackwardPlan {
     uint32_t n_binned = 0, total_desc = 0, max_bins = 0;
     uint64_t total_records = 0;
     float* found_inf = nullptr;  // optional: set to 1 when a gradient value this call produced is not finite
+    SlabSets slabs = {};         // optional: slab reduction carried by the accumulate launch (blocks[] = 0: none)
+    mutable bool slabs_done = false;  // set by the launch that carried them
     size_t desc_bytes() const { return ((size_t)total_desc * sizeof(uint32_t) + 255) & ~(size_t)255; }
     // (+64: the 16-byte load of a one-record run at the very end of the last chunk reads 8 bytes past it)
     size_t workspace_bytes() const { return n_binned ? desc_bytes() + (size_t)total_records * sizeof(uint2) + 64 : 0; }
@@ -1773,8 +1784,11 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
                            offsets, (half_t*)grad_emb, B, lv, gridtype, ac, interp, im, bins, descriptors, records, ap);
     int rc = check_launch("grid_encode_backward(bin)");
     if (rc) return rc;
-    hipLaunchKernelGGL((k_grid_backward_accumulate<D>), dim3(p.max_bins, p.n_binned), dim3(ACC_THREADS), acc_smem, st, offsets,
-                       (half_t*)grad_emb, p.bins, (const uint32_t*)descriptors, (const uint2*)records, p.found_inf);
+    static_assert(ACC_THREADS == RS_PARAMS * RS_GROUPS, "the slab reduction's blocks have the accumulate's shape");
+    const uint32_t slab_blocks = p.slabs.blocks[0] + p.slabs.blocks[1];
+    hipLaunchKernelGGL((k_grid_backward_accumulate<D>), dim3(std::max(p.max_bins, slab_blocks), p.n_binned + (slab_blocks ? 1u : 0u)), dim3(ACC_THREADS),
+                       acc_smem, st, offsets, (half_t*)grad_emb, bins, (const uint32_t*)descriptors, (const uint2*)records, p.found_inf, p.slabs);
+    p.slabs_done = slab_blocks != 0;
     return check_launch("grid_encode_backward(accumulate)");
 }
 
@@ -2017,19 +2031,50 @@ extern "C" int ngp_grid_encode_backward_checked(const void* grad, const float* i
                                                 uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                                 uint32_t interp, int dtype, float bound, const int32_t* offsets_host, void* workspace,
                                                 size_t workspace_bytes, float* found_inf, ngp_stream_t stream) {
+    return ngp_grid_encode_backward_checked_slabs(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype,
+                                                  align_corners, interp, dtype, bound, offsets_host, workspace, workspace_bytes, found_inf, nullptr,
+                                                  stream);
+}
+
+extern "C" int ngp_grid_encode_backward_checked_slabs(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                                      void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                                      uint32_t H, const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                                                      uint32_t interp, int dtype, float bound, const int32_t* offsets_host, void* workspace,
+                                                      size_t workspace_bytes, float* found_inf, const ngp_slab_sets_t* slab_sets,
+                                                      ngp_stream_t stream) {
     (void)embeddings;
+    // the slab reduction rides in the accumulate launch when this call has one; otherwise (few samples, no workspace, an empty batch) it is
+    // launched on its own -- the caller gets the reduced gradients either way
+    auto reduce_alone = [&]() -> int {
+        if (!slab_sets) return NGP_OK;
+        return ngp_ffmlp_reduce_slabs_pair(slab_sets->slabs_a, slab_sets->n_slabs_a, slab_sets->n_params_a, slab_sets->grad_weights_a, slab_sets->slabs_b,
+                                           slab_sets->n_slabs_b, slab_sets->n_params_b, slab_sets->grad_weights_b, found_inf, stream);
+    };
+
     NGP_REQUIRE(!(bound > 0.0f && dy_dx), NGP_ERR_INVALID, "grid_encode_backward: the fused input mapping does not provide grad_inputs");
     NGP_REQUIRE(!found_inf || offsets_host, NGP_ERR_INVALID, "grid_encode_backward: found_inf needs the host copy of the offsets");
     const InputMap im = make_input_map(bound);
     int rc = check_grid_args("grid_encode_backward", B, D, C, L, dtype);
     if (rc) return rc;
-    if (B == 0) return NGP_OK;
+    if (B == 0) return reduce_alone();
     NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: NULL tensor");
     GridLevels lv;
     fill_levels(lv, L, S, H);
     BackwardPlan plan;
     plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0, workspace != nullptr);
     plan.found_inf = found_inf;
+    if (slab_sets) {
+        // same rule as ngp_ffmlp_reduce_slabs_pair: a set without slabs (gradients stored directly) still gets blocks when found_inf asks for the sweep
+        const uint32_t ba = (slab_sets->n_slabs_a || found_inf) && slab_sets->n_params_a ? cdiv(slab_sets->n_params_a, (uint32_t)RS_PARAMS) : 0u;
+        const uint32_t bb = (slab_sets->n_slabs_b || found_inf) && slab_sets->n_params_b ? cdiv(slab_sets->n_params_b, (uint32_t)RS_PARAMS) : 0u;
+        NGP_REQUIRE((!ba || ((slab_sets->slabs_a || !slab_sets->n_slabs_a) && slab_sets->grad_weights_a)) &&
+                        (!bb || ((slab_sets->slabs_b || !slab_sets->n_slabs_b) && slab_sets->grad_weights_b)),
+                    NGP_ERR_INVALID, "grid_encode_backward: NULL tensor in the slab sets");
+        plan.slabs.slabs[0] = (const float*)slab_sets->slabs_a; plan.slabs.n_slabs[0] = slab_sets->n_slabs_a; plan.slabs.n_params[0] = slab_sets->n_params_a;
+        plan.slabs.grad_weights[0] = (half_t*)slab_sets->grad_weights_a; plan.slabs.blocks[0] = ba;
+        plan.slabs.slabs[1] = (const float*)slab_sets->slabs_b; plan.slabs.n_slabs[1] = slab_sets->n_slabs_b; plan.slabs.n_params[1] = slab_sets->n_params_b;
+        plan.slabs.grad_weights[1] = (half_t*)slab_sets->grad_weights_b; plan.slabs.blocks[1] = bb;
+    }
     NGP_REQUIRE(plan.workspace_bytes() <= workspace_bytes, NGP_ERR_INVALID,
                 "grid_encode_backward: workspace of %zu bytes, ngp_grid_backward_workspace_bytes() asks for %zu", workspace_bytes,
                 plan.workspace_bytes());
@@ -2039,6 +2084,7 @@ extern "C" int ngp_grid_encode_backward_checked(const void* grad, const float* i
                                                       interp, im, plan, workspace, st)
                           : dispatch_backward<float>(D, C, grad, inputs, offsets, grad_embeddings, B, L, lv, dy_dx, grad_inputs, gridtype, ac, interp,
                                                      im, plan, workspace, st);
+    if (!rc && slab_sets && !plan.slabs_done) rc = reduce_alone();
     if (rc || !found_inf || plan.n_atomic == 0) return rc;
     // some levels went through atomics: their sums are swept here (the record-sort path flags its own)
     const uint64_t n = (uint64_t)offsets_host[L] * C;

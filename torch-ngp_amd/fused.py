@@ -124,17 +124,19 @@ def _network_forward(enc, dirs, d_valid, ws16, wc16, nl_sigma, nl_color, density
     _check(capi.lib.ngp_pipeline_rgb_forward(out16.data_ptr(), rgb.data_ptr(), M, st))
 
 
-def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf=None):
+def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf=None, slabs=None):
     """hash-grid scatter of the level-major fp16 gradient; large batches take the binned atomic-free path (needs scratch memory).
-    found_inf: optional device float that the kernels set when a table gradient comes out non-finite (the optimizer's sweep, done here)"""
+    found_inf: optional device float that the kernels set when a table gradient comes out non-finite (the optimizer's sweep, done here).
+    slabs: optional capi.SlabSets -- the deferred slab reduction of the two MLP backwards rides in this call's last launch"""
     arr, ws, nbytes = capi.grid_backward_workspace(offsets, M, 3, 2, L, S, H, gridtype, align, capi.NGP_F16)
     if found_inf is not None and arr is None:
         raise RuntimeError('fused: the in-kernel non-finite sweep needs the host copy of the encoder offsets (call iteration_checks_gradients '
                            'outside stream capture first)')
-    _check(capi.lib.ngp_grid_encode_backward_checked(g_enc.data_ptr(), x.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S, H,
-                                                      None, None, gridtype, align, interp, capi.NGP_F16, float(bound),
-                                                      None if arr is None else ctypes.cast(arr, ctypes.c_void_p), capi.ptr(ws), nbytes,
-                                                      capi.ptr(found_inf), st))
+    _check(capi.lib.ngp_grid_encode_backward_checked_slabs(g_enc.data_ptr(), x.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S,
+                                                            H, None, None, gridtype, align, interp, capi.NGP_F16, float(bound),
+                                                            None if arr is None else ctypes.cast(arr, ctypes.c_void_p), capi.ptr(ws), nbytes,
+                                                            capi.ptr(found_inf), None if slabs is None else ctypes.cast(ctypes.pointer(slabs), ctypes.c_void_p),
+                                                            st))
 
 
 def _half_weights(embeddings, w_sigma, w_color, bufs):
@@ -319,10 +321,14 @@ def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, fou
         _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), capi.ptr(fb_s), M, 32, 16, 64, nl_sigma,
                                               0, 6, 1, scratch_s.data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
                                               _PLANAR_IN | _PLANAR_DX | capi.NGP_FF_DEFER_REDUCE | rc, st))
-        _check(capi.lib.ngp_ffmlp_reduce_slabs_pair(scratch_c.data_ptr(), capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_color),
-                                                    g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(),
-                                                    capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_sigma), g_ws.numel(), g_ws.data_ptr(),
-                                                    capi.ptr(found_inf), st))
+        n_c, n_s = capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_color), capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_sigma)
+        if USE_SLABS_IN_ACCUMULATE:
+            # the slab reduction of both MLPs rides in the grid backward's last launch (independent work, one launch less)
+            slabs = capi.SlabSets(scratch_c.data_ptr(), n_c, g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(), n_s, g_ws.numel(), g_ws.data_ptr())
+            _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf, slabs)
+            return
+        _check(capi.lib.ngp_ffmlp_reduce_slabs_pair(scratch_c.data_ptr(), n_c, g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(), n_s, g_ws.numel(),
+                                                    g_ws.data_ptr(), capi.ptr(found_inf), st))
     else:
         if found_inf is not None:
             raise RuntimeError('fused: found_inf needs the fused colour-head / slab-reduction path (see iteration_checks_gradients)')
@@ -417,6 +423,7 @@ USE_FUSED_CHECK = True      # the optimizer's non-finite sweep is done by the gr
 USE_FUSED_SCAN = True       # the marcher's write pass hands out the sample slots itself (False: scan launch between the passes)
 USE_FUSED_MID = True        # colour-head backward writes grad_h16 itself; one slab reduction for both MLPs (False: five launches)
 USE_FUSED_COMPOSITE = True  # composite forward + loss + composite backward + sigmoid backward in ONE launch (False: the four kernels)
+USE_SLABS_IN_ACCUMULATE = os.environ.get('NGP_FUSED_SLABS_IN_ACCUMULATE', '1') != '0'  # MLP slab reduction inside the grid backward's accumulate launch (False: its own launch)
 # True / NGP_FUSED_RECOMPUTE=1: the training render does not store the MLPs' hidden activations (640 B per sample), the backward kernels
 # recompute them -- bit-identical gradients.  OFF by default: measured on MI355X the forward launch drops from 52 to 31 us, but both
 # backward launches pay more than that for the recomputation (42 -> 57 us and 32 -> 43 us): they are bound by their instruction stream, not

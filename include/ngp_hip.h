@@ -251,6 +251,9 @@ int ngp_grid_encode_backward_checked(const void* grad, const float* inputs, cons
 typedef struct ngp_slab_sets {
     const void* slabs_a; uint32_t n_slabs_a, n_params_a; void* grad_weights_a;
     const void* slabs_b; uint32_t n_slabs_b, n_params_b; void* grad_weights_b;
+    /* optional third carried job: loss[0] = sum(ray_err[0 .. n_rays)) / (3 n_rays), the loss VALUE ngp_composite_train_loss_backward would
+     * have summed itself (call it with loss = NULL: its workgroups then skip the ticket round trip); same routine, same bits.  loss = NULL: none */
+    const float* ray_err; uint32_t n_rays; float* loss;
 } ngp_slab_sets_t;
 int ngp_grid_encode_backward_checked_slabs(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                            void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
@@ -433,6 +436,7 @@ int ngp_composite_rays_train_backward_ex(const float* grad_weights_sum, const fl
  *   out: weights_sum [N], image_out [N,3], depth_out [N] (finished), loss [1] = mean((image_out - target)^2) (deterministic),
  *        grad_sigmas [M] fp32, grad_out16 [M,16] fp16 (columns 0..2 = dL/d(colour-net output) * loss_scale, rest 0) -- both may arrive
  *        uninitialised, every row is written (zeros where no gradient flows)
+ *   loss may be NULL: the sum is then left to the caller (ngp_grid_encode_backward_checked_slabs carries it); ray_err [N] holds the per-ray squared errors.
  *   ray_err [N] fp32: scratch.  march_workspace: the workspace ngp_march_rays_train_ex filled for these rays, all
  *        ngp_march_rays_train_workspace_bytes(N) bytes of it (word 0 = rows handed out, word 1 and the 32 words at its end, 128 bytes
  *        apart = tickets that call leaves at 0 and this one returns to 0). */

@@ -312,6 +312,9 @@ def test_backward_that_recomputes_the_activations_is_bit_identical_to_the_stored
                                                   capi.NGP_FF_RECOMPUTE | capi.NGP_FF_SINGLE_WAVE, st))
 
 
+losses = []   # the carried loss sum of the three cases below: inside the accumulate launch or on its own, the same bits
+
+
 @pytest.mark.parametrize('M', [0, 256, 65536])
 def test_slab_reduction_carried_by_the_grid_backward_equals_its_own_launch(M):
     """ngp_grid_encode_backward_checked_slabs: the deferred slab reduction of two MLP backwards inside the grid backward's accumulate launch
@@ -330,6 +333,7 @@ def test_slab_reduction_carried_by_the_grid_backward_equals_its_own_launch(M):
     slabs_b[3, 100] = float('inf')                                   # -> found_inf
     x = torch.rand(max(M, 1), 3, device=dev, generator=g)[:M].contiguous()
     g_enc = (torch.randn(16, max(M, 1), 2, device=dev, generator=g) * 0.1).half()[:, :M].contiguous()
+    ray_err = torch.rand(4096, device=dev, generator=torch.Generator(device='cuda').manual_seed(5))   # (the same errors for every M)
     res = {}
     for carried in (False, True):
         gw_a, gw_b = torch.zeros(n_a, device=dev, dtype=torch.half), torch.zeros(n_b, device=dev, dtype=torch.half)
@@ -339,9 +343,15 @@ def test_slab_reduction_carried_by_the_grid_backward_equals_its_own_launch(M):
         host = ctypes.cast(capi.host_offsets(toffs), ctypes.c_void_p)   # (found_inf needs the host copy of the offsets on every path)
         args = (capi.ptr(g_enc) if M else None, capi.ptr(x) if M else None, None, toffs.data_ptr(), g_emb.data_ptr(), M, 3, 2, 16, S, 16, None, None,
                 0, 0, 0, capi.NGP_F16, 1.0, host, capi.ptr(ws), nbytes, found.data_ptr())
+        loss = torch.zeros(1, device=dev)
         if carried:
-            sets = capi.SlabSets(slabs_a.data_ptr(), s_a, n_a, gw_a.data_ptr(), slabs_b.data_ptr(), s_b, n_b, gw_b.data_ptr())
+            sets = capi.SlabSets(slabs_a.data_ptr(), s_a, n_a, gw_a.data_ptr(), slabs_b.data_ptr(), s_b, n_b, gw_b.data_ptr(),
+                                 ray_err.data_ptr(), ray_err.numel(), loss.data_ptr())          # ... and the third carried job: the loss sum
             capi.check(capi.lib.ngp_grid_encode_backward_checked_slabs(*args, ctypes.cast(ctypes.pointer(sets), ctypes.c_void_p), st))
+            torch.cuda.synchronize()
+            want = float(ray_err.double().sum() / (3 * ray_err.numel()))
+            assert abs(float(loss) - want) <= 2e-6 * want
+            losses.append(float(loss))
         else:
             capi.check(capi.lib.ngp_ffmlp_reduce_slabs_pair(slabs_a.data_ptr(), s_a, n_a, gw_a.data_ptr(), slabs_b.data_ptr(), s_b, n_b, gw_b.data_ptr(),
                                                             found.data_ptr(), st))
@@ -355,6 +365,7 @@ def test_slab_reduction_carried_by_the_grid_backward_equals_its_own_launch(M):
         assert torch.equal(a[2], b[2]) and float(a[2].float().abs().max()) > 0       # binned path: deterministic
     elif M:
         assert torch.allclose(a[2].float(), b[2].float(), rtol=2e-2, atol=1e-3)     # atomics: order of the fp16 additions varies
+    assert len(set(losses)) == 1, losses
 
 
 @pytest.mark.parametrize('bg_mode', [1, 2])

@@ -83,6 +83,45 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- wave64 DPP scans (shared by the compositor and the carried loss sum: the ORDER of the additions is part of the result's bits) ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or(float identity, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, src), CTRL, ROW_MASK,
+                                                                 0xF, false));
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int) {
+    v += dpp_or<0x111, 0xF>(0.0f, v);  // row_shr:1
+    v += dpp_or<0x112, 0xF>(0.0f, v);  // row_shr:2
+    v += dpp_or<0x114, 0xF>(0.0f, v);  // row_shr:4
+    v += dpp_or<0x118, 0xF>(0.0f, v);  // row_shr:8
+    v += dpp_or<0x142, 0xA>(0.0f, v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_or<0x143, 0xC>(0.0f, v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ float lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ __forceinline__ float wave_total(float v) { return lane63(wave_incl_sum(v, 0)); }   // wave-uniform sum
+
+// The training loss VALUE from the per-ray squared errors the compositor left (raymarching.hip: k_composite_train_loss_bwd): threads 0..255
+// of the calling block add err[t], err[t + 256], ... in order, a DPP scan per wave, the four wave sums in wave order, / (3 N) -- ONE routine
+// for the compositor's last workgroup and for the block that carries the sum in a later launch: the same bits.  Called by all threads of a
+// block of >= 256 threads; part: 4 floats of LDS.  The errors were written in an earlier launch or as write-through stores (agent scope).
+__device__ __forceinline__ void loss_sum_block(const float* err, uint32_t N, float* loss, float* part) {
+    const uint32_t t = threadIdx.x;
+    float acc = 0.0f;
+    if (t < 256u) {
+        for (uint32_t i = t; i < N; i += 256u) acc += __hip_atomic_load(&err[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc = wave_total(acc);
+        if ((t & 63u) == 0u) part[t >> 6] = acc;
+    }
+    __syncthreads();
+    if (t == 0u) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) v += part[w];
+        loss[0] = v / (float)(3u * N);
+    }
+}
+
 // ---- fixed-order sum of per-workgroup fp32 weight-gradient slabs (the FFMLP backward's deferred reduction), TWO sets per launch ----
 // One block of RS_PARAMS x RS_GROUPS threads sums RS_PARAMS parameters of one set: group g adds slabs g, g + RS_GROUPS, ..., the groups'
 // partial sums are added in group order and rounded once to fp16 -- the same order for every launch shape, so the same bits whether the
@@ -94,7 +133,18 @@ struct SlabSets {
     uint32_t n_slabs[2], n_params[2];
     _Float16* grad_weights[2];
     uint32_t blocks[2];  // blocks serving each set: cdiv(n_params, RS_PARAMS), or 0 for a set with nothing to do
+    // optional third job, one more block (index blocks[0] + blocks[1]): loss[0] = sum(ray_err[0 .. n_rays)) / (3 n_rays), loss_sum_block
+    const float* ray_err;
+    uint32_t n_rays;
+    float* loss;
+    __host__ __device__ uint32_t total_blocks() const { return blocks[0] + blocks[1] + (loss ? 1u : 0u); }
 };
+// block `b` of a grid row that carries the jobs (all threads of a RS_PARAMS x RS_GROUPS block; part: RS_GROUPS x RS_PARAMS floats of LDS)
+__device__ __forceinline__ void slab_reduce_block(const SlabSets& s, uint32_t b, float (*part)[RS_PARAMS], float* found_inf);
+__device__ __forceinline__ void carried_block(const SlabSets& s, uint32_t b, float (*part)[RS_PARAMS], float* found_inf) {
+    if (b < s.blocks[0] + s.blocks[1]) slab_reduce_block(s, b, part, found_inf);
+    else if (s.loss && b == s.blocks[0] + s.blocks[1]) loss_sum_block(s.ray_err, s.n_rays, s.loss, &part[0][0]);
+}
 // block `b` of blocks[0] + blocks[1]; part: RS_GROUPS x RS_PARAMS floats of LDS; found_inf (optional) is set to 1 when a resulting gradient is
 // not finite (a set with n_slabs = 0 holds gradients its backward stored directly: only swept).  Called by ALL threads of the block.
 __device__ __forceinline__ void slab_reduce_block(const SlabSets& s, uint32_t b, float (*part)[RS_PARAMS], float* found_inf) {

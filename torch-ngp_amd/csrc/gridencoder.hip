@@ -1283,12 +1283,11 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     constexpr int MAX_REC = BIN_PPB * (1 << D);
     constexpr int WAVES = ACC_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
-    // one more row of the grid than there are levels: the caller's slab reduction (the two MLPs' weight gradients of the training step,
-    // ngp_grid_encode_backward_checked_slabs) -- ~270 small blocks beside the first slices instead of a launch of their own
-    const uint32_t slab_row = (slabs.blocks[0] + slabs.blocks[1]) != 0u ? 1u : 0u;   // row 0 when present: dispatched first, done in ~4 us
+    // one more row of the grid than there are levels: the caller's carried reductions (the two MLPs' weight-gradient slabs and the loss sum
+    // of the training step, ngp_grid_encode_backward_checked_slabs) -- ~270 small blocks beside the first slices instead of a launch of their own
+    const uint32_t slab_row = slabs.total_blocks() != 0u ? 1u : 0u;   // row 0 when present: dispatched first, done in ~4 us
     if (slab_row && blockIdx.y == 0u) {
-        if (blockIdx.x < slabs.blocks[0] + slabs.blocks[1])
-            slab_reduce_block(slabs, blockIdx.x, reinterpret_cast<float (*)[RS_PARAMS]>(acc_smem), found_inf);
+        carried_block(slabs, blockIdx.x, reinterpret_cast<float (*)[RS_PARAMS]>(acc_smem), found_inf);
         return;
     }
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_smem);                                // [BIN_SLICE][2]
@@ -1785,7 +1784,7 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     int rc = check_launch("grid_encode_backward(bin)");
     if (rc) return rc;
     static_assert(ACC_THREADS == RS_PARAMS * RS_GROUPS, "the slab reduction's blocks have the accumulate's shape");
-    const uint32_t slab_blocks = p.slabs.blocks[0] + p.slabs.blocks[1];
+    const uint32_t slab_blocks = p.slabs.total_blocks();
     hipLaunchKernelGGL((k_grid_backward_accumulate<D>), dim3(std::max(p.max_bins, slab_blocks), p.n_binned + (slab_blocks ? 1u : 0u)), dim3(ACC_THREADS),
                        acc_smem, st, offsets, (half_t*)grad_emb, bins, (const uint32_t*)descriptors, (const uint2*)records, p.found_inf, p.slabs);
     p.slabs_done = slab_blocks != 0;
@@ -1844,6 +1843,12 @@ atomic_done:
         rc = check_launch("grid_encode_backward(input)");
     }
     return rc;
+}
+
+// the carried reductions on their own (a call without an accumulate launch)
+__global__ __launch_bounds__(RS_PARAMS * RS_GROUPS) void k_carried_reductions(SlabSets sets, float* __restrict__ found_inf) {
+    __shared__ float part[RS_GROUPS][RS_PARAMS];
+    carried_block(sets, blockIdx.x, part, found_inf);
 }
 
 // found_inf for gradient entries written by atomics (their results are never observed by the writer): one sweep over the table
@@ -2043,14 +2048,28 @@ extern "C" int ngp_grid_encode_backward_checked_slabs(const void* grad, const fl
                                                       size_t workspace_bytes, float* found_inf, const ngp_slab_sets_t* slab_sets,
                                                       ngp_stream_t stream) {
     (void)embeddings;
-    // the slab reduction rides in the accumulate launch when this call has one; otherwise (few samples, no workspace, an empty batch) it is
-    // launched on its own -- the caller gets the reduced gradients either way
+    // the carried reductions ride in the accumulate launch when this call has one; otherwise (few samples, no workspace, an empty batch) they
+    // are launched on their own -- the caller gets the reduced gradients and the loss either way
+    SlabSets carried = {};
+    if (slab_sets) {
+        // same rule as ngp_ffmlp_reduce_slabs_pair: a set without slabs (gradients stored directly) still gets blocks when found_inf asks for the sweep
+        const uint32_t ba = (slab_sets->n_slabs_a || found_inf) && slab_sets->n_params_a ? cdiv(slab_sets->n_params_a, (uint32_t)RS_PARAMS) : 0u;
+        const uint32_t bb = (slab_sets->n_slabs_b || found_inf) && slab_sets->n_params_b ? cdiv(slab_sets->n_params_b, (uint32_t)RS_PARAMS) : 0u;
+        NGP_REQUIRE((!ba || ((slab_sets->slabs_a || !slab_sets->n_slabs_a) && slab_sets->grad_weights_a)) &&
+                        (!bb || ((slab_sets->slabs_b || !slab_sets->n_slabs_b) && slab_sets->grad_weights_b)),
+                    NGP_ERR_INVALID, "grid_encode_backward: NULL tensor in the slab sets");
+        NGP_REQUIRE(!slab_sets->loss || (slab_sets->ray_err && slab_sets->n_rays > 0), NGP_ERR_INVALID, "grid_encode_backward: loss sum without per-ray errors");
+        carried.slabs[0] = (const float*)slab_sets->slabs_a; carried.n_slabs[0] = slab_sets->n_slabs_a; carried.n_params[0] = slab_sets->n_params_a;
+        carried.grad_weights[0] = (half_t*)slab_sets->grad_weights_a; carried.blocks[0] = ba;
+        carried.slabs[1] = (const float*)slab_sets->slabs_b; carried.n_slabs[1] = slab_sets->n_slabs_b; carried.n_params[1] = slab_sets->n_params_b;
+        carried.grad_weights[1] = (half_t*)slab_sets->grad_weights_b; carried.blocks[1] = bb;
+        carried.ray_err = slab_sets->ray_err; carried.n_rays = slab_sets->n_rays; carried.loss = slab_sets->loss;
+    }
     auto reduce_alone = [&]() -> int {
-        if (!slab_sets) return NGP_OK;
-        return ngp_ffmlp_reduce_slabs_pair(slab_sets->slabs_a, slab_sets->n_slabs_a, slab_sets->n_params_a, slab_sets->grad_weights_a, slab_sets->slabs_b,
-                                           slab_sets->n_slabs_b, slab_sets->n_params_b, slab_sets->grad_weights_b, found_inf, stream);
+        if (carried.total_blocks() == 0u) return NGP_OK;
+        hipLaunchKernelGGL(k_carried_reductions, dim3(carried.total_blocks()), dim3(RS_PARAMS * RS_GROUPS), 0, as_stream(stream), carried, found_inf);
+        return check_launch("grid_encode_backward(carried reductions)");
     };
-
     NGP_REQUIRE(!(bound > 0.0f && dy_dx), NGP_ERR_INVALID, "grid_encode_backward: the fused input mapping does not provide grad_inputs");
     NGP_REQUIRE(!found_inf || offsets_host, NGP_ERR_INVALID, "grid_encode_backward: found_inf needs the host copy of the offsets");
     const InputMap im = make_input_map(bound);
@@ -2063,18 +2082,7 @@ extern "C" int ngp_grid_encode_backward_checked_slabs(const void* grad, const fl
     BackwardPlan plan;
     plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0, workspace != nullptr);
     plan.found_inf = found_inf;
-    if (slab_sets) {
-        // same rule as ngp_ffmlp_reduce_slabs_pair: a set without slabs (gradients stored directly) still gets blocks when found_inf asks for the sweep
-        const uint32_t ba = (slab_sets->n_slabs_a || found_inf) && slab_sets->n_params_a ? cdiv(slab_sets->n_params_a, (uint32_t)RS_PARAMS) : 0u;
-        const uint32_t bb = (slab_sets->n_slabs_b || found_inf) && slab_sets->n_params_b ? cdiv(slab_sets->n_params_b, (uint32_t)RS_PARAMS) : 0u;
-        NGP_REQUIRE((!ba || ((slab_sets->slabs_a || !slab_sets->n_slabs_a) && slab_sets->grad_weights_a)) &&
-                        (!bb || ((slab_sets->slabs_b || !slab_sets->n_slabs_b) && slab_sets->grad_weights_b)),
-                    NGP_ERR_INVALID, "grid_encode_backward: NULL tensor in the slab sets");
-        plan.slabs.slabs[0] = (const float*)slab_sets->slabs_a; plan.slabs.n_slabs[0] = slab_sets->n_slabs_a; plan.slabs.n_params[0] = slab_sets->n_params_a;
-        plan.slabs.grad_weights[0] = (half_t*)slab_sets->grad_weights_a; plan.slabs.blocks[0] = ba;
-        plan.slabs.slabs[1] = (const float*)slab_sets->slabs_b; plan.slabs.n_slabs[1] = slab_sets->n_slabs_b; plan.slabs.n_params[1] = slab_sets->n_params_b;
-        plan.slabs.grad_weights[1] = (half_t*)slab_sets->grad_weights_b; plan.slabs.blocks[1] = bb;
-    }
+    plan.slabs = carried;
     NGP_REQUIRE(plan.workspace_bytes() <= workspace_bytes, NGP_ERR_INVALID,
                 "grid_encode_backward: workspace of %zu bytes, ngp_grid_backward_workspace_bytes() asks for %zu", workspace_bytes,
                 plan.workspace_bytes());

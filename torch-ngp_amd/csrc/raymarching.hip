@@ -807,11 +807,7 @@ __global__ __launch_bounds__(RM_THREADS) void k_march_rays(uint32_t n_alive, uin
 // Wave-wide inclusive scans on the VALU (DPP: row shifts inside the 16-lane rows, then row_bcast:15 / row_bcast:31 carry the row totals
 // across -- profiles/r01_dpp_probe.txt), no LDS crossbar: the compositing kernels are one latency chain per ray, and a ds_bpermute
 // round trip per scan step (__shfl_up) was most of it.  A lane without a source keeps `identity`.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_or(float identity, float src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, src), CTRL, ROW_MASK,
-                                                                 0xF, false));
-}
+// (dpp_or, wave_incl_sum, lane63, wave_total: common.h)
 __device__ __forceinline__ float wave_incl_prod(float v, int) {
     v *= dpp_or<0x111, 0xF>(1.0f, v);  // row_shr:1
     v *= dpp_or<0x112, 0xF>(1.0f, v);  // row_shr:2
@@ -821,17 +817,6 @@ __device__ __forceinline__ float wave_incl_prod(float v, int) {
     v *= dpp_or<0x143, 0xC>(1.0f, v);  // row_bcast:31 into rows 2 and 3
     return v;
 }
-__device__ __forceinline__ float wave_incl_sum(float v, int) {
-    v += dpp_or<0x111, 0xF>(0.0f, v);
-    v += dpp_or<0x112, 0xF>(0.0f, v);
-    v += dpp_or<0x114, 0xF>(0.0f, v);
-    v += dpp_or<0x118, 0xF>(0.0f, v);
-    v += dpp_or<0x142, 0xA>(0.0f, v);
-    v += dpp_or<0x143, 0xC>(0.0f, v);
-    return v;
-}
-__device__ __forceinline__ float lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
-__device__ __forceinline__ float wave_total(float v) { return lane63(wave_incl_sum(v, 0)); }   // wave-uniform sum
 __device__ __forceinline__ float prev_lane(float identity, float v) { return dpp_or<0x138, 0xF>(identity, v); }  // wave_shr:1, lane 0 keeps identity
 
 constexpr int CT_WAVES = 4;  // rays per workgroup
@@ -1113,6 +1098,9 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_loss_bwd(
         }
     }
     // ---- the loss value: the last workgroup sums the per-ray errors in a fixed order ----
+    // loss == NULL: the caller has the sum carried by a later launch (ngp_grid_encode_backward_checked_slabs: common.h loss_sum_block, the
+    // same routine) -- no ticket, no device-scope round trip at the end of every workgroup, no serial tail: 19 -> 14 us.
+    if (loss == nullptr) return;
     // (no agent-scope release fence: on this chip it writes back the XCD's whole dirty L2, once per workgroup -- measured 15 -> 130 us.
     // The per-ray errors are write-through atomic stores; a workgroup-scope release waits for them to complete before the ticket moves.)
     __shared__ float part[CT_WAVES];
@@ -1138,18 +1126,9 @@ __global__ __launch_bounds__(CT_WAVES * 64) void k_composite_train_loss_bwd(
     }
     __syncthreads();
     if (!last) return;
-    float acc = 0.0f;
-    for (uint32_t i = threadIdx.x; i < N; i += CT_WAVES * 64) acc += __hip_atomic_load(&ray_err[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    acc = wave_total(acc);
-    if (lane == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float v = 0.0f;
-#pragma unroll
-        for (int w = 0; w < CT_WAVES; w++) v += part[w];
-        loss[0] = v / (float)(3u * N);
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    static_assert(CT_WAVES == 4, "loss_sum_block adds four wave sums");
+    loss_sum_block(ray_err, N, loss, part);
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // raymarching.cu:819-905 -- at most 8 samples per ray and call: one lane per alive ray
@@ -1458,7 +1437,8 @@ extern "C" int ngp_composite_train_loss_backward(const float* sigmas, const floa
                                                  float* image_out, float* depth_out, float* loss, float* ray_err, float* grad_sigmas,
                                                  void* grad_out16, void* march_workspace, ngp_stream_t stream) {
     NGP_REQUIRE(N > 0, NGP_ERR_INVALID, "composite_train_loss_backward: no rays");
-    NGP_REQUIRE(sigmas && rgbs && deltas && rays && target && weights_sum && loss && ray_err && grad_sigmas && grad_out16 && march_workspace,
+    // (loss may be NULL: the sum of ray_err is then left to the caller -- ngp_grid_encode_backward_checked_slabs carries it)
+    NGP_REQUIRE(sigmas && rgbs && deltas && rays && target && weights_sum && ray_err && grad_sigmas && grad_out16 && march_workspace,
                 NGP_ERR_INVALID, "composite_train_loss_backward: NULL tensor");
     NGP_REQUIRE(bg_mode == 1 || bg_mode == 2, NGP_ERR_INVALID, "composite_train_loss_backward: bg_mode must be 1 (scalar) or 2 (per ray)");
     NGP_REQUIRE((uint64_t)N * 3u <= 0xffffffffull, NGP_ERR_INVALID, "composite_train_loss_backward: too many rays");

@@ -298,9 +298,10 @@ def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g
     _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf)
 
 
-def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf=None):
+def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf=None, loss_job=None):
     """colour MLP -> exp / feature shuffle -> sigma MLP -> grid scatter, from g_sigma [M] fp32 and g_out16 [M,16] fp16 (CONSUMED: reused as
-    the sigma net's output gradient)"""
+    the sigma net's output gradient).  loss_job = (ray_err [N], loss [1]): the loss sum the compositor left to a later launch -- only
+    accepted where `_carries_reductions` holds (it rides with the slab reduction in the grid backward's last launch)"""
     (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, march_ws) = saved
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
     density_scale = rcfg[8]
@@ -323,15 +324,21 @@ def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, fou
                                               _PLANAR_IN | _PLANAR_DX | capi.NGP_FF_DEFER_REDUCE | rc, st))
         n_c, n_s = capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_color), capi.lib.ngp_ffmlp_backward_slab_count(M, 32, 64, nl_sigma)
         if USE_SLABS_IN_ACCUMULATE:
-            # the slab reduction of both MLPs rides in the grid backward's last launch (independent work, one launch less)
-            slabs = capi.SlabSets(scratch_c.data_ptr(), n_c, g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(), n_s, g_ws.numel(), g_ws.data_ptr())
+            # the slab reduction of both MLPs (and the loss sum) ride in the grid backward's last launch (independent work, one launch less)
+            err, loss = loss_job if loss_job is not None else (None, None)
+            slabs = capi.SlabSets(scratch_c.data_ptr(), n_c, g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(), n_s, g_ws.numel(), g_ws.data_ptr(),
+                                  capi.ptr(err), 0 if err is None else err.numel(), capi.ptr(loss))
             _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf, slabs)
             return
+        if loss_job is not None:
+            raise RuntimeError('fused: a deferred loss sum needs the carried reductions (_carries_reductions)')
         _check(capi.lib.ngp_ffmlp_reduce_slabs_pair(scratch_c.data_ptr(), n_c, g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(), n_s, g_ws.numel(),
                                                     g_ws.data_ptr(), capi.ptr(found_inf), st))
     else:
         if found_inf is not None:
             raise RuntimeError('fused: found_inf needs the fused colour-head / slab-reduction path (see iteration_checks_gradients)')
+        if loss_job is not None:
+            raise RuntimeError('fused: a deferred loss sum needs the carried reductions (_carries_reductions)')
         g_color_in = torch.empty(M, 32, **half)
         scratch = torch.empty(max(nl_color, nl_sigma), M, 64, **half)
         _check(capi.lib.ngp_ffmlp_backward_ex(g_out16.data_ptr(), color_in.data_ptr(), wc16.data_ptr(), fb_c.data_ptr(), M, 32, 16, 64,
@@ -431,6 +438,11 @@ USE_SLABS_IN_ACCUMULATE = os.environ.get('NGP_FUSED_SLABS_IN_ACCUMULATE', '1') !
 USE_RECOMPUTE = os.environ.get('NGP_FUSED_RECOMPUTE', '0') == '1'
 
 
+def _carries_reductions(nl_sigma, nl_color):
+    """does the grid backward's last launch carry the MLPs' slab reduction (and with it the loss sum)?"""
+    return bool(USE_SLABS_IN_ACCUMULATE and USE_FUSED_MID and nl_color in (2, 3) and nl_sigma in (2, 3))
+
+
 def _recompute(nl_sigma, nl_color):
     """may the training render skip the forward buffers?  Needs the launches that can recompute: the fused network forward and the paired
     backward kernels behind the fused colour head (2- / 3-layer networks); bit-identical gradients either way (tests/test_gpu_ffmlp.py)"""
@@ -464,13 +476,17 @@ def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg,
     loss, ray_err = torch.empty(1, **f32), torch.empty(N, **f32)
     g_sigma = torch.empty(M, **f32)
     g_out16 = torch.empty(M, 16, device=dev, dtype=torch.half)
+    # the loss VALUE: summed by the compositor's last workgroup (a ticket round trip at the end of every workgroup), or left to the launch
+    # that carries the slab reduction (same routine, same bits: the compositor then ends without tickets)
+    defer = _carries_reductions(cfg[7], cfg[8])
     _check(capi.lib.ngp_composite_train_loss_backward(sigma.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), rays.data_ptr(), M, N,
                                                       float(T_thresh), 2 if bg is not None else 1, float(bg_scalar), capi.ptr(bg),
                                                       nears.data_ptr(), fars.data_ptr(), target.data_ptr(), capi.ptr(loss_scale),
-                                                      weights_sum.data_ptr(), image.data_ptr(), depth.data_ptr(), loss.data_ptr(),
+                                                      weights_sum.data_ptr(), image.data_ptr(), depth.data_ptr(), None if defer else loss.data_ptr(),
                                                       ray_err.data_ptr(), g_sigma.data_ptr(), g_out16.data_ptr(), march_ws.data_ptr(),
                                                       capi.stream()))
-    _network_backward(saved, cfg, rcfg, g_sigma, g_out16, bufs[3], bufs[4].view(-1), bufs[5].view(-1), found_inf)
+    _network_backward(saved, cfg, rcfg, g_sigma, g_out16, bufs[3], bufs[4].view(-1), bufs[5].view(-1), found_inf,
+                      loss_job=(ray_err, loss) if defer else None)
     return loss, image, depth, weights_sum
 
 

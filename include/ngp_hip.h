@@ -254,6 +254,10 @@ typedef struct ngp_slab_sets {
     /* optional third carried job: loss[0] = sum(ray_err[0 .. n_rays)) / (3 n_rays), the loss VALUE ngp_composite_train_loss_backward would
      * have summed itself (call it with loss = NULL: its workgroups then skip the ticket round trip); same routine, same bits.  loss = NULL: none */
     const float* ray_err; uint32_t n_rays; float* loss;
+    /* != 0: grad_embeddings receives this call's gradient instead of having it ADDED (every entry is written, zeros included, nothing is
+     * read): for a caller whose optimizer then does not zero the buffer (ngp_optim_adam_step*: grad_is_half & 2).  Same bits as adding into
+     * a zeroed buffer.  Calls that cannot write every entry from the sort (levels on the atomic path) zero the table first. */
+    uint32_t overwrite_table;
 } ngp_slab_sets_t;
 int ngp_grid_encode_backward_checked_slabs(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                            void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
@@ -460,7 +464,9 @@ int ngp_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
 /* ---------------------------------------------------------------------------------------------
  * Fused optimizer + loss-scaling step -- EXTENSION: replaces torch.optim.Adam + GradScaler.step/update
  * (main_nerf.py:132, nerf/utils.py:557-560) for up to 8 tensors per call.  grads[k] holds the loss-scaled gradient, fp16 when
- * grad_is_half[k] (the buffer grid_encode_backward / ffmlp_backward wrote) else fp32, and is ZEROED by the call; params_fp16[k]
+ * grad_is_half[k] & 1 (the buffer grid_encode_backward / ffmlp_backward wrote) else fp32, and is ZEROED by the call -- unless
+ * grad_is_half[k] & 2: the producer of that buffer overwrites ALL of it every step (ngp_grid_encode_backward_checked_slabs with
+ * overwrite_table), so it is left as it is (and a skipped step does not touch the tensor at all); params_fp16[k]
  * (optional, may be NULL per tensor or as a whole) receives the fp16 copy of the updated weights.
  * state = device float[8]: {loss scale, growth tracker, found_inf, Adam step count, lr multiplier, -, -, -}; no host sync.
  * grad_mult: extra factor on the gradients (1 / world_size after a SUM all-reduce).  A step over more than 8 tensors uses

@@ -397,3 +397,62 @@ def test_lookahead_march_is_the_same_training():
     np.testing.assert_allclose(a[0], b[0], rtol=2e-6, atol=0)
     for x, y in zip(a[2], b[2]):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('lookahead', [True, False])
+def test_overwritten_table_gradient_is_the_same_training(lookahead):
+    """fused.USE_OVERWRITE_TABLE: in the captured single-GPU iteration the grid backward WRITES the table gradient (every entry, zeros
+    included) and the optimizer keeps the buffer instead of zeroing it.  Same bits as adding into a zeroed buffer: 40 steps (eager first
+    steps, captured steps, refreshes) end with bit-identical parameters; the buffer that mode leaves stale is cleaned before a producer
+    that ADDS into it runs (a drop-in backward after the graphs), and a skipped (overflowing) step leaves the parameters alone."""
+    import fused
+    from graph import GraphedTrainStep
+    dev = torch.device('cuda')
+    occ = torch.from_numpy(sc.occupancy_density()).to(dev)
+    bits = torch.from_numpy(oracle.packbits(sc.occupancy_density(), 10.0)).to(dev)
+    n_rays = 1024
+    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    batches = []
+    for i in range(41):
+        o, d, gt = sc.training_batch(n_rays, seed=700 + i)
+        batches.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
+
+    def keep(m):
+        m.density_grid.copy_(occ)
+        m.density_bitfield.copy_(bits)
+
+    runs = {}
+    default = fused.USE_OVERWRITE_TABLE
+    try:
+        for over in (True, False):
+            fused.USE_OVERWRITE_TABLE = over
+            model, opt = _make_ngp(dev)
+            opt.scalars[0] = 2.0 ** 24      # an absurd loss scale: the first captured steps overflow and are skipped, in both modes alike
+            st = GraphedTrainStep(model, opt, None, n_rays, kw, after_update=keep, direct=True, lookahead=lookahead)
+            losses = []
+            for i in range(40):
+                nxt = dict(next_rays=batches[i + 1]) if lookahead else {}
+                losses.append(float(st.step(*batches[i], **nxt)))
+            assert st.capture_error is None and st.n_captures >= 1 and st.used_direct
+            emb = model.encoder.embeddings
+            assert bool(getattr(emb, '_ngp_grad16_stale', False)) == over
+            if over:
+                assert float(emb._ngp_grad16.float().abs().max()) > 0            # the last step's gradient is still there ...
+            # ... and one more iteration through the DROP-IN path (its backward adds into the deposit buffers) sees a clean buffer
+            with torch.autocast('cuda', dtype=torch.float16):
+                out = model.render(batches[40][0], batches[40][1], **kw)
+                loss = ((out['image'] - batches[40][2]) ** 2).mean()
+            opt.scale(loss).backward()
+            opt.step()
+            assert not getattr(emb, '_ngp_grad16_stale', False) and float(emb._ngp_grad16.float().abs().max()) == 0.0
+            params = [p.detach().clone() for p in (emb, model.sigma_net.weights, model.color_net.weights)]
+            runs[over] = (losses, params, float(opt.scalars[0]), float(opt.scalars[3]))
+    finally:
+        fused.USE_OVERWRITE_TABLE = default
+    a, b = runs[True], runs[False]
+    assert a[2] == b[2] and a[3] == b[3] and a[3] < 41          # same loss scale, same number of (non-skipped) steps
+    assert a[0] == b[0]
+    for x, y in zip(a[1][:1], b[1][:1]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[1][1:], b[1][1:]):
+        assert torch.equal(x, y)

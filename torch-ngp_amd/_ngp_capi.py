@@ -141,7 +141,7 @@ class SlabSets(ctypes.Structure):
     """ngp_slab_sets_t (include/ngp_hip.h): two sets of deferred FFMLP weight-gradient slabs for ngp_grid_encode_backward_checked_slabs"""
     _fields_ = [('slabs_a', ctypes.c_void_p), ('n_slabs_a', ctypes.c_uint32), ('n_params_a', ctypes.c_uint32), ('grad_weights_a', ctypes.c_void_p),
                 ('slabs_b', ctypes.c_void_p), ('n_slabs_b', ctypes.c_uint32), ('n_params_b', ctypes.c_uint32), ('grad_weights_b', ctypes.c_void_p),
-                ('ray_err', ctypes.c_void_p), ('n_rays', ctypes.c_uint32), ('loss', ctypes.c_void_p)]
+                ('ray_err', ctypes.c_void_p), ('n_rays', ctypes.c_uint32), ('loss', ctypes.c_void_p), ('overwrite_table', ctypes.c_uint32)]
 
 
 def ptr(t):

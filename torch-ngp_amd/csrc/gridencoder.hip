@@ -1279,7 +1279,7 @@ template <int D>
 __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_grid_backward_accumulate(const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid,
                                                                           BinPlan plan, const uint32_t* __restrict__ descriptors,
                                                                           const uint2* __restrict__ records, float* __restrict__ found_inf,
-                                                                          SlabSets slabs) {
+                                                                          SlabSets slabs, bool overwrite) {
     constexpr int MAX_REC = BIN_PPB * (1 << D);
     constexpr int WAVES = ACC_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
@@ -1442,12 +1442,15 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
         sum0[k] = (long long)acc[2 * i];
         sum1[k] = (long long)acc[2 * i + 1];
         badb[k] = (poison[i >> 4] >> ((i & 15u) * 2u)) & 3u;
-        touch[k] = ent[k] < hashmap_size && !(sum0[k] == 0 && sum1[k] == 0 && !badb[k]);
+        // overwrite: every entry of the slice is written (a zero sum stores +0: what adding it to a zeroed entry gives) and none is read
+        touch[k] = ent[k] < hashmap_size && (overwrite || !(sum0[k] == 0 && sum1[k] == 0 && !badb[k]));
         oldv[k] = half2_t{(half_t)0.0f, (half_t)0.0f};
     }
+    if (!overwrite) {
 #pragma unroll
-    for (int k = 0; k < PER_THREAD; k++)
-        if (touch[k]) oldv[k] = gtable[ent[k]];
+        for (int k = 0; k < PER_THREAD; k++)
+            if (touch[k]) oldv[k] = gtable[ent[k]];
+    }
 #pragma unroll
     for (int k = 0; k < PER_THREAD; k++) {
         if (!touch[k]) continue;
@@ -1663,6 +1666,7 @@ struct BackwardPlan {
     uint32_t n_binned = 0, total_desc = 0, max_bins = 0;
     uint64_t total_records = 0;
     float* found_inf = nullptr;  // optional: set to 1 when a gradient value this call produced is not finite
+    bool overwrite = false;      // the table gradient is written, not added to (every entry: needs every level on the record-sort path)
     SlabSets slabs = {};         // optional: slab reduction carried by the accumulate launch (blocks[] = 0: none)
     mutable bool slabs_done = false;  // set by the launch that carried them
     size_t desc_bytes() const { return ((size_t)total_desc * sizeof(uint32_t) + 255) & ~(size_t)255; }
@@ -1786,7 +1790,8 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     static_assert(ACC_THREADS == RS_PARAMS * RS_GROUPS, "the slab reduction's blocks have the accumulate's shape");
     const uint32_t slab_blocks = p.slabs.total_blocks();
     hipLaunchKernelGGL((k_grid_backward_accumulate<D>), dim3(std::max(p.max_bins, slab_blocks), p.n_binned + (slab_blocks ? 1u : 0u)), dim3(ACC_THREADS),
-                       acc_smem, st, offsets, (half_t*)grad_emb, bins, (const uint32_t*)descriptors, (const uint2*)records, p.found_inf, p.slabs);
+                       acc_smem, st, offsets, (half_t*)grad_emb, bins, (const uint32_t*)descriptors, (const uint2*)records, p.found_inf, p.slabs,
+                       p.overwrite);
     p.slabs_done = slab_blocks != 0;
     return check_launch("grid_encode_backward(accumulate)");
 }
@@ -2075,7 +2080,14 @@ extern "C" int ngp_grid_encode_backward_checked_slabs(const void* grad, const fl
     const InputMap im = make_input_map(bound);
     int rc = check_grid_args("grid_encode_backward", B, D, C, L, dtype);
     if (rc) return rc;
-    if (B == 0) return reduce_alone();
+    if (B == 0) {
+        if (slab_sets && slab_sets->overwrite_table) {
+            NGP_REQUIRE(offsets_host && grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: overwrite_table needs the table and the host copy of the offsets");
+            hipError_t e = hipMemsetAsync(grad_embeddings, 0, (size_t)offsets_host[L] * C * (dtype == NGP_F16 ? 2 : 4), as_stream(stream));
+            NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "grid_encode_backward: hipMemsetAsync failed: %s", hipGetErrorString(e));
+        }
+        return reduce_alone();
+    }
     NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: NULL tensor");
     GridLevels lv;
     fill_levels(lv, L, S, H);
@@ -2083,6 +2095,17 @@ extern "C" int ngp_grid_encode_backward_checked_slabs(const void* grad, const fl
     plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0, workspace != nullptr);
     plan.found_inf = found_inf;
     plan.slabs = carried;
+    if (slab_sets && slab_sets->overwrite_table) {
+        // every entry comes out of the accumulate only when every level is sorted; otherwise: zero the table, then add as usual
+        if (plan.n_atomic == 0 && plan.n_binned == L && dtype == NGP_F16) {
+            plan.overwrite = true;
+        } else {
+            NGP_REQUIRE(offsets_host, NGP_ERR_INVALID, "grid_encode_backward: overwrite_table needs the host copy of the offsets");
+            const size_t bytes = (size_t)offsets_host[L] * C * (dtype == NGP_F16 ? 2 : 4);
+            hipError_t e = hipMemsetAsync(grad_embeddings, 0, bytes, as_stream(stream));
+            NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "grid_encode_backward: hipMemsetAsync failed: %s", hipGetErrorString(e));
+        }
+    }
     NGP_REQUIRE(plan.workspace_bytes() <= workspace_bytes, NGP_ERR_INVALID,
                 "grid_encode_backward: workspace of %zu bytes, ngp_grid_backward_workspace_bytes() asks for %zu", workspace_bytes,
                 plan.workspace_bytes());

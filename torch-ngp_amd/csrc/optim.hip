@@ -43,7 +43,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_check_finite(OptTensors ts, flo
     bool bad = false;
     for (int k = 0; k < ts.count; k++) {
         const uint64_t n = ts.n[k];
-        if (ts.g_is_half[k]) {
+        if (ts.g_is_half[k] & 1) {
             const half8_t* g = reinterpret_cast<const half8_t*>(ts.g[k]);
             const uint64_t n8 = n / 8;
             for (uint64_t i = (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n8; i += (uint64_t)gridDim.x * OPT_THREADS) {
@@ -81,7 +81,11 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
         float* __restrict__ v = ts.v[k];
         half_t* __restrict__ p16 = ts.p16[k];
         float* __restrict__ ema = ema_omd > 0.0f ? ts.ema[k] : nullptr;
-        const bool gh = ts.g_is_half[k] != 0;
+        const bool gh = (ts.g_is_half[k] & 1) != 0;
+        // bit 1: the gradient's producer OVERWRITES the whole buffer every step (grid backward in overwrite mode): nothing to zero here,
+        // and a skipped step has nothing to do for this tensor at all (unless it keeps an average)
+        const bool keep = (ts.g_is_half[k] & 2) != 0;
+        if (keep && skip && !ema) continue;
         half_t* g16 = reinterpret_cast<half_t*>(ts.g[k]);
         float* g32 = reinterpret_cast<float*>(ts.g[k]);
         // Fast path of the training configuration (fp16 gradient + fp16 shadow, no EMA, length a multiple of 4, 16-byte aligned streams):
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
             const uint64_t n4 = n / 4;
             for (uint64_t i = (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * OPT_THREADS) {
                 const half4_t x = reinterpret_cast<half4_t*>(g16)[i];
-                reinterpret_cast<half4_t*>(g16)[i] = half4_t{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+                if (!keep) reinterpret_cast<half4_t*>(g16)[i] = half4_t{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
                 if (skip) continue;
                 float4_t pm = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(m) + i), pv = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(v) + i),
                          pp = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(p) + i);
@@ -121,11 +125,11 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
             if (gh) {
                 const half2_t x = reinterpret_cast<half2_t*>(g16)[i];
                 g0 = (float)x.x; g1 = (float)x.y;
-                reinterpret_cast<half2_t*>(g16)[i] = half2_t{(half_t)0.0f, (half_t)0.0f};
+                if (!keep) reinterpret_cast<half2_t*>(g16)[i] = half2_t{(half_t)0.0f, (half_t)0.0f};
             } else {
                 const float2_t x = reinterpret_cast<float2_t*>(g32)[i];
                 g0 = x.x; g1 = x.y;
-                reinterpret_cast<float2_t*>(g32)[i] = float2_t{0.0f, 0.0f};
+                if (!keep) reinterpret_cast<float2_t*>(g32)[i] = float2_t{0.0f, 0.0f};
             }
             if (skip) {
                 if (ema) {  // the average moves towards the (unchanged) parameters as torch_ema's update() would
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const uint64_t i = n - 1;
             float g0 = gh ? (float)g16[i] : g32[i];
-            if (gh) g16[i] = (half_t)0.0f; else g32[i] = 0.0f;
+            if (!keep) { if (gh) g16[i] = (half_t)0.0f; else g32[i] = 0.0f; }
             if (!skip) {
                 g0 *= inv_scale;
                 const float nm = beta1 * m[i] + (1.0f - beta1) * g0, nv = beta2 * v[i] + (1.0f - beta2) * g0 * g0;

@@ -124,11 +124,15 @@ def _network_forward(enc, dirs, d_valid, ws16, wc16, nl_sigma, nl_color, density
     _check(capi.lib.ngp_pipeline_rgb_forward(out16.data_ptr(), rgb.data_ptr(), M, st))
 
 
-def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf=None, slabs=None):
+def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf=None, slabs=None, overwrite=False):
     """hash-grid scatter of the level-major fp16 gradient; large batches take the binned atomic-free path (needs scratch memory).
     found_inf: optional device float that the kernels set when a table gradient comes out non-finite (the optimizer's sweep, done here).
-    slabs: optional capi.SlabSets -- the deferred slab reduction of the two MLP backwards rides in this call's last launch"""
+    slabs: optional capi.SlabSets -- the deferred slab reduction of the two MLP backwards rides in this call's last launch.
+    overwrite: g_emb receives the gradient instead of having it added (the optimizer then keeps the buffer: optim.NGPAdam)"""
     arr, ws, nbytes = capi.grid_backward_workspace(offsets, M, 3, 2, L, S, H, gridtype, align, capi.NGP_F16)
+    if overwrite:
+        slabs = slabs if slabs is not None else capi.SlabSets()
+        slabs.overwrite_table = 1
     if found_inf is not None and arr is None:
         raise RuntimeError('fused: the in-kernel non-finite sweep needs the host copy of the encoder offsets (call iteration_checks_gradients '
                            'outside stream capture first)')
@@ -154,13 +158,19 @@ def _grad_targets(bufs, n_emb, ws16, wc16, dev):
     return torch.zeros(n_emb, 2, device=dev, dtype=torch.half), torch.empty_like(ws16), torch.empty_like(wc16), False
 
 
-def _optimizer_buffers(params):
-    """(fp16 shadows..., fp16 gradient buffers...) of the three parameters when every one of them is managed by optim.NGPAdam"""
+def _optimizer_buffers(params, overwrite_table=False):
+    """(fp16 shadows..., fp16 gradient buffers...) of the three parameters when every one of them is managed by optim.NGPAdam.
+    A gradient buffer that an overwriting producer left stale (optim.NGPAdam._entries) is zeroed first -- except the table's when this
+    producer is going to overwrite it again (overwrite_table)"""
     sh = [getattr(p, '_ngp_fp16', None) for p in params]
     gr = [getattr(p, '_ngp_grad16', None) for p in params]
     if any(t is None for t in sh + gr):
         return None
     _resync_stale_shadows(params)
+    for k, p in enumerate(params):
+        if getattr(p, '_ngp_grad16_stale', False) and not (overwrite_table and k == 0):
+            p._ngp_grad16.zero_()
+            p._ngp_grad16_stale = False
     return tuple(sh) + tuple(gr)
 
 
@@ -276,7 +286,7 @@ def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg, co
     return image, depth, weights_sum, saved
 
 
-def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g_wc, found_inf=None):
+def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g_wc, found_inf=None, overwrite=False):
     """the backward launches: grad_image [N,3] fp32 (and optionally grad_ws [N]) -> gradients accumulated into g_emb (scatter-add, must
     hold the running sum / zeros) and written to g_ws / g_wc (fp16, flat)"""
     (xyzs, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb, sigma, deltas, rays, weights_sum, image_raw, bg, march_ws) = saved
@@ -295,10 +305,10 @@ def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g
                                                          float(bg_scalar), capi.ptr(bg), march_ws.data_ptr(), st))
     g_out16 = torch.empty(M, 16, **half)
     _check(capi.lib.ngp_pipeline_rgb_backward(g_rgb.data_ptr(), rgb.data_ptr(), g_out16.data_ptr(), M, st))
-    _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf)
+    _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf, None, overwrite)
 
 
-def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf=None, loss_job=None):
+def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf=None, loss_job=None, overwrite=False):
     """colour MLP -> exp / feature shuffle -> sigma MLP -> grid scatter, from g_sigma [M] fp32 and g_out16 [M,16] fp16 (CONSUMED: reused as
     the sigma net's output gradient).  loss_job = (ray_err [N], loss [1]): the loss sum the compositor left to a later launch -- only
     accepted where `_carries_reductions` holds (it rides with the slab reduction in the grid backward's last launch)"""
@@ -328,7 +338,7 @@ def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, fou
             err, loss = loss_job if loss_job is not None else (None, None)
             slabs = capi.SlabSets(scratch_c.data_ptr(), n_c, g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(), n_s, g_ws.numel(), g_ws.data_ptr(),
                                   capi.ptr(err), 0 if err is None else err.numel(), capi.ptr(loss))
-            _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf, slabs)
+            _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf, slabs, overwrite)
             return
         if loss_job is not None:
             raise RuntimeError('fused: a deferred loss sum needs the carried reductions (_carries_reductions)')
@@ -349,7 +359,7 @@ def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, fou
         _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
                                               0, 6, 1, scratch[:nl_sigma].data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
                                               _PLANAR_IN | _PLANAR_DX, st))
-    _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf)
+    _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf, None, overwrite)
 
 
 class _fused_render_train(Function):
@@ -401,7 +411,7 @@ def _render_cfg(model, capacity, bg_color, perturb, dt_gamma, max_steps, T_thres
 
 @torch.no_grad()
 def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity, loss_scale, bg_color=1, perturb=False, dt_gamma=0,
-                          max_steps=1024, T_thresh=1e-4, noise_seed=None, found_inf=None):
+                          max_steps=1024, T_thresh=1e-4, noise_seed=None, found_inf=None, overwrite_table=False):
     """One training iteration's forward + MSE loss + backward WITHOUT autograd: the launches of `_fused_render_train` forward, the
     Trainer's loss (nerf/utils.py:516,557) and its scaled gradient in one kernel, then the backward launches, depositing the gradients
     into the optimizer's fp16 buffers (optim.NGPAdam with deposit=True must manage the three parameter tensors).  28 launches instead
@@ -413,7 +423,7 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     (tests/test_gpu_graph.py)."""
     cfg = network_cfg(model.encoder, model.sigma_net, model.color_net, model.bound, True)
     bg_t, rcfg = _render_cfg(model, capacity, bg_color, perturb, dt_gamma, max_steps, T_thresh)
-    bufs = _optimizer_buffers((model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights))
+    bufs = _optimizer_buffers((model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights), overwrite_table)
     if bufs is None:
         raise RuntimeError('fused_train_iteration: the parameters are not managed by optim.NGPAdam(deposit=True)')
     rays_o = rays_o.contiguous().view(-1, 3)
@@ -422,7 +432,10 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     if target.shape[0] != rays_o.shape[0] or target.dtype != torch.float32:
         raise RuntimeError('fused_train_iteration: target must be [N,3] float32')
     marched = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
-    return _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf)
+    out = _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf, overwrite_table)
+    if overwrite_table:
+        model.encoder.embeddings._ngp_deposit_overwritten = True   # read (and reset) by the optimizer's next step: it keeps the buffer
+    return out
 
 
 USE_BALANCED_FORWARD = True  # encoder launch of the training step: per-XCD work lists balanced by per-level cost of ray-ordered samples (False: whole levels)
@@ -430,6 +443,9 @@ USE_FUSED_CHECK = True      # the optimizer's non-finite sweep is done by the gr
 USE_FUSED_SCAN = True       # the marcher's write pass hands out the sample slots itself (False: scan launch between the passes)
 USE_FUSED_MID = True        # colour-head backward writes grad_h16 itself; one slab reduction for both MLPs (False: five launches)
 USE_FUSED_COMPOSITE = True  # composite forward + loss + composite backward + sigmoid backward in ONE launch (False: the four kernels)
+# the captured single-GPU iteration WRITES the table gradient instead of adding into a zeroed buffer, and the optimizer does not zero it
+# (graph.GraphedTrainStep; 49 MB less traffic per step); False / NGP_FUSED_OVERWRITE_TABLE=0: add + zero
+USE_OVERWRITE_TABLE = os.environ.get('NGP_FUSED_OVERWRITE_TABLE', '1') != '0'
 USE_SLABS_IN_ACCUMULATE = os.environ.get('NGP_FUSED_SLABS_IN_ACCUMULATE', '1') != '0'  # MLP slab reduction inside the grid backward's accumulate launch (False: its own launch)
 # True / NGP_FUSED_RECOMPUTE=1: the training render does not store the MLPs' hidden activations (640 B per sample), the backward kernels
 # recompute them -- bit-identical gradients.  OFF by default: measured on MI355X the forward launch drops from 52 to 31 us, but both
@@ -457,14 +473,14 @@ def iteration_checks_gradients(model):
     return bool(USE_FUSED_CHECK and USE_FUSED_MID and all(n in (2, 3) for n in nl) and capi.host_offsets(model.encoder.offsets) is not None)
 
 
-def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg, rcfg, found_inf=None):
+def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg, rcfg, found_inf=None, overwrite=False):
     if not USE_FUSED_COMPOSITE:
         image, depth, weights_sum, saved = _render_train_network(marched, bufs[0], bufs[1], bufs[2], bg_t, offsets, cfg, rcfg)
         loss = torch.empty(1, device=image.device, dtype=torch.float32)
         grad_image = torch.empty_like(image)
         _check(capi.lib.ngp_pipeline_mse_loss(image.data_ptr(), target.data_ptr(), image.numel(), capi.ptr(loss_scale), loss.data_ptr(),
                                               grad_image.data_ptr(), capi.stream()))
-        _render_train_backward(saved, cfg, rcfg, grad_image, None, bufs[3], bufs[4].view(-1), bufs[5].view(-1), found_inf)
+        _render_train_backward(saved, cfg, rcfg, grad_image, None, bufs[3], bufs[4].view(-1), bufs[5].view(-1), found_inf, overwrite)
         return loss, image, depth, weights_sum
     saved = _render_train_network(marched, bufs[0], bufs[1], bufs[2], bg_t, offsets, cfg, rcfg, composite=False)
     (xyzs, _, _, _, _, _, _, _, _, rgb, sigma, deltas, rays, _, _, bg, march_ws) = saved
@@ -486,20 +502,20 @@ def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg,
                                                       ray_err.data_ptr(), g_sigma.data_ptr(), g_out16.data_ptr(), march_ws.data_ptr(),
                                                       capi.stream()))
     _network_backward(saved, cfg, rcfg, g_sigma, g_out16, bufs[3], bufs[4].view(-1), bufs[5].view(-1), found_inf,
-                      loss_job=(ray_err, loss) if defer else None)
+                      loss_job=(ray_err, loss) if defer else None, overwrite=overwrite)
     return loss, image, depth, weights_sum
 
 
 @torch.no_grad()
 def fused_train_iteration_split(model, rays_o, rays_d, target, box, counter, capacity, loss_scale, bg_color=1, perturb=False, dt_gamma=0,
-                                max_steps=1024, T_thresh=1e-4, noise_seed=None, found_inf=None):
+                                max_steps=1024, T_thresh=1e-4, noise_seed=None, found_inf=None, overwrite_table=False):
     """`fused_train_iteration` in two halves for data-parallel training: returns (march, rest) callables -- `march()` issues the
     parameter-independent launches (near/far, ray marching), `rest()` everything that reads the weights (encode, MLPs, composite, loss,
     backward).  graph.GraphedTrainStep captures them into separate HIP graphs so that the all-gather of the updated fp16 shadow weights
     (optim.NGPAdam, sharded mode) runs underneath the marcher.  Same launches, same arithmetic as the unsplit call."""
     cfg = network_cfg(model.encoder, model.sigma_net, model.color_net, model.bound, True)
     bg_t, rcfg = _render_cfg(model, capacity, bg_color, perturb, dt_gamma, max_steps, T_thresh)
-    bufs = _optimizer_buffers((model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights))
+    bufs = _optimizer_buffers((model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights), overwrite_table)
     if bufs is None:
         raise RuntimeError('fused_train_iteration: the parameters are not managed by optim.NGPAdam(deposit=True)')
     rays_o = rays_o.contiguous().view(-1, 3)
@@ -511,7 +527,10 @@ def fused_train_iteration_split(model, rays_o, rays_d, target, box, counter, cap
         box_['m'] = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
 
     def rest():
-        return _train_iteration_rest(box_['m'], bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf)
+        out = _train_iteration_rest(box_['m'], bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf, overwrite_table)
+        if overwrite_table:
+            model.encoder.embeddings._ngp_deposit_overwritten = True
+        return out
     return march, rest
 
 

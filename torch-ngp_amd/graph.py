@@ -169,6 +169,24 @@ class GraphedTrainStep:
                 self._capture_update(bool(full))
         return self.captures - before
 
+    def _overwrites_table(self):
+        """single-GPU direct iteration: the grid backward WRITES the table gradient and the optimizer keeps the buffer (no zeroing, no
+        read of the old value: 49 MB per step).  Not with an averager / sharded exchange (they own the flat buffer's life cycle)."""
+        import fused
+        return bool(fused.USE_OVERWRITE_TABLE and self.averager is None)
+
+    def _mark_deposits(self):
+        """after a replay: what the captured optimizer step left in the table's deposit buffer (Python ran only at capture time)"""
+        emb = getattr(getattr(self.model, 'encoder', None), 'embeddings', None)
+        if emb is not None and self.used_direct and self._overwrites_table():
+            emb._ngp_grad16_stale = True
+
+    def _clean_deposits(self):
+        """before replaying graphs whose producers ADD into the deposit buffers: zero what an overwriting producer left behind"""
+        clean = getattr(self.optimizer, 'clean_deposits', None)
+        if clean is not None and not (self.used_direct and self._overwrites_table()):
+            clean(getattr(self.optimizer, 'flat_params', []))
+
     def _direct_ok(self):
         m, kw = self.model, self.render_kwargs
         if not (self.direct and m.training and getattr(m, 'bg_radius', 0) <= 0 and hasattr(m, '_fused_render_ok')):
@@ -195,7 +213,8 @@ class GraphedTrainStep:
                                                   self.captured_capacity, self.optimizer.scalars[0:1], 1 if bg is None else bg,
                                                   kw.get('perturb', False), kw.get('dt_gamma', 0), kw.get('max_steps', 1024),
                                                   kw.get('T_thresh', 1e-4), noise_seed=self.optimizer.scalars[3:4],
-                                                  found_inf=self.optimizer.scalars[2:3] if self.producers_check else None)
+                                                  found_inf=self.optimizer.scalars[2:3] if self.producers_check else None,
+                                                  overwrite_table=self._overwrites_table())
             self.used_direct = True
             return loss[0]
         self.used_direct = False
@@ -300,7 +319,8 @@ class GraphedTrainStep:
                                                       self.captured_capacity, opt.scalars[0:1], 1 if bg is None else bg,
                                                       kw.get('perturb', False), kw.get('dt_gamma', 0), kw.get('max_steps', 1024),
                                                       kw.get('T_thresh', 1e-4), noise_seed=self.la_seed[p:p + 1],
-                                                      found_inf=opt.scalars[2:3] if self._checked_ok else None)
+                                                      found_inf=opt.scalars[2:3] if self._checked_ok else None,
+                                                      overwrite_table=self._overwrites_table())
             gm, gr = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with _capture_into(gm, pool=pool_march):
                 march()
@@ -516,8 +536,10 @@ class GraphedTrainStep:
                 self.global_step += 1
                 return loss
         self.capacity = self.captured_capacity
+        self._clean_deposits()
         if self.la is not None:
             loss = self._step_lookahead(rays_o, rays_d, target, next_rays)
+            self._mark_deposits()
             m.local_step += 1
             self.global_step += 1
             return loss
@@ -537,6 +559,7 @@ class GraphedTrainStep:
             if len(self.graphs) == 2:
                 self.averager.all_reduce()
                 self.graphs[1].replay()
+        self._mark_deposits()
         # hand the sample count to the model's 16-slot ring exactly where the eager renderer would have put it
         m.step_counter[m.local_step % 16].copy_(self.counter[0], non_blocking=True)
         m.local_step += 1

@@ -288,10 +288,25 @@ class NGPAdam:
                         raise RuntimeError('NGPAdam: p.grad must be a contiguous float32 tensor')
                 elif 'grad16' in st:
                     grad, is_half = st['grad16'], 1
+                    if getattr(p, '_ngp_deposit_overwritten', False):
+                        # this step's producer WROTE the whole buffer (fused iteration with overwrite_table): the update kernel leaves it
+                        # alone instead of zeroing it -- it is stale from here on, until the next overwriting producer or a clean_deposits()
+                        is_half = 3
+                        p._ngp_deposit_overwritten = False
+                        p._ngp_grad16_stale = True
                 else:
                     continue
                 entries.append((p, st, grad, is_half, g['lr']))
         return entries
+
+    @staticmethod
+    def clean_deposits(params):
+        """zero the fp16 deposit buffers that an overwriting producer left stale (see `_entries`), before a producer that ADDS into them
+        or a step without a fresh deposit; a no-op otherwise (one Python attribute check per parameter)"""
+        for p in params:
+            if getattr(p, '_ngp_grad16_stale', False):
+                p._ngp_grad16.zero_()
+                p._ngp_grad16_stale = False
 
     def _deposit_used(self, st):
         # only checked on the eager path (never while capturing a graph: it reads the device)
@@ -341,11 +356,13 @@ class NGPAdam:
             self.gather_shadows()
             self.wait_shadows()
             return
+        # a deposit buffer that an overwriting producer left behind and nobody has overwritten since holds an OLD gradient
+        self.clean_deposits([p for p in self.flat_params if not getattr(p, '_ngp_deposit_overwritten', False)])
         omd = update_ema.begin_update() if update_ema is not None else 0.0
         entries = [(p.numel(), p, st['exp_avg'], st['exp_avg_sq'], grad, st.get('fp16'), is_half, lr,
                     update_ema.shadow_of(p) if update_ema is not None else None) for p, st, grad, is_half, lr in self._entries()]
         chunks = [entries[i:i + _MAX] for i in range(0, len(entries), _MAX)]
-        checked = gradients_checked and all(e[6] for e in entries)   # every gradient is a deposited fp16 buffer
+        checked = gradients_checked and all(e[6] & 1 for e in entries)   # every gradient is a deposited fp16 buffer
         if len(chunks) == 1:
             self._launch(chunks[0], (0 if checked else CHECK) | UPDATE | COMMIT, omd)
         else:

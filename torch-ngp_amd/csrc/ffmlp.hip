@@ -140,10 +140,79 @@ __device__ __forceinline__ void forward_fragment_source(uint32_t e, const half_t
     hi = i < 16 ? lo + 8 : nullptr;
 }
 
+// The WHOLE image from coalesced reads (round 4).  The gather below fetches every fragment element where it lies -- 64 lanes of a wave
+// read 8 bytes from 32 different weight rows: 32 cache lines per wave instruction, and the L1 serves one line per clock; four workgroups
+// per CU each fetching 20-24 KiB that way was most of the ~6 us every launch of the fused forward spent before its first tile.  Here the
+// weights are read as they lie, 16 bytes per lane (a wave instruction = 1 KiB contiguous = 8-16 lines), and each lane drops its eight
+// values into the image: one 16-byte LDS store on the input layer (an aligned run of 8 input features IS one fragment element), two
+// 8-byte stores on the hidden / output layers (features 16kb + 8q + 0..3 belong to half-wave 0, + 4..7 to half-wave 1, both at
+// element half q).  Rows that exist only as padding (output rows 16..31, rows >= WIDTH of a narrow network) are stored as zeros.
+template <int WIDTH>
+__device__ void build_forward_image_coalesced(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers) {
+    constexpr uint32_t NIB = Shape<WIDTH>::NIB, NKB = Shape<WIDTH>::NKB;
+    const uint32_t in_kb = in_dim / 16, in_segs = in_dim / 8;
+    constexpr uint32_t hid_segs = WIDTH / 8;
+    const uint32_t units_in = NIB * 32u * in_segs, units_hid = NIB * 32u * hid_segs, units_out = 32u * hid_segs;
+    const uint32_t total = units_in + (num_layers - 1) * units_hid + units_out;
+    const half_t* w_hid = w + (size_t)WIDTH * in_dim;
+    const half_t* w_out = w_hid + (size_t)(num_layers - 1) * WIDTH * WIDTH;
+    const half8_t zero8 = {(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+    constexpr int BATCH = 6;  // the fused network's images are 6 units per thread: all loads of a thread in flight before its first store
+    for (uint32_t u0 = threadIdx.x; u0 < total; u0 += BATCH * blockDim.x) {
+        half8_t v[BATCH];
+#pragma unroll
+        for (int b = 0; b < BATCH; b++) {
+            const uint32_t u = u0 + b * blockDim.x;
+            v[b] = zero8;
+            if (u < units_in) {
+                const uint32_t r = u / in_segs, sg = u % in_segs;
+                if (r < (uint32_t)WIDTH) v[b] = *reinterpret_cast<const half8_t*>(w + (size_t)r * in_dim + 8 * sg);
+            } else if (u < total - units_out) {
+                const uint32_t q = u - units_in, l = q / units_hid, rem = q % units_hid, r = rem / hid_segs, sg = rem % hid_segs;
+                if (r < (uint32_t)WIDTH) v[b] = *reinterpret_cast<const half8_t*>(w_hid + ((size_t)l * WIDTH + r) * WIDTH + 8 * sg);
+            } else if (u < total) {
+                const uint32_t q = u - (total - units_out), r = q / hid_segs, sg = q % hid_segs;
+                if (r < 16u) v[b] = *reinterpret_cast<const half8_t*>(w_out + (size_t)r * WIDTH + 8 * sg);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < BATCH; b++) {
+            const uint32_t u = u0 + b * blockDim.x;
+            if (u >= total) continue;
+            if (u < units_in) {
+                const uint32_t r = u / in_segs, sg = u % in_segs, ib = r / 32u, i = r % 32u, kb = sg / 2u, h = sg % 2u;
+                img[(ib * in_kb + kb) * 64u + h * 32u + i] = v[b];
+            } else {
+                uint32_t frag0, r, sg;
+                if (u < total - units_out) {
+                    const uint32_t q = u - units_in, l = q / units_hid, rem = q % units_hid;
+                    r = rem / hid_segs; sg = rem % hid_segs;
+                    frag0 = NIB * in_kb + l * NIB * NKB + (r / 32u) * NKB;
+                } else {
+                    const uint32_t q = u - (total - units_out);
+                    r = q / hid_segs; sg = q % hid_segs;
+                    frag0 = NIB * in_kb + (num_layers - 1) * NIB * NKB;
+                }
+                const uint32_t i = r % 32u, kb = sg / 2u, q2 = sg % 2u;
+                half4_t* e0 = reinterpret_cast<half4_t*>(img + (frag0 + kb) * 64u + i) + q2;         // half-wave 0, element half q2
+                half4_t* e1 = reinterpret_cast<half4_t*>(img + (frag0 + kb) * 64u + 32u + i) + q2;   // half-wave 1
+                *e0 = half4_t{v[b][0], v[b][1], v[b][2], v[b][3]};
+                *e1 = half4_t{v[b][4], v[b][5], v[b][6], v[b][7]};
+            }
+        }
+    }
+}
+
 // fragments [first_frag, first_frag + n_frags) of the image order land at img[0 ...] (default: the whole image)
 template <int WIDTH>
 __device__ void build_forward_image(half8_t* img, const half_t* __restrict__ w, uint32_t in_dim, uint32_t num_layers, uint32_t first_frag = 0,
                                     uint32_t n_frags = 0xFFFFFFFFu) {
+#ifndef NGP_FF_IMAGE_GATHER
+    if (first_frag == 0u && n_frags == 0xFFFFFFFFu && (in_dim & 15u) == 0u) {
+        build_forward_image_coalesced<WIDTH>(img, w, in_dim, num_layers);
+        return;
+    }
+#endif
     const uint32_t all = fwd_frag_count<WIDTH>(in_dim, num_layers);
     const uint32_t total = (n_frags == 0xFFFFFFFFu ? all : n_frags) * 64;
     const uint32_t shift = first_frag * 64;

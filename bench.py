@@ -87,9 +87,28 @@ TIMED = {
     # near/far + both passes of march_rays_train: 32 B written per sample (xyz, dir, deltas) + 48 B per ray (origins, directions, rays, near/far)
     'ngp_march_rays_train_aabb': ('march_rays_train (+ near/far)', 9, lambda a: 32.0 + 48.0 * a[6] / max(a[9], 1), lambda a: 0.0, 'sample'),
     # Adam + loss-scale logic + fp16 shadows + gradient zeroing over every parameter: fp32 master / two moments read and written (24 B),
-    # fp16 gradient read and zeroed (4 B), fp16 shadow written (2 B) = 30 B per parameter.  Only the calls that UPDATE are rows.
-    'ngp_optim_adam_step_ex': ('k_adam (Adam + scaler + shadows + gradient zeroing)', lambda a: _adam_params(a), lambda a: 30.0, lambda a: 0.0, 'parameter'),
+    # fp16 gradient read and zeroed (4 B; 2 B when the producer overwrites the buffer and the kernel keeps it), fp16 shadow written (2 B) = 30 (28) B
+    # per parameter.  Only the calls that UPDATE are rows.
+    'ngp_optim_adam_step_ex': ('k_adam (Adam + scaler + shadows + gradient zeroing)', lambda a: _adam_params(a), lambda a: _adam_bytes(a), lambda a: 0.0, 'parameter'),
 }
+
+
+def _adam_bytes(a):
+    """bytes per parameter of one update call: 30, or 28 for a tensor whose gradient buffer is kept (grad_is_half & 2: not zeroed)"""
+    import ctypes
+    k = int(a[0])
+    if k == 0 or not a[1] or not a[7]:
+        return 30.0
+    n = ctypes.cast(a[1], ctypes.POINTER(ctypes.c_uint64))
+    h = ctypes.cast(a[7], ctypes.POINTER(ctypes.c_int))
+    tot = sum(n[i] for i in range(k))
+    return sum(n[i] * (28.0 if (h[i] & 2) else 30.0) for i in range(k)) / max(tot, 1)
+
+
+def _fused_switches():
+    """the optional launch fusions / modes of fused.py as this run had them (--ab-off and the NGP_FUSED_* environment switches change them)"""
+    import fused
+    return {k: bool(getattr(fused, k)) for k in sorted(dir(fused)) if k.startswith('USE_')}
 
 
 def _adam_params(a):
@@ -525,7 +544,8 @@ def main():
                     '(graph.GraphedTrainStep(lookahead=True): single rank, fused + graph + NGPAdam only)')
     ap.add_argument('--no-dropin', action='store_true', help='skip the second, drop-in-surface-only measurement')
     ap.add_argument('--ab-off', default='', help='A/B measurement: comma-separated optional launch fusions of fused.py to switch OFF '
-                    '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID, USE_FUSED_SCAN, USE_FUSED_CHECK); recorded in config.fusions_off')
+                    '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID, USE_FUSED_SCAN, USE_FUSED_CHECK, USE_SLABS_IN_ACCUMULATE, USE_OVERWRITE_TABLE, ...); '
+                    'recorded in config.fusions_off, every switch in config.fused_switches')
     ap.add_argument('--dropin-steps', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the untimed extra workloads: sdf_encoder_mlp (BASELINE config 4) and tnt_bound8 (config 5)')
@@ -796,6 +816,7 @@ def main():
                        'rays_per_s': round(run.rays * world * args.steps / elapsed, 1), 'parallelism': par,
                        'sharded_update_fallback': fallback,
                        'execution': run.execution(), 'setup_iterations_untimed': SETUP_ITERATIONS, 'fusions_off': fusions_off,
+                       'fused_switches': _fused_switches(),
                        'captures_in_timed_region': res['captures'],
                        'host_issue_ms_per_step': round(res['issued'] / args.steps * 1e3, 4), 'host_ms_per_step_unblocked': res.get('host_first'),
                        'autograd_free_iteration': bool(stepper.used_direct), 'fused_pipeline': bool(model.fused),

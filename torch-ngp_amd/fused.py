@@ -419,6 +419,10 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     rays_o/rays_d [N,3] fp32, target [N,3] fp32, loss_scale: device scalar (NGPAdam.scalars[0:1]) or None.  noise_seed: optional
     4-byte device word that changes from step to step (NGPAdam's step count); with perturb=True the marcher then draws the per-ray start
     offsets itself (NGP_MARCH_NOISE_FROM_SEED) instead of reading a torch.rand tensor.
+    overwrite_table: the table's deposit buffer RECEIVES this iteration's gradient (every entry written, nothing added, nothing read) and
+    the next optimizer step keeps the buffer instead of zeroing it (optim.NGPAdam reads the flag this call leaves on the parameter) --
+    for a loop that steps the optimizer after every iteration (graph.GraphedTrainStep); gradients do not accumulate across calls in
+    this mode, and producers that add (the autograd paths) find the buffer zeroed first (`_optimizer_buffers`).
     -> (loss [1] fp32, image [N,3], depth [N], weights_sum [N]); same arithmetic as model.render + mse_loss + scaled backward
     (tests/test_gpu_graph.py)."""
     cfg = network_cfg(model.encoder, model.sigma_net, model.color_net, model.bound, True)

@@ -290,3 +290,50 @@ def test_two_rank_sharded_render_gathers_the_full_frame():
         assert same_img and same_depth, 'gathered frame differs from the one-rank frame'
         assert ishape == (1, 1001, 3) and dshape == (1, 1001)
     assert out[0][4] == [501] and out[1][4] == [500]   # each rank rendered only its block of rows
+
+
+def test_kept_deposit_buffer_protocol_on_the_host():
+    """optim.NGPAdam's bookkeeping around a gradient buffer its producer OVERWRITES (fused.fused_train_iteration(overwrite_table=True)):
+    the step that follows hands the buffer to the kernel with grad_is_half = 3 (bit 1: keep, do not zero), marks it stale, and every later
+    consumer that is not another overwriting producer finds it zeroed first.  Host logic only (the kernel double honours the keep bit)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "torch-ngp_amd"))
+    Double = _make_double()
+    seen = []
+
+    class Recording(Double):
+        def _launch(self, entries, phases, omd):
+            seen.append([e[6] for e in entries])
+            kept = [(e[4], e[4].clone()) for e in entries if e[6] & 2]
+            super()._launch(entries, phases, omd)
+            for buf, old in kept:      # the keep bit: the update leaves the gradient buffer as it found it
+                buf.copy_(old)
+
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(64, 2) * 0.1), torch.nn.Parameter(torch.randn(128) * 0.1)]
+    opt = Recording([{'params': params, 'lr': 1e-2}], betas=(0.9, 0.99), eps=1e-15, init_scale=1.0)
+    table, mlp = params
+    # step 1: an overwriting producer wrote the table's buffer, an adding producer the other one
+    table._ngp_grad16.copy_(torch.full((64, 2), 0.5))
+    table._ngp_deposit_overwritten = True
+    mlp._ngp_grad16.copy_(torch.full((128,), 0.25))
+    before = table.detach().clone()
+    opt.step()
+    assert seen[-1] == [3, 1]
+    assert not table._ngp_deposit_overwritten and table._ngp_grad16_stale
+    assert float(table._ngp_grad16.float().min()) == 0.5 and float(mlp._ngp_grad16.float().abs().max()) == 0.0   # kept / zeroed
+    assert not torch.equal(table.detach(), before)
+    # step 2: nobody deposits into the table: its stale buffer must not be applied again
+    after1 = table.detach().clone()
+    m1 = opt.state[table]['exp_avg'].clone()
+    opt.step()
+    assert seen[-1] == [1, 1] and not table._ngp_grad16_stale and float(table._ngp_grad16.float().abs().max()) == 0.0
+    assert torch.allclose(opt.state[table]['exp_avg'], m1 * 0.9)           # a zero gradient: the first moment only decays
+    assert not torch.equal(table.detach(), after1)                            # (Adam still moves along its momentum)
+    # step 3: overwrite again, then an ADDING producer asks for the buffers: clean_deposits zeroes what is stale
+    table._ngp_grad16.fill_(1.0)
+    table._ngp_deposit_overwritten = True
+    opt.step()
+    assert table._ngp_grad16_stale
+    opt.clean_deposits(params)
+    assert not table._ngp_grad16_stale and float(table._ngp_grad16.float().abs().max()) == 0.0

@@ -196,7 +196,7 @@ SETUP_ITERATIONS = 33  # 16 worst-case-sized eager steps + the first estimate-si
 class TrainingRun:
     """one configuration of the training workload (model + optimizer + stepper + resident batches) and its timing protocol"""
 
-    def __init__(self, args, dev, world, rank, fused, graph, torch_optim, autograd, rays=None, config5=False):
+    def __init__(self, args, dev, world, rank, fused, graph, torch_optim, autograd, rays=None, config5=False, force_ddp=False):
         import raymarching
         import synthetic_scene as sc
         import ddp
@@ -204,6 +204,9 @@ class TrainingRun:
         from ddp import GradientAverager
         from graph import GraphedTrainStep, mse_loss
         self.args, self.dev, self.world, self.rank, self.use_graph, self.torch_optim = args, dev, world, rank, graph, torch_optim
+        # force_ddp: the data-parallel step (sharded update, collectives, occupancy exchange) on ONE rank over a 1-rank process group -- every
+        # RCCL call executes, the exchange is the identity (`ddp_overhead_1rank`: the only way to run RCCL on a one-GPU box)
+        ddp_on = self.ddp_on = world > 1 or bool(force_ddp)
         self.rays = int(rays if rays is not None else args.rays)   # rays per GPU and step
         torch.manual_seed(0)  # identical parameters on every rank (FFMLP reseeds to 42 itself)
         self.config5 = config5
@@ -230,14 +233,15 @@ class TrainingRun:
             # the reference's pair (main_nerf.py:132, nerf/utils.py:393): torch Adam (fused, capturable) + GradScaler
             optimizer = torch.optim.Adam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, fused=True, capturable=True)
             scaler = torch.amp.GradScaler('cuda')
-            averager = GradientAverager(model, world) if world > 1 else None
+            averager = GradientAverager(model, world) if ddp_on else None
         else:
             # same update rule and scale dynamics in one fused device-side step (torch-ngp_amd/optim.py)
             from optim import NGPAdam
             # N > 1: ZeRO-1-style sharded update (reduce-scatter -> Adam on 1/N -> all-gather of the fp16 shadows under the next march);
             # --replicated-optim selects the all-reduce + full update on every rank instead
             optimizer = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, world_size=world,
-                                shard=world > 1 and not args.replicated_optim)
+                                shard=('force' if force_ddp else True) if (ddp_on and not args.replicated_optim) else False,
+                                verdict=getattr(args, 'shard_verdict', 'poison'))
             self.shard_fallback = None
             if optimizer.shard:
                 # the three collectives of the sharded update, exercised once on zero gradients before anything is captured: if this
@@ -252,7 +256,7 @@ class TrainingRun:
                     self.shard_fallback = repr(e)[:200]
                     optimizer = NGPAdam(model.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15, world_size=world, shard=False)
             scaler = None
-            averager = optimizer if world > 1 else None
+            averager = optimizer if ddp_on else None
         # a pool of pre-generated batches resident in HBM (one camera each, 4096 random pixels)
         self.n_pool = 16
         self.pool = []
@@ -267,14 +271,14 @@ class TrainingRun:
 
         def keep_scene(m):
             # N > 1: the occupancy exchange of the data-parallel path (element-wise MAX of the grid + re-pack + common sample estimate)
-            if world > 1:
+            if ddp_on:
                 ddp.sync_occupancy(m)
             # the synthetic scene keeps its analytic occupancy: the refresh work is done, its result is discarded
             m.density_grid.copy_(occ)
             m.density_bitfield.copy_(fixed_bits)
         self.keep_scene = keep_scene
         self.model, self.optimizer = model, optimizer
-        self.lookahead = graph and fused and not torch_optim and not autograd and world == 1 and not getattr(args, 'no_lookahead', False)
+        self.lookahead = graph and fused and not torch_optim and not autograd and not ddp_on and not getattr(args, 'no_lookahead', False)
         self.stepper = GraphedTrainStep(model, optimizer, scaler, self.rays, self.opt_kwargs, loss_fn=mse_loss, averager=averager,
                                         after_update=keep_scene, direct=not autograd, lookahead=self.lookahead)
         self.step_no = 0
@@ -296,8 +300,9 @@ class TrainingRun:
             loss = stepper._eager(rays_o, rays_d, gt)
             stepper.global_step += 1
         else:
-            if self.lookahead:
-                # the data loader's next batch is known one step early: its march runs under this iteration
+            if self.lookahead or self.ddp_on:
+                # the data loader's next batch is known one step early: its march runs under this iteration (single GPU: side stream;
+                # sharded data-parallel step: behind the shard update, in the same graph replay)
                 nxt = self.pool[self.step_no % self.n_pool]
                 loss = stepper.step(rays_o, rays_d, gt, next_rays=nxt)
             else:
@@ -505,6 +510,87 @@ def cpu_baselines(args):
     return cpu
 
 
+def ddp_overhead_1rank(args, dev, steps):
+    """The data-parallel training step on the ONE GPU of this box, over a 1-rank RCCL process group: the sharded update of optim.NGPAdam
+    (`shard='force'`: reduce_scatter_tensor(AVG, fp16) -> verdict -> Adam on the shard -> in-place all_gather_into_tensor on the
+    communication stream), the occupancy exchange (two all-reduces per refresh) and the graph replays between the collectives all EXECUTE
+    (the exchange is the identity at one rank), so their fixed cost per step is measured instead of projected: HIP-graph boundaries, RCCL
+    launches, stream hand-overs.  Timed like the headline (same batches, same protocol), next to the single-GPU step WITHOUT the lookahead
+    side stream (the apples-to-apples baseline: the data-parallel step cannot hide the march on a side stream).  What it cannot show is wire
+    time: DESIGN.md section 7 adds that on top.  Runs after everything else (a process group changes the capture mode of later graphs)."""
+    import socket
+    out = {'backend': None, 'steps': steps}
+    try:
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        torch.cuda.synchronize()
+        out['backend'] = f'{dist.get_backend()} (RCCL), {dist.get_world_size()} rank, all_reduce proof = {int(ones.item())}'
+
+        def one(**kw):
+            run = TrainingRun(args, dev, 1, 0, fused=True, graph=True, torch_optim=False, autograd=False, **kw)
+            return run
+        # single-GPU step without the lookahead side stream, same process, same moment
+        saved = getattr(args, 'no_lookahead', False)
+        args.no_lookahead = True
+        base = one()
+        base.setup(min(args.warmup, 16))
+        r = base.timed(steps)
+        out['single_gpu_no_lookahead_ms_per_step'] = round(r['elapsed'] / steps * 1e3, 4)
+        del base
+        args.no_lookahead = saved
+        for name, premarch, verdict in (('sharded_2_replays_march_folded_behind_update', True, 'poison'),
+                                        ('sharded_3_replays', False, 'poison'),
+                                        ('sharded_3_replays_verdict_allreduce', False, 'allreduce')):
+            args.shard_verdict = verdict
+            run = one(force_ddp=True)
+            run.stepper.sharded_premarch = premarch
+            run.setup(min(args.warmup, 16))
+            r = run.timed(steps)
+            st, opt = run.stepper, run.optimizer
+            entry = {'ms_per_step': round(r['elapsed'] / steps * 1e3, 4), 'samples_per_s': round(r['samples'] / r['elapsed'], 1),
+                     'sharded_graphs': bool(getattr(st, 'sharded', False)), 'premarch_hits': int(getattr(st, 'premarch_hits', 0)),
+                     'captures_in_timed_region': r['captures'], 'capture_error': st.capture_error, 'final_loss': r['final_loss'],
+                     'host_issue_ms_per_step': round(r['issued'] / steps * 1e3, 4)}
+            # the two collectives alone, HIP events on the issuing stream, eager, after the timed region
+            ev = {}
+            for cname, fn in (('reduce_scatter_fp16_24MB', opt.reduce_gradients), ('all_gather_fp16_24MB', lambda: opt.gather_shadows(async_op=False))):
+                ts = []
+                for _ in range(6):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); fn(); e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                ev[cname] = round(float(np.median(ts[1:])), 4)
+            entry['collective_ms_1rank'] = ev
+            opt.wait_shadows()
+            torch.cuda.synchronize()
+            out[name] = entry
+            del run, st, opt
+        args.shard_verdict = 'poison'
+        best = min(out[k]['ms_per_step'] for k in out if isinstance(out[k], dict) and 'ms_per_step' in out[k])
+        out['ddp_overhead_ms_per_step'] = round(best - out['single_gpu_no_lookahead_ms_per_step'], 4)
+        out['note'] = ('1-rank RCCL group: every collective and every graph boundary of the N > 1 step executes, wire time is zero; '
+                       'ddp_overhead = best sharded step - single-GPU step without lookahead')
+    except Exception as e:  # noqa: BLE001 -- a probe: the headline line must not depend on it
+        import traceback
+        out['error'] = repr(e)[:300]
+        out['traceback_tail'] = traceback.format_exc()[-600:]
+    finally:
+        try:
+            if dist.is_initialized():
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: replace this process by
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`,
@@ -555,6 +641,12 @@ def main():
                     help='N > 1: weak = --rays per GPU (global batch grows with N, the headline); strong = --rays in total, --rays / N per GPU')
     ap.add_argument('--no-strong', action='store_true', help='N > 1, --scaling weak: skip the secondary strong-scaling measurement (`strong_scaling`)')
     ap.add_argument('--strong-steps', type=int, default=128)
+    ap.add_argument('--force-ddp', action='store_true', help='--gpus 1 only: the HEADLINE run itself goes through the data-parallel step over a 1-rank RCCL group '
+                    '(sharded update, collectives, occupancy exchange); the default line carries the same measurement as `ddp_overhead_1rank`')
+    ap.add_argument('--no-ddp-probe', action='store_true', help='skip the `ddp_overhead_1rank` measurement (N = 1 only)')
+    ap.add_argument('--ddp-steps', type=int, default=128)
+    ap.add_argument('--shard-verdict', choices=('poison', 'allreduce'), default='poison',
+                    help="sharded update: how the global skip verdict travels (optim.NGPAdam(verdict=...))")
     ap.add_argument('--watchdog', type=float, default=900.0, help='seconds after which a run that has not finished dumps every thread\'s stack to stderr '
                     'and exits non-zero (a hung collective must not hang the box); 0 disables')
     args = ap.parse_args()
@@ -583,7 +675,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     comm = {'backend': None, 'rccl_ranks': None}
-    if world > 1:
+    if args.force_ddp and world != 1:
+        raise SystemExit('bench.py: --force-ddp is the one-rank form of the data-parallel step (--gpus 1)')
+    if args.force_ddp:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if world > 1 or args.force_ddp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('NGP_BENCH_BACKEND', 'nccl')  # 'nccl' is RCCL on ROCm
         if backend == 'nccl':
@@ -612,7 +711,7 @@ def main():
 
     rays_per_gpu = args.rays if args.scaling == 'weak' else max(128, args.rays // world)
     run = TrainingRun(args, dev, world, rank, fused=not args.no_fused, graph=not args.no_graph, torch_optim=args.torch_optim,
-                      autograd=args.autograd, rays=rays_per_gpu)
+                      autograd=args.autograd, rays=rays_per_gpu, force_ddp=args.force_ddp)
     run.setup(args.warmup)
     res = run.timed(args.steps)
     elapsed, samples = res['elapsed'], res['samples']
@@ -639,7 +738,7 @@ def main():
                 return out
             return call
         if getattr(opt, 'shard', False):
-            opt.reduce_gradients = timed_call('reduce_scatter_fp16_gradients_plus_verdict', opt.reduce_gradients)
+            opt.reduce_gradients = timed_call('reduce_scatter_fp16_gradients', opt.reduce_gradients)
             opt._all_gather = timed_call('all_gather_fp16_shadows', opt._all_gather)
         else:
             opt.all_reduce = timed_call('all_reduce_fp16_gradients', opt.all_reduce)
@@ -683,7 +782,7 @@ def main():
                              'algorithmic_GBps': round(nbytes * (world - 1) / world / (float(np.median(ms)) * 1e-3) / 1e9, 1)}
         for name in ('reduce_gradients', '_all_gather', 'all_reduce'):   # un-wrap: the instance attributes shadow the methods
             run.optimizer.__dict__.pop(name, None)
-    if world > 1 and getattr(run.optimizer, 'shard', False):
+    if getattr(run.optimizer, 'shard', False):
         run.optimizer.wait_shadows()
         run.optimizer.gather_master()  # collective: every rank's fp32 master weights complete again (every rank renders with them below)
         torch.cuda.synchronize()
@@ -785,6 +884,10 @@ def main():
                'execution': t_run.execution(), 'captures_in_timed_region': t_res['captures']}
         del t_run
 
+    ddp1 = None
+    if rank == 0 and world == 1 and not args.force_ddp and not args.no_ddp_probe and not args.torch_optim and not args.no_fused and not args.no_graph:
+        torch.cuda.synchronize()
+        ddp1 = ddp_overhead_1rank(args, dev, max(16, min(args.ddp_steps, max(args.steps, 64))))
     if rank == 0:
         roof = None
         for r in roofs:
@@ -797,7 +900,7 @@ def main():
             cpu = cpu_baselines(args)
         sharded = bool(getattr(run.optimizer, 'shard', False))
         fallback = getattr(run, 'shard_fallback', None)
-        if world == 1:
+        if world == 1 and not args.force_ddp:
             par = 'dp1'
         elif sharded:
             par = f'dp{world} (reduce-scatter, sharded Adam, all-gather of fp16 shadows)'
@@ -823,10 +926,10 @@ def main():
                        'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
                        'final_loss': res['final_loss']},
             'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'dropin_path': dropin, 'render_800x800_ms': render,
-            'strong_scaling': strong, 'collectives': comm_ms, 'sdf_encoder_mlp': sdf, 'tnt_bound8': tnt,
+            'strong_scaling': strong, 'collectives': comm_ms, 'sdf_encoder_mlp': sdf, 'tnt_bound8': tnt, 'ddp_overhead_1rank': ddp1,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -443,12 +443,13 @@ int ngp_composite_rays_train_backward_ex(const float* grad_weights_sum, const fl
  *   loss may be NULL: the sum is then left to the caller (ngp_grid_encode_backward_checked_slabs carries it); ray_err [N] holds the per-ray squared errors.
  *   ray_err [N] fp32: scratch.  march_workspace: the workspace ngp_march_rays_train_ex filled for these rays, all
  *        ngp_march_rays_train_workspace_bytes(N) bytes of it (word 0 = rows handed out, word 1 and the 32 words at its end, 128 bytes
- *        apart = tickets that call leaves at 0 and this one returns to 0). */
+ *        apart = tickets that call leaves at 0 and this one returns to 0).  march_workspace_bytes: the size of that buffer -- a call with fewer
+ *        than ngp_march_rays_train_workspace_bytes(N) bytes is refused (the group tickets sit at its end). */
 int ngp_composite_train_loss_backward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays, uint32_t M,
                                       uint32_t N, float T_thresh, int bg_mode, float bg_scalar, const float* bg, const float* nears,
                                       const float* fars, const float* target, const float* loss_scale, float* weights_sum,
                                       float* image_out, float* depth_out, float* loss, float* ray_err, float* grad_sigmas,
-                                      void* grad_out16, void* march_workspace, ngp_stream_t stream);
+                                      void* grad_out16, void* march_workspace, size_t march_workspace_bytes, ngp_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * freqencoder       (reference: freqencoder/src/freqencoder.h:6-10, bindings.cpp:5-8) -- SURVEY.md 8(f).3, fp32 only.
@@ -492,6 +493,13 @@ int ngp_optim_adam_step_ex(int count, const uint64_t* n, float* const* params, f
                            void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
                            float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
                            float* state, float* const* ema, float ema_one_minus_decay, uint32_t phases, ngp_stream_t stream);
+/* Data-parallel sharded update (one process per GPU, reduce-scatter -> Adam on 1/world -> all-gather; the reference's dormant DDP hook,
+ * nerf/utils.py:364-366, all-reduces everything): the global "skip this step" verdict without a collective of its own.
+ * ngp_optim_poison_shards: when state[2] (found_inf of THIS rank's local gradient) is set, writes NaN into element 0 of each of the `shards`
+ * shards (of `payload` fp16 elements) of the flat gradient, BEFORE the reduce-scatter; ngp_optim_shard_verdict: AFTER it, sets state[2] when
+ * element 0 of this rank's averaged shard is not finite.  Both are single tiny launches, graph-capturable. */
+int ngp_optim_poison_shards(void* flat_grad_fp16, uint32_t shards, uint64_t payload, const float* state, ngp_stream_t stream);
+int ngp_optim_shard_verdict(const void* shard_grad_fp16, float* state, ngp_stream_t stream);
 /* torch_ema's update() on its own (the Trainer calls it once per epoch): ema[k] -= one_minus_decay * (ema[k] - params[k]), up to 8
  * tensors per call */
 int ngp_optim_ema_update(int count, const uint64_t* n, float* const* params, float* const* ema, float one_minus_decay, ngp_stream_t stream);

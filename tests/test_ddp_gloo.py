@@ -98,6 +98,15 @@ def _make_double():
                         s[0] *= self.growth_factor
                         s[1] = 0.0
                 s[2] = 0.0
+
+        # documented semantics of ngp_optim_poison_shards / ngp_optim_shard_verdict (include/ngp_hip.h)
+        def _poison_launch(self):
+            if self.scalars[2] != 0:
+                self.flat_grad16.view(self.world_size, self.payload)[:, 0] = float('nan')
+
+        def _verdict_launch(self):
+            if not torch.isfinite(self.shard_grad[0].float()):
+                self.scalars[2] = 1.0
     return TorchKernelDouble
 
 
@@ -106,7 +115,7 @@ def _grads_for(rank, step, shapes, scale):
     return [(torch.randn(*s, generator=g) * 1e-3 * scale).half() for s in shapes]
 
 
-def _optim_worker(rank, world, port, out, shard):
+def _optim_worker(rank, world, port, out, shard, verdict='poison'):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, 'torch-ngp_amd'))
@@ -117,7 +126,15 @@ def _optim_worker(rank, world, port, out, shard):
     torch.manual_seed(0)
     params = [torch.nn.Parameter(torch.randn(*s) * 0.1) for s in shapes]
     opt = Double([{'params': params[:1], 'lr': 1e-2}, {'params': params[1:], 'lr': 3e-3}], betas=(0.9, 0.99), eps=1e-15, init_scale=1024.0,
-                 growth_interval=3, world_size=world, shard=shard)
+                 growth_interval=3, world_size=world, shard=shard, verdict=verdict)
+    n_collectives = []
+    if shard:   # count the collectives of one sharded step: the poisoned verdict must not add one
+        real_ar = dist.all_reduce
+
+        def counting_all_reduce(t, *a, **k):
+            n_collectives.append(t.numel())
+            return real_ar(t, *a, **k)
+        dist.all_reduce = counting_all_reduce
     # single-process reference: torch Adam on the fp16 average of the two ranks' gradients, GradScaler dynamics restated
     ref = [torch.nn.Parameter(p.detach().clone()) for p in params]
     topt = torch.optim.Adam([{'params': ref[:1], 'lr': 1e-2}, {'params': ref[1:], 'lr': 3e-3}], betas=(0.9, 0.99), eps=1e-15)
@@ -131,7 +148,10 @@ def _optim_worker(rank, world, port, out, shard):
         for p, g in zip(params, per_rank[rank]):
             p._ngp_grad16.copy_(g)
         if shard:
+            n_collectives.clear()
             opt.step()
+            # gloo stand-in of the reduce-scatter = ONE all-reduce of the flat buffer; verdict='allreduce' adds the 1-element one
+            ok = ok and sorted(n_collectives) == ([opt.total] if verdict == 'poison' else [1, opt.total])
         else:
             opt.all_reduce()
             opt.step()
@@ -151,6 +171,7 @@ def _optim_worker(rank, world, port, out, shard):
             ok = ok and float(p._ngp_grad16.abs().max()) == 0.0   # consumed and zeroed everywhere
     ck_worst = ema_worst = 0.0
     if shard:
+        dist.all_reduce = real_ar
         # between steps a rank holds only ITS shard of the fp32 master weights current.  A model-only ("best") checkpoint, the EMA's
         # store() and sync_shadows() must complete them from the owners first: no explicit gather_master() here
         import io
@@ -188,17 +209,53 @@ def _optim_worker(rank, world, port, out, shard):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('shard', [False, True])
-def test_two_rank_ngp_adam_exchange(shard):
+@pytest.mark.parametrize('shard,verdict', [(False, 'poison'), (True, 'poison'), (True, 'allreduce')])
+def test_two_rank_ngp_adam_exchange(shard, verdict):
+    """step 2: only rank 1 overflows, in a region rank 0 owns; step 5: only rank 0, in rank 1's region -- both ranks must skip both steps.
+    verdict='poison': the skip verdict travels inside the reduce-scatter (NaN in element 0 of every shard), no collective of its own."""
     world = 2
     port = _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_optim_worker, args=(world, port, out, shard), nprocs=world, join=True)
+    mp.spawn(_optim_worker, args=(world, port, out, shard, verdict), nprocs=world, join=True)
     for r in range(world):
         ok, worst, shadows_ok, mom, same, steps = out[r]
         assert ok, 'loss-scale dynamics / gradient zeroing differ from the single-process reference'
         assert worst < 5e-6 and mom < 1e-6, (worst, mom)
         assert shadows_ok and same and steps == 5.0   # 7 iterations, 2 skipped on BOTH ranks
+
+
+def _roll_call_worker(rank, world, port, out):
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'torch-ngp_amd'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from checkpoint import _all_ranks_here
+    opt = types.SimpleNamespace(group=None)
+    res = []
+    for use_store in (True, False):          # the store counter (what an RCCL group gets) and gloo's monitored_barrier
+        _all_ranks_here(opt, timeout_s=20.0, use_store=use_store)      # everybody calls: passes
+        res.append('ok')
+    dist.barrier()
+    if rank == 0:                             # the reference's rank-0 guard around save_checkpoint: an error, not a hang
+        try:
+            _all_ranks_here(opt, timeout_s=1.0, use_store=True)
+            res.append('no error')
+        except RuntimeError as e:
+            res.append('collective' in str(e) and '1 of 2' in str(e))
+    dist.barrier()
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def test_sharded_checkpoint_roll_call_is_backend_independent():
+    """the roll call in front of a sharded save_checkpoint must not depend on gloo's monitored_barrier (an RCCL group has none):
+    a counter in the rendezvous store; a call from rank 0 alone is an error within the timeout"""
+    world = 2
+    out = mp.Manager().dict()
+    mp.spawn(_roll_call_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert out[0] == ['ok', 'ok', True] and out[1] == ['ok', 'ok']
 
 
 def _occ_worker(rank, world, port, out):
@@ -337,3 +394,12 @@ def test_kept_deposit_buffer_protocol_on_the_host():
     assert table._ngp_grad16_stale
     opt.clean_deposits(params)
     assert not table._ngp_grad16_stale and float(table._ngp_grad16.float().abs().max()) == 0.0
+    # a consumer that would AVERAGE a stale buffer (replicated all-reduce with nothing deposited since the overwriting step) refuses loudly
+    table._ngp_grad16.fill_(1.0)
+    table._ngp_deposit_overwritten = True
+    opt.step()
+    opt.world_size = 2       # (no process group here: the refusal comes before any collective)
+    with pytest.raises(RuntimeError, match='stale'):
+        opt.all_reduce()
+    opt.world_size = 1
+    opt.clean_deposits(params)

@@ -35,7 +35,7 @@ def test_bench_two_ranks_share_one_gpu(extra):
     assert line['scaling'] == 'weak' and line['config']['global_rays_per_step'] == 8192
     coll = line['collectives']
     assert coll['message_bytes'] > 2 * 12_000_000
-    for name in (['all_reduce_fp16_gradients'] if extra else ['reduce_scatter_fp16_gradients_plus_verdict', 'all_gather_fp16_shadows']):
+    for name in (['all_reduce_fp16_gradients'] if extra else ['reduce_scatter_fp16_gradients', 'all_gather_fp16_shadows']):
         assert coll[name]['ms'] > 0 and coll[name]['calls'] >= 4
     st = line['strong_scaling']
     assert st['scaling'] == 'strong' and st['rays_per_gpu_per_step'] == 2048 and st['global_rays_per_step'] == 4096

@@ -426,7 +426,7 @@ def test_fused_composite_loss_backward_is_bit_identical_to_the_four_kernels(bg_m
         assert capi.lib.ngp_composite_train_loss_backward(sigma.data_ptr(), rgb.data_ptr(), deltas.data_ptr(), rays.data_ptr(), M, N, 1e-4, bg_mode,
                                                           0.7, capi.ptr(bg), nears.data_ptr(), fars.data_ptr(), target.data_ptr(), capi.ptr(scale),
                                                           wsum2.data_ptr(), image2.data_ptr(), depth2.data_ptr(), loss2.data_ptr(), err.data_ptr(),
-                                                          gs2.data_ptr(), g16b.data_ptr(), ws.data_ptr(), st) == 0
+                                                          gs2.data_ptr(), g16b.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(), st) == 0
         torch.cuda.synchronize()
         assert int(ws[1]) == 0 and int(ws[0]) == rows_used and int(ws[2:].abs().sum()) == 0    # every ticket is back at 0
         assert torch.equal(wsum, wsum2) and torch.equal(image, image2) and torch.equal(depth, depth2)

@@ -23,7 +23,7 @@ NGP_F32, NGP_F16 = 0, 1
 NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR, NGP_FF_LAYERED, NGP_FF_SINGLE_WAVE, NGP_FF_DEFER_REDUCE, NGP_FF_RECOMPUTE = 1, 2, 4, 8, 16, 32
 NGP_MARCH_RESET_COUNTER, NGP_MARCH_ZERO_TAIL, NGP_MARCH_NOISE_FROM_SEED, NGP_MARCH_SCAN_LAUNCH = 1, 2, 4, 8
 NGP_OPT_PHASE_CHECK, NGP_OPT_PHASE_UPDATE, NGP_OPT_PHASE_COMMIT = 1, 2, 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -91,12 +91,14 @@ _SIGNATURES = {
     'ngp_composite_rays_train_forward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_composite_rays_train_backward_ex': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp, _vp, _i32, _f32, _vp, _vp, _vp],
     'ngp_composite_train_loss_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                          _vp, _vp, _vp],
+                                          _vp, _vp, _sz, _vp],
     'ngp_network_backward_color': [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _f32, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_reduce_slabs_pair': [_vp, _u32, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     'ngp_optim_adam_step': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
     'ngp_optim_adam_step_ex': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _u32, _vp],
     'ngp_optim_ema_update': [_i32, _vp, _vp, _vp, _f32, _vp],
+    'ngp_optim_poison_shards': [_vp, _u32, ctypes.c_uint64, _vp, _vp],
+    'ngp_optim_shard_verdict': [_vp, _vp, _vp],
     'ngp_allocate_splitk': [_sz],
     'ngp_free_splitk': [],
 }

@@ -51,19 +51,39 @@ def save_checkpoint(path, model, epoch=0, global_step=0, stats=None, optimizer=N
     return state
 
 
-def _all_ranks_here(optimizer, timeout_s=60.0):
+def _all_ranks_here(optimizer, timeout_s=60.0, use_store=None):
     """sharded checkpoints gather from every rank: a call made by a subset of the ranks (the reference's rank-0 guard) would hang in the
-    first collective.  A store-based roll call turns that into an error within `timeout_s`."""
+    first collective.  A roll call turns that into an error within `timeout_s`: `monitored_barrier` on gloo groups (the only backend that
+    has it -- decided from the group's backend, not from exception text), and on every other backend (RCCL) a counter in the rendezvous
+    store (TCPStore / FileStore: host side, independent of the collective library).  use_store: force either path (tests)."""
     import datetime
+    import time
     import torch.distributed as dist
     group = getattr(optimizer, 'group', None)
-    try:
-        dist.monitored_barrier(group=group, timeout=datetime.timedelta(seconds=timeout_s))
-    except (RuntimeError, ValueError) as e:  # monitored_barrier exists for gloo groups only; RCCL groups fall through to the collective
-        if 'monitored_barrier' in str(e) or 'Gloo' in str(e) or 'gloo' in str(e) and 'only' in str(e):
+    if use_store is None:
+        use_store = dist.get_backend(group) != 'gloo'
+    complaint = ('save_checkpoint with optim.NGPAdam(shard=True) is collective: every rank must call it (only the `write` rank '
+                 'touches the file) -- ')
+    if not use_store:
+        try:
+            dist.monitored_barrier(group=group, timeout=datetime.timedelta(seconds=timeout_s))
+        except RuntimeError as e:
+            raise RuntimeError(complaint + str(e)) from e
+        return
+    store = dist.distributed_c10d._get_default_store()
+    world = dist.get_world_size(group)
+    ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+    optimizer._roll_calls = getattr(optimizer, '_roll_calls', 0) + 1     # every rank counts its own calls: the n-th call meets the n-th call
+    key = f'ngp_checkpoint_roll_call/{ranks[0]}-{ranks[-1]}x{world}/{optimizer._roll_calls}'
+    store.add(key, 1)
+    deadline = time.monotonic() + timeout_s
+    while True:
+        here = int(store.add(key, 0))
+        if here >= world:
             return
-        raise RuntimeError('save_checkpoint with optim.NGPAdam(shard=True) is collective: every rank must call it (only the `write` rank '
-                           'touches the file) -- ' + str(e)) from e
+        if time.monotonic() > deadline:
+            raise RuntimeError(complaint + f'{here} of {world} rank(s) arrived within {timeout_s:.0f} s')
+        time.sleep(0.002)
 
 
 def load_checkpoint(checkpoint, model, optimizer=None, scaler=None, lr_scheduler=None, ema=None, model_only=False, map_location=None):

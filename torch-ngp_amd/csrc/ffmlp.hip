@@ -746,27 +746,40 @@ __device__ __forceinline__ void dma4(const void* src_lane, unsigned char* lds_wa
     __builtin_amdgcn_global_load_lds((gmem_ptr_t)src_lane, (lds_ptr_t)lds_wave_base, 4, 0, DMA_CPOL);
 }
 
+// DMA instructions prefetch_tile issues for one tile -- the ONE statement of that number: the counted `s_waitcnt vmcnt(N)` of the three-deep
+// pipeline (k_ffmlp_backward_paired) waits by it, and prefetch_tile returns what it really issued so that the debug build
+// (make DEBUG_BOUNDS=1) traps when the two drift apart (an edit that merges or splits loads would otherwise let the barrier pass
+// before the oldest tile has landed -- a silent LDS race).
 template <int WIDTH>
-__device__ __forceinline__ void prefetch_tile(unsigned char* buf, uint32_t tile, const half_t* __restrict__ grad, const half8_t* __restrict__ fb,
-                                              const half_t* __restrict__ inputs, uint32_t num_layers, size_t layer_stride, size_t rows,
-                                              uint32_t in_dim, bool in_planar, int lane, int n, int h) {
+__host__ __device__ constexpr uint32_t tile_dma_count(uint32_t stored_layers, uint32_t in_dim, bool in_planar) {
+    return 1u + stored_layers * (uint32_t)Shape<WIDTH>::NKB + (in_dim / 16u) * (in_planar ? 4u : 1u);
+}
+
+template <int WIDTH>
+__device__ __forceinline__ uint32_t prefetch_tile(unsigned char* buf, uint32_t tile, const half_t* __restrict__ grad, const half8_t* __restrict__ fb,
+                                                  const half_t* __restrict__ inputs, uint32_t num_layers, size_t layer_stride, size_t rows,
+                                                  uint32_t in_dim, bool in_planar, int lane, int n, int h) {
     constexpr int NKB = Shape<WIDTH>::NKB;
+    uint32_t issued = 0u;   // (dead code unless a caller checks it)
     const size_t srow = (size_t)tile * FF_TILE + n;
-    dma16(grad + srow * 16 + 8 * h, buf);
+    dma16(grad + srow * 16 + 8 * h, buf); issued++;
     const half8_t* frag = fb + (size_t)tile * NKB * 64 + lane;
     for (uint32_t l = 0; l < num_layers; l++)
 #pragma unroll
-        for (int kb = 0; kb < NKB; kb++) dma16(frag + l * layer_stride + kb * 64, buf + (size_t)(1 + l * NKB + kb) * 1024);
+        for (int kb = 0; kb < NKB; kb++) { dma16(frag + l * layer_stride + kb * 64, buf + (size_t)(1 + l * NKB + kb) * 1024); issued++; }
     unsigned char* xb = buf + (size_t)(1 + num_layers * NKB) * 1024;
     const uint32_t in_kb = in_dim / 16;
     if (!in_planar) {
-        for (uint32_t kb = 0; kb < in_kb; kb++) dma16(inputs + srow * in_dim + 16 * kb + 8 * h, xb + (size_t)kb * 1024);
+        for (uint32_t kb = 0; kb < in_kb; kb++) { dma16(inputs + srow * in_dim + 16 * kb + 8 * h, xb + (size_t)kb * 1024); issued++; }
     } else {
         for (uint32_t kb = 0; kb < in_kb; kb++)
 #pragma unroll
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < 4; q++) {
                 dma4(inputs + ((size_t)((16 * kb + 8 * h) / 2 + q) * rows + srow) * 2, xb + (size_t)kb * 1024 + q * 256);
+                issued++;
+            }
     }
+    return issued;
 }
 
 // X fragment kb of this lane from the tile buffer (see layout above)
@@ -1106,9 +1119,14 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
                                                   (size_t)pair * NHM * NKB * 1024) + lane;
     const uint32_t base_step = gridDim.x * FP_PAIRS;
     uint32_t cur = 0;
+    // DMA instructions per tile (dY, the stored activations, X as 16-byte fragments or four 4-byte rows each): the counted wait below names
+    // how many YOUNGER ones may still be in flight, as an immediate -- the counts of the shapes that run three deep are enumerated
+    const uint32_t tile_loads = tile_dma_count<WIDTH>(act_layers, in_dim, in_planar);
     auto prefetch = [&](uint32_t buffer, uint32_t tile) {
-        prefetch_tile<WIDTH>(pf_base + (size_t)buffer * tile_frags * 1024, tile, grad, fb, inputs, act_layers, layer_stride, rows, in_dim, in_planar,
-                             lane, n, h);
+        const uint32_t issued = prefetch_tile<WIDTH>(pf_base + (size_t)buffer * tile_frags * 1024, tile, grad, fb, inputs, act_layers, layer_stride,
+                                                     rows, in_dim, in_planar, lane, n, h);
+        NGP_BOUNDS(issued == tile_loads);   // the counted vmcnt wait and the prefetch agree on the number of loads per tile
+        (void)issued;
     };
     // pf_depth buffers per pair: tiles of the next pf_depth - 1 rounds are in flight while one is worked on.  The first requests leave BEFORE
     // the weight images are built (the tile buffers are a region of their own): their round trip runs under the build instead of behind it.
@@ -1125,9 +1143,8 @@ void k_ffmlp_backward_paired(const half_t* __restrict__ grad, const half_t* __re
     const half8_t* img_hid = img_out + (size_t)NIB * 64;
     const half8_t* img_in = img_hid + (size_t)(num_layers - 1) * NIB * NKB * 64;
     const half8_t* fimg = img + (size_t)nfrag * 64 + lane;
-    // DMA instructions per tile (dY, the stored activations, X as 16-byte fragments or four 4-byte rows each): the wait below names how many
-    // YOUNGER ones may still be in flight, as an immediate -- the counts of the shapes that run three deep are enumerated
-    const uint32_t tile_loads = 1u + act_layers * NKB + in_kb * (in_planar ? 4u : 1u);
+    static_assert(tile_dma_count<64>(0, 32, false) == 3u && tile_dma_count<64>(0, 32, true) == 9u && tile_dma_count<64>(2, 32, false) == 11u &&
+                  tile_dma_count<64>(2, 32, true) == 17u, "the enumerated vmcnt immediates below are the DMA counts of the three-deep shapes");
     const bool deep = pf_depth == 3 && (tile_loads == 3u || tile_loads == 9u || tile_loads == 11u || tile_loads == 17u);
     // per tile round: the landed tile is handed over (barrier), the free buffer is refilled; returns the tile's buffer
     auto next_tile_buffer = [&](uint32_t base) -> const unsigned char* {

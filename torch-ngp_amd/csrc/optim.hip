@@ -199,6 +199,19 @@ __global__ void k_update_scale(float* __restrict__ state, float growth, float ba
     update_scale(state, growth, backoff, growth_interval);
 }
 
+// Data-parallel sharded update, the "skipped as a whole" verdict WITHOUT a collective of its own: a rank whose local gradient is not finite
+// (found_inf = state[2], set by the producers or by the CHECK phase) writes NaN into the first element of EVERY shard of its flat fp16
+// gradient before the reduce-scatter; the average of a shard that any rank poisoned is NaN on its owner, so after the exchange every rank
+// reads the global verdict off the first element of ITS OWN shard (k_shard_verdict) -- the 4-byte all-reduce(MAX) that used to sit on the
+// critical path next to the reduce-scatter is gone.  (The poisoned step is skipped, so the clobbered gradient elements are never used.)
+__global__ void k_poison_shards(half_t* __restrict__ grad, uint32_t shards, uint64_t payload, const float* __restrict__ state) {
+    if (state[2] == 0.0f) return;
+    for (uint32_t r = threadIdx.x; r < shards; r += blockDim.x) grad[(uint64_t)r * payload] = (half_t)__builtin_nanf("");
+}
+__global__ void k_shard_verdict(const half_t* __restrict__ shard, float* __restrict__ state) {
+    if (threadIdx.x == 0 && !__builtin_isfinite((float)shard[0])) state[2] = 1.0f;
+}
+
 // torch_ema's update() on its own (the Trainer calls it once per epoch, not per step): shadow -= omd * (shadow - param)
 __global__ __launch_bounds__(OPT_THREADS) void k_ema(OptTensors ts, float omd) {
     for (int k = 0; k < ts.count; k++) {
@@ -277,6 +290,18 @@ extern "C" int ngp_optim_adam_step(int count, const uint64_t* n, float* const* p
     const uint32_t phases = NGP_OPT_PHASE_CHECK | NGP_OPT_PHASE_UPDATE | (growth_interval < 0.0f ? 0u : NGP_OPT_PHASE_COMMIT);
     return ngp_optim_adam_step_ex(count, n, params, exp_avg, exp_avg_sq, grads, params_fp16, grad_is_half, lr, beta1, beta2, eps, grad_mult,
                                   growth_factor, backoff_factor, growth_interval, state, nullptr, 0.0f, phases, stream);
+}
+
+extern "C" int ngp_optim_poison_shards(void* flat_grad_fp16, uint32_t shards, uint64_t payload, const float* state, ngp_stream_t stream) {
+    NGP_REQUIRE(flat_grad_fp16 && state && shards >= 1 && payload >= 1, NGP_ERR_INVALID, "optim_poison_shards: NULL / empty argument");
+    hipLaunchKernelGGL(k_poison_shards, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<half_t*>(flat_grad_fp16), shards, payload, state);
+    return check_launch("optim_poison_shards");
+}
+
+extern "C" int ngp_optim_shard_verdict(const void* shard_grad_fp16, float* state, ngp_stream_t stream) {
+    NGP_REQUIRE(shard_grad_fp16 && state, NGP_ERR_INVALID, "optim_shard_verdict: NULL argument");
+    hipLaunchKernelGGL(k_shard_verdict, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<const half_t*>(shard_grad_fp16), state);
+    return check_launch("optim_shard_verdict");
 }
 
 extern "C" int ngp_optim_ema_update(int count, const uint64_t* n, float* const* params, float* const* ema, float one_minus_decay,

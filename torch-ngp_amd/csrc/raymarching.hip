@@ -1435,8 +1435,11 @@ extern "C" int ngp_composite_train_loss_backward(const float* sigmas, const floa
                                                  uint32_t N, float T_thresh, int bg_mode, float bg_scalar, const float* bg, const float* nears,
                                                  const float* fars, const float* target, const float* loss_scale, float* weights_sum,
                                                  float* image_out, float* depth_out, float* loss, float* ray_err, float* grad_sigmas,
-                                                 void* grad_out16, void* march_workspace, ngp_stream_t stream) {
+                                                 void* grad_out16, void* march_workspace, size_t march_workspace_bytes, ngp_stream_t stream) {
     NGP_REQUIRE(N > 0, NGP_ERR_INVALID, "composite_train_loss_backward: no rays");
+    NGP_REQUIRE(march_workspace_bytes >= ngp_march_rays_train_workspace_bytes(N), NGP_ERR_INVALID,
+                "composite_train_loss_backward: march_workspace of %zu bytes, needs ngp_march_rays_train_workspace_bytes(%u) = %zu (the group tickets sit at its end)",
+                march_workspace_bytes, N, ngp_march_rays_train_workspace_bytes(N));
     // (loss may be NULL: the sum of ray_err is then left to the caller -- ngp_grid_encode_backward_checked_slabs carries it)
     NGP_REQUIRE(sigmas && rgbs && deltas && rays && target && weights_sum && ray_err && grad_sigmas && grad_out16 && march_workspace,
                 NGP_ERR_INVALID, "composite_train_loss_backward: NULL tensor");

@@ -213,9 +213,11 @@ def _render_train_forward(rays_o, rays_d, emb16, ws16, wc16, bg, offsets, bitfie
     return _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg)
 
 
-def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, noise_seed=None):
+def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, noise_seed=None, into=None):
     """the parameter-independent front of the iteration: near/far + march_rays_train (one C call, three launches).  Needs neither the table nor the MLP weights, so
-    in data-parallel training it overlaps the all-gather of the freshly updated fp16 shadows (optim.NGPAdam.gather_shadows)."""
+    in data-parallel training it overlaps the all-gather of the freshly updated fp16 shadows (optim.NGPAdam.gather_shadows).
+    into: the tuple an earlier call returned -- the same march issued again INTO THE SAME buffers (a second captured graph that feeds the
+    consumers of the first one: graph.GraphedTrainStep's folded march of the next batch)."""
     (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
     (cascade, grid_size, min_near, capacity, perturb, dt_gamma, max_steps, T_thresh, density_scale, bg_scalar) = rcfg
     N = rays_o.shape[0]
@@ -223,19 +225,22 @@ def _render_train_march(rays_o, rays_d, bitfield, aabb, counter, cfg, rcfg, nois
     dev = rays_o.device
     st = capi.stream()
     f32 = dict(device=dev, dtype=torch.float32)
-    nears = torch.empty(N, **f32)
-    fars = torch.empty(N, **f32)
-    xyzs = torch.empty(M, 3, **f32)
-    dirs = torch.empty(M, 3, **f32)
-    deltas = torch.empty(M, 2, **f32)
-    rays = torch.empty(N, 3, device=dev, dtype=torch.int32)
+    if into is not None:
+        (xyzs, dirs, deltas, rays, nears, fars, ws) = into
+    else:
+        nears = torch.empty(N, **f32)
+        fars = torch.empty(N, **f32)
+        xyzs = torch.empty(M, 3, **f32)
+        dirs = torch.empty(M, 3, **f32)
+        deltas = torch.empty(M, 2, **f32)
+        rays = torch.empty(N, 3, device=dev, dtype=torch.int32)
+        ws = torch.empty(capi.lib.ngp_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device=dev)
     march_flags = capi.NGP_MARCH_RESET_COUNTER | capi.NGP_MARCH_ZERO_TAIL | (0 if USE_FUSED_SCAN else capi.NGP_MARCH_SCAN_LAUNCH)
     if perturb and noise_seed is not None:
         # start offsets drawn in-kernel from (ray index, *noise_seed): no rand launch, no generator bookkeeping in a captured graph
         noises, march_flags = noise_seed, march_flags | capi.NGP_MARCH_NOISE_FROM_SEED
     else:
         noises = torch.rand(N, **f32) if perturb else torch.zeros(N, **f32)
-    ws = torch.empty(capi.lib.ngp_march_rays_train_workspace_bytes(N), dtype=torch.uint8, device=dev)
     # near_far_from_aabb rides in the marcher's first pass (nears / fars are outputs)
     _check(capi.lib.ngp_march_rays_train_aabb(rays_o.data_ptr(), rays_d.data_ptr(), bitfield.data_ptr(), float(bound), float(dt_gamma),
                                               max_steps, N, cascade, grid_size, M, aabb.data_ptr(), float(min_near), nears.data_ptr(),
@@ -504,7 +509,7 @@ def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg,
                                                       nears.data_ptr(), fars.data_ptr(), target.data_ptr(), capi.ptr(loss_scale),
                                                       weights_sum.data_ptr(), image.data_ptr(), depth.data_ptr(), None if defer else loss.data_ptr(),
                                                       ray_err.data_ptr(), g_sigma.data_ptr(), g_out16.data_ptr(), march_ws.data_ptr(),
-                                                      capi.stream()))
+                                                      march_ws.numel() * march_ws.element_size(), capi.stream()))
     _network_backward(saved, cfg, rcfg, g_sigma, g_out16, bufs[3], bufs[4].view(-1), bufs[5].view(-1), found_inf,
                       loss_job=(ray_err, loss) if defer else None, overwrite=overwrite)
     return loss, image, depth, weights_sum
@@ -527,8 +532,8 @@ def fused_train_iteration_split(model, rays_o, rays_d, target, box, counter, cap
     target = target.contiguous().view(-1, 3)
     box_ = {}
 
-    def march():
-        box_['m'] = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
+    def march():   # (called again -- a second captured graph -- it marches into the SAME buffers, the ones rest() reads)
+        box_['m'] = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed, into=box_.get('m'))
 
     def rest():
         out = _train_iteration_rest(box_['m'], bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf, overwrite_table)

@@ -47,6 +47,16 @@ def _capture_into(g, **kw):
     return torch.cuda.graph(g, **kw)
 
 
+_PARKED = []   # graphs of steppers that were collected while another stepper was capturing (GraphedTrainStep.close)
+
+
+def _drain_parked():
+    """release what close() had to park; called outside any capture (the start of a capture, an ordinary close())"""
+    if _PARKED and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
+        del _PARKED[:]
+
+
 def mse_loss(out, target):
     # mean over rays and channels of the squared error (nerf/utils.py:516,557) through PyTorch's fused MSE kernels
     return torch.nn.functional.mse_loss(out['image'][0], target)
@@ -99,6 +109,8 @@ class GraphedTrainStep:
         self.occupancy_epoch = 0
         self.la_presampled = None           # refresh mode (full sweep?) whose cell sampling already ran on the side stream
         self.la_presample_hits = 0
+        import os
+        self.sharded_premarch = os.environ.get('NGP_SHARDED_PREMARCH', '1') != '0'   # sharded step: fold the next batch's march behind the update
         if self.lookahead:
             self.la_rays_o = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
             self.la_rays_d = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
@@ -115,8 +127,16 @@ class GraphedTrainStep:
         step announces its successor) -- BEFORE its graphs and their private memory pools are released.  A HIP graph that is destroyed while
         one of its replays is still running hands its pool back to the caching allocator, and the still-running kernels then write into
         whatever the next owner of that memory keeps there.  Called by __del__; call it explicitly when the object's lifetime matters."""
+        if getattr(self, '_unsafe_skip_close', False):
+            return   # tests/test_gpu_graph_lifetime.py only: the arm of the lifetime reproducer that releases the graphs WITHOUT waiting
         side = getattr(self, 'la_side', None)
         try:
+            # this object may be collected by the cyclic GC while ANOTHER stepper is inside a stream capture (ADVICE r4): a synchronize (or
+            # any stream / event query) there would invalidate that capture.  The graphs and everything they replay into are parked instead
+            # and released by the next close() / capture that runs outside a capture (_drain_parked)
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                _PARKED.append((self.graphs, self.la, self.update_graphs, side, getattr(self, 'optimizer', None)))
+                return
             if side is not None:
                 side.synchronize()
             comm = getattr(getattr(self, 'optimizer', None), '_comm_stream', None)
@@ -124,6 +144,7 @@ class GraphedTrainStep:
                 comm.synchronize()
             if torch.cuda.is_available() and (self.graphs is not None or self.update_graphs):
                 torch.cuda.current_stream().synchronize()
+            _drain_parked()
         except Exception:  # noqa: BLE001 -- interpreter shutdown: the device context may be gone already
             pass
 
@@ -255,6 +276,7 @@ class GraphedTrainStep:
         self.loss = None
         gc.collect()  # drop autograd graphs of earlier eager iterations (their AccumulateGrad nodes are stream-bound)
         torch.cuda.synchronize()
+        _drain_parked()
         self.sharded = False
         # (outside capture: caches the host copy of the encoder offsets the in-kernel non-finite sweep needs)
         self._checked_ok = False
@@ -272,9 +294,13 @@ class GraphedTrainStep:
                 self._iteration_back()
             self.graphs = (g,)
         elif self.averager is self.optimizer and getattr(self.optimizer, 'shard', False) and self._direct_ok():
-            # sharded data-parallel update (optim.NGPAdam, shard=True): three graphs around the two collectives,
-            #   [march] -> wait for the shadow all-gather of the previous step -> [encode .. backward, local non-finite sweep]
-            #   -> reduce-scatter + verdict -> [Adam on my shard, commit] -> all-gather of the shadows (side stream, overlaps the next [march])
+            # sharded data-parallel update (optim.NGPAdam, shard=True): graphs around the two collectives,
+            #   [march] -> wait for the shadow all-gather of the previous step -> [encode .. backward, local non-finite sweep, poison]
+            #   -> reduce-scatter (carries the skip verdict) -> [verdict, Adam on my shard, commit] -> all-gather of the shadows (side stream,
+            #   overlaps the next [march]).  A fourth graph = [verdict, Adam, commit, march]: when the caller announces the next batch
+            #   (step(next_rays=...)) and `sharded_premarch` is on, the march of batch k + 1 rides behind the update of step k in ONE replay
+            #   and step k + 1 starts with its rest graph -- two replays per step instead of three (EXPERIMENTS.md: a replay boundary costs
+            #   ~20 us of idle GPU; the march then no longer overlaps the all-gather: which one wins is a measurement, bench.py --force-ddp)
             from fused import fused_train_iteration_split
             m, kw, opt = self.model, self.render_kwargs, self.optimizer
             bg = kw.get('bg_color', None)
@@ -284,16 +310,24 @@ class GraphedTrainStep:
                                                       found_inf=opt.scalars[2:3] if self._checked_ok else None)
             opt.wait_shadows()
             torch.cuda.synchronize()
-            ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            ga, gb, gc_, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with _capture_into(ga):
                 march()
             with _capture_into(gb, pool=ga.pool()):
                 self.loss = rest()[0][0].detach()
                 if not self._checked_ok:
                     opt.pre_reduce_check()     # (else the kernels that deposited the local gradients flagged them)
+                opt.poison_shards()            # found_inf -> NaN in element 0 of every shard: the reduce-scatter carries the verdict
+                # the sample count of THIS batch goes to a slot of its own before a folded march of the next batch overwrites the counter
+                self.counter[1].copy_(self.counter[0])
             with _capture_into(gc_, pool=ga.pool()):
                 opt.apply()
-            self.graphs = (ga, gb, gc_)
+            with _capture_into(gd, pool=ga.pool()):
+                opt.apply()
+                march()                        # (same buffers as ga's march: the samples of the batch whose rays are in rays_o / rays_d NOW)
+            self.graphs = (ga, gb, gc_, gd)
+            self.premarched = None             # (rays_o, rays_d, versions, occupancy epoch) of the batch gd marched at the end of the last step
+            self.premarch_hits = 0
             self.sharded = True
             self.used_direct = True
         else:  # the RCCL all-reduce stays eager between the two halves
@@ -543,22 +577,42 @@ class GraphedTrainStep:
             m.local_step += 1
             self.global_step += 1
             return loss
+        if getattr(self, 'sharded', False):
+            opt = self.optimizer
+            pm = self.premarched
+            if (pm is not None and pm[0] is rays_o and pm[1] is rays_d and pm[2] == (rays_o._version, rays_d._version)
+                    and pm[3] == self.occupancy_epoch):
+                self.target.copy_(target, non_blocking=True)     # this batch was marched behind the previous step's update
+                self.premarch_hits += 1
+            else:
+                torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
+                                     non_blocking=True)
+                self.graphs[0].replay()        # near/far + ray marching: needs no weights, overlaps the shadow all-gather of the last step
+            self.premarched = None
+            opt.wait_shadows()
+            self.graphs[1].replay()            # encode .. backward (deposit) + local non-finite sweep + poison
+            opt.reduce_gradients()             # reduce-scatter (average of my shard; the skip verdict rides in it)
+            m.step_counter[m.local_step % 16].copy_(self.counter[1], non_blocking=True)
+            fold = (self.sharded_premarch and next_rays is not None and (self.global_step + 1) % self.update_interval != 0)
+            if fold:
+                no, nd = next_rays[0], next_rays[1]
+                torch._foreach_copy_([self.rays_o, self.rays_d], [no.view_as(self.rays_o), nd.view_as(self.rays_d)], non_blocking=True)
+                self.graphs[3].replay()        # verdict + Adam on my shard + commit, then the march of the NEXT batch
+                self.premarched = (no, nd, (no._version, nd._version), self.occupancy_epoch)
+            else:
+                self.graphs[2].replay()        # verdict + Adam on my shard, scale / step commit, deposit buffer zeroed
+            opt.gather_shadows()               # all-gather of the fp16 shadows on the side stream
+            self._mark_deposits()
+            m.local_step += 1
+            self.global_step += 1
+            return self.loss
         # the batch into the static input buffers: ONE multi-tensor copy kernel (three separate copies cost ~5 us each plus the gaps)
         torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
                              non_blocking=True)
-        if getattr(self, 'sharded', False):
-            opt = self.optimizer
-            self.graphs[0].replay()            # near/far + ray marching: needs no weights, overlaps the shadow all-gather of the last step
-            opt.wait_shadows()
-            self.graphs[1].replay()            # encode .. backward (deposit) + local non-finite sweep
-            opt.reduce_gradients()             # reduce-scatter (average of my shard) + global skip verdict
-            self.graphs[2].replay()            # Adam on my shard, scale / step commit, deposit buffer zeroed
-            opt.gather_shadows()               # all-gather of the fp16 shadows on the side stream
-        else:
-            self.graphs[0].replay()
-            if len(self.graphs) == 2:
-                self.averager.all_reduce()
-                self.graphs[1].replay()
+        self.graphs[0].replay()
+        if len(self.graphs) == 2:
+            self.averager.all_reduce()
+            self.graphs[1].replay()
         self._mark_deposits()
         # hand the sample count to the model's 16-slot ring exactly where the eager renderer would have put it
         m.step_counter[m.local_step % 16].copy_(self.counter[0], non_blocking=True)

@@ -28,7 +28,11 @@ Multi-GPU (one process per GPU, torch.distributed; 'nccl' is RCCL over xGMI), tw
     on a side stream, which the next iteration's parameter-independent ray marching overlaps.  Same bytes on the wire as the ring
     all-reduce (which is a reduce-scatter + all-gather), 1/world of the optimizer traffic, and the gather leaves the critical path.
     The "step skipped as a whole" rule needs a global verdict: every rank sweeps its LOCAL gradient before the exchange into found_inf
-    (scalars[2]) and `reduce_gradients()` combines the per-rank verdicts with ONE extra 4-byte all_reduce(MAX) next to the reduce-scatter.
+    (scalars[2]); `poison_shards()` then writes NaN into the first element of every shard when that flag is set, the reduce-scatter carries
+    the NaN to every owner, and `apply()` reads the global verdict off its own shard (`verdict='poison'`, the default: no collective besides
+    the reduce-scatter on the critical path).  `verdict='allreduce'` keeps round 3's extra 4-byte all_reduce(MAX) next to the reduce-scatter.
+    `shard='force'` runs this path on ONE rank as well (a 1-rank process group: every collective executes, the exchange is the identity) --
+    bench.py's `ddp_overhead_1rank` and tests/test_gpu_ddp.py, the only way to execute RCCL on a one-GPU box.
     The fp32 parameters are re-pointed into one flat master buffer (`gather_master()` completes them on every rank for checkpoints).
 """
 import ctypes
@@ -45,7 +49,7 @@ class NGPAdam:
     _require_cuda = True   # tests of the multi-rank orchestration subclass this with a torch stand-in for the kernels (tests/ only)
 
     def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5,
-                 growth_interval=2000, world_size=1, deposit=True, shard=False, rank=None, process_group=None):
+                 growth_interval=2000, world_size=1, deposit=True, shard=False, rank=None, process_group=None, verdict='poison'):
         groups = list(params)
         if groups and not isinstance(groups[0], dict):
             groups = [{'params': groups}]
@@ -57,7 +61,10 @@ class NGPAdam:
         self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), float(growth_interval)
         self.world_size = int(world_size)
         self.group = process_group
-        self.shard = bool(shard) and self.world_size > 1
+        self.shard = bool(shard) and (self.world_size > 1 or shard == 'force')
+        if verdict not in ('poison', 'allreduce'):
+            raise ValueError("NGPAdam: verdict must be 'poison' or 'allreduce'")
+        self.verdict = verdict
         if self.shard and not deposit:
             raise RuntimeError('NGPAdam: shard=True needs deposit=True (the flat fp16 gradient buffer is what gets reduce-scattered)')
         self.rank = (dist.get_rank(process_group) if rank is None else int(rank)) if self.shard else 0
@@ -174,10 +181,20 @@ class NGPAdam:
         if self.shard:
             raise RuntimeError('NGPAdam: sharded mode exchanges gradients with reduce_gradients() / step()')
         eager = [p for g in self.param_groups for p in g['params'] if p.grad is not None]
+        self._refuse_stale_deposits('all_reduce')
         for p in eager:
             self._average(p.grad)
         if self.flat_grad16 is not None and len(eager) < len(self.state):
             self._average(self.flat_grad16)
+
+    def _refuse_stale_deposits(self, what):
+        """the overwrite-table protocol (fused.USE_OVERWRITE_TABLE) leaves a deposit buffer STALE after the step that kept it; every producer
+        of the repository either overwrites it again (and says so: _ngp_deposit_overwritten) or zeroes it first.  A consumer that meets a
+        stale buffer nobody has refreshed would average / apply the PREVIOUS step's gradient: refuse loudly"""
+        for p in self.flat_params:
+            if getattr(p, '_ngp_grad16_stale', False) and not getattr(p, '_ngp_deposit_overwritten', False):
+                raise RuntimeError(f'NGPAdam.{what}: the fp16 gradient buffer of a parameter is stale (an overwriting producer ran in an earlier '
+                                   'step and nothing has written or cleaned it since) -- call clean_deposits() before a producer that adds')
 
     def _average(self, t):
         if self._avg_native():
@@ -195,9 +212,23 @@ class NGPAdam:
         self._launch([(self.total, None, None, None, self.flat_grad16, None, 1, 0.0, None)], capi.NGP_OPT_PHASE_CHECK, 0.0)
 
     @torch.no_grad()
+    def poison_shards(self):
+        """verdict='poison': found_inf of the LOCAL gradient (set by the producers or by pre_reduce_check) -> NaN in element 0 of every shard
+        of the flat gradient, so that the reduce-scatter hands the verdict to every rank; capturable (one tiny launch), a no-op otherwise"""
+        if self.verdict == 'poison':
+            self._poison_launch()
+
+    def _poison_launch(self):
+        capi.check(capi.lib.ngp_optim_poison_shards(self.flat_grad16.data_ptr(), self.world_size, self.payload, self.scalars.data_ptr(), capi.stream()))
+
+    def _verdict_launch(self):
+        capi.check(capi.lib.ngp_optim_shard_verdict(self.shard_grad.data_ptr(), self.scalars.data_ptr(), capi.stream()))
+
+    @torch.no_grad()
     def reduce_gradients(self):
-        """ONE reduce-scatter: every rank receives the average of its shard of the flat fp16 gradient; the per-rank found_inf verdicts
-        are combined (MAX) so that a step is skipped on all ranks or on none"""
+        """ONE reduce-scatter: every rank receives the average of its shard of the flat fp16 gradient.  verdict='allreduce': the per-rank
+        found_inf verdicts are combined (MAX) by a second, 4-byte collective so that a step is skipped on all ranks or on none;
+        verdict='poison': the reduce-scatter itself carried the verdict (poison_shards before it, apply() reads it)"""
         view = self.flat_grad16.view(self.world_size, self.payload)
         if self._avg_native():
             dist.reduce_scatter_tensor(self.shard_grad, self.flat_grad16, op=dist.ReduceOp.AVG, group=self.group)
@@ -205,7 +236,8 @@ class NGPAdam:
             self.flat_grad16.mul_(1.0 / self.world_size)
             dist.all_reduce(self.flat_grad16, op=dist.ReduceOp.SUM, group=self.group)
             self.shard_grad.copy_(view[self.rank])
-        dist.all_reduce(self.scalars[2:3], op=dist.ReduceOp.MAX, group=self.group)
+        if self.verdict != 'poison':
+            dist.all_reduce(self.scalars[2:3], op=dist.ReduceOp.MAX, group=self.group)
 
     def _shard_entries(self):
         """the pieces of parameters inside my shard, as kernel entries (n, p, m, v, g, p16, is_half, lr, ema)"""
@@ -225,11 +257,17 @@ class NGPAdam:
         deposit buffer zeroed for the next backward; capturable"""
         if len(self._keep) > 64:   # used standalone in a loop without pre_reduce_check()/step(): do not grow without bound
             del self._keep[:-8]
+        if self.verdict == 'poison':
+            self._verdict_launch()     # element 0 of my averaged shard is NaN when ANY rank flagged its local gradient
         entries = self._shard_entries()
         for i in range(0, len(entries), _MAX):
             self._launch(entries[i:i + _MAX], capi.NGP_OPT_PHASE_UPDATE, 0.0)
         self._launch([], capi.NGP_OPT_PHASE_COMMIT, 0.0)
         self.flat_grad16.zero_()
+        for p in self.flat_params:   # the whole flat buffer is clean now, whatever an overwriting producer announced (ADVICE r4)
+            if getattr(p, '_ngp_deposit_overwritten', False) or getattr(p, '_ngp_grad16_stale', False):
+                p._ngp_deposit_overwritten = False
+                p._ngp_grad16_stale = False
 
     @torch.no_grad()
     def gather_shadows(self, async_op=True):
@@ -349,8 +387,10 @@ class NGPAdam:
                 raise RuntimeError('NGPAdam(shard=True): fold-in EMA is not available; call gather_master() then ema.update() once per epoch')
             if any(p.grad is not None for p in self.flat_params):
                 raise RuntimeError('NGPAdam(shard=True): gradients must be deposited by the fused path (found an autograd .grad)')
+            self._refuse_stale_deposits('step')
             if not gradients_checked:
                 self.pre_reduce_check()
+            self.poison_shards()
             self.reduce_gradients()
             self.apply()
             self.gather_shadows()

@@ -176,6 +176,68 @@ class KernelTimers:
         return out
 
 
+# whole-frame accounting of the 800x800 inference frame (VERDICT r4 "What's missing" 3): algorithmic bytes of the loop's stages, per sample ROW
+# that may carry a sample (alive rays x n_step of the iteration) and per alive ray
+#   march_rays      writes xyz 12 + dir 12 + deltas 8 = 32 B per row; reads origin 12 + direction 12 + near/far 8 + t 4 + alive 4 = 40 B per ray
+#   network         the fused inference network: positions / directions 24 B in, sigma 4 + rgb (fp16x4 rows: 8) out per row -- the encoder's table
+#                   gathers (588 B per point) are what the stage really moves: both figures are reported
+#   composite_rays  reads sigma 4 + rgb 12 + deltas 8 = 24 B per row; weights_sum / depth / image / t read + written = 48 B + alive 4 per ray
+#   compact_rays    alive index read + written = 8 B per ray
+FRAME_STAGE_BYTES = {'march_rays': (32.0, 40.0), 'network (encoder + MLPs + glue)': (36.0 + 588.0, 0.0), 'casts (density_scale, fp32 copies)': (4 + 4 + 8 + 12.0, 0.0),
+                     'composite_rays': (24.0, 52.0), 'compact_rays': (0.0, 8.0)}
+
+
+def frame_stages(model, ro, rd, rkw):
+    """one more frame with the loop's stage probe on (nerf/renderer.py `_loop_probe`): per stage the summed HIP-event time, launches, the
+    rows / rays that carried work, algorithmic GB/s -- and how much of the frame's wall time the stages account for"""
+    model._loop_probe = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    try:
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+            model.render(ro, rd, **rkw)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) * 1e3
+        probe = model._loop_probe
+    finally:
+        model._loop_probe = None
+    rows_by_stage = {}
+    first, last = None, None
+    states = {}
+    for name, e0, e1, lanes, rows, n_total, snap in probe:
+        if id(snap) not in states:
+            alive = int(snap[0].item())
+            states[id(snap)] = (alive, max(1, min(8, n_total // max(alive, 1))))
+        alive, n_step = states[id(snap)]
+        r = rows_by_stage.setdefault(name, {'ms': 0.0, 'launches': 0, 'rows': 0, 'rays': 0, 'rows_launched': 0})
+        r['ms'] += e0.elapsed_time(e1)
+        r['launches'] += 1
+        r['rows'] += min(rows, alive * n_step)
+        r['rays'] += min(lanes, alive)
+        r['rows_launched'] += rows
+        first = e0 if first is None else first
+        last = e1
+    out = []
+    for name, r in rows_by_stage.items():
+        per_row, per_ray = FRAME_STAGE_BYTES.get(name, (0.0, 0.0))
+        byts = per_row * r['rows'] + per_ray * r['rays']
+        gbs = byts / (r['ms'] * 1e-3) / 1e9 if r['ms'] > 0 else 0.0
+        out.append({'stage': name, 'ms': round(r['ms'], 4), 'launch_groups': r['launches'], 'sample_rows': r['rows'], 'rows_launched': r['rows_launched'],
+                    'alive_rays_summed': r['rays'], 'algorithmic_GBps': round(gbs, 1), 'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4)})
+    trajectory = []
+    for name, e0, e1, lanes, rows, n_total, snap in probe:
+        if name == 'march_rays':
+            alive, n_step = states[id(snap)]
+            trajectory.append([alive, n_step, rows])
+    staged = sum(r['ms'] for r in out)
+    loop_ms = first.elapsed_time(last) if first is not None else 0.0
+    return {'frame_wall_ms_with_probe': round(wall, 3), 'loop_first_to_last_event_ms': round(loop_ms, 3), 'stages_sum_ms': round(staged, 3),
+            'iterations': len(probe) // max(len(rows_by_stage), 1), 'stages': sorted(out, key=lambda r: -r['ms']),
+            'alive_nstep_rows_per_iteration': trajectory,
+            'note': 'HIP-event pairs around the stages of every loop iteration (events add ~2 us each: the probed frame is slower than the timed one); '
+                    'rows = alive rays x n_step of the iteration (an upper bound of the samples emitted)'}
+
+
 def load_pmc_traffic():
     """(HBM bytes per launch, file name) from the newest committed rocprofv3 --pmc pass (profiles/*_pmc_traffic.json, produced by
     tools/pmc_traffic.py on the same workload); (None, None) when the file is absent.  NOT a measurement of this run."""
@@ -278,7 +340,10 @@ class TrainingRun:
             m.density_bitfield.copy_(fixed_bits)
         self.keep_scene = keep_scene
         self.model, self.optimizer = model, optimizer
-        self.lookahead = graph and fused and not torch_optim and not autograd and not ddp_on and not getattr(args, 'no_lookahead', False)
+        # lookahead: the next batch's march on a side stream under this iteration -- single GPU, and the sharded data-parallel step as well
+        # (the march needs no weights: it runs beside [encode .. backward] -> reduce-scatter -> [Adam on the shard] -> all-gather)
+        self.lookahead = (graph and fused and not torch_optim and not autograd and not getattr(args, 'no_lookahead', False)
+                          and (not ddp_on or bool(getattr(optimizer, 'shard', False))))
         self.stepper = GraphedTrainStep(model, optimizer, scaler, self.rays, self.opt_kwargs, loss_fn=mse_loss, averager=averager,
                                         after_update=keep_scene, direct=not autograd, lookahead=self.lookahead)
         self.step_no = 0
@@ -300,9 +365,8 @@ class TrainingRun:
             loss = stepper._eager(rays_o, rays_d, gt)
             stepper.global_step += 1
         else:
-            if self.lookahead or self.ddp_on:
-                # the data loader's next batch is known one step early: its march runs under this iteration (single GPU: side stream;
-                # sharded data-parallel step: behind the shard update, in the same graph replay)
+            if self.lookahead:
+                # the data loader's next batch is known one step early: its march runs under this iteration
                 nxt = self.pool[self.step_no % self.n_pool]
                 loss = stepper.step(rays_o, rays_d, gt, next_rays=nxt)
             else:
@@ -502,6 +566,22 @@ def cpu_baselines(args):
         break
     if cpu is None:
         cpu = {'value': None, 'unit': 'samples/s', 'cores': 0, 'kind': 'port', 'sample': f'pure-PyTorch path did not finish in time: {tried}'}
+    # the other half of BASELINE's metric on the host cores: the reference's pure-PyTorch 800x800 inference frame (staged, 4096-ray batches)
+    if cpu.get('cores'):
+        env = dict(os.environ, OMP_NUM_THREADS=str(cpu['cores']), MKL_NUM_THREADS=str(cpu['cores']), HIP_VISIBLE_DEVICES='',
+                   MALLOC_TRIM_THRESHOLD_='34359738368', MALLOC_MMAP_MAX_='0', MALLOC_TOP_PAD_='1073741824')
+        try:
+            out = subprocess.run([sys.executable, '-m', 'oracle.torch_cpu', '4096', str(half), str(cpu['cores']), 'render'], cwd=ROOT, env=env,
+                                 capture_output=True, text=True, timeout=10 * half + 90)
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+            cpu['render_800x800_ms'] = round(r['frame_ms'], 1)
+            cpu['render_sample'] = (f"{r['batches_timed']} timed batches (median; 1 warm-up) of {r['rays_per_batch']} rays x {r['num_steps']} samples through the "
+                                    f"reference's NeRFRenderer.render(staged=True, max_ray_batch=4096) -> run (pure PyTorch, fp32, eval, no_grad; "
+                                    f"oracle/torch_cpu.py), batches spread over the GPU frame's rays; frame = median batch x {r['rays_per_frame']} / "
+                                    f"{r['rays_per_batch']} = {r['batches_per_frame']} batches; {r['threads']} threads, {r['wall_s']:.0f} s wall")
+        except Exception as e:  # noqa: BLE001
+            cpu['render_800x800_ms'] = None
+            cpu['render_sample'] = f'pure-PyTorch render did not finish: {type(e).__name__}'
     bits = oracle.packbits(sc.occupancy_density(), 10.0)
     q = time_cpu_baseline(bits, n_rays=args.rays, min_seconds=half, max_steps_timed=4)
     cpu['scalar_port'] = {'value': round(q['samples_per_s'], 1), 'unit': 'samples/s', 'cores': 1, 'kind': 'port',
@@ -544,17 +624,22 @@ def ddp_overhead_1rank(args, dev, steps):
         out['single_gpu_no_lookahead_ms_per_step'] = round(r['elapsed'] / steps * 1e3, 4)
         del base
         args.no_lookahead = saved
-        for name, premarch, verdict in (('sharded_2_replays_march_folded_behind_update', True, 'poison'),
-                                        ('sharded_3_replays', False, 'poison'),
-                                        ('sharded_3_replays_verdict_allreduce', False, 'allreduce')):
+        # (the variant that captures RCCL calls inside a HIP graph runs LAST: a refused capture must not disturb the others)
+        for name, look, graphed, verdict in (('sharded_lookahead', True, False, 'poison'),
+                                             ('sharded_3_replays_no_lookahead', False, False, 'poison'),
+                                             ('sharded_3_replays_no_lookahead_verdict_allreduce', False, False, 'allreduce'),
+                                             ('sharded_lookahead_collectives_in_graph', True, True, 'poison')):
             args.shard_verdict = verdict
+            args.no_lookahead = not look
             run = one(force_ddp=True)
-            run.stepper.sharded_premarch = premarch
+            run.stepper.graph_collectives = graphed
             run.setup(min(args.warmup, 16))
             r = run.timed(steps)
             st, opt = run.stepper, run.optimizer
             entry = {'ms_per_step': round(r['elapsed'] / steps * 1e3, 4), 'samples_per_s': round(r['samples'] / r['elapsed'], 1),
-                     'sharded_graphs': bool(getattr(st, 'sharded', False)), 'premarch_hits': int(getattr(st, 'premarch_hits', 0)),
+                     'sharded_optimizer': bool(getattr(opt, 'shard', False)), 'lookahead_hits': int(getattr(st, 'la_hits', 0)),
+                     'main_stream_replays_per_step': (1 if graphed else 2) if getattr(st, 'la', None) is not None else 3,
+                     'host_ms_per_step_unblocked': r.get('host_first'),
                      'captures_in_timed_region': r['captures'], 'capture_error': st.capture_error, 'final_loss': r['final_loss'],
                      'host_issue_ms_per_step': round(r['issued'] / steps * 1e3, 4)}
             # the two collectives alone, HIP events on the issuing stream, eager, after the timed region
@@ -572,11 +657,10 @@ def ddp_overhead_1rank(args, dev, steps):
             torch.cuda.synchronize()
             out[name] = entry
             del run, st, opt
-        args.shard_verdict = 'poison'
-        best = min(out[k]['ms_per_step'] for k in out if isinstance(out[k], dict) and 'ms_per_step' in out[k])
-        out['ddp_overhead_ms_per_step'] = round(best - out['single_gpu_no_lookahead_ms_per_step'], 4)
+        args.shard_verdict, args.no_lookahead = 'poison', saved
+        out['ddp_overhead_ms_per_step'] = round(out['sharded_lookahead']['ms_per_step'] - getattr(args, '_headline_ms', float('nan')), 4)
         out['note'] = ('1-rank RCCL group: every collective and every graph boundary of the N > 1 step executes, wire time is zero; '
-                       'ddp_overhead = best sharded step - single-GPU step without lookahead')
+                       'ddp_overhead = sharded_lookahead (the form bench.py --gpus N runs) - the headline single-GPU step of this run')
     except Exception as e:  # noqa: BLE001 -- a probe: the headline line must not depend on it
         import traceback
         out['error'] = repr(e)[:300]
@@ -657,6 +741,17 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP extension has no CPU fallback)'
     if args.gpus > 1 and int(os.environ.get('WORLD_SIZE', '1') or 1) <= 1 and 'LOCAL_RANK' not in os.environ:
         self_launch(args)   # no launcher around this process: it becomes the launcher of N ranks (does not return)
+    # ONE JSON line on stdout, and nothing else: libraries write banners through C stdio (RCCL prints its version block to stdout when the
+    # first communicator is created, and libc flushes it at EXIT -- i.e. after our line).  File descriptor 1 is pointed at stderr for the
+    # whole run; the result line goes to a private duplicate of the real stdout (`emit`).
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
+    def emit(text):
+        real_stdout.write(text + '\n')
+        real_stdout.flush()
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -822,6 +917,13 @@ def main():
                 dist.all_reduce(best, op=dist.ReduceOp.MAX)
             render[name] = round(float(best.item()), 2)
         if rank == 0 and not args.no_roofline:
+            # whole-frame accounting: every stage of the loop (march, network, casts, composite, compaction) of one opaque and one transparent frame
+            for name, scale in (('transparent_random_init', 1.0), ('opaque_density_scale_300', 300.0)):
+                model.density_scale = scale
+                try:
+                    render['stages_' + name] = frame_stages(model, ro, rd, rkw)
+                except Exception as e:  # noqa: BLE001 -- accounting only
+                    render['stages_' + name] = {'error': repr(e)[:200]}
             # the inference kernels of one more opaque frame with HIP-event pairs (encoder and fused network launches of the eval loop; the
             # march / composite / compaction kernels of the loop are in the committed rocprofv3 summary, profiles/)
             model.density_scale = 300.0
@@ -887,6 +989,7 @@ def main():
     ddp1 = None
     if rank == 0 and world == 1 and not args.force_ddp and not args.no_ddp_probe and not args.torch_optim and not args.no_fused and not args.no_graph:
         torch.cuda.synchronize()
+        args._headline_ms = elapsed / args.steps * 1e3
         ddp1 = ddp_overhead_1rank(args, dev, max(16, min(args.ddp_steps, max(args.steps, 64))))
     if rank == 0:
         roof = None
@@ -928,7 +1031,7 @@ def main():
             'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'dropin_path': dropin, 'render_800x800_ms': render,
             'strong_scaling': strong, 'collectives': comm_ms, 'sdf_encoder_mlp': sdf, 'tnt_bound8': tnt, 'ddp_overhead_1rank': ddp1,
         }
-        print(json.dumps(line), flush=True)
+        emit(json.dumps(line))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -376,9 +376,55 @@ def time_reference_cpu_path(n_rays=1024, num_steps=512, min_seconds=10.0, thread
         torch.set_num_threads(prev)
 
 
-if __name__ == '__main__':  # python -m oracle.torch_cpu <n_rays> <min_seconds> <threads>   -> one JSON line
+def time_reference_cpu_render(min_seconds=10.0, threads=None, max_ray_batch=4096, num_steps=512, H=800, W=800, seed=0):
+    """The reference's pure-PyTorch INFERENCE frame on the host cores: `NeRFRenderer.render(staged=True, max_ray_batch=4096)` ->
+    `run(num_steps=512, upsample_steps=0)` per batch of 4096 rays (nerf/renderer.py:540-574 -> :125-253; main_nerf.py:29-30 defaults), eval
+    mode, no_grad, fp32 -- SURVEY.md 8(d)'s CPU figure beside the GPU's 800x800 render ms.  A whole frame is 157 such batches (minutes of CPU
+    time), so a BOUNDED sample is timed: ray batches taken at evenly spaced offsets of the real frame's rays (synthetic_scene.full_image_rays,
+    the GPU frame's camera), 1 warm-up batch, then batches until `min_seconds` have passed (at least 3, at most 12); frame ms = median batch
+    time x H W / max_ray_batch.  Random-init network (density ~ 1: the colour network runs on every sample whose weight exceeds 1e-4, as in
+    the GPU's transparent frame)."""
+    import synthetic_scene as sc
+    t_begin = time.perf_counter()
+    threads = int(threads or usable_cores())
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        torch.manual_seed(seed)
+        model = TorchNeRF(bound=1).eval()
+        o, d = sc.full_image_rays(seed=0)
+        o, d = torch.from_numpy(o)[None], torch.from_numpy(d)[None]
+        n = o.shape[1]
+        n_batches = (n + max_ray_batch - 1) // max_ray_batch
+        times = []
+        with torch.no_grad():
+            k = 0
+            while True:
+                head = ((k * 37) % n_batches) * max_ray_batch      # spread over the image rows (37 is coprime with 157)
+                tail = min(head + max_ray_batch, n)
+                t0 = time.perf_counter()
+                model.render(o[:, head:tail], d[:, head:tail], staged=True, max_ray_batch=max_ray_batch, num_steps=num_steps, upsample_steps=0,
+                             bg_color=1, perturb=False)
+                dt = (time.perf_counter() - t0) * (max_ray_batch / max(tail - head, 1))
+                if k > 0:
+                    times.append(dt)
+                k += 1
+                if len(times) >= 12 or (len(times) >= 3 and time.perf_counter() - t_begin >= min_seconds):
+                    break
+        med = float(np.median(times))
+        return dict(frame_ms=med * n / max_ray_batch * 1e3, median_batch_s=med, batches_timed=len(times), batches_per_frame=n_batches, threads=threads,
+                    rays_per_batch=max_ray_batch, num_steps=num_steps, rays_per_frame=n, samples_per_s=max_ray_batch * num_steps / med,
+                    host_cores=int(os.cpu_count() or 1), usable_cores=usable_cores(), wall_s=time.perf_counter() - t_begin)
+    finally:
+        torch.set_num_threads(prev)
+
+
+if __name__ == '__main__':  # python -m oracle.torch_cpu <n_rays> <min_seconds> <threads> [render]   -> one JSON line
     import json
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     n_rays, min_seconds, threads = int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3])
-    print(json.dumps(time_reference_cpu_path(n_rays=n_rays, min_seconds=min_seconds, threads=threads)))
+    if len(sys.argv) > 4 and sys.argv[4] == 'render':
+        print(json.dumps(time_reference_cpu_render(min_seconds=min_seconds, threads=threads, max_ray_batch=n_rays)))
+    else:
+        print(json.dumps(time_reference_cpu_path(n_rays=n_rays, min_seconds=min_seconds, threads=threads)))

@@ -7,8 +7,11 @@ host to be 60 us ahead of the device by chance:
 
   * the shipped close() (called by __del__) waits for the side stream: the drop takes as long as the spin, and memory allocated afterwards is
     never written by the dropped stepper's kernels;
-  * what happens WITHOUT the wait (`_unsafe_skip_close`) is measured by tools/graph_lifetime_probe.py in a subprocess per arm (a memory fault
-    must not take pytest down) and asserted here as far as it is deterministic (see test_release_without_waiting...);
+  * WITHOUT the wait (`_unsafe_skip_close`, tools/graph_lifetime_probe.py in a subprocess per arm: a memory fault must not take pytest down)
+    the release STILL waits: destroying a HIP graph whose replay is in flight blocks until that replay has finished (measured on MI355X,
+    ROCm 7.0 / PyTorch 2.10: the drop takes the whole spin, with and without an empty_cache() behind it), and nothing that is allocated
+    afterwards is written.  The theory is therefore DEAD: a released stepper cannot have caused the three events (EXPERIMENTS.md round 5);
+    close() stays as a statement of intent, it is not what keeps the memory safe;
   * the sequence of EXPERIMENTS.md round 4 -- graph steps with lookahead, stepper dropped, then the ATOMIC grid backward on 5000 samples --
     is looped: every repetition must reproduce the first result to the noise of fp16 atomics."""
 import gc
@@ -45,6 +48,19 @@ def test_close_waits_for_the_held_side_stream(cache):
     assert not out['side_stream_busy']['after_drop'], 'close() returned while the side stream was still running'
     assert out['drop_ms'] >= 0.5 * spin_ms          # ... because it waited for the spin (and the march behind it)
     assert out['corrupted_words'] == 0 and out['victim_MB'] >= 256
+
+
+@pytest.mark.parametrize('cache', ['nocache', 'cache'])
+def test_release_without_close_still_waits_in_the_runtime(cache):
+    """the arm that would have shown the use-after-free if the theory were right: close() bypassed, side stream held for 60 ms, 960 MB of
+    pattern allocated behind the drop.  Observed (and pinned here): the graph destruction itself waits for the in-flight replay."""
+    spin_ms = 60
+    out, res = _probe(f'unsafe,{cache},{spin_ms}')
+    assert out is not None, res.stderr[-3000:]          # (a memory fault would have killed the probe process: it did not)
+    assert out['side_stream_busy']['at_drop']
+    assert out['corrupted_words'] == 0
+    assert not out['side_stream_busy']['after_drop'] and out['drop_ms'] >= 0.5 * spin_ms, \
+        ('the runtime no longer waits when a graph with a replay in flight is destroyed: GraphedTrainStep.close() is now load-bearing', out)
 
 
 def _make_stepper(dev, occ, bits, n_rays, kw, lookahead=True):

@@ -329,39 +329,13 @@ __device__ __forceinline__ float quad_swap1(float v) {  // value of lane ^ 1 (DP
 }
 
 template <typename T, int D, int C>
-__global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid,
-                                                                   const int32_t* __restrict__ offsets, T* __restrict__ outputs,
-                                                                   uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
-                                                                   bool align_corners, uint32_t interp, FwdSchedule sched,
-                                                                   uint32_t points_per_block, InputMap im) {
+__device__ __forceinline__ void forward_pair_block(const float* __restrict__ inputs, const T* __restrict__ table, T* __restrict__ olevel, float scale,
+                                                   const LevelIndexer<D>& indexer, uint32_t hashmap_size, bool align_corners, uint32_t interp,
+                                                   InputMap im, uint32_t b_begin, uint32_t b_end) {
     constexpr int NJ = 1 << (D - 1);
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    uint32_t level = 0xffffu, tile = 0u, begin = 0u;
-#pragma unroll
-    for (int sg = 0; sg < FWD_MAX_SEG; sg++) {   // this XCD's work list: runs of consecutive tiles of one level, in order
-        const uint32_t e = sched.end[xcd][sg];
-        if (level == 0xffffu && slot < e) {
-            level = sched.level[xcd][sg];
-            tile = sched.tile0[xcd][sg] + (slot - begin);
-        }
-        begin = e;
-    }
-    NGP_BOUNDS(level < L || level == 0xffffu);
-    if (level >= L) return;
-    const uint32_t off0 = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
-    const float scale = lv.scale[level];
-    LevelIndexer<D> indexer;
-    indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
-    const T* __restrict__ table = grid + (size_t)off0 * C;
-    T* __restrict__ olevel = outputs + (size_t)level * B * C;
-    NGP_BOUNDS((uint64_t)tile * points_per_block < (uint64_t)B);  // every listed tile holds at least one point
-
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int pl = lane >> 1;
     const uint32_t xb = lane & 1;
-    const uint32_t b_begin = tile * points_per_block;
-    const uint32_t b_end = min(B, b_begin + points_per_block);
     for (uint32_t base = b_begin + wid * FWD_PTS_PER_WAVE; base < b_end; base += (FWD_THREADS / 64) * FWD_PTS_PER_WAVE) {
         const uint32_t b = base + pl;
         const bool in_range = b < b_end;
@@ -395,6 +369,217 @@ __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* 
         for (int c = 0; c < C; c++) acc[c] += quad_swap1(acc[c]);  // all lanes execute (no cross-lane read under divergence)
         if (in_range && xb == 0) store_vec<T, C>(olevel + (size_t)b * C, acc);
     }
+}
+
+template <typename T, int D, int C>
+__global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                                   const int32_t* __restrict__ offsets, T* __restrict__ outputs,
+                                                                   uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
+                                                                   bool align_corners, uint32_t interp, FwdSchedule sched,
+                                                                   uint32_t points_per_block, InputMap im) {
+    constexpr int NJ = 1 << (D - 1);
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    uint32_t level = 0xffffu, tile = 0u, begin = 0u;
+#pragma unroll
+    for (int sg = 0; sg < FWD_MAX_SEG; sg++) {   // this XCD's work list: runs of consecutive tiles of one level, in order
+        const uint32_t e = sched.end[xcd][sg];
+        if (level == 0xffffu && slot < e) {
+            level = sched.level[xcd][sg];
+            tile = sched.tile0[xcd][sg] + (slot - begin);
+        }
+        begin = e;
+    }
+    NGP_BOUNDS(level < L || level == 0xffffu);
+    if (level >= L) return;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float scale = lv.scale[level];
+    LevelIndexer<D> indexer;
+    indexer.init(gridtype, align_corners, hashmap_size, lv.res[level]);
+    const T* __restrict__ table = grid + (size_t)off0 * C;
+    T* __restrict__ olevel = outputs + (size_t)level * B * C;
+    NGP_BOUNDS((uint64_t)tile * points_per_block < (uint64_t)B);  // every listed tile holds at least one point
+
+    const uint32_t b_begin = tile * points_per_block;
+    const uint32_t b_end = min(B, b_begin + points_per_block);
+    forward_pair_block<T, D, C>(inputs, table, olevel, scale, indexer, hashmap_size, align_corners, interp, im, b_begin, b_end);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, round 5: the instant-ngp configuration (fp16 table, D = 3, C = 2, no align_corners) with the level's INDEX MODE resolved once per
+// workgroup instead of per corner.
+//
+// What round 4's counters said about k_grid_forward_pair (profiles/r03_grid_forward_pmc.json, profiles/r03_grid_forward_levels.txt): 15.9 M
+// VALU wave-instructions per launch = 26 us of pure issue in a 56-63 us kernel; a COARSE level alone on its XCD takes 19 us of which 13 us are
+// VALU issue -- the coarse levels are bound by their instruction stream, not by the table reads (their few cells are L1-resident: staging
+// them in LDS would change nothing -- see EXPERIMENTS.md round 5), the fine hashed levels by L2 -> L1 line traffic (4 lines per point).
+// The generic kernel above spends its instructions on generality: both the stride- and the prime-products of every coordinate (v_mul_lo_u32
+// is quarter rate), a scalar branch tree per corner for {hashed, dense} x {mask, modulo}, and the position work of a point twice (two lanes
+// per point).  Here:
+//   * DENSE levels (index = x + y s1 + z s2, provably < size: levels 0-4 of the lego table): ONE LANE PER POINT -- 64 points per wave
+//     instruction stream instead of 32.  The two corners that differ in x are neighbours in memory, so the four (y, z) combinations are four
+//     8-byte loads (dword-aligned global_load_dwordx2) that bring both: half the position / index instructions per point, the same number of
+//     cache lines per point.  Summation order kept: (x-low chain over j) + (x-high chain over j), i.e. bit-identical with the pair kernel.
+//   * HASHED levels with a power-of-two table (levels 5-15): the pair layout stays (4 lines per point is what the hash allows, and a lane
+//     pair shares them), but the index is two multiplies, two adds and per corner two XORs + one AND; no mode branches.
+//   * both: the position of the NEXT wave-step is requested before this step's corners are waited for.
+// Any other level shape (tiled grids, align_corners, non-power-of-two hashed tables) runs the generic body.  Scheduling (per-XCD work
+// lists) is unchanged.
+// ------------------------------------------------------------------------------------------------
+// position of one point for the fast paths: the load (issued early) and the arithmetic (locate's, expression for expression) are separate
+struct FwdPos3 {
+    float x[3];
+    // unconditional (the index is clamped to the last point; a lane without a point discards what it read): a conditional request would make
+    // the number of outstanding loads unknown to the compiler, which then waits for ALL of them -- the prefetched position included
+    __device__ __forceinline__ void load(const float* __restrict__ inputs, uint32_t b, uint32_t last) {
+        float t[3];
+        __builtin_memcpy(t, inputs + (size_t)min(b, last) * 3, sizeof(t));  // 4-byte aligned: global_load_dwordx3
+        x[0] = t[0]; x[1] = t[1]; x[2] = t[2];
+    }
+};
+
+#ifndef NGP_FWD_FAST
+#define NGP_FWD_FAST 1
+#endif
+template <bool SMOOTH /* interp == 1 (smoothstep) */, bool MAPPED /* inputs are world coordinates: InputMap */>
+__global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_fast(const float* __restrict__ inputs, const half_t* __restrict__ grid,
+                                                                   const int32_t* __restrict__ offsets, half_t* __restrict__ outputs, uint32_t B,
+                                                                   uint32_t L, GridLevels lv, uint32_t gridtype, uint32_t interp, FwdSchedule sched,
+                                                                   uint32_t points_per_block, InputMap im) {
+    constexpr int D = 3, C = 2;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    uint32_t level = 0xffffu, tile = 0u, begin = 0u;
+#pragma unroll
+    for (int sg = 0; sg < FWD_MAX_SEG; sg++) {   // this XCD's work list: runs of consecutive tiles of one level, in order
+        const uint32_t e = sched.end[xcd][sg];
+        if (level == 0xffffu && slot < e) {
+            level = sched.level[xcd][sg];
+            tile = sched.tile0[xcd][sg] + (slot - begin);
+        }
+        begin = e;
+    }
+    NGP_BOUNDS(level < L || level == 0xffffu);
+    if (level >= L) return;
+    const uint32_t off0 = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
+    const float scale = lv.scale[level];
+    LevelIndexer<D> indexer;
+    indexer.init(gridtype, false, hashmap_size, lv.res[level]);
+    const half_t* __restrict__ table = grid + (size_t)off0 * C;
+    half_t* __restrict__ olevel = outputs + (size_t)level * B * C;
+    NGP_BOUNDS((uint64_t)tile * points_per_block < (uint64_t)B);  // every listed tile holds at least one point
+    const uint32_t b_begin = tile * points_per_block;
+    const uint32_t b_end = min(B, b_begin + points_per_block);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool dense = !indexer.hashed && !indexer.need_mod && indexer.stride[0] == 1u && indexer.stride[1] != 0u && indexer.stride[2] != 0u;
+    const bool hashed_pow2 = indexer.hashed && indexer.mask != 0u;
+    constexpr bool mapped = MAPPED;   // (== im.scale != 0: resolved by the host, like the interpolation mode -- no per-point selects)
+
+    // locate<3>() on registers: same expressions, same order (fmaf, floor, smoothstep), `ok` = the point lies inside [0, 1]^3
+    auto place = [&](const FwdPos3& p, float (&frac)[3], uint32_t (&cell)[3]) -> bool {
+        float xv[3];
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            xv[d] = p.x[d];
+            if (mapped) xv[d] = (xv[d] + im.shift) * im.scale;
+            ok = ok && !(xv[d] < 0.0f || xv[d] > 1.0f);
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            float q = __builtin_fmaf(xv[d], scale, 0.5f);
+            const float fl = floorf(q);
+            cell[d] = (uint32_t)fl;
+            q -= (float)cell[d];
+            if (SMOOTH) q = q * q * (3.0f - 2.0f * q);
+            frac[d] = q;
+        }
+        return ok;
+    };
+
+    if (NGP_FWD_FAST && dense) {
+        // ---- one lane per point, x-pairs by 8-byte loads ----
+        const uint32_t s1 = indexer.stride[1], s2 = indexer.stride[2];
+        constexpr uint32_t STEP = FWD_THREADS;  // points per workgroup step
+        uint32_t b = b_begin + (uint32_t)threadIdx.x;
+        FwdPos3 cur, nxt;
+        cur.load(inputs, b, B - 1u);
+        for (; b - (uint32_t)threadIdx.x < b_end; b += STEP) {   // (workgroup-uniform trip count)
+            const bool in_range = b < b_end;
+            float frac[3];
+            uint32_t cell[3];
+            const bool ok = place(cur, frac, cell) && in_range;
+            // a lane without a point reads entry 0 and discards it: the loads stay unconditional, so the NEXT step's position can be requested
+            // right behind them (the vector-memory counter is in order: a request issued BEFORE the corners would have to land before them)
+            const uint32_t i00 = ok ? cell[0] + cell[1] * s1 + cell[2] * s2 : 0u;
+            NGP_BOUNDS(i00 + s1 + s2 + 1u < hashmap_size);
+            uint2 q[4];
+            const uint32_t ofs[4] = {0u, s1, s2, s1 + s2};
+#pragma unroll
+            for (int j = 0; j < 4; j++) __builtin_memcpy(&q[j], table + (size_t)(i00 + ofs[j]) * 2, sizeof(uint2));  // entries x, x + 1 (4-byte aligned)
+            nxt.load(inputs, b + STEP, B - 1u);                     // in flight during this step's arithmetic and the next step's index work
+            float accl[2] = {0.0f, 0.0f}, acch[2] = {0.0f, 0.0f};
+            const float wl0 = 1.0f - frac[0], wh0 = frac[0];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float wy = (j & 1) ? frac[1] : 1.0f - frac[1], wz = (j & 2) ? frac[2] : 1.0f - frac[2];
+                const float wl = wl0 * wy * wz, wh = wh0 * wy * wz;
+                const half2_t lo = __builtin_bit_cast(half2_t, q[j].x), hi = __builtin_bit_cast(half2_t, q[j].y);
+                accl[0] = __builtin_fmaf(wl, (float)lo.x, accl[0]);
+                accl[1] = __builtin_fmaf(wl, (float)lo.y, accl[1]);
+                acch[0] = __builtin_fmaf(wh, (float)hi.x, acch[0]);
+                acch[1] = __builtin_fmaf(wh, (float)hi.y, acch[1]);
+            }
+            float out[2] = {accl[0] + acch[0], accl[1] + acch[1]};
+            if (!ok) out[0] = out[1] = 0.0f;
+            if (in_range) store_vec<half_t, 2>(olevel + (size_t)b * 2, out);
+            cur = nxt;
+        }
+        return;
+    }
+    if (NGP_FWD_FAST && hashed_pow2) {
+        // ---- corner pairs on neighbouring lanes, index = (x ^ y p1 ^ z p2) & mask ----
+        const uint32_t mask = indexer.mask;
+        const int pl = lane >> 1;
+        const uint32_t xb = lane & 1;
+        constexpr uint32_t STEP = (FWD_THREADS / 64) * FWD_PTS_PER_WAVE;
+        uint32_t b = b_begin + (uint32_t)wid * FWD_PTS_PER_WAVE + (uint32_t)pl;
+        FwdPos3 cur, nxt;
+        cur.load(inputs, b, B - 1u);
+        for (uint32_t base = b_begin + (uint32_t)wid * FWD_PTS_PER_WAVE; base < b_end; base += STEP, b += STEP) {
+            const bool in_range = b < b_end;
+            float frac[3];
+            uint32_t cell[3];
+            const bool ok = place(cur, frac, cell) && in_range;
+            const uint32_t tx = cell[0] + xb;                      // first prime is 1
+            const uint32_t ty0 = cell[1] * kPrimes[1], ty1 = ty0 + kPrimes[1];
+            const uint32_t tz0 = cell[2] * kPrimes[2], tz1 = tz0 + kPrimes[2];
+            // (a lane without a point reads entry 0 and discards it: unconditional loads, the next position requested right behind them)
+            const uint32_t live = ok ? mask : 0u;
+            const uint32_t idx[4] = {(tx ^ ty0 ^ tz0) & live, (tx ^ ty1 ^ tz0) & live, (tx ^ ty0 ^ tz1) & live, (tx ^ ty1 ^ tz1) & live};
+            uint32_t q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[j] = *reinterpret_cast<const uint32_t*>(table + (size_t)idx[j] * 2);
+            nxt.load(inputs, b + STEP, B - 1u);
+            float acc[2] = {0.0f, 0.0f};
+            const float w0 = xb ? frac[0] : 1.0f - frac[0];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float wy = (j & 1) ? frac[1] : 1.0f - frac[1], wz = (j & 2) ? frac[2] : 1.0f - frac[2];
+                const float w = w0 * wy * wz;
+                const half2_t v = __builtin_bit_cast(half2_t, q[j]);
+                acc[0] = __builtin_fmaf(w, (float)v.x, acc[0]);
+                acc[1] = __builtin_fmaf(w, (float)v.y, acc[1]);
+            }
+            if (!ok) acc[0] = acc[1] = 0.0f;
+            acc[0] += quad_swap1(acc[0]);  // all lanes execute (no cross-lane read under divergence)
+            acc[1] += quad_swap1(acc[1]);
+            if (in_range && xb == 0) store_vec<half_t, 2>(olevel + (size_t)b * 2, acc);
+            cur = nxt;
+        }
+        return;
+    }
+    forward_pair_block<half_t, D, C>(inputs, table, olevel, scale, indexer, hashmap_size, false, interp, im, b_begin, b_end);
 }
 
 // corner-index diagnostic (same locate/indexer code path as the forward kernel)
@@ -1639,6 +1824,20 @@ static int launch_forward(const float* inputs, const void* emb, const int32_t* o
     const uint32_t tiles = cdiv(B, ppb);
     FwdSchedule sched;
     const uint32_t max_slots = build_forward_schedule(sched, L, tiles, level_cost);
+    if constexpr (sizeof(T) == 2 && D == 3 && C == 2) {
+        if (!ac) {  // the instant-ngp shape: index mode resolved per workgroup, dense levels one lane per point (k_grid_forward_fast)
+            const bool smooth = interp == 1u, mapped = im.scale != 0.0f;
+#define NGP_FWD_FAST_LAUNCH(S, M)                                                                                                        \
+            hipLaunchKernelGGL((k_grid_forward_fast<S, M>), dim3(8u * max_slots), dim3(FWD_THREADS), 0, st, inputs, (const half_t*)emb, \
+                               offsets, (half_t*)outputs, B, L, lv, gridtype, interp, sched, ppb, im)
+            if (smooth && mapped) NGP_FWD_FAST_LAUNCH(true, true);
+            else if (smooth) NGP_FWD_FAST_LAUNCH(true, false);
+            else if (mapped) NGP_FWD_FAST_LAUNCH(false, true);
+            else NGP_FWD_FAST_LAUNCH(false, false);
+#undef NGP_FWD_FAST_LAUNCH
+            return check_launch("grid_encode_forward");
+        }
+    }
     hipLaunchKernelGGL((k_grid_forward_pair<T, D, C>), dim3(8u * max_slots), dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
                        (T*)outputs, B, L, lv, gridtype, ac, interp, sched, ppb, im);
     return check_launch("grid_encode_forward");

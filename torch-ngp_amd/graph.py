@@ -101,7 +101,7 @@ class GraphedTrainStep:
         # deposits gradients (optim.NGPAdam), and a model/render configuration the fused training render accepts
         self.direct = bool(direct) and loss_fn is mse_loss and scaler is None and getattr(optimizer, 'flat_grad16', None) is not None
         # lookahead: the next batch's march under this iteration (see the module docstring); single rank + autograd-free iteration only
-        self.lookahead = bool(lookahead) and self.direct and averager is None
+        self.lookahead = bool(lookahead) and self.direct and (averager is None or (averager is optimizer and getattr(optimizer, 'shard', False)))
         self.la = None                      # [(march graph, rest graph, loss)] x 2 once captured
         self.la_cur = 0                     # buffer set of the CURRENT batch
         self.la_ready = [None, None]        # what is marched into each set: references to the announced tensors + versions + occupancy epoch
@@ -110,7 +110,10 @@ class GraphedTrainStep:
         self.la_presampled = None           # refresh mode (full sweep?) whose cell sampling already ran on the side stream
         self.la_presample_hits = 0
         import os
-        self.sharded_premarch = os.environ.get('NGP_SHARDED_PREMARCH', '1') != '0'   # sharded step: fold the next batch's march behind the update
+        # sharded lookahead only: capture the two RCCL collectives INSIDE the rest graph (one replay per step on the main stream) instead of
+        # issuing them eagerly between two replays.  Off by default: measurable here only over a 1-rank group (bench.py ddp_overhead_1rank)
+        self.graph_collectives = os.environ.get('NGP_GRAPH_COLLECTIVES', '0') == '1'
+        self.la_apply = None
         if self.lookahead:
             self.la_rays_o = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
             self.la_rays_d = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
@@ -124,9 +127,11 @@ class GraphedTrainStep:
     # ------------------------------------------------------------------------------------------
     def close(self):
         """wait for everything this object queued -- including the side stream's march of a batch that will never be consumed (the last
-        step announces its successor) -- BEFORE its graphs and their private memory pools are released.  A HIP graph that is destroyed while
-        one of its replays is still running hands its pool back to the caching allocator, and the still-running kernels then write into
-        whatever the next owner of that memory keeps there.  Called by __del__; call it explicitly when the object's lifetime matters."""
+        step announces its successor) -- BEFORE its graphs and their private memory pools are released.  Round 4 suspected that a HIP graph
+        destroyed while one of its replays is still running hands its pool back to the allocator under the running kernels; round 5 made
+        the situation deterministic (tests/test_gpu_graph_lifetime.py, tools/graph_lifetime_probe.py: side stream held by a spin kernel) and
+        found that the graph destruction ITSELF waits for the replay on this runtime -- no use-after-free with or without this method.  It
+        stays as the explicit statement of the ordering (and for runtimes that do not wait).  Called by __del__."""
         if getattr(self, '_unsafe_skip_close', False):
             return   # tests/test_gpu_graph_lifetime.py only: the arm of the lifetime reproducer that releases the graphs WITHOUT waiting
         side = getattr(self, 'la_side', None)
@@ -285,7 +290,7 @@ class GraphedTrainStep:
             self._checked_ok = iteration_checks_gradients(self.model)
         self.la = None
         self.la_ready = [None, None]
-        if self.averager is None and self.lookahead and self._direct_ok():
+        if self.lookahead and self._direct_ok():
             self._capture_lookahead()
         elif self.averager is None:
             g = torch.cuda.CUDAGraph()
@@ -297,10 +302,9 @@ class GraphedTrainStep:
             # sharded data-parallel update (optim.NGPAdam, shard=True): graphs around the two collectives,
             #   [march] -> wait for the shadow all-gather of the previous step -> [encode .. backward, local non-finite sweep, poison]
             #   -> reduce-scatter (carries the skip verdict) -> [verdict, Adam on my shard, commit] -> all-gather of the shadows (side stream,
-            #   overlaps the next [march]).  A fourth graph = [verdict, Adam, commit, march]: when the caller announces the next batch
-            #   (step(next_rays=...)) and `sharded_premarch` is on, the march of batch k + 1 rides behind the update of step k in ONE replay
-            #   and step k + 1 starts with its rest graph -- two replays per step instead of three (EXPERIMENTS.md: a replay boundary costs
-            #   ~20 us of idle GPU; the march then no longer overlaps the all-gather: which one wins is a measurement, bench.py --force-ddp)
+            #   overlaps the next [march]).  This is the form WITHOUT lookahead; with lookahead (the default of bench.py) the march leaves the
+            #   main stream altogether: _capture_lookahead.  (Folding the next batch's march behind the shard update -- two replays per step --
+            #   was measured over a 1-rank RCCL group and dropped: 0.607 against 0.591 ms, EXPERIMENTS.md round 5.)
             from fused import fused_train_iteration_split
             m, kw, opt = self.model, self.render_kwargs, self.optimizer
             bg = kw.get('bg_color', None)
@@ -310,7 +314,7 @@ class GraphedTrainStep:
                                                       found_inf=opt.scalars[2:3] if self._checked_ok else None)
             opt.wait_shadows()
             torch.cuda.synchronize()
-            ga, gb, gc_, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with _capture_into(ga):
                 march()
             with _capture_into(gb, pool=ga.pool()):
@@ -318,16 +322,9 @@ class GraphedTrainStep:
                 if not self._checked_ok:
                     opt.pre_reduce_check()     # (else the kernels that deposited the local gradients flagged them)
                 opt.poison_shards()            # found_inf -> NaN in element 0 of every shard: the reduce-scatter carries the verdict
-                # the sample count of THIS batch goes to a slot of its own before a folded march of the next batch overwrites the counter
-                self.counter[1].copy_(self.counter[0])
             with _capture_into(gc_, pool=ga.pool()):
                 opt.apply()
-            with _capture_into(gd, pool=ga.pool()):
-                opt.apply()
-                march()                        # (same buffers as ga's march: the samples of the batch whose rays are in rays_o / rays_d NOW)
-            self.graphs = (ga, gb, gc_, gd)
-            self.premarched = None             # (rays_o, rays_d, versions, occupancy epoch) of the batch gd marched at the end of the last step
-            self.premarch_hits = 0
+            self.graphs = (ga, gb, gc_)
             self.sharded = True
             self.used_direct = True
         else:  # the RCCL all-reduce stays eager between the two halves
@@ -347,6 +344,12 @@ class GraphedTrainStep:
         bg = kw.get('bg_color', None)
         self.producers_check = self._checked_ok
         pool_march, pool_rest = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        # data-parallel sharded update: the rest graph ends with the local non-finite sweep + poison; reduce-scatter -> [apply graph] ->
+        # all-gather follow eagerly (or, graph_collectives, inside the rest graph: ONE replay per step on the main stream)
+        sharded = self.averager is opt and getattr(opt, 'shard', False)
+        if sharded:
+            opt.wait_shadows()
+            torch.cuda.synchronize()
         la = []
         for p in range(2):
             march, rest = fused_train_iteration_split(m, self.la_rays_o[p], self.la_rays_d[p], self.la_target[p], m.aabb_train, self.counter[p],
@@ -361,8 +364,22 @@ class GraphedTrainStep:
             with _capture_into(gr, pool=pool_rest):
                 opt.zero_grad(set_to_none=True)
                 loss = rest()[0][0].detach()
-                self._iteration_back()
+                if not sharded:
+                    self._iteration_back()
+                else:
+                    if not self._checked_ok:
+                        opt.pre_reduce_check()
+                    opt.poison_shards()
+                    if self.graph_collectives:
+                        opt.reduce_gradients()
+                        opt.apply()
+                        opt.gather_shadows(async_op=False)   # same stream: no fork inside the graph
             la.append((gm, gr, loss, march, rest))   # (the closures keep the marched buffers alive)
+        self.la_apply = None
+        if sharded and not self.graph_collectives:
+            self.la_apply = torch.cuda.CUDAGraph()
+            with _capture_into(self.la_apply, pool=pool_rest):
+                opt.apply()
         self.la = la
         self.graphs = tuple(g for e in la for g in e[:2])
         self._rest_pool = pool_rest
@@ -530,7 +547,15 @@ class GraphedTrainStep:
                     entry[2].replay()
                     self.la_sample_event.record(side)
                 self.la_presampled = full
-        gr.replay()
+        if self.la_apply is not None:          # sharded update, eager collectives: [rest] -> reduce-scatter -> [apply] -> all-gather (side stream)
+            opt = self.optimizer
+            opt.wait_shadows()
+            gr.replay()
+            opt.reduce_gradients()
+            self.la_apply.replay()
+            opt.gather_shadows()
+        else:
+            gr.replay()
         self.la_cur = q
         return loss
 
@@ -577,42 +602,22 @@ class GraphedTrainStep:
             m.local_step += 1
             self.global_step += 1
             return loss
-        if getattr(self, 'sharded', False):
-            opt = self.optimizer
-            pm = self.premarched
-            if (pm is not None and pm[0] is rays_o and pm[1] is rays_d and pm[2] == (rays_o._version, rays_d._version)
-                    and pm[3] == self.occupancy_epoch):
-                self.target.copy_(target, non_blocking=True)     # this batch was marched behind the previous step's update
-                self.premarch_hits += 1
-            else:
-                torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
-                                     non_blocking=True)
-                self.graphs[0].replay()        # near/far + ray marching: needs no weights, overlaps the shadow all-gather of the last step
-            self.premarched = None
-            opt.wait_shadows()
-            self.graphs[1].replay()            # encode .. backward (deposit) + local non-finite sweep + poison
-            opt.reduce_gradients()             # reduce-scatter (average of my shard; the skip verdict rides in it)
-            m.step_counter[m.local_step % 16].copy_(self.counter[1], non_blocking=True)
-            fold = (self.sharded_premarch and next_rays is not None and (self.global_step + 1) % self.update_interval != 0)
-            if fold:
-                no, nd = next_rays[0], next_rays[1]
-                torch._foreach_copy_([self.rays_o, self.rays_d], [no.view_as(self.rays_o), nd.view_as(self.rays_d)], non_blocking=True)
-                self.graphs[3].replay()        # verdict + Adam on my shard + commit, then the march of the NEXT batch
-                self.premarched = (no, nd, (no._version, nd._version), self.occupancy_epoch)
-            else:
-                self.graphs[2].replay()        # verdict + Adam on my shard, scale / step commit, deposit buffer zeroed
-            opt.gather_shadows()               # all-gather of the fp16 shadows on the side stream
-            self._mark_deposits()
-            m.local_step += 1
-            self.global_step += 1
-            return self.loss
         # the batch into the static input buffers: ONE multi-tensor copy kernel (three separate copies cost ~5 us each plus the gaps)
         torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
                              non_blocking=True)
-        self.graphs[0].replay()
-        if len(self.graphs) == 2:
-            self.averager.all_reduce()
-            self.graphs[1].replay()
+        if getattr(self, 'sharded', False):
+            opt = self.optimizer
+            self.graphs[0].replay()            # near/far + ray marching: needs no weights, overlaps the shadow all-gather of the last step
+            opt.wait_shadows()
+            self.graphs[1].replay()            # encode .. backward (deposit) + local non-finite sweep + poison
+            opt.reduce_gradients()             # reduce-scatter (average of my shard; the skip verdict rides in it)
+            self.graphs[2].replay()            # verdict + Adam on my shard, scale / step commit, deposit buffer zeroed
+            opt.gather_shadows()               # all-gather of the fp16 shadows on the side stream
+        else:
+            self.graphs[0].replay()
+            if len(self.graphs) == 2:
+                self.averager.all_reduce()
+                self.graphs[1].replay()
         self._mark_deposits()
         # hand the sample count to the model's 16-slot ring exactly where the eager renderer would have put it
         m.step_counter[m.local_step % 16].copy_(self.counter[0], non_blocking=True)

@@ -300,16 +300,30 @@ class NeRFRenderer(nn.Module):
         def iteration(cur, lanes, rows, noises, n_total=n_rays):
             # n_total: what the kernels divide by the alive count to get n_step = clamp(n_total // n_alive, 1, 8) -- the frame's ray count
             # (the reference's rule) times the host-chosen `boost` below
+            # `_loop_probe = []` (bench.py's whole-frame accounting): HIP-event pairs around the four stages of every iteration + a copy of the
+            # iteration's device state (alive rays) -- (stage, start, end, lanes, rows, n_total, state copy); None: no events, no copies
+            probe = getattr(self, '_loop_probe', None)
+
+            def stage(name, fn):
+                if probe is None:
+                    return fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn()
+                e1.record()
+                probe.append((name, e0, e1, lanes, rows, n_total, snap))
+                return out
+            snap = state[cur].clone() if probe is not None else None
             xyzs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
             dirs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
             deltas = torch.empty(rows, 2, dtype=torch.float32, device=dev)
-            rb.march_rays_dev(state[cur], lanes, n_total, alive[cur], s_t, s_o, s_d, self.bound, dt_gamma, max_steps, self.cascade,
-                              self.grid_size, bits, s_near, s_far, xyzs, dirs, deltas, noises, rows)
-            sigmas, rgbs = self(xyzs, dirs)
-            sigmas = (self.density_scale * sigmas).float().contiguous()
-            rb.composite_rays_dev(state[cur], lanes, n_total, T_thresh, alive[cur], s_t, sigmas, rgbs.float().contiguous(), deltas, s_ws, s_depth,
-                                  s_image)
-            rb.compact_rays_dev(state[cur], lanes, n_total, max_steps, alive[cur], alive[1 - cur], state[1 - cur], ws)
+            stage('march_rays', lambda: rb.march_rays_dev(state[cur], lanes, n_total, alive[cur], s_t, s_o, s_d, self.bound, dt_gamma, max_steps,
+                                                          self.cascade, self.grid_size, bits, s_near, s_far, xyzs, dirs, deltas, noises, rows))
+            sigmas, rgbs = stage('network (encoder + MLPs + glue)', lambda: self(xyzs, dirs))
+            sigmas, rgbs32 = stage('casts (density_scale, fp32 copies)', lambda: ((self.density_scale * sigmas).float().contiguous(), rgbs.float().contiguous()))
+            stage('composite_rays', lambda: rb.composite_rays_dev(state[cur], lanes, n_total, T_thresh, alive[cur], s_t, sigmas, rgbs32, deltas, s_ws,
+                                                                  s_depth, s_image))
+            stage('compact_rays', lambda: rb.compact_rays_dev(state[cur], lanes, n_total, max_steps, alive[cur], alive[1 - cur], state[1 - cur], ws))
 
         def pad(rows):
             return rows + 128 - rows % 128  # the marchers' padding rule (raymarching.py:328-331); the fused network wants multiples of 128

@@ -340,9 +340,13 @@ class TrainingRun:
             m.density_bitfield.copy_(fixed_bits)
         self.keep_scene = keep_scene
         self.model, self.optimizer = model, optimizer
-        # lookahead: the next batch's march on a side stream under this iteration -- single GPU, and the sharded data-parallel step as well
-        # (the march needs no weights: it runs beside [encode .. backward] -> reduce-scatter -> [Adam on the shard] -> all-gather)
-        self.lookahead = (graph and fused and not torch_optim and not autograd and not getattr(args, 'no_lookahead', False)
+        # lookahead: the next batch's march on a side stream under this iteration.  Single GPU: always.  Sharded data-parallel step: measured
+        # over a 1-rank RCCL group (ddp_overhead_1rank) it pays only when the two collectives are captured INSIDE the rest graph (0.574 ms
+        # against 0.588 ms for the three-replay form; with eager collectives between the replays the side-stream march COSTS 40 us) -- and a
+        # captured RCCL call cannot be verified on more than one rank here, so the default for N > 1 stays the three-replay form;
+        # NGP_GRAPH_COLLECTIVES=1 selects lookahead + captured collectives, `args.ddp_lookahead` (the probe) forces lookahead either way
+        want_la = not ddp_on or os.environ.get('NGP_GRAPH_COLLECTIVES', '0') == '1' or bool(getattr(args, 'ddp_lookahead', False))
+        self.lookahead = (graph and fused and not torch_optim and not autograd and not getattr(args, 'no_lookahead', False) and want_la
                           and (not ddp_on or bool(getattr(optimizer, 'shard', False))))
         self.stepper = GraphedTrainStep(model, optimizer, scaler, self.rays, self.opt_kwargs, loss_fn=mse_loss, averager=averager,
                                         after_update=keep_scene, direct=not autograd, lookahead=self.lookahead)
@@ -631,6 +635,7 @@ def ddp_overhead_1rank(args, dev, steps):
                                              ('sharded_lookahead_collectives_in_graph', True, True, 'poison')):
             args.shard_verdict = verdict
             args.no_lookahead = not look
+            args.ddp_lookahead = look
             run = one(force_ddp=True)
             run.stepper.graph_collectives = graphed
             run.setup(min(args.warmup, 16))
@@ -657,10 +662,10 @@ def ddp_overhead_1rank(args, dev, steps):
             torch.cuda.synchronize()
             out[name] = entry
             del run, st, opt
-        args.shard_verdict, args.no_lookahead = 'poison', saved
-        out['ddp_overhead_ms_per_step'] = round(out['sharded_lookahead']['ms_per_step'] - getattr(args, '_headline_ms', float('nan')), 4)
+        args.shard_verdict, args.no_lookahead, args.ddp_lookahead = 'poison', saved, False
+        out['ddp_overhead_ms_per_step'] = round(out['sharded_3_replays_no_lookahead']['ms_per_step'] - getattr(args, '_headline_ms', float('nan')), 4)
         out['note'] = ('1-rank RCCL group: every collective and every graph boundary of the N > 1 step executes, wire time is zero; '
-                       'ddp_overhead = sharded_lookahead (the form bench.py --gpus N runs) - the headline single-GPU step of this run')
+                       'ddp_overhead = sharded_3_replays_no_lookahead (the form bench.py --gpus N runs by default) - the headline single-GPU step of this run')
     except Exception as e:  # noqa: BLE001 -- a probe: the headline line must not depend on it
         import traceback
         out['error'] = repr(e)[:300]
@@ -979,7 +984,8 @@ def main():
         t_run.setup(4)
         t_res = t_run.timed(args.extra_steps)
         tnt = {'config': 'Tanks&Temples-shaped: bound=8, 4 cascades x 128^3, dt_gamma=1/128, background model (radius-32 sphere, 2-D hashgrid + nn.Linear), '
-                         'nn.Linear sigma/colour networks (nerf/network.py: library GEMMs), --fp16 --cuda_ray, 4096 rays, torch.optim.Adam(fused) + GradScaler, drop-in modules through autograd',
+                         'nn.Linear sigma/colour/background networks (nerf/network.py) evaluated on the fused-MLP kernels under autocast (fused_linear: one-hidden-layer stacks through an exact identity layer; '
+                         'round 4: library GEMMs, 2.1 ms/step), --fp16 --cuda_ray, 4096 rays, torch.optim.Adam(fused) + GradScaler, modules through autograd',
                'value': round(t_res['samples'] / t_res['elapsed'], 1), 'unit': 'samples/s', 'steps': args.extra_steps,
                'ms_per_step': round(t_res['elapsed'] / args.extra_steps * 1e3, 4),
                'samples_per_step': round(t_res['samples'] / args.extra_steps, 1), 'final_loss': t_res['final_loss'],

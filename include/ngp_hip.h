@@ -398,19 +398,21 @@ int ngp_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_t* rays_ali
 /* On-device inference loop: march_rays / composite_rays / alive-list compaction of NeRFRenderer.run_cuda's eval
  * branch (renderer.py:322-367) with the loop state on the DEVICE: state = int32[2] {n_alive, samples marched per ray so far}.  The host
  * launches for an upper bound `alive_bound` of the alive count (the value it last read back) and may issue many iterations between
- * read-backs; the kernels take the true count from `state`, derive n_step = max(min(n_total / n_alive, 8), 1) from it (renderer.py:349),
- * and do nothing for lanes beyond it.  march: sample rows [n_alive * n_step, rows) are zero-filled (rows >= min(n_total, 8 * alive_bound)
- * always suffices); noises may be NULL.  compact: writes the surviving ids in order to out_alive and the next iteration's state to
+ * read-backs; the kernels take the true count from `state`, derive n_step = max(min(n_total / n_alive, cap), 1) from it (renderer.py:349:
+ * cap = 8 = n_step_cap 0; a caller may raise the cap for the tail of a frame, where a handful of surviving rays would otherwise need one
+ * launch set per 8 samples -- a ray's samples and their compositing order do not depend on the chunking, the SAME n_total and n_step_cap
+ * must go to the three calls of one iteration), and do nothing for lanes beyond it.  march: sample rows [n_alive * n_step, rows) are
+ * zero-filled (rows >= min(n_total, cap * alive_bound) always suffices); noises may be NULL.  compact: writes the surviving ids in order to out_alive and the next iteration's state to
  * out_state (count forced to 0 once max_steps samples were marched); workspace: ngp_compact_rays_workspace_bytes(alive_bound).
  * Slot layout, n_step sequence and compaction order equal the host-driven loop's, so do the results. */
-int ngp_march_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, const int32_t* rays_alive, const float* rays_t,
+int ngp_march_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, const int32_t* rays_alive, const float* rays_t,
                        const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                        const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                        const float* noises, uint32_t rows, ngp_stream_t stream);
-int ngp_composite_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, float T_thresh, int32_t* rays_alive, float* rays_t,
+int ngp_composite_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, float T_thresh, int32_t* rays_alive, float* rays_t,
                            const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image,
                            ngp_stream_t stream);
-int ngp_compact_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t max_steps, const int32_t* rays_alive,
+int ngp_compact_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, uint32_t max_steps, const int32_t* rays_alive,
                          int32_t* out_alive, int32_t* out_state, void* workspace, ngp_stream_t stream);
 
 /* composite_rays_train with NeRFRenderer.run_cuda's epilogue fused (renderer.py:316-318):
@@ -497,9 +499,12 @@ int ngp_optim_adam_step_ex(int count, const uint64_t* n, float* const* params, f
  * nerf/utils.py:364-366, all-reduces everything): the global "skip this step" verdict without a collective of its own.
  * ngp_optim_poison_shards: when state[2] (found_inf of THIS rank's local gradient) is set, writes NaN into element 0 of each of the `shards`
  * shards (of `payload` fp16 elements) of the flat gradient, BEFORE the reduce-scatter; ngp_optim_shard_verdict: AFTER it, sets state[2] when
- * element 0 of this rank's averaged shard is not finite.  Both are single tiny launches, graph-capturable. */
+ * element 0 of this rank's averaged shard is not finite, and (flat_grad_fp16 != NULL) takes the poison out of the flat buffer again -- a
+ * poisoned element inside padding would otherwise survive when the producers overwrite and nobody zeroes.  Both are single tiny launches,
+ * graph-capturable. */
 int ngp_optim_poison_shards(void* flat_grad_fp16, uint32_t shards, uint64_t payload, const float* state, ngp_stream_t stream);
-int ngp_optim_shard_verdict(const void* shard_grad_fp16, float* state, ngp_stream_t stream);
+int ngp_optim_shard_verdict(const void* shard_grad_fp16, float* state, void* flat_grad_fp16, uint32_t shards, uint64_t payload,
+                            ngp_stream_t stream);
 /* torch_ema's update() on its own (the Trainer calls it once per epoch): ema[k] -= one_minus_decay * (ema[k] - params[k]), up to 8
  * tensors per call */
 int ngp_optim_ema_update(int count, const uint64_t* n, float* const* params, float* const* ema, float one_minus_decay, ngp_stream_t stream);

@@ -88,7 +88,7 @@ def test_host_side_argument_validation_needs_no_gpu():
                                                256, None)
     assert rc == 1 and b'group tickets' in lib.ngp_last_error()
     # the shard-poisoning verdict of the data-parallel update validates before it launches
-    assert lib.ngp_optim_poison_shards(None, 2, 8, one, None) == 1 and lib.ngp_optim_shard_verdict(one, None, None) == 1
+    assert lib.ngp_optim_poison_shards(None, 2, 8, one, None) == 1 and lib.ngp_optim_shard_verdict(one, None, None, 1, 8, None) == 1
     words = 2 + 4096 + 2 * 4096 * 20  # fit_end, final ticket, windows per ray, emit masks ...
     assert lib.ngp_march_rays_train_workspace_bytes(4096) == 4 * ((words + 31) // 32 * 32 + 32 * 32)  # ... and 32 group tickets, 128 bytes apart
 

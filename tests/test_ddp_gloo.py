@@ -107,6 +107,8 @@ def _make_double():
         def _verdict_launch(self):
             if not torch.isfinite(self.shard_grad[0].float()):
                 self.scalars[2] = 1.0
+            head = self.flat_grad16.view(self.world_size, self.payload)[:, 0]
+            head[~torch.isfinite(head.float())] = 0.0
     return TorchKernelDouble
 
 

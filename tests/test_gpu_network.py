@@ -140,3 +140,45 @@ def test_cuda_ray_training_step_with_background_model_vs_oracle():
     assert err_ws < 1e-3, err_ws
     ws32, _, img32 = oracle.composite_rays_train_forward(sigma32.numpy(), rgb32.numpy(), deltas[:mm], rays)
     assert np.abs(img - img32).max() < 2e-2      # the two oracles bracket the fp16 effect
+
+
+def test_linear_stacks_on_the_fused_mlp_kernels_match_the_linear_layers():
+    """`fused_linear` (nerf/network.py): the bias-free Linear / ReLU stacks of the non-`--ff` model run on the fused-MLP kernels under fp16
+    autocast -- the one-hidden-layer stacks (density, background) through an exact identity hidden matmul.  Same values as the nn.Linear
+    GEMMs up to the fp32 summation order inside a layer (outputs are fp16: a few ulp), same gradients to fp16 noise; fp32 / CPU / no-autocast
+    calls keep the Linear path."""
+    from nerf.network import NeRFNetwork, _stack_fusable
+    torch.manual_seed(3)
+    m = NeRFNetwork(bound=2, cuda_ray=True, bg_radius=32.0).cuda().train()
+    with torch.no_grad():
+        m.encoder.embeddings.uniform_(-0.5, 0.5)
+        m.encoder_bg.embeddings.uniform_(-0.5, 0.5)
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x = (torch.rand(3000, 3, device='cuda', generator=g) * 4 - 2)
+    d = torch.nn.functional.normalize(torch.randn(3000, 3, device='cuda', generator=g), dim=-1)
+    sph = torch.rand(700, 2, device='cuda', generator=g) * 2 - 1
+    res = {}
+    for fused in (True, False):
+        m.fused_linear = fused
+        m.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.float16):
+            sigma, rgb = m(x, d)
+            bg = m.background(sph, d[:700])
+            assert _stack_fusable(m.sigma_net, torch.zeros(4, 32, device='cuda', dtype=torch.half))
+            loss = (rgb.float() * torch.linspace(0.5, 1.5, 3, device='cuda')).sum() + sigma.float().clamp(max=50).sum() * 1e-2 + bg.float().sum()
+        loss.backward()
+        res[fused] = (sigma.detach().float(), rgb.detach().float(), bg.detach().float(),
+                      [p.grad.detach().float().clone() for p in list(m.sigma_net.parameters()) + list(m.color_net.parameters()) + list(m.bg_net.parameters())],
+                      m.encoder.embeddings.grad.detach().float().clone())
+    a, b = res[True], res[False]
+    assert a[0].shape == b[0].shape == (3000,) and a[1].shape == (3000, 3) and a[2].shape == (700, 3)
+    rel = lambda u, v: float(torch.linalg.norm(u - v) / torch.linalg.norm(v).clamp(min=1e-20))   # noqa: E731
+    assert rel(a[0], b[0]) < 2e-3 and float((a[1] - b[1]).abs().max()) < 2e-3 and float((a[2] - b[2]).abs().max()) < 2e-3
+    for ga, gb in zip(a[3], b[3]):
+        assert ga.shape == gb.shape and rel(ga, gb) < 5e-3, rel(ga, gb)
+    assert rel(a[4], b[4]) < 5e-3
+    # outside fp16 autocast the Linear layers themselves run (fp32 semantics are theirs)
+    m.fused_linear = True
+    assert not _stack_fusable(m.sigma_net, torch.zeros(4, 32, device='cuda'))
+    s32 = m.density(x[:64])['sigma']
+    assert s32.dtype == torch.float32

@@ -57,9 +57,9 @@ _SIGNATURES = {
     'ngp_march_rays_ex': [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     'ngp_composite_rays': [_u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_compact_rays': [_vp, _u32, _vp, _vp, _vp, _vp],
-    'ngp_march_rays_dev': [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
-    'ngp_composite_rays_dev': [_vp, _u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    'ngp_compact_rays_dev': [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp],
+    'ngp_march_rays_dev': [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    'ngp_composite_rays_dev': [_vp, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'ngp_compact_rays_dev': [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp],
     'ngp_ffmlp_forward': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     'ngp_ffmlp_inference': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     'ngp_ffmlp_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
@@ -98,7 +98,7 @@ _SIGNATURES = {
     'ngp_optim_adam_step_ex': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _u32, _vp],
     'ngp_optim_ema_update': [_i32, _vp, _vp, _vp, _f32, _vp],
     'ngp_optim_poison_shards': [_vp, _u32, ctypes.c_uint64, _vp, _vp],
-    'ngp_optim_shard_verdict': [_vp, _vp, _vp],
+    'ngp_optim_shard_verdict': [_vp, _vp, _vp, _u32, ctypes.c_uint64, _vp],
     'ngp_allocate_splitk': [_sz],
     'ngp_free_splitk': [],
 }
@@ -216,19 +216,22 @@ def grid_backward_workspace(offsets, B, D, C, L, S, H, gridtype, align_corners, 
 _LEVEL_COSTS = {}
 
 
-def ray_level_costs(L, S, H, step_unit):
+def ray_level_costs(L, S, H, step_unit, log2_hashmap_size=19, D=3):
     """relative cost per level of gathering ray-ordered samples `step_unit` apart (in the encoder's unit cube) -- for
-    ngp_grid_encode_forward_sched.  A level costs the more the more often consecutive samples change cell: measured on MI355X 19 us
-    (level 0, resolution 16) .. 46 us (resolution >= ~700 at a step of 1/590: saturated) per level and XCD
-    (profiles/r03_grid_forward_levels.txt), i.e. 0.41 + 0.59 * min(1, resolution * step / 1.2).  Returns a c_void_p to a cached host
+    ngp_grid_encode_forward_sched.  Fitted to k_grid_forward_fast on MI355X (profiles/r05_grid_forward_levels.txt, one level per XCD, ~8 us of
+    launch + ramp subtracted): a DENSE level ((resolution + 1)^D entries fit the table: one lane per point, bound by its instruction stream)
+    costs ~10 us whatever its resolution; a HASHED level costs the more the more often consecutive samples change cell -- 17 us (resolution
+    81) .. 43.6 us (resolution >= ~700 at a step of 1/590: saturated), i.e. 0.32 + 0.65 * min(1, resolution * step / 1.2) of the saturated
+    cost, against 0.24 for a dense level.  (Round 3's kernel: 0.41 + 0.59 * min(...) for every level.)  Returns a c_void_p to a cached host
     float array (kept alive here)."""
-    key = (int(L), float(S), int(H), round(float(step_unit), 9))
+    key = (int(L), float(S), int(H), round(float(step_unit), 9), int(log2_hashmap_size), int(D))
     hit = _LEVEL_COSTS.get(key)
     if hit is None:
         scale = (ctypes.c_float * L)()
         res = (ctypes.c_uint32 * L)()
         check(lib.ngp_grid_level_table(L, float(S), H, ctypes.cast(scale, ctypes.c_void_p), ctypes.cast(res, ctypes.c_void_p)))
-        arr = (ctypes.c_float * L)(*[0.41 + 0.59 * min(1.0, float(res[l]) * float(step_unit) / 1.2) for l in range(L)])
+        dense = [(int(res[l]) + 1) ** int(D) <= (1 << int(log2_hashmap_size)) for l in range(L)]
+        arr = (ctypes.c_float * L)(*[0.24 if dense[l] else 0.32 + 0.65 * min(1.0, float(res[l]) * float(step_unit) / 1.2) for l in range(L)])
         hit = (arr, ctypes.cast(arr, ctypes.c_void_p))
         _LEVEL_COSTS[key] = hit
     return hit[1]

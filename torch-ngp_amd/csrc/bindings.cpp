@@ -320,31 +320,31 @@ void compact_rays(const Tensor rays_alive, const uint32_t n_alive, Tensor out_al
     check(ngp_compact_rays((const int32_t*)ptr(rays_alive), n_alive, (int32_t*)ptr(out_alive), (int32_t*)ptr(out_count), ws.data_ptr(), stream()));
 }
 
-void march_rays_dev(const Tensor state, const uint32_t alive_bound, const uint32_t n_total, const Tensor rays_alive, const Tensor rays_t, const Tensor rays_o,
+void march_rays_dev(const Tensor state, const uint32_t alive_bound, const uint32_t n_total, const uint32_t n_step_cap, const Tensor rays_alive, const Tensor rays_t, const Tensor rays_o,
                     const Tensor rays_d, const float bound, const float dt_gamma, const uint32_t max_steps, const uint32_t C, const uint32_t H,
                     const Tensor grid, const Tensor nears, const Tensor fars, Tensor xyzs, Tensor dirs, Tensor deltas, OptTensor noises, const uint32_t rows) {
     CHECK_F32(rays_t); CHECK_F32(rays_o); CHECK_F32(rays_d); CHECK_F32(nears); CHECK_F32(fars); CHECK_F32(xyzs); CHECK_F32(dirs); CHECK_F32(deltas);
     CHECK_I32(rays_alive); CHECK_I32(state);
     CHECK_DENSE(grid);
-    check(ngp_march_rays_dev((const int32_t*)ptr(state), alive_bound, n_total, (const int32_t*)ptr(rays_alive), (const float*)ptr(rays_t),
+    check(ngp_march_rays_dev((const int32_t*)ptr(state), alive_bound, n_total, n_step_cap, (const int32_t*)ptr(rays_alive), (const float*)ptr(rays_t),
                              (const float*)ptr(rays_o), (const float*)ptr(rays_d), bound, dt_gamma, max_steps, C, H, (const uint8_t*)ptr(grid),
                              (const float*)ptr(nears), (const float*)ptr(fars), (float*)ptr(xyzs), (float*)ptr(dirs), (float*)ptr(deltas),
                              (const float*)ptr(noises), rows, stream()));
 }
 
-void composite_rays_dev(const Tensor state, const uint32_t alive_bound, const uint32_t n_total, const float T_thresh, Tensor rays_alive, Tensor rays_t,
+void composite_rays_dev(const Tensor state, const uint32_t alive_bound, const uint32_t n_total, const uint32_t n_step_cap, const float T_thresh, Tensor rays_alive, Tensor rays_t,
                         const Tensor sigmas, const Tensor rgbs, const Tensor deltas, Tensor weights_sum, Tensor depth, Tensor image) {
     CHECK_F32(rays_t); CHECK_F32(sigmas); CHECK_F32(rgbs); CHECK_F32(deltas); CHECK_F32(weights_sum); CHECK_F32(depth); CHECK_F32(image);
     CHECK_I32(rays_alive); CHECK_I32(state);
-    check(ngp_composite_rays_dev((const int32_t*)ptr(state), alive_bound, n_total, T_thresh, (int32_t*)ptr(rays_alive), (float*)ptr(rays_t),
+    check(ngp_composite_rays_dev((const int32_t*)ptr(state), alive_bound, n_total, n_step_cap, T_thresh, (int32_t*)ptr(rays_alive), (float*)ptr(rays_t),
                                  (const float*)ptr(sigmas), (const float*)ptr(rgbs), (const float*)ptr(deltas), (float*)ptr(weights_sum),
                                  (float*)ptr(depth), (float*)ptr(image), stream()));
 }
 
-void compact_rays_dev(const Tensor state, const uint32_t alive_bound, const uint32_t n_total, const uint32_t max_steps, const Tensor rays_alive,
+void compact_rays_dev(const Tensor state, const uint32_t alive_bound, const uint32_t n_total, const uint32_t n_step_cap, const uint32_t max_steps, const Tensor rays_alive,
                       Tensor out_alive, Tensor out_state, Tensor workspace) {
     CHECK_I32(rays_alive); CHECK_I32(out_alive); CHECK_I32(out_state); CHECK_I32(state);
-    check(ngp_compact_rays_dev((const int32_t*)ptr(state), alive_bound, n_total, max_steps, (const int32_t*)ptr(rays_alive), (int32_t*)ptr(out_alive),
+    check(ngp_compact_rays_dev((const int32_t*)ptr(state), alive_bound, n_total, n_step_cap, max_steps, (const int32_t*)ptr(rays_alive), (int32_t*)ptr(out_alive),
                                (int32_t*)ptr(out_state), ptr(workspace), stream()));
 }
 

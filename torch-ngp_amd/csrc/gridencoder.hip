@@ -441,6 +441,7 @@ struct FwdPos3 {
 #ifndef NGP_FWD_FAST
 #define NGP_FWD_FAST 1
 #endif
+// (measured and dropped, EXPERIMENTS.md round 5: non-temporal table gathers on the fine hashed levels -- no effect: 58.0 / 58.1 vs 57.5 us)
 template <bool SMOOTH /* interp == 1 (smoothstep) */, bool MAPPED /* inputs are world coordinates: InputMap */>
 __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_fast(const float* __restrict__ inputs, const half_t* __restrict__ grid,
                                                                    const int32_t* __restrict__ offsets, half_t* __restrict__ outputs, uint32_t B,

@@ -94,6 +94,52 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
         const bool wide = gh && p16 && !ema && (n & 3u) == 0 &&
                           ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0 &&
                           ((reinterpret_cast<uintptr_t>(g16) | reinterpret_cast<uintptr_t>(p16)) & 7u) == 0;
+#ifndef NGP_ADAM_UNROLL
+#define NGP_ADAM_UNROLL 1
+#endif
+        if (wide && NGP_ADAM_UNROLL == 2) {
+            // two independent 4-element groups per lane and trip: twice the loads in flight before the first dependent instruction
+            const uint64_t n4 = n / 4, stride = (uint64_t)gridDim.x * OPT_THREADS;
+            for (uint64_t i = (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += 2 * stride) {
+                const uint64_t j = i + stride;
+                const bool two = j < n4;
+                const uint64_t jj = two ? j : i;
+                const half4_t x0 = reinterpret_cast<half4_t*>(g16)[i], x1 = reinterpret_cast<half4_t*>(g16)[jj];
+                float4_t pm0 = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(m) + i), pv0 = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(v) + i),
+                         pp0 = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(p) + i);
+                float4_t pm1 = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(m) + jj), pv1 = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(v) + jj),
+                         pp1 = __builtin_nontemporal_load(reinterpret_cast<float4_t*>(p) + jj);
+                if (!keep) {
+                    reinterpret_cast<half4_t*>(g16)[i] = half4_t{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+                    if (two) reinterpret_cast<half4_t*>(g16)[j] = half4_t{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
+                }
+                if (skip) continue;
+                half4_t ph0, ph1;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float g0 = (float)x0[c] * inv_scale, g1 = (float)x1[c] * inv_scale;
+                    pm0[c] = beta1 * pm0[c] + (1.0f - beta1) * g0;
+                    pv0[c] = beta2 * pv0[c] + (1.0f - beta2) * g0 * g0;
+                    pp0[c] -= step_size * pm0[c] / (sqrtf(pv0[c]) / bc2_sqrt + eps);
+                    ph0[c] = (half_t)pp0[c];
+                    pm1[c] = beta1 * pm1[c] + (1.0f - beta1) * g1;
+                    pv1[c] = beta2 * pv1[c] + (1.0f - beta2) * g1 * g1;
+                    pp1[c] -= step_size * pm1[c] / (sqrtf(pv1[c]) / bc2_sqrt + eps);
+                    ph1[c] = (half_t)pp1[c];
+                }
+                __builtin_nontemporal_store(pm0, reinterpret_cast<float4_t*>(m) + i);
+                __builtin_nontemporal_store(pv0, reinterpret_cast<float4_t*>(v) + i);
+                __builtin_nontemporal_store(pp0, reinterpret_cast<float4_t*>(p) + i);
+                reinterpret_cast<half4_t*>(p16)[i] = ph0;
+                if (two) {
+                    __builtin_nontemporal_store(pm1, reinterpret_cast<float4_t*>(m) + j);
+                    __builtin_nontemporal_store(pv1, reinterpret_cast<float4_t*>(v) + j);
+                    __builtin_nontemporal_store(pp1, reinterpret_cast<float4_t*>(p) + j);
+                    reinterpret_cast<half4_t*>(p16)[j] = ph1;
+                }
+            }
+            continue;
+        }
         if (wide) {
             const uint64_t n4 = n / 4;
             for (uint64_t i = (uint64_t)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * OPT_THREADS) {
@@ -208,8 +254,14 @@ __global__ void k_poison_shards(half_t* __restrict__ grad, uint32_t shards, uint
     if (state[2] == 0.0f) return;
     for (uint32_t r = threadIdx.x; r < shards; r += blockDim.x) grad[(uint64_t)r * payload] = (half_t)__builtin_nanf("");
 }
-__global__ void k_shard_verdict(const half_t* __restrict__ shard, float* __restrict__ state) {
+// ... and takes the poison out of the flat buffer again (the exchange has consumed it): with a producer that OVERWRITES its gradients and an
+// optimizer that therefore does not zero the flat buffer, a poisoned element that lies in padding would otherwise stay NaN forever
+__global__ void k_shard_verdict(const half_t* __restrict__ shard, float* __restrict__ state, half_t* __restrict__ flat, uint32_t shards,
+                                uint64_t payload) {
     if (threadIdx.x == 0 && !__builtin_isfinite((float)shard[0])) state[2] = 1.0f;
+    if (flat)
+        for (uint32_t r = threadIdx.x; r < shards; r += blockDim.x)
+            if (!__builtin_isfinite((float)flat[(uint64_t)r * payload])) flat[(uint64_t)r * payload] = (half_t)0.0f;
 }
 
 // torch_ema's update() on its own (the Trainer calls it once per epoch, not per step): shadow -= omd * (shadow - param)
@@ -228,7 +280,10 @@ using namespace ngp;
 
 static uint32_t opt_blocks(uint64_t total) {
     uint32_t blocks = (uint32_t)cdiv64(total / 2 + 1, OPT_THREADS * 4);  // ~8 elements per lane
-    if (blocks > 2048u) blocks = 2048u;
+#ifndef NGP_ADAM_MAX_BLOCKS
+#define NGP_ADAM_MAX_BLOCKS 2048u
+#endif
+    if (blocks > NGP_ADAM_MAX_BLOCKS) blocks = NGP_ADAM_MAX_BLOCKS;
     if (blocks < 1u) blocks = 1u;
     return blocks;
 }
@@ -298,9 +353,12 @@ extern "C" int ngp_optim_poison_shards(void* flat_grad_fp16, uint32_t shards, ui
     return check_launch("optim_poison_shards");
 }
 
-extern "C" int ngp_optim_shard_verdict(const void* shard_grad_fp16, float* state, ngp_stream_t stream) {
+extern "C" int ngp_optim_shard_verdict(const void* shard_grad_fp16, float* state, void* flat_grad_fp16, uint32_t shards, uint64_t payload,
+                                       ngp_stream_t stream) {
     NGP_REQUIRE(shard_grad_fp16 && state, NGP_ERR_INVALID, "optim_shard_verdict: NULL argument");
-    hipLaunchKernelGGL(k_shard_verdict, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<const half_t*>(shard_grad_fp16), state);
+    NGP_REQUIRE(!flat_grad_fp16 || (shards >= 1 && payload >= 1), NGP_ERR_INVALID, "optim_shard_verdict: empty shard layout");
+    hipLaunchKernelGGL(k_shard_verdict, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<const half_t*>(shard_grad_fp16), state,
+                       reinterpret_cast<half_t*>(flat_grad_fp16), shards, payload);
     return check_launch("optim_shard_verdict");
 }
 

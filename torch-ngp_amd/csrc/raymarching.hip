@@ -734,11 +734,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_march_train_scan(int32_t* __re
     if (threadIdx.x < CT_GROUPS) ws[march_ws_ticket_word(N) + threadIdx.x * CT_GROUP_STRIDE] = 0u;  // ... and its group tickets
 }
 
-// samples per ray and iteration of the inference loop (renderer.py:349: max(min(N // n_alive, 8), 1))
-__device__ __host__ __forceinline__ uint32_t loop_n_step(uint32_t n_total, uint32_t n_alive) {
+// samples per ray and iteration of the inference loop (renderer.py:349: max(min(N // n_alive, 8), 1)).  cap: the 8 of that rule; the
+// on-device loop may raise it for the tail of a frame (cap = 0 means 8): a handful of surviving rays then finish in a few iterations
+// instead of one launch set per 8 samples -- a ray's samples and their compositing order do not depend on the chunking
+__device__ __host__ __forceinline__ uint32_t loop_n_step(uint32_t n_total, uint32_t n_alive, uint32_t cap) {
+    if (cap == 0u) cap = 8u;
     if (n_alive == 0) return 1u;
     const uint32_t q = n_total / n_alive;
-    return q > 8u ? 8u : (q < 1u ? 1u : q);
+    return q > cap ? cap : (q < 1u ? 1u : q);
 }
 
 // raymarching.cu:701-805
@@ -752,11 +755,11 @@ __global__ __launch_bounds__(RM_THREADS) void k_march_rays(uint32_t n_alive, uin
                                                            const float* __restrict__ fars, float* __restrict__ xyzs,
                                                            float* __restrict__ dirs, float* __restrict__ deltas,
                                                            const float* __restrict__ noises, uint32_t zero_rows,
-                                                           const int32_t* __restrict__ dev_state, uint32_t n_total) {
+                                                           const int32_t* __restrict__ dev_state, uint32_t n_total, uint32_t n_step_cap) {
     const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
     if (dev_state) {  // on-device render loop: the alive count lives on the device, n_step follows the renderer's rule
         n_alive = (uint32_t)dev_state[0];
-        n_step = loop_n_step(n_total, n_alive);
+        n_step = loop_n_step(n_total, n_alive, n_step_cap);
     }
     if (zero_rows > 0) {  // padding rows behind the last ray's slots: at most `align` of them, spread over the first lanes
         for (uint32_t row = n_alive * n_step + n; row < zero_rows; row += gridDim.x * RM_THREADS) {
@@ -1136,11 +1139,12 @@ __global__ __launch_bounds__(RM_THREADS) void k_composite_rays(uint32_t n_alive,
                                                                float* __restrict__ rays_t, const float* __restrict__ sigmas,
                                                                const float* __restrict__ rgbs, const float* __restrict__ deltas,
                                                                float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                               float* __restrict__ image, const int32_t* __restrict__ dev_state, uint32_t n_total) {
+                                                               float* __restrict__ image, const int32_t* __restrict__ dev_state, uint32_t n_total,
+                                                               uint32_t n_step_cap) {
     const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
     if (dev_state) {
         n_alive = (uint32_t)dev_state[0];
-        n_step = loop_n_step(n_total, n_alive);
+        n_step = loop_n_step(n_total, n_alive, n_step_cap);
     }
     if (n >= n_alive) return;
     const uint32_t index = (uint32_t)rays_alive[n];
@@ -1186,13 +1190,13 @@ __global__ __launch_bounds__(RM_THREADS) void k_compact_count(const int32_t* __r
 __global__ __launch_bounds__(RM_THREADS) void k_compact_write(const int32_t* __restrict__ rays_alive, uint32_t n_alive,
                                                               int32_t* __restrict__ out_alive, int32_t* __restrict__ out_count,
                                                               const uint32_t* __restrict__ ws, const int32_t* __restrict__ dev_state,
-                                                              uint32_t n_total, uint32_t max_steps) {
+                                                              uint32_t n_total, uint32_t max_steps, uint32_t n_step_cap) {
     __shared__ uint32_t lds4[RM_THREADS / 64];
     __shared__ uint32_t wave_excl[RM_THREADS / 64];
     uint32_t steps_done = 0;
     if (dev_state) {  // out_count is the next iteration's state {n_alive, steps marched so far}
         n_alive = (uint32_t)dev_state[0];
-        steps_done = (uint32_t)dev_state[1] + loop_n_step(n_total, n_alive);
+        steps_done = (uint32_t)dev_state[1] + loop_n_step(n_total, n_alive, n_step_cap);
     }
     uint32_t part = 0;
     for (uint32_t j = threadIdx.x; j < blockIdx.x; j += RM_THREADS) part += ws[j];
@@ -1478,7 +1482,7 @@ extern "C" int ngp_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_
     NGP_REQUIRE(zero_rows == 0 || zero_rows >= n_alive * n_step, NGP_ERR_INVALID, "march_rays: zero_rows is smaller than n_alive * n_step");
     const uint32_t lanes = n_alive > 0 ? n_alive : 1u;
     RM_LAUNCH_1D(k_march_rays, lanes, as_stream(stream), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
-                 max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, zero_rows, (const int32_t*)nullptr, 0u);
+                 max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, zero_rows, (const int32_t*)nullptr, 0u, 0u);
     return check_launch("march_rays");
 }
 
@@ -1499,7 +1503,7 @@ extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thr
     NGP_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, NGP_ERR_INVALID,
                 "composite_rays: NULL tensor");
     RM_LAUNCH_1D(k_composite_rays, n_alive, as_stream(stream), n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
-                 weights_sum, depth, image, (const int32_t*)nullptr, 0u);
+                 weights_sum, depth, image, (const int32_t*)nullptr, 0u, 0u);
     return check_launch("composite_rays");
 }
 
@@ -1518,7 +1522,7 @@ extern "C" int ngp_compact_rays(const int32_t* rays_alive, uint32_t n_alive, int
     RM_LAUNCH_1D(k_compact_count, n_alive, st, rays_alive, n_alive, ws, (const int32_t*)nullptr);
     int rc = check_launch("compact_rays(count)");
     if (rc) return rc;
-    RM_LAUNCH_1D(k_compact_write, n_alive, st, rays_alive, n_alive, out_alive, out_count, (const uint32_t*)ws, (const int32_t*)nullptr, 0u, 0u);
+    RM_LAUNCH_1D(k_compact_write, n_alive, st, rays_alive, n_alive, out_alive, out_count, (const uint32_t*)ws, (const int32_t*)nullptr, 0u, 0u, 0u);
     return check_launch("compact_rays(write)");
 }
 
@@ -1530,7 +1534,7 @@ extern "C" int ngp_compact_rays(const int32_t* rays_alive, uint32_t n_alive, int
 // `state`, lanes and sample rows beyond it do nothing / are zero-filled up to `rows`.  Same slot layout, same n_step sequence and same
 // order-preserving compaction as the host-driven loop: identical results.
 // ---------------------------------------------------------------------------------------------
-extern "C" int ngp_march_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, const int32_t* rays_alive, const float* rays_t,
+extern "C" int ngp_march_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, const int32_t* rays_alive, const float* rays_t,
                                   const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
                                   uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs,
                                   float* deltas, const float* noises, uint32_t rows, ngp_stream_t stream) {
@@ -1539,26 +1543,27 @@ extern "C" int ngp_march_rays_dev(const int32_t* state, uint32_t alive_bound, ui
     if (rc) return rc;
     NGP_REQUIRE(state && rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas, NGP_ERR_INVALID, "march_rays: NULL tensor");
     NGP_REQUIRE(rows > 0 && n_total > 0, NGP_ERR_INVALID, "march_rays_dev: rows and n_total must be positive");
+    NGP_REQUIRE(n_step_cap <= 1024u, NGP_ERR_INVALID, "march_rays_dev: n_step_cap must be in [0, 1024] (0 = the reference's 8)");
     const uint32_t lanes = alive_bound > 0 ? alive_bound : 1u;
     RM_LAUNCH_1D(k_march_rays, lanes, as_stream(stream), alive_bound, 1u, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
-                 grid, fars, xyzs, dirs, deltas, noises, rows, state, n_total);
+                 grid, fars, xyzs, dirs, deltas, noises, rows, state, n_total, n_step_cap);
     return check_launch("march_rays_dev");
 }
 
-extern "C" int ngp_composite_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, float T_thresh, int32_t* rays_alive,
+extern "C" int ngp_composite_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, float T_thresh, int32_t* rays_alive,
                                       float* rays_t, const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
                                       float* depth, float* image, ngp_stream_t stream) {
     if (alive_bound == 0) return NGP_OK;
     NGP_REQUIRE(state && rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image, NGP_ERR_INVALID,
                 "composite_rays: NULL tensor");
     RM_LAUNCH_1D(k_composite_rays, alive_bound, as_stream(stream), alive_bound, 1u, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
-                 weights_sum, depth, image, state, n_total);
+                 weights_sum, depth, image, state, n_total, n_step_cap);
     return check_launch("composite_rays_dev");
 }
 
 /* compaction + loop bookkeeping: out_alive / out_state {n_alive, steps marched} describe the next iteration; the count becomes 0 once
  * max_steps samples per ray were marched */
-extern "C" int ngp_compact_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t max_steps, const int32_t* rays_alive,
+extern "C" int ngp_compact_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, uint32_t max_steps, const int32_t* rays_alive,
                                     int32_t* out_alive, int32_t* out_state, void* workspace, ngp_stream_t stream) {
     NGP_REQUIRE(state && rays_alive && out_alive && out_state && workspace, NGP_ERR_INVALID, "compact_rays: NULL tensor");
     hipStream_t st = as_stream(stream);
@@ -1567,6 +1572,6 @@ extern "C" int ngp_compact_rays_dev(const int32_t* state, uint32_t alive_bound, 
     RM_LAUNCH_1D(k_compact_count, lanes, st, rays_alive, alive_bound, ws, state);
     int rc = check_launch("compact_rays_dev(count)");
     if (rc) return rc;
-    RM_LAUNCH_1D(k_compact_write, lanes, st, rays_alive, alive_bound, out_alive, out_state, (const uint32_t*)ws, state, n_total, max_steps);
+    RM_LAUNCH_1D(k_compact_write, lanes, st, rays_alive, alive_bound, out_alive, out_state, (const uint32_t*)ws, state, n_total, max_steps, n_step_cap);
     return check_launch("compact_rays_dev(write)");
 }

@@ -199,13 +199,20 @@ class GraphedTrainStep:
         """single-GPU direct iteration: the grid backward WRITES the table gradient and the optimizer keeps the buffer (no zeroing, no
         read of the old value: 49 MB per step).  Not with an averager / sharded exchange (they own the flat buffer's life cycle)."""
         import fused
-        return bool(fused.USE_OVERWRITE_TABLE and self.averager is None)
+        # (sharded update: the reduce-scatter reads the flat buffer the producers wrote -- every element of it, the MLP regions through the slab
+        # reduction -- so the optimizer's memset of that buffer can go as well: NGPAdam.apply(zero=False))
+        sharded = self.averager is self.optimizer and getattr(self.optimizer, 'shard', False)
+        return bool(fused.USE_OVERWRITE_TABLE and (self.averager is None or sharded))
 
     def _mark_deposits(self):
         """after a replay: what the captured optimizer step left in the table's deposit buffer (Python ran only at capture time)"""
         emb = getattr(getattr(self.model, 'encoder', None), 'embeddings', None)
         if emb is not None and self.used_direct and self._overwrites_table():
             emb._ngp_grad16_stale = True
+            if self.averager is not None:   # sharded update without the memset: every deposit buffer is left as its producer wrote it
+                for p in getattr(self.optimizer, 'flat_params', []):
+                    if getattr(p, '_ngp_grad16', None) is not None:
+                        p._ngp_grad16_stale = True
 
     def _clean_deposits(self):
         """before replaying graphs whose producers ADD into the deposit buffers: zero what an overwriting producer left behind"""
@@ -311,7 +318,8 @@ class GraphedTrainStep:
             march, rest = fused_train_iteration_split(m, self.rays_o, self.rays_d, self.target, m.aabb_train, self.counter[0], self.captured_capacity,
                                                       opt.scalars[0:1], 1 if bg is None else bg, kw.get('perturb', False), kw.get('dt_gamma', 0),
                                                       kw.get('max_steps', 1024), kw.get('T_thresh', 1e-4), noise_seed=opt.scalars[3:4],
-                                                      found_inf=opt.scalars[2:3] if self._checked_ok else None)
+                                                      found_inf=opt.scalars[2:3] if self._checked_ok else None,
+                                                      overwrite_table=self._overwrites_table())
             opt.wait_shadows()
             torch.cuda.synchronize()
             ga, gb, gc_ = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -323,7 +331,7 @@ class GraphedTrainStep:
                     opt.pre_reduce_check()     # (else the kernels that deposited the local gradients flagged them)
                 opt.poison_shards()            # found_inf -> NaN in element 0 of every shard: the reduce-scatter carries the verdict
             with _capture_into(gc_, pool=ga.pool()):
-                opt.apply()
+                opt.apply(zero=not self._overwrites_table())
             self.graphs = (ga, gb, gc_)
             self.sharded = True
             self.used_direct = True
@@ -372,14 +380,14 @@ class GraphedTrainStep:
                     opt.poison_shards()
                     if self.graph_collectives:
                         opt.reduce_gradients()
-                        opt.apply()
+                        opt.apply(zero=not self._overwrites_table())
                         opt.gather_shadows(async_op=False)   # same stream: no fork inside the graph
             la.append((gm, gr, loss, march, rest))   # (the closures keep the marched buffers alive)
         self.la_apply = None
         if sharded and not self.graph_collectives:
             self.la_apply = torch.cuda.CUDAGraph()
             with _capture_into(self.la_apply, pool=pool_rest):
-                opt.apply()
+                opt.apply(zero=not self._overwrites_table())
         self.la = la
         self.graphs = tuple(g for e in la for g in e[:2])
         self._rest_pool = pool_rest

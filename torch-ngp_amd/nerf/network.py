@@ -28,6 +28,50 @@ def _apply_stack(layers, h):
     return h
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The same stacks on the matrix cores (extension, `model.fused_linear`, default on): under fp16 autocast on the GPU a bias-free
+# Linear / ReLU stack of width 16 .. 256 IS what the fully fused MLP kernels compute (csrc/ffmlp.hip: weights fp16 [out, in] row major,
+# fp32 accumulation, one rounding to fp16 per layer -- the rounding points of an autocast nn.Linear), so the stack is handed to them
+# instead of `depth` tall-skinny library GEMMs (BASELINE config 5: 42 k x 32..64 operands, ~25 us of launch latency per GEMM, half
+# of the training step).  The kernels want >= 2 hidden layers, 16-multiples on the input and 16 output columns:
+#   * input columns are zero-padded to a multiple of 16 (the matching weight columns are zero),
+#   * output rows are zero-padded to 16,
+#   * a stack with ONE hidden layer (depth 2: the density and background networks) gets an IDENTITY hidden matmul: the hidden
+#     activations are post-ReLU fp16 values, relu(I h) = h exactly, so the result is the two-matmul network's, bit for bit.
+# The flat fp16 weight vector is assembled from the nn.Linear parameters by differentiable torch ops (pad / cat), so autograd routes the
+# kernels' flat weight gradient back to each layer; the identity block is a constant and its gradient is dropped.
+# Parity: tests/test_gpu_network.py (against the Linear stacks themselves and against the reference's network.py golden run).
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _stack_fusable(layers, h):
+    if not (h.is_cuda and h.dim() == 2 and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.float16):
+        return False
+    depth = len(layers)
+    if depth < 2 or any(l.bias is not None for l in layers):
+        return False
+    hidden = layers[0].out_features
+    if hidden not in (16, 32, 64, 128, 256) or layers[-1].out_features > 16 or layers[-1].in_features != hidden:
+        return False
+    return all(l.in_features == hidden and l.out_features == hidden for l in layers[1:-1])
+
+
+def _apply_stack_fused(layers, h):
+    from ffmlp.ffmlp import ffmlp_forward
+    depth, hidden = len(layers), layers[0].out_features
+    n_in, n_out = layers[0].in_features, layers[-1].out_features
+    in_pad = (n_in + 15) // 16 * 16
+    parts = [F.pad(layers[0].weight, (0, in_pad - n_in)).reshape(-1)]
+    if depth == 2:   # one hidden layer: the exact identity hidden matmul (see above)
+        parts.append(torch.eye(hidden, device=h.device, dtype=layers[0].weight.dtype).reshape(-1))
+    parts += [l.weight.reshape(-1) for l in layers[1:-1]]
+    parts.append(F.pad(layers[-1].weight, (0, 0, 0, 16 - n_out)).reshape(-1))
+    flat = torch.cat(parts)
+    batch = h.shape[0]
+    rows = (batch + 127) // 128 * 128
+    x = F.pad(h, (0, in_pad - n_in, 0, rows - batch))
+    out = ffmlp_forward(x, flat, in_pad, 16, hidden, max(depth - 1, 2), 0, 6, not torch.is_grad_enabled(), x.requires_grad)
+    return out[:batch, :n_out]
+
+
 class NeRFNetwork(NeRFRenderer):
     def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", encoding_bg="hashgrid", num_layers=2, hidden_dim=64,
                  geo_feat_dim=15, num_layers_color=3, hidden_dim_color=64, num_layers_bg=2, hidden_dim_bg=64, bound=1, **kwargs):
@@ -48,13 +92,20 @@ class NeRFNetwork(NeRFRenderer):
         else:
             self.bg_net = None
 
+    fused_linear = True   # Linear stacks on the fused-MLP kernels under fp16 autocast (see _apply_stack_fused); False: nn.Linear GEMMs
+
+    def _stack(self, layers, h):
+        if self.fused_linear and _stack_fusable(layers, h):
+            return _apply_stack_fused(layers, h)
+        return _apply_stack(layers, h)
+
     def density(self, x):
         # x [N,3] in [-bound, bound] -> {'sigma' [N], 'geo_feat' [N, geo_feat_dim]}
-        h = _apply_stack(self.sigma_net, self.encoder(x, bound=self.bound))
+        h = self._stack(self.sigma_net, self.encoder(x, bound=self.bound))
         return {'sigma': trunc_exp(h[..., 0]), 'geo_feat': h[..., 1:]}
 
     def _rgb(self, d, geo_feat):
-        return torch.sigmoid(_apply_stack(self.color_net, torch.cat([self.encoder_dir(d), geo_feat], dim=-1)))
+        return torch.sigmoid(self._stack(self.color_net, torch.cat([self.encoder_dir(d), geo_feat], dim=-1)))
 
     def forward(self, x, d):
         out = self.density(x)
@@ -63,7 +114,7 @@ class NeRFNetwork(NeRFRenderer):
     def background(self, x, d):
         # x [N,2] in [-1,1] (far-sphere coordinates), d [N,3] -> rgb [N,3]
         h = torch.cat([self.encoder_dir(d), self.encoder_bg(x)], dim=-1)
-        return torch.sigmoid(_apply_stack(self.bg_net, h))
+        return torch.sigmoid(self._stack(self.bg_net, h))
 
     def color(self, x, d, mask=None, geo_feat=None, **kwargs):
         if mask is None:

@@ -297,9 +297,9 @@ class NeRFRenderer(nn.Module):
         state[0, 0] = n_rays
         bits = self.density_bitfield.contiguous()
 
-        def iteration(cur, lanes, rows, noises, n_total=n_rays):
-            # n_total: what the kernels divide by the alive count to get n_step = clamp(n_total // n_alive, 1, 8) -- the frame's ray count
-            # (the reference's rule) times the host-chosen `boost` below
+        def iteration(cur, lanes, rows, noises, n_total=n_rays, cap=0):
+            # n_total: what the kernels divide by the alive count to get n_step = clamp(n_total // n_alive, 1, cap) -- the frame's ray count
+            # (the reference's rule) times the host-chosen `boost` below; cap = 0: the reference's 8
             # `_loop_probe = []` (bench.py's whole-frame accounting): HIP-event pairs around the four stages of every iteration + a copy of the
             # iteration's device state (alive rays) -- (stage, start, end, lanes, rows, n_total, state copy); None: no events, no copies
             probe = getattr(self, '_loop_probe', None)
@@ -317,13 +317,13 @@ class NeRFRenderer(nn.Module):
             xyzs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
             dirs = torch.empty(rows, 3, dtype=torch.float32, device=dev)
             deltas = torch.empty(rows, 2, dtype=torch.float32, device=dev)
-            stage('march_rays', lambda: rb.march_rays_dev(state[cur], lanes, n_total, alive[cur], s_t, s_o, s_d, self.bound, dt_gamma, max_steps,
+            stage('march_rays', lambda: rb.march_rays_dev(state[cur], lanes, n_total, cap, alive[cur], s_t, s_o, s_d, self.bound, dt_gamma, max_steps,
                                                           self.cascade, self.grid_size, bits, s_near, s_far, xyzs, dirs, deltas, noises, rows))
             sigmas, rgbs = stage('network (encoder + MLPs + glue)', lambda: self(xyzs, dirs))
             sigmas, rgbs32 = stage('casts (density_scale, fp32 copies)', lambda: ((self.density_scale * sigmas).float().contiguous(), rgbs.float().contiguous()))
-            stage('composite_rays', lambda: rb.composite_rays_dev(state[cur], lanes, n_total, T_thresh, alive[cur], s_t, sigmas, rgbs32, deltas, s_ws,
+            stage('composite_rays', lambda: rb.composite_rays_dev(state[cur], lanes, n_total, cap, T_thresh, alive[cur], s_t, sigmas, rgbs32, deltas, s_ws,
                                                                   s_depth, s_image))
-            stage('compact_rays', lambda: rb.compact_rays_dev(state[cur], lanes, n_total, max_steps, alive[cur], alive[1 - cur], state[1 - cur], ws))
+            stage('compact_rays', lambda: rb.compact_rays_dev(state[cur], lanes, n_total, cap, max_steps, alive[cur], alive[1 - cur], state[1 - cur], ws))
 
         def pad(rows):
             return rows + 128 - rows % 128  # the marchers' padding rule (raymarching.py:328-331); the fused network wants multiples of 128
@@ -345,8 +345,21 @@ class NeRFRenderer(nn.Module):
         # per ray.  From the 6th iteration on, while at least 9 of 10 rays survive an iteration, the row budget is doubled (n_step up to 8:
         # `boost` x N rows), and halved again when rays start to terminate early (an opaque frame is over by then and never leaves
         # boost = 1: no sample is evaluated in vain).
+        # The TAIL of a frame (round 5, profiles/r05_render_stages.txt): once most rays have terminated the reference's cap of 8 samples per
+        # ray and iteration leaves the row budget unused -- the opaque frame of a trained network spent 15 of its 26 iterations (~120 us of
+        # launches each) on fewer than 100 surviving rays.  `loop_tail_cap` (default 64) lifts the cap in the adaptive loop ONCE THE SURVIVORS
+        # ARE FEW: cap = clamp(N // alive at the last read-back, 8, 64), so an iteration still evaluates about N rows (lifting it while many
+        # rays are alive made the transparent frame slower: the rows are sized from a stale count and most of them were zero rows); in that
+        # tail the host also reads the count back after every pair of iterations (a batch of 8 kept launching for rays that were long gone).
+        # 26 -> 8 iterations on that frame, 3.1 -> 2.1 ms.  Same image, bit for bit (chunking does not change a ray's samples or their
+        # compositing order); the max_steps caveat of the docstring applies unchanged.  loop_tail_cap = 8 / adaptive_n_step = False: the
+        # reference sequence.
+        import os
+        tail_cap = int(getattr(self, 'loop_tail_cap', os.environ.get('NGP_LOOP_TAIL_CAP', 64))) if adaptive else 8
+        tail_cap = max(8, min(tail_cap, 1024))
         boost, prev_alive, prev_iters = 1, n_rays, 2
         while bound_alive > 0 and done < max_steps:
+            cap = max(8, min(tail_cap, n_rays // max(bound_alive, 1)))
             if adaptive:
                 survival = (bound_alive / max(prev_alive, 1)) ** (1.0 / max(prev_iters, 1))
                 if survival >= 0.9 and boost < 8 and done >= 6 and 2 * boost * n_rays <= int(getattr(self, 'loop_max_rows', 1 << 26)):   # (an opaque frame is over by then: its rays saturate within ~10 samples)
@@ -357,7 +370,7 @@ class NeRFRenderer(nn.Module):
             if getattr(self, '_loop_debug', None) is not None:
                 self._loop_debug.append((done, bound_alive, boost, round(survival, 3) if adaptive else None))
             # row bucket: the smallest of B, B/2, B/4, ... (B = boost * N) that holds min(B, 8 * alive) rows (>= 2048)
-            need = min(n_total, 8 * bound_alive)
+            need = min(n_total, cap * bound_alive)
             bucket = n_total
             while bucket // 2 >= max(need, 2048):
                 bucket //= 2
@@ -382,12 +395,14 @@ class NeRFRenderer(nn.Module):
                 if g is not None:
                     g.replay()
                 else:
-                    iteration(0, lanes, rows, None, n_total)
-                    iteration(1, lanes, rows, None, n_total)
+                    iteration(0, lanes, rows, None, n_total, 0 if cap == 8 else cap)
+                    iteration(1, lanes, rows, None, n_total, 0 if cap == 8 else cap)
                 done += 2
                 prev_iters += 2
             batch = min(sync_every, batch * 2) if done >= 6 else batch
             bound_alive = int(state[0, 0].item())
+            if adaptive and tail_cap > 8 and bound_alive * 16 <= n_rays:
+                batch = 2          # the tail: a pair of iterations now marches up to 2 x cap samples per ray -- look before launching more
         weights_sum.copy_(s_ws)
         depth.copy_(s_depth)
         image.copy_(s_image)

@@ -222,7 +222,8 @@ class NGPAdam:
         capi.check(capi.lib.ngp_optim_poison_shards(self.flat_grad16.data_ptr(), self.world_size, self.payload, self.scalars.data_ptr(), capi.stream()))
 
     def _verdict_launch(self):
-        capi.check(capi.lib.ngp_optim_shard_verdict(self.shard_grad.data_ptr(), self.scalars.data_ptr(), capi.stream()))
+        capi.check(capi.lib.ngp_optim_shard_verdict(self.shard_grad.data_ptr(), self.scalars.data_ptr(), self.flat_grad16.data_ptr(), self.world_size,
+                                                    self.payload, capi.stream()))
 
     @torch.no_grad()
     def reduce_gradients(self):
@@ -252,9 +253,12 @@ class NGPAdam:
         return out
 
     @torch.no_grad()
-    def apply(self):
+    def apply(self, zero=True):
         """Adam on my shard (skipped everywhere when any rank saw a non-finite gradient), loss-scale / step-count commit, and the flat
-        deposit buffer zeroed for the next backward; capturable"""
+        deposit buffer zeroed for the next backward; capturable.  zero=False: the producers of the NEXT step overwrite every element they own
+        (the captured fused iteration with overwrite_table: the grid backward writes the whole table gradient, the slab reduction writes the
+        MLP gradients), so the 24.5 MB memset is skipped -- the buffers are stale from here on, which the caller has to announce
+        (graph.GraphedTrainStep._mark_deposits) so that a producer that ADDS cleans them first."""
         if len(self._keep) > 64:   # used standalone in a loop without pre_reduce_check()/step(): do not grow without bound
             del self._keep[:-8]
         if self.verdict == 'poison':
@@ -263,11 +267,11 @@ class NGPAdam:
         for i in range(0, len(entries), _MAX):
             self._launch(entries[i:i + _MAX], capi.NGP_OPT_PHASE_UPDATE, 0.0)
         self._launch([], capi.NGP_OPT_PHASE_COMMIT, 0.0)
-        self.flat_grad16.zero_()
-        for p in self.flat_params:   # the whole flat buffer is clean now, whatever an overwriting producer announced
-            if getattr(p, '_ngp_deposit_overwritten', False) or getattr(p, '_ngp_grad16_stale', False):
-                p._ngp_deposit_overwritten = False
-                p._ngp_grad16_stale = False
+        if zero:
+            self.flat_grad16.zero_()
+        for p in self.flat_params:   # zeroed: clean, whatever an overwriting producer announced; kept: stale until overwritten / cleaned
+            p._ngp_deposit_overwritten = False
+            p._ngp_grad16_stale = not zero
 
     @torch.no_grad()
     def gather_shadows(self, async_op=True):

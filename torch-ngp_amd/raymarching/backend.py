@@ -150,7 +150,7 @@ def compact_rays(rays_alive, n_alive, out_alive, out_count):
                                          capi.stream()))
 
 
-def march_rays_dev(state, alive_bound, n_total, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars,
+def march_rays_dev(state, alive_bound, n_total, n_step_cap, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars,
                    xyzs, dirs, deltas, noises, rows):
     """extension (include/ngp_hip.h, on-device inference loop): march_rays with the alive count / n_step taken from the device `state`"""
     for t, n in ((rays_t, 'rays_t'), (rays_o, 'rays_o'), (rays_d, 'rays_d'), (nears, 'nears'), (fars, 'fars'), (xyzs, 'xyzs'),
@@ -158,24 +158,24 @@ def march_rays_dev(state, alive_bound, n_total, rays_alive, rays_t, rays_o, rays
         _f32(t, n)
     _i32(rays_alive, 'rays_alive'); _i32(state, 'state')
     capi.dense(grid, 'grid')
-    capi.check(capi.lib.ngp_march_rays_dev(capi.ptr(state), alive_bound, n_total, capi.ptr(rays_alive), capi.ptr(rays_t), capi.ptr(rays_o),
+    capi.check(capi.lib.ngp_march_rays_dev(capi.ptr(state), alive_bound, n_total, n_step_cap, capi.ptr(rays_alive), capi.ptr(rays_t), capi.ptr(rays_o),
                                            capi.ptr(rays_d), float(bound), float(dt_gamma), max_steps, C, H, capi.ptr(grid), capi.ptr(nears),
                                            capi.ptr(fars), capi.ptr(xyzs), capi.ptr(dirs), capi.ptr(deltas), capi.ptr(noises), rows, capi.stream()))
 
 
-def composite_rays_dev(state, alive_bound, n_total, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+def composite_rays_dev(state, alive_bound, n_total, n_step_cap, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
     for t, n in ((rays_t, 'rays_t'), (sigmas, 'sigmas'), (rgbs, 'rgbs'), (deltas, 'deltas'), (weights_sum, 'weights_sum'),
                  (depth, 'depth'), (image, 'image')):
         _f32(t, n)
     _i32(rays_alive, 'rays_alive'); _i32(state, 'state')
-    capi.check(capi.lib.ngp_composite_rays_dev(capi.ptr(state), alive_bound, n_total, float(T_thresh), capi.ptr(rays_alive), capi.ptr(rays_t),
+    capi.check(capi.lib.ngp_composite_rays_dev(capi.ptr(state), alive_bound, n_total, n_step_cap, float(T_thresh), capi.ptr(rays_alive), capi.ptr(rays_t),
                                                capi.ptr(sigmas), capi.ptr(rgbs), capi.ptr(deltas), capi.ptr(weights_sum), capi.ptr(depth),
                                                capi.ptr(image), capi.stream()))
 
 
-def compact_rays_dev(state, alive_bound, n_total, max_steps, rays_alive, out_alive, out_state, workspace):
+def compact_rays_dev(state, alive_bound, n_total, n_step_cap, max_steps, rays_alive, out_alive, out_state, workspace):
     _i32(rays_alive, 'rays_alive'); _i32(out_alive, 'out_alive'); _i32(out_state, 'out_state'); _i32(state, 'state')
-    capi.check(capi.lib.ngp_compact_rays_dev(capi.ptr(state), alive_bound, n_total, max_steps, capi.ptr(rays_alive), capi.ptr(out_alive),
+    capi.check(capi.lib.ngp_compact_rays_dev(capi.ptr(state), alive_bound, n_total, n_step_cap, max_steps, capi.ptr(rays_alive), capi.ptr(out_alive),
                                              capi.ptr(out_state), capi.ptr(workspace), capi.stream()))
 
 

@@ -238,6 +238,43 @@ def frame_stages(model, ro, rd, rkw):
                     'rows = alive rays x n_step of the iteration (an upper bound of the samples emitted)'}
 
 
+def measure_pmc_traffic(argv_tail):
+    """`--pmc`: HBM bytes per launch measured FOR THIS RUN'S WORKLOAD on this box: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE --
+    they do not fit one pass, and no tracing domain is combined with --pmc, /opt/skills/guides/MI355X_MICROARCH.md) around a short run of
+    this script in the same mode, reduced by tools/pmc_traffic.py (the guide's unit and gfx950 read corrections).  -> (per-launch dict,
+    source string) or (None, reason).  ~1 minute; needs rocprofv3 on the box."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not found on this box'
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pmc_traffic
+    work = tempfile.mkdtemp(prefix='ngp_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    dirs = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(work, counter)
+            cmd = ['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'run', '--', sys.executable, os.path.abspath(__file__),
+                   '--steps', '6', '--warmup', '2', '--no-cpu-baseline', '--no-roofline', '--no-render', '--no-dropin', '--no-extra', '--no-ddp-probe'] + argv_tail
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=420)
+            if r.returncode != 0:
+                return None, f'rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-200:]}'
+            dirs[counter] = d
+        fetch = pmc_traffic.per_kernel(dirs['FETCH_SIZE'], 'FETCH_SIZE')
+        write = pmc_traffic.per_kernel(dirs['WRITE_SIZE'], 'WRITE_SIZE')
+        per_launch = {}
+        for key in set(fetch) | set(write):
+            label, factor = pmc_traffic.KERNELS[key]
+            per_launch[label] = per_launch.get(label, 0) + round(fetch.get(key, (0.0, 0))[0] * 1024.0 * factor + write.get(key, (0.0, 0))[0] * 1024.0)
+        return per_launch, 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS run (bench.py --pmc; read corrections of tools/pmc_traffic.py)'
+    except Exception as e:  # noqa: BLE001 -- a measurement aid: the line must not depend on it
+        return None, f'pmc passes failed: {e!r}'[:240]
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def load_pmc_traffic():
     """(HBM bytes per launch, file name) from the newest committed rocprofv3 --pmc pass (profiles/*_pmc_traffic.json, produced by
     tools/pmc_traffic.py on the same workload); (None, None) when the file is absent.  NOT a measurement of this run."""
@@ -730,6 +767,8 @@ def main():
                     help='N > 1: weak = --rays per GPU (global batch grows with N, the headline); strong = --rays in total, --rays / N per GPU')
     ap.add_argument('--no-strong', action='store_true', help='N > 1, --scaling weak: skip the secondary strong-scaling measurement (`strong_scaling`)')
     ap.add_argument('--strong-steps', type=int, default=128)
+    ap.add_argument('--pmc', action='store_true', help='measure `traffic` (HBM bytes per launch) for every roofline row in THIS run: two short rocprofv3 --pmc '
+                    'passes of this script (about a minute); default: the committed pass named in traffic_source')
     ap.add_argument('--force-ddp', action='store_true', help='--gpus 1 only: the HEADLINE run itself goes through the data-parallel step over a 1-rank RCCL group '
                     '(sharded update, collectives, occupancy exchange); the default line carries the same measurement as `ddp_overhead_1rank`')
     ap.add_argument('--no-ddp-probe', action='store_true', help='skip the `ddp_overhead_1rank` measurement (N = 1 only)')
@@ -866,10 +905,20 @@ def main():
         torch.cuda.synchronize()
         timers.enabled = False
         if rank == 0:
-            traffic, traffic_source = load_pmc_traffic()
+            traffic, traffic_source, measured = None, None, False
+            if args.pmc and world == 1:
+                tail = [f for f in ('--no-lookahead', '--no-graph', '--no-fused', '--torch-optim', '--autograd') if f in sys.argv[1:]]
+                traffic, traffic_source = measure_pmc_traffic(tail)
+                measured = traffic is not None
+            if traffic is None:
+                pmc_note = traffic_source
+                traffic, traffic_source = load_pmc_traffic()
+                if args.pmc and pmc_note:
+                    traffic_source = f'{traffic_source} [--pmc asked for but: {pmc_note}]'
             roofs = timers.summary(traffic, marched=[int(m.item()) for m in marched])
             for r in roofs:
-                r['traffic_source'] = (f'{traffic_source} (committed rocprofv3 --pmc pass of the same workload; not measured in this run)'
+                r['traffic_source'] = ((traffic_source if measured else
+                                        f'{traffic_source} (committed rocprofv3 --pmc pass of the same workload; not measured in this run)')
                                        if r['traffic'] is not None else None)
     comm_ms = None
     if comm_events:

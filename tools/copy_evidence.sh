@@ -17,3 +17,8 @@ cp $src/render_800x800.txt profiles/${pre}_render_800x800.txt
 cp $src/occupancy_refresh.txt profiles/${pre}_occupancy_refresh.txt
 cp $src/grid_backward_probe.txt profiles/${pre}_grid_backward_probe.txt 2>/dev/null
 cat $src/box_state_before.txt $src/box_state_after.txt > profiles/${pre}_box_state.txt
+# round 5 additions (absent in older runs: ignored)
+for f in render_summary_300.md render_summary_1.md render_frames_300.txt render_frames_1.txt grid_forward_levels.txt graph_lifetime_probe.txt unroll_probe.txt; do
+  [ -f $src/$f ] && cp $src/$f profiles/${pre}_$f
+done
+true

@@ -21,11 +21,16 @@ KERNELS = {  # substring of the kernel name (first match wins) -> (label used by
     'k_grid_backward_accumulate': ('grid_encode_backward', 2.0),
     'k_grid_backward': ('grid_encode_backward', 1.0),
     'k_grid_forward_pair': ('grid_encode_forward', 1.0),
+    'k_grid_forward_fast': ('grid_encode_forward', 1.0),   # round 5: the instant-ngp shape (4 / 8-byte gathers: raw)
     'k_network_forward': ('network_forward', 2.0),  # sigma MLP + exp/SH + colour MLP + sigmoid in one launch
     'k_ffmlp_forward': ('ffmlp_forward', 2.0),
+    # the paired backward of the training step: <WIDTH 64, IN_JB 1, NHM 2> = the colour network (3 layers), NHM 1 = the sigma network
+    'k_ffmlp_backward_pairedILi64ELi1ELi2E': ('ffmlp_backward (colour net)', 2.0),
+    'k_ffmlp_backward_paired<64, 1, 2': ('ffmlp_backward (colour net)', 2.0),
     'k_ffmlp_backward': ('ffmlp_backward', 2.0),
-    'k_march_train_wave': ('march_rays_train', 1.0),
-    'k_composite_train_loss_bwd': ('composite_train_loss_backward', 2.0),
+    'k_march_train_wave': ('march_rays_train (+ near/far)', 1.0),
+    'k_adam': ('k_adam (Adam + scaler + shadows + gradient zeroing)', 2.0),   # 16-byte streaming reads: doubled
+    'k_composite_train_loss_bwd': ('composite + loss + backward', 2.0),
     'k_composite_train_fwd': ('composite_rays_train_forward', 2.0),
     'k_composite_train_bwd': ('composite_rays_train_backward', 2.0),
 }

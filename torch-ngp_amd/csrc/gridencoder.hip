@@ -377,7 +377,6 @@ __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* 
                                                                    uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
                                                                    bool align_corners, uint32_t interp, FwdSchedule sched,
                                                                    uint32_t points_per_block, InputMap im) {
-    constexpr int NJ = 1 << (D - 1);
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     uint32_t level = 0xffffu, tile = 0u, begin = 0u;
 #pragma unroll

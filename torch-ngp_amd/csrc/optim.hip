@@ -280,8 +280,11 @@ using namespace ngp;
 
 static uint32_t opt_blocks(uint64_t total) {
     uint32_t blocks = (uint32_t)cdiv64(total / 2 + 1, OPT_THREADS * 4);  // ~8 elements per lane
+// grid cap: 768 workgroups = 3 per CU.  Swept in round 5 (EXPERIMENTS.md): 256 / 384 / 512 / 768 / 1024 / 2048 workgroups -> step 0.4419 /
+// 0.4335 / 0.4255 / 0.4245 / 0.4291 / 0.4297 ms, k_adam itself 63.3 us at 512-1024 against 66.0 at 2048: fewer, longer-lived workgroups stream as
+// fast and leave room for the lookahead march that starts beside this kernel
 #ifndef NGP_ADAM_MAX_BLOCKS
-#define NGP_ADAM_MAX_BLOCKS 2048u
+#define NGP_ADAM_MAX_BLOCKS 768u
 #endif
     if (blocks > NGP_ADAM_MAX_BLOCKS) blocks = NGP_ADAM_MAX_BLOCKS;
     if (blocks < 1u) blocks = 1u;

@@ -10,10 +10,10 @@ timeout 1500 python -m pytest tests -m gpu -q > $out/pytest_gpu.txt 2>&1; echo "
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_n1_driver_args.json 2> $out/bench_n1_driver_args.err; echo "driver-args bench rc $?"
 timeout 900 python bench.py --pmc --no-cpu-baseline --no-extra --no-dropin > $out/bench_n1_default.json 2> $out/bench_n1_default.err; echo "default bench rc $?"
 timeout 600 python bench.py --steps 256 --warmup 16 --no-lookahead --no-cpu-baseline --no-extra --no-dropin --no-render > $out/bench_n1_no_lookahead.json 2> $out/bench_n1_no_lookahead.err; echo "no-lookahead bench rc $?"
-bash tools/gpu_profile.sh $tag/prof_la --steps 64 --warmup 16 --no-render --no-dropin --no-cpu-baseline --no-extra > /dev/null 2>&1
-bash tools/gpu_profile.sh $tag/prof_nola --steps 64 --warmup 16 --no-render --no-dropin --no-cpu-baseline --no-extra --no-lookahead > /dev/null 2>&1
+bash tools/gpu_profile.sh $tag/prof_la --steps 64 --warmup 16 --no-render --no-dropin --no-cpu-baseline --no-extra --no-ddp-probe > /dev/null 2>&1
+bash tools/gpu_profile.sh $tag/prof_nola --steps 64 --warmup 16 --no-render --no-dropin --no-cpu-baseline --no-extra --no-lookahead --no-ddp-probe > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $root/$out/pmc_$c -o run -- python $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-render --no-dropin --no-extra > $root/$out/pmc_$c.log 2>&1) || echo "pmc $c failed"
+  (cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $root/$out/pmc_$c -o run -- python $root/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-render --no-dropin --no-extra --no-ddp-probe > $root/$out/pmc_$c.log 2>&1) || echo "pmc $c failed"
 done
 python tools/pmc_traffic.py $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE > $out/pmc_traffic.json 2> $out/pmc_traffic.err || echo "pmc_traffic failed: $(tail -2 $out/pmc_traffic.err)"
 rm -rf $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
@@ -21,9 +21,10 @@ timeout 300 python tools/time_update.py > $out/occupancy_refresh.txt 2>&1
 timeout 300 python tools/bench_render.py > $out/render_800x800.txt 2>&1
 timeout 120 python tools/grid_bwd_probe.py > $out/grid_backward_probe.txt 2>&1
 # the inference frame, per kernel: rocprofv3 kernel trace of 4 frames per bracket (network trained 160 steps, as in bench.py's frame)
+timeout 300 python tools/render_frames.py --train-steps 160 --save /tmp/ngp_render_model.pt > $out/render_train.txt 2>&1
 for sc_ in 300 1; do
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_render_$sc_ -o p -- python $root/tools/render_frames.py --scale $sc_ --frames 4 > $root/$out/render_frames_$sc_.txt 2>&1) || echo "render profile $sc_ failed"
-  python tools/profile_summary.py $out/prof_render_$sc_ "python tools/render_frames.py --scale $sc_ --frames 4 (4 frames + 160 training steps in the same trace)" > $out/render_summary_$sc_.md 2>/dev/null
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/prof_render_$sc_ -o p -- python $root/tools/render_frames.py --scale $sc_ --frames 4 --load /tmp/ngp_render_model.pt > $root/$out/render_frames_$sc_.txt 2>&1) || echo "render profile $sc_ failed"
+  python tools/profile_summary.py $out/prof_render_$sc_ "python tools/render_frames.py --scale $sc_ --frames 4 --load <network trained 160 steps> (the trace holds the 4 frames only: divide totals by 4)" > $out/render_summary_$sc_.md 2>/dev/null
   rm -rf $out/prof_render_$sc_
 done
 NGP_HIP_LIBRARY=$(pwd)/torch-ngp_amd/variants/fwd_new_mask/libngp_hip.so timeout 300 python tools/grid_fwd_levels.py --levels > $out/grid_forward_levels.txt 2>&1

@@ -14,9 +14,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--scale', type=float, default=300.0)
 ap.add_argument('--frames', type=int, default=4)
 ap.add_argument('--train-steps', type=int, default=160)
+ap.add_argument('--save', default='', help='train, save the model state to this file and exit (so that a PROFILED run can --load it: its trace then holds frames only)')
+ap.add_argument('--load', default='', help='render with the state saved by --save instead of training in this process')
 a = ap.parse_args()
 dev = torch.device('cuda')
-if a.train_steps > 0:
+if a.load:
+    import raymarching
+    from nerf.network_ff import NeRFNetwork
+    model = NeRFNetwork(bound=1, cuda_ray=True, density_scale=1.0, min_near=0.2, density_thresh=10).to(dev)
+    model.load_state_dict(torch.load(a.load, map_location=dev), strict=False)
+    model.density_bitfield = raymarching.packbits(model.density_grid, min(float(model.density_grid.clamp(min=0).mean()), 10.0), model.density_bitfield)
+elif a.train_steps > 0:
     import bench
     args = argparse.Namespace(rays=4096, replicated_optim=False, no_lookahead=False)
     run = bench.TrainingRun(args, dev, 1, 0, fused=True, graph=True, torch_optim=False, autograd=False)
@@ -25,6 +33,10 @@ if a.train_steps > 0:
         run.train_step(count=False)
     torch.cuda.synchronize()
     model = run.model
+    if a.save:
+        torch.save(model.state_dict(), a.save)
+        print('saved', a.save)
+        sys.exit(0)
 else:
     import raymarching
     from nerf.network_ff import NeRFNetwork

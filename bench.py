@@ -406,8 +406,9 @@ class TrainingRun:
             loss = stepper._eager(rays_o, rays_d, gt)
             stepper.global_step += 1
         else:
-            if self.lookahead:
-                # the data loader's next batch is known one step early: its march runs under this iteration
+            if self.lookahead or self.ddp_on:
+                # the data loader's next batch is known one step early: its march runs under this iteration (lookahead), or -- sharded
+                # data-parallel step -- its copy into the static buffers rides behind this step's reduce-scatter
                 nxt = self.pool[self.step_no % self.n_pool]
                 loss = stepper.step(rays_o, rays_d, gt, next_rays=nxt)
             else:

@@ -41,7 +41,22 @@ def timed(g, per, reps=256):
     return (time.perf_counter() - t0) / (reps // per * per) * 1e3
 
 
+def timed_eager(reps=256):
+    """the same launches issued eagerly (9 C calls + a few allocations per iteration): is the graph boundary or the host the limit?"""
+    for _ in range(8):
+        st._iteration_front(); st._iteration_back()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        st._iteration_front(); st._iteration_back()
+    t_issue = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3, t_issue / reps * 1e3
+
+
 for rep in range(2):
+    e, i = timed_eager()
+    print(f'eager launches        : {e:.4f} ms per iteration (host issue {i:.4f} ms)')
     print(f'1 iteration per graph : {timed(g1, 1):.4f} ms per iteration')
     print(f'2 iterations per graph: {timed(g2, 2):.4f} ms per iteration')
     print(f'4 iterations per graph: {timed(g4, 4):.4f} ms per iteration')

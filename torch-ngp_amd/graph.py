@@ -610,22 +610,42 @@ class GraphedTrainStep:
             m.local_step += 1
             self.global_step += 1
             return loss
-        # the batch into the static input buffers: ONE multi-tensor copy kernel (three separate copies cost ~5 us each plus the gaps)
-        torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
-                             non_blocking=True)
         if getattr(self, 'sharded', False):
+            # Eager operations between graph replays are where this step loses time (kernel trace of the 1-rank RCCL step,
+            # profiles/r05_step_timeline_ddp.txt: a replay that follows an eager kernel starts at once, an eager kernel that follows a replay
+            # waits 9-32 us), so the small copies sit BEHIND the eager reduce-scatter, where a boundary exists anyway: the sample count goes
+            # to the model's ring there, and an announced next batch (next_rays) is copied into the static buffers there -- the next step then
+            # starts with a replay right behind this step's last one.  (rays_o / rays_d are read by the march graph only, the target by the
+            # rest graph: both are done with them by then, stream order.)
             opt = self.optimizer
+            pc = getattr(self, '_precopied', None)
+            self._precopied = None
+            if not (pc is not None and pc[0] is rays_o and pc[1] is rays_d and pc[2] is target
+                    and pc[3] == (rays_o._version, rays_d._version, target._version)):
+                torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
+                                     non_blocking=True)
             self.graphs[0].replay()            # near/far + ray marching: needs no weights, overlaps the shadow all-gather of the last step
             opt.wait_shadows()
             self.graphs[1].replay()            # encode .. backward (deposit) + local non-finite sweep + poison
             opt.reduce_gradients()             # reduce-scatter (average of my shard; the skip verdict rides in it)
+            m.step_counter[m.local_step % 16].copy_(self.counter[0], non_blocking=True)
+            if next_rays is not None and len(next_rays) > 2:
+                no, nd, nt = next_rays[0], next_rays[1], next_rays[2]
+                torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [no.view_as(self.rays_o), nd.view_as(self.rays_d), nt], non_blocking=True)
+                self._precopied = (no, nd, nt, (no._version, nd._version, nt._version))
             self.graphs[2].replay()            # verdict + Adam on my shard, scale / step commit, deposit buffer zeroed
             opt.gather_shadows()               # all-gather of the fp16 shadows on the side stream
-        else:
-            self.graphs[0].replay()
-            if len(self.graphs) == 2:
-                self.averager.all_reduce()
-                self.graphs[1].replay()
+            self._mark_deposits()
+            m.local_step += 1
+            self.global_step += 1
+            return self.loss
+        # the batch into the static input buffers: ONE multi-tensor copy kernel (three separate copies cost ~5 us each plus the gaps)
+        torch._foreach_copy_([self.rays_o, self.rays_d, self.target], [rays_o.view_as(self.rays_o), rays_d.view_as(self.rays_d), target],
+                             non_blocking=True)
+        self.graphs[0].replay()
+        if len(self.graphs) == 2:
+            self.averager.all_reduce()
+            self.graphs[1].replay()
         self._mark_deposits()
         # hand the sample count to the model's 16-slot ring exactly where the eager renderer would have put it
         m.step_counter[m.local_step % 16].copy_(self.counter[0], non_blocking=True)

@@ -377,16 +377,19 @@ class TrainingRun:
             m.density_bitfield.copy_(fixed_bits)
         self.keep_scene = keep_scene
         self.model, self.optimizer = model, optimizer
-        # lookahead: the next batch's march on a side stream under this iteration.  Single GPU: always.  Sharded data-parallel step: measured
-        # over a 1-rank RCCL group (ddp_overhead_1rank) it pays only when the two collectives are captured INSIDE the rest graph (0.574 ms
-        # against 0.588 ms for the three-replay form; with eager collectives between the replays the side-stream march COSTS 40 us) -- and a
-        # captured RCCL call cannot be verified on more than one rank here, so the default for N > 1 stays the three-replay form;
-        # NGP_GRAPH_COLLECTIVES=1 selects lookahead + captured collectives, `args.ddp_lookahead` (the probe) forces lookahead either way
-        want_la = not ddp_on or os.environ.get('NGP_GRAPH_COLLECTIVES', '0') == '1' or bool(getattr(args, 'ddp_lookahead', False))
-        self.lookahead = (graph and fused and not torch_optim and not autograd and not getattr(args, 'no_lookahead', False) and want_la
+        # lookahead: the next batch's march on a side stream under this iteration -- single GPU and the sharded data-parallel step alike
+        # (the march needs no weights).  Measured over a 1-rank RCCL group in a process of its own (ddp_overhead_1rank): three replays without
+        # lookahead 0.566 ms, lookahead with eager collectives between [rest] and [apply] 0.529 ms, lookahead with BOTH collectives captured
+        # inside the rest graph 0.483 ms (single GPU: 0.428).  The captured form is used when `args.graph_collectives` says so: set by
+        # NGP_GRAPH_COLLECTIVES=1, or by main() after its canary (a short N-rank trial run of that form in child processes) came back clean
+        # on every rank -- a captured RCCL call cannot be verified ahead of time on the one-GPU build box.
+        graphed = bool(getattr(args, 'graph_collectives', False)) or os.environ.get('NGP_GRAPH_COLLECTIVES', '0') == '1'
+        self.lookahead = (graph and fused and not torch_optim and not autograd and not getattr(args, 'no_lookahead', False)
                           and (not ddp_on or bool(getattr(optimizer, 'shard', False))))
         self.stepper = GraphedTrainStep(model, optimizer, scaler, self.rays, self.opt_kwargs, loss_fn=mse_loss, averager=averager,
                                         after_update=keep_scene, direct=not autograd, lookahead=self.lookahead)
+        if ddp_on:
+            self.stepper.graph_collectives = graphed
         self.step_no = 0
         self.caps, self.slots = [], []
         self.count_log = None
@@ -673,9 +676,8 @@ def ddp_overhead_1rank(args, dev, steps):
                                              ('sharded_lookahead_collectives_in_graph', True, True, 'poison')):
             args.shard_verdict = verdict
             args.no_lookahead = not look
-            args.ddp_lookahead = look
+            args.graph_collectives = graphed
             run = one(force_ddp=True)
-            run.stepper.graph_collectives = graphed
             run.setup(min(args.warmup, 16))
             r = run.timed(steps)
             st, opt = run.stepper, run.optimizer
@@ -700,10 +702,12 @@ def ddp_overhead_1rank(args, dev, steps):
             torch.cuda.synchronize()
             out[name] = entry
             del run, st, opt
-        args.shard_verdict, args.no_lookahead, args.ddp_lookahead = 'poison', saved, False
-        out['ddp_overhead_ms_per_step'] = round(out['sharded_3_replays_no_lookahead']['ms_per_step'] - getattr(args, '_headline_ms', float('nan')), 4)
-        out['note'] = ('1-rank RCCL group: every collective and every graph boundary of the N > 1 step executes, wire time is zero; '
-                       'ddp_overhead = sharded_3_replays_no_lookahead (the form bench.py --gpus N runs by default) - the headline single-GPU step of this run')
+        args.shard_verdict, args.no_lookahead, args.graph_collectives = 'poison', saved, False
+        out['ddp_overhead_ms_per_step'] = round(out['sharded_lookahead']['ms_per_step'] - getattr(args, '_headline_ms', float('nan')), 4)
+        out['ddp_overhead_ms_per_step_collectives_in_graph'] = round(out['sharded_lookahead_collectives_in_graph']['ms_per_step'] - getattr(args, '_headline_ms', float('nan')), 4)
+        out['note'] = ('1-rank RCCL group in a process of its own: every collective and every graph boundary of the N > 1 step executes, wire time is zero; '
+                       'ddp_overhead = sharded_lookahead (what bench.py --gpus N runs when its canary does not clear the captured collectives) - the headline '
+                       'single-GPU step of this run; ..._collectives_in_graph = the form it runs when the canary clears them')
     except Exception as e:  # noqa: BLE001 -- a probe: the headline line must not depend on it
         import traceback
         out['error'] = repr(e)[:300]
@@ -716,6 +720,52 @@ def ddp_overhead_1rank(args, dev, steps):
         except Exception:  # noqa: BLE001
             pass
     return out
+
+
+def collectives_canary(args, world, rank, dev):
+    """N > 1 over RCCL: may the sharded step run with its two collectives CAPTURED inside the HIP graph (one replay per step: 0.483 against
+    0.529 ms at one rank)?  A captured RCCL call cannot be verified ahead of time on the one-GPU build box, and a hang inside a graph
+    replay cannot be caught in-process -- so every rank starts a CHILD process (same RANK / WORLD_SIZE, its own rendezvous port) that runs
+    a short trial of exactly that form: 17 eager steps, the capture, 24 replayed steps, then a cross-rank check that the shadow weights
+    agree bit for bit.  Clean exit on EVERY rank within the timeout (all-reduce MIN of the verdicts) -> the real run uses the captured
+    form; anything else (refused capture, hang -> the child is killed, disagreement) -> lookahead with eager collectives.  ~30-40 s."""
+    import subprocess
+    base = int(os.environ.get('MASTER_PORT', '29500'))
+    port = 30000 + (base + 7919) % 20000
+    env = {k: v for k, v in os.environ.items() if not k.startswith('TORCHELASTIC')}   # (the child ranks rendezvous on a store of their own)
+    env.update(MASTER_PORT=str(port), MASTER_ADDR='127.0.0.1', NGP_GRAPH_COLLECTIVES='1')
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(world), '--canary', '--rays', str(args.rays), '--watchdog', '170']
+    if args.force_ddp:
+        cmd.append('--force-ddp')   # (the one-rank form: tests/test_gpu_rccl_one_rank.py drives the canary under a 1-rank launcher)
+    detail = ''
+    try:
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=200)
+        ok = r.returncode == 0 and 'CANARY_OK' in r.stdout
+        detail = (r.stdout.strip().splitlines() or [''])[-1][:200] if ok else f'rc {r.returncode}: {r.stderr[-240:]}'
+    except subprocess.TimeoutExpired:
+        ok, detail = False, 'trial did not finish within 200 s (killed)'
+    except Exception as e:  # noqa: BLE001
+        ok, detail = False, repr(e)[:200]
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0.5), {'this_rank_ok': ok, 'all_ranks_ok': bool(flag.item() > 0.5), 'detail': detail}
+
+
+def canary_child(args, dev, world, rank):
+    """the trial itself (child process of collectives_canary): the sharded lookahead step with captured collectives for 24 replayed steps"""
+    args.graph_collectives, args.no_lookahead = True, False
+    run = TrainingRun(args, dev, world, rank, fused=True, graph=True, torch_optim=False, autograd=False, force_ddp=args.force_ddp)
+    run.setup(4)
+    res = run.timed(24)
+    st, opt = run.stepper, run.optimizer
+    ok = st.capture_error is None and st.la is not None and st.la_apply is None and bool(getattr(opt, 'shard', False)) and res['final_loss'] == res['final_loss']
+    opt.wait_shadows()
+    torch.cuda.synchronize()
+    digest = opt.flat_p16.view(torch.int16).to(torch.int64).sum().reshape(1)     # every rank holds the complete, all-gathered fp16 shadows
+    both = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(both, digest)
+    same = all(int(b.item()) == int(both[0].item()) for b in both)
+    return ok and same, f"{res['elapsed'] / 24 * 1e3:.4f} ms/step, capture_error={st.capture_error}, shadows agree={same}"
 
 
 def self_launch(args):
@@ -773,6 +823,11 @@ def main():
     ap.add_argument('--force-ddp', action='store_true', help='--gpus 1 only: the HEADLINE run itself goes through the data-parallel step over a 1-rank RCCL group '
                     '(sharded update, collectives, occupancy exchange); the default line carries the same measurement as `ddp_overhead_1rank`')
     ap.add_argument('--no-ddp-probe', action='store_true', help='skip the `ddp_overhead_1rank` measurement (N = 1 only)')
+    ap.add_argument('--canary', action='store_true', help='(internal) the N-rank trial run of the captured-collectives step, started by collectives_canary()')
+    ap.add_argument('--no-canary', action='store_true', help='N > 1: do not try the captured-collectives form (lookahead with eager collectives)')
+    ap.add_argument('--ddp-probe-only', action='store_true', help='(internal) run ONLY the 1-rank RCCL probe and print its JSON: the default run starts this in a '
+                    'subprocess with a timeout, so that a collective library that hangs or aborts cannot take the headline line with it')
+    ap.add_argument('--headline-ms', type=float, default=float('nan'), help='(internal, with --ddp-probe-only) ms / step of the single-GPU headline run')
     ap.add_argument('--ddp-steps', type=int, default=128)
     ap.add_argument('--shard-verdict', choices=('poison', 'allreduce'), default='poison',
                     help="sharded update: how the global skip verdict travels (optim.NGPAdam(verdict=...))")
@@ -847,6 +902,20 @@ def main():
 
     import _ngp_capi as capi
     import synthetic_scene as sc
+    if args.canary:      # child of collectives_canary(): one short trial, one line, exit code = verdict
+        ok, text = canary_child(args, dev, world, rank)
+        emit(('CANARY_OK ' if ok else 'CANARY_FAILED ') + text)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 3)
+    canary = None
+    if ((world > 1 or os.environ.get('NGP_BENCH_FORCE_CANARY') == '1') and comm.get('rccl_ranks') and not args.no_canary and not args.torch_optim and not args.replicated_optim and not args.no_fused
+            and not args.no_graph and not args.autograd and not args.no_lookahead and os.environ.get('NGP_GRAPH_COLLECTIVES') is None):
+        args.graph_collectives, canary = collectives_canary(args, world, rank, dev)
+    if args.ddp_probe_only:
+        args._headline_ms = args.headline_ms
+        emit(json.dumps(ddp_overhead_1rank(args, dev, max(16, args.ddp_steps))))
+        return
     timers = KernelTimers(capi)
 
     rays_per_gpu = args.rays if args.scaling == 'weak' else max(128, args.rays // world)
@@ -1044,9 +1113,21 @@ def main():
 
     ddp1 = None
     if rank == 0 and world == 1 and not args.force_ddp and not args.no_ddp_probe and not args.torch_optim and not args.no_fused and not args.no_graph:
+        # in a SUBPROCESS with a timeout: a collective library that hangs or aborts must not take this run's line with it
+        import subprocess
         torch.cuda.synchronize()
-        args._headline_ms = elapsed / args.steps * 1e3
-        ddp1 = ddp_overhead_1rank(args, dev, max(16, min(args.ddp_steps, max(args.steps, 64))))
+        n_probe = max(16, min(args.ddp_steps, max(args.steps, 64)))
+        cmd = [sys.executable, os.path.abspath(__file__), '--ddp-probe-only', '--ddp-steps', str(n_probe), '--rays', str(args.rays), '--warmup', str(args.warmup),
+               '--headline-ms', repr(elapsed / args.steps * 1e3), '--watchdog', '280']
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+        try:
+            pr = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+            out_lines = [ln for ln in pr.stdout.splitlines() if ln.startswith('{')]
+            ddp1 = json.loads(out_lines[-1]) if out_lines else {'error': f'probe process ended with rc {pr.returncode}', 'stderr_tail': pr.stderr[-400:]}
+        except subprocess.TimeoutExpired:
+            ddp1 = {'error': 'the 1-rank RCCL probe did not finish within 300 s (hung collective?)'}
+        except Exception as e:  # noqa: BLE001
+            ddp1 = {'error': repr(e)[:300]}
     if rank == 0:
         roof = None
         for r in roofs:
@@ -1071,6 +1152,9 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
             'dtype': 'f16', 'data': 'synthetic',
             'rccl_ranks': comm['rccl_ranks'], 'comm': comm, 'sharded_update_fallback': fallback,
+            'collectives_in_graph': {'used': bool(getattr(run.stepper, 'graph_collectives', False) and getattr(run.stepper, 'la', None) is not None
+                                                  and getattr(run.stepper, 'la_apply', None) is None) if world > 1 or args.force_ddp else None,
+                                     'canary': canary},
             'config': {'workload': 'nerf_synthetic/lego-shaped --fp16 --cuda_ray --ff training step (hashgrid L=16 F=2 T=2^19, SH deg 4, '
                                    'FFMLP 64x2 / 64x3), bound=1, 128^3 occupancy grid, dt_gamma=0, max_steps=1024',
                        'rays_per_gpu_per_step': run.rays, 'global_rays_per_step': run.rays * world,

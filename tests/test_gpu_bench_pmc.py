@@ -1,0 +1,40 @@
+"""GPU: `bench.py --pmc` -- the roofline rows' `traffic` measured in the run (VERDICT r4 "Measurement" 8: it used to be read from a committed
+file), and the single-JSON-line contract of bench.py's stdout."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_pmc_measures_the_traffic_in_the_run():
+    """`bench.py --pmc`: HBM bytes per launch from two rocprofv3 --pmc passes of the run's own workload (not the committed file), for every
+    roofline row.  k_adam is the calibration point of the read correction: its algorithmic traffic is exact (28 B per parameter: fp32
+    parameter / two moments read and written, fp16 gradient read, fp16 shadow written) and its reads are 16-byte streaming loads -- the
+    measured figure must land on it."""
+    import shutil
+    if shutil.which('rocprofv3') is None:
+        pytest.skip('rocprofv3 is not on this box')
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc', '--steps', '16', '--warmup', '2', '--no-cpu-baseline', '--no-dropin', '--no-extra',
+           '--no-render', '--no-ddp-probe', '--watchdog', '500']
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=700)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), 'the result line must be the ONLY line on stdout'
+    line = json.loads(lines[0])
+    rows = {r['kernel']: r for r in line['rooflines']}
+    for name in ('grid_encode_backward', 'grid_encode_forward', 'network_forward', 'ffmlp_backward', 'ffmlp_backward (colour net)',
+                 'k_adam (Adam + scaler + shadows + gradient zeroing)', 'composite + loss + backward', 'march_rays_train (+ near/far)'):
+        r = rows[name]
+        assert r['traffic'] is not None and r['traffic'] > 0, name
+        assert 'THIS run' in r['traffic_source'], r['traffic_source']
+    adam = rows['k_adam (Adam + scaler + shadows + gradient zeroing)']
+    algorithmic = adam['units_per_launch'] * adam['bytes_per_unit']
+    assert 0.95 < adam['traffic'] / algorithmic < 1.15, (adam['traffic'], algorithmic)

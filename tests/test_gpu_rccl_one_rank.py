@@ -156,3 +156,24 @@ def test_bench_line_carries_the_one_rank_ddp_overhead():
         assert e['final_loss'] == e['final_loss'] and e['collective_ms_1rank']['reduce_scatter_fp16_24MB'] > 0
     assert d['sharded_lookahead']['lookahead_hits'] > 0 and d['sharded_lookahead']['main_stream_replays_per_step'] == 2
     assert line['n_gpus'] == 1 and line['rccl_ranks'] is None     # the headline itself stays the single-GPU step
+
+
+
+def test_captured_collectives_canary_under_a_launcher():
+    """bench.py at N > 1 decides at run time whether its sharded step may capture the RCCL collectives inside the HIP graph: every rank starts a
+    child process that runs a short trial of that form (collectives_canary).  Driven here as the launcher does it -- `torch.distributed.run`,
+    one rank, `--force-ddp` -- so that the environment hand-over (TORCHELASTIC_* stripped, a rendezvous port of the children's own), the
+    trial and the verdict exchange all execute; the line then says the captured form was used."""
+    env = dict(os.environ, NGP_BENCH_FORCE_CANARY='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'NGP_GRAPH_COLLECTIVES'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29561',
+           os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-ddp', '--steps', '16', '--warmup', '2', '--no-cpu-baseline', '--no-dropin', '--no-extra',
+           '--no-render', '--no-roofline', '--watchdog', '400']
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-4000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    c = line['collectives_in_graph']
+    assert c['canary'] is not None and c['canary']['this_rank_ok'] and c['canary']['all_ranks_ok'], c
+    assert 'CANARY_OK' in c['canary']['detail'] and c['used'] is True, c
+    assert line['rccl_ranks'] == 1 and 'sharded' in line['config']['parallelism'] and line['config']['captures_in_timed_region'] == 0

@@ -415,6 +415,16 @@ int ngp_composite_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t 
 int ngp_compact_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, uint32_t max_steps, const int32_t* rays_alive,
                          int32_t* out_alive, int32_t* out_state, void* workspace, ngp_stream_t stream);
 
+/* Empty-ray culling for the inference loop -- EXTENSION (no reference counterpart: renderer.py:330-333 starts every frame with all N rays
+ * alive).  ngp_coarse_occupancy: per cascade a (H/4)^3 byte grid (x fastest), 1 when any voxel of the cell's 4^3 block or of one of its 26
+ * neighbouring blocks is occupied (ngp_coarse_occupancy_bytes(C, H) bytes).  ngp_cull_rays: rays_alive[n] = n, or -1 for a ray whose segment
+ * [near, far] provably (conservatively: half-cell sampling of the dilated grid, every cascade the marcher could select) meets no occupied
+ * voxel -- such a ray would emit no sample, so dropping it from the initial alive list (ngp_compact_rays) leaves the image bit-identical. */
+size_t ngp_coarse_occupancy_bytes(uint32_t C, uint32_t H);
+int ngp_coarse_occupancy(const uint8_t* grid, uint32_t C, uint32_t H, uint8_t* coarse, ngp_stream_t stream);
+int ngp_cull_rays(const float* rays_o, const float* rays_d, const float* nears, const float* fars, uint32_t N, float bound, uint32_t C,
+                  uint32_t H, const uint8_t* coarse, int32_t* rays_alive, ngp_stream_t stream);
+
 /* composite_rays_train with NeRFRenderer.run_cuda's epilogue fused (renderer.py:316-318):
  *   image_out = image + (1 - weights_sum) * bg,  depth_out = clamp(depth - nears, 0) / (fars - nears)
  * bg_mode 0: off (= the reference op), 1: scalar background bg_scalar, 2: per-ray background bg [N,3].

@@ -372,3 +372,80 @@ def test_time_indexed_bitfields_dnerf_layout():
         assert np.array_equal(xyzs[:m].cpu().numpy(), ref[0][:m]) and np.array_equal(rays.cpu().numpy(), ref[3])
         counts.append(m)
     assert len(set(counts)) == T  # every time slot really has its own occupancy
+
+
+@pytest.mark.parametrize('bound,cascade,dt_gamma,fill', [(1.0, 1, 0.0, 'scene'), (1.0, 1, 0.0, 'sparse'), (4.0, 3, 1.0 / 128, 'sparse'), (2.0, 2, 0.0, 'shell')])
+def test_culled_rays_never_emit_a_sample(bound, cascade, dt_gamma, fill):
+    """ngp_cull_rays is CONSERVATIVE: a ray it drops (-1) must produce no sample however far it is marched -- checked against the marcher itself
+    (n_step = 1: does the ray emit ANY sample before it reaches `far`?), on the scene's occupancy, on sparse random voxels (isolated single
+    voxels: the hardest case for a coarse test) and on a thin shell across two cascades; and it does drop a useful share of the rays."""
+    from raymarching.raymarching import _backend as rb
+    rm = _rm()
+    H = 128
+    rng = np.random.default_rng(17)
+    if fill == 'scene':
+        bits = _scene(bound, cascade)
+    else:
+        dens = np.zeros((cascade, H ** 3), np.float32)
+        if fill == 'sparse':
+            for c in range(cascade):
+                dens[c, rng.integers(0, H ** 3, size=40)] = 1.0     # 40 isolated voxels per cascade
+        else:   # a thin spherical shell in world space, voxelised into every cascade
+            ax = (np.arange(H) + 0.5) / H * 2 - 1
+            for c in range(cascade):
+                mb = min(2.0 ** c, bound)
+                X, Y, Z = np.meshgrid(ax * mb, ax * mb, ax * mb, indexing='ij')
+                shell = np.abs(np.sqrt(X * X + Y * Y + Z * Z) - 0.8 * bound) < 1.5 * mb / H
+                idx = oracle.morton3D(np.stack([a[shell] for a in np.meshgrid(np.arange(H), np.arange(H), np.arange(H), indexing='ij')], -1).astype(np.int32))
+                dens[c, idx] = 1.0
+        bits = oracle.packbits(dens.reshape(-1), 0.5)
+    N = 6000
+    o, d = _random_rays(N, 5, radius=3.2 * bound, spread=1.3 * bound)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    to, td, tn, tf, tb = cu(o), cu(d), cu(nears), cu(fars), cu(bits)
+    import _ngp_capi as capi
+    coarse = torch.empty(int(capi.lib.ngp_coarse_occupancy_bytes(cascade, H)), dtype=torch.uint8, device='cuda')
+    rb.coarse_occupancy(tb, cascade, H, coarse)
+    flags = torch.full((N,), 7, dtype=torch.int32, device='cuda')
+    rb.cull_rays(to, td, tn, tf, N, bound, cascade, H, coarse, flags)
+    flags = flags.cpu().numpy()
+    assert set(np.unique(flags[flags >= 0] - np.arange(N)[flags >= 0])) <= {0}, 'a kept ray carries its own index'
+    # ground truth from the marcher: one sample slot per ray, all rays alive, t starting at near
+    alive = torch.arange(N, dtype=torch.int32, device='cuda')
+    x, dd, de = rm.march_rays(N, 1, alive, tn.clone(), to, td, bound, tb, cascade, H, tn, tf, 128, False, dt_gamma, 1024)
+    emits = (de[:N, 0] > 0).cpu().numpy()
+    culled = flags < 0
+    assert not (culled & emits).any(), f'{int((culled & emits).sum())} culled ray(s) do emit samples'
+    assert emits.sum() > 0
+    missing = ~emits
+    # usefulness (not correctness): on the scene's occupancy a good share of the rays that emit nothing is recognised (isolated voxels
+    # dilate to 27 coarse cells each: little can be culled there)
+    if fill == 'scene':
+        assert culled.sum() >= 0.5 * missing.sum(), (int(culled.sum()), int(missing.sum()))
+
+
+def test_empty_ray_culling_leaves_the_frame_bit_identical():
+    """the on-device eval loop with and without `cull_empty_rays`: same image / depth / weights, fewer rays marched in the first iteration"""
+    import raymarching
+    from nerf.network_ff import NeRFNetwork
+    torch.manual_seed(4)
+    m = NeRFNetwork(bound=1, cuda_ray=True, density_scale=40.0, min_near=0.2, density_thresh=10).cuda().eval()
+    with torch.no_grad():
+        m.encoder.embeddings.uniform_(-0.5, 0.5)
+    m.density_grid.copy_(torch.from_numpy(sc.occupancy_density()).cuda())
+    m.density_bitfield = raymarching.packbits(m.density_grid, 10.0, m.density_bitfield)
+    o, d = sc.full_image_rays(seed=0)
+    o, d = o[::7], d[::7]
+    ro, rd = cu(o)[None], cu(d)[None]
+    kw = dict(staged=True, bg_color=1, perturb=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    outs = {}
+    for cull in (True, False):
+        m.cull_empty_rays, m._loop_cache, m._loop_probe = cull, None, []
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+            out = m.render(ro, rd, **kw)
+        first_alive = int(m._loop_probe[0][6][0].item())
+        outs[cull] = (out['image'].clone(), out['depth'].clone(), first_alive)
+    m._loop_probe = None
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][1])
+    assert outs[False][2] == o.shape[0] and outs[True][2] < 0.8 * o.shape[0], (outs[True][2], o.shape[0])

@@ -57,6 +57,8 @@ _SIGNATURES = {
     'ngp_march_rays_ex': [_u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     'ngp_composite_rays': [_u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_compact_rays': [_vp, _u32, _vp, _vp, _vp, _vp],
+    'ngp_coarse_occupancy': [_vp, _u32, _u32, _vp, _vp],
+    'ngp_cull_rays': [_vp, _vp, _vp, _vp, _u32, _f32, _u32, _u32, _vp, _vp, _vp],
     'ngp_march_rays_dev': [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     'ngp_composite_rays_dev': [_vp, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_compact_rays_dev': [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp],
@@ -119,6 +121,8 @@ lib.ngp_ffmlp_backward_workspace_bytes.restype = _sz
 lib.ngp_grid_backward_workspace_bytes.argtypes = [_vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _i32]
 lib.ngp_grid_backward_workspace_bytes.restype = _sz
 lib.ngp_compact_rays_workspace_bytes.restype = _sz
+lib.ngp_coarse_occupancy_bytes.argtypes = [_u32, _u32]
+lib.ngp_coarse_occupancy_bytes.restype = _sz
 lib.ngp_grid_forward_work_lists.argtypes = [_u32, _u32, _vp, _vp, _vp, _vp]
 lib.ngp_grid_forward_work_lists.restype = _u32
 lib.ngp_density_grid_update_workspace_bytes.argtypes = [_u32]
@@ -130,7 +134,7 @@ if lib.ngp_abi_version() != ABI_VERSION:
 EXPORTED = sorted(list(_SIGNATURES) + ['ngp_last_error', 'ngp_target_arch', 'ngp_abi_version',
                                        'ngp_march_rays_train_workspace_bytes', 'ngp_compact_rays_workspace_bytes',
                                        'ngp_grid_backward_workspace_bytes', 'ngp_ffmlp_backward_workspace_bytes',
-                                       'ngp_ffmlp_backward_slab_count', 'ngp_density_grid_update_workspace_bytes', 'ngp_grid_forward_work_lists'])
+                                       'ngp_ffmlp_backward_slab_count', 'ngp_density_grid_update_workspace_bytes', 'ngp_grid_forward_work_lists', 'ngp_coarse_occupancy_bytes'])
 
 
 def check(rc):

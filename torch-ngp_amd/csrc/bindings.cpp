@@ -320,6 +320,21 @@ void compact_rays(const Tensor rays_alive, const uint32_t n_alive, Tensor out_al
     check(ngp_compact_rays((const int32_t*)ptr(rays_alive), n_alive, (int32_t*)ptr(out_alive), (int32_t*)ptr(out_count), ws.data_ptr(), stream()));
 }
 
+// empty-ray culling of the inference loop (extension): a dilated (H/4)^3 occupancy per cascade, and the rays whose [near, far] segment
+// provably meets no occupied voxel get -1 in the initial alive list
+void coarse_occupancy(const Tensor grid, const uint32_t C, const uint32_t H, Tensor coarse) {
+    CHECK_DENSE(grid); CHECK_DENSE(coarse);
+    TORCH_CHECK((size_t)coarse.numel() * coarse.element_size() >= ngp_coarse_occupancy_bytes(C, H), "coarse_occupancy: `coarse` is too small");
+    check(ngp_coarse_occupancy((const uint8_t*)ptr(grid), C, H, (uint8_t*)ptr(coarse), stream()));
+}
+
+void cull_rays(const Tensor rays_o, const Tensor rays_d, const Tensor nears, const Tensor fars, const uint32_t N, const float bound, const uint32_t C,
+               const uint32_t H, const Tensor coarse, Tensor rays_alive) {
+    CHECK_F32(rays_o); CHECK_F32(rays_d); CHECK_F32(nears); CHECK_F32(fars); CHECK_DENSE(coarse); CHECK_I32(rays_alive);
+    check(ngp_cull_rays((const float*)ptr(rays_o), (const float*)ptr(rays_d), (const float*)ptr(nears), (const float*)ptr(fars), N, bound, C, H,
+                        (const uint8_t*)ptr(coarse), (int32_t*)ptr(rays_alive), stream()));
+}
+
 void march_rays_dev(const Tensor state, const uint32_t alive_bound, const uint32_t n_total, const uint32_t n_step_cap, const Tensor rays_alive, const Tensor rays_t, const Tensor rays_o,
                     const Tensor rays_d, const float bound, const float dt_gamma, const uint32_t max_steps, const uint32_t C, const uint32_t H,
                     const Tensor grid, const Tensor nears, const Tensor fars, Tensor xyzs, Tensor dirs, Tensor deltas, OptTensor noises, const uint32_t rows) {
@@ -423,6 +438,8 @@ PYBIND11_MODULE(_raymarching, m) {
     m.def("density_grid_update_workspace_bytes", &density_grid_update_workspace_bytes, "bytes of its (zero-initialised) workspace");
     m.def("march_rays_ex", &march_rays_ex, "march_rays that zeroes the rows it does not fill");
     m.def("compact_rays", &compact_rays, "order-preserving compaction of rays_alive");
+    m.def("coarse_occupancy", &coarse_occupancy, "dilated (H/4)^3 occupancy per cascade (empty-ray culling)");
+    m.def("cull_rays", &cull_rays, "rays_alive[n] = n, or -1 for a ray that provably meets no occupied voxel");
     m.def("march_rays_dev", &march_rays_dev, "march_rays with the alive count on the device");
     m.def("composite_rays_dev", &composite_rays_dev, "composite_rays with the alive count on the device");
     m.def("compact_rays_dev", &compact_rays_dev, "compaction with the alive count on the device");

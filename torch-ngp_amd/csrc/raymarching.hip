@@ -1227,6 +1227,81 @@ __global__ __launch_bounds__(RM_THREADS) void k_compact_write(const int32_t* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Empty-ray culling for the inference loop (extension, round 5).  In the first iteration of an 800x800 frame every ray is alive and more
+// than half of them never meet an occupied voxel: each of those walks the whole box voxel by voxel (~90 instructions per voxel, 284 us
+// for the iteration) to emit nothing.  Which rays those are can be decided CONSERVATIVELY without the walk:
+//   k_coarse_occupancy: per cascade a (H/4)^3 grid, cell = 1 when any voxel of its 4^3 block OR OF ANY OF THE 26 NEIGHBOURING BLOCKS is
+//       occupied (the bitfield is in Morton order: a 4^3 block is 8 consecutive bytes).  (8^3 blocks were tried first: the dilated hull of
+//       the lego-shaped scene then holds 76 % of the frame's rays -- 45 % really meet a voxel);
+//   k_cull_rays: a ray is sampled from near to far at steps of HALF a coarse cell (of the finest cascade whose extent holds the point);
+//       a sample looks up its cell in every cascade the marcher could select there (level >= the position's exponent).  Every point of
+//       the segment lies within half a cell of a sample, i.e. inside the dilated neighbourhood of that sample's cell: a ray that keeps
+//       finding 0 cannot touch an occupied voxel of any cascade, with a whole coarse cell of margin against rounding differences between this test
+//       and the marcher (4 voxels; the two disagree by rounding only).  Such rays get -1 in the alive list (they would have produced no sample: same image, bit for bit); everything
+//       else -- including every doubtful case -- is marched as before.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t COARSE_SHIFT = 2;   // coarse cell = (1 << COARSE_SHIFT)^3 voxels
+__global__ __launch_bounds__(RM_THREADS) void k_coarse_occupancy(const uint8_t* __restrict__ grid, uint32_t C, uint32_t H, uint8_t* __restrict__ coarse) {
+    const uint32_t R = H >> COARSE_SHIFT, cells = R * R * R;
+    const uint32_t i = blockIdx.x * RM_THREADS + threadIdx.x;
+    if (i >= C * cells) return;
+    const uint32_t c = i / cells, k = i - c * cells;
+    const int cx = (int)(k % R), cy = (int)((k / R) % R), cz = (int)(k / (R * R));
+    const uint8_t* __restrict__ g = grid + (size_t)c * ((size_t)H * H * H / 8);
+    uint32_t any = 0u;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int x = cx + dx, y = cy + dy, z = cz + dz;
+                if (x < 0 || y < 0 || z < 0 || x >= (int)R || y >= (int)R || z >= (int)R) continue;
+                static_assert(COARSE_SHIFT == 2, "a 4^3 block of the Morton-ordered bitfield is 64 bits");
+                const uint2 v = *reinterpret_cast<const uint2*>(g + (size_t)morton3D_1((uint32_t)x, (uint32_t)y, (uint32_t)z) * 8);
+                any |= v.x | v.y;
+            }
+    coarse[i] = any ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(RM_THREADS) void k_cull_rays(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                          const float* __restrict__ nears, const float* __restrict__ fars, uint32_t N, float bound,
+                                                          uint32_t C, uint32_t H, const uint8_t* __restrict__ coarse, int32_t* __restrict__ rays_alive) {
+    const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t R = H >> COARSE_SHIFT, cells = R * R * R;
+    const float Rf = (float)R, Cm1 = (float)C - 1.0f;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float near = nears[n], far = fars[n];
+    const float dlen = sqrtf(dx * dx + dy * dy + dz * dz);
+    bool keep = false;
+    // (a ray with near >= far -- it misses the box -- is not marched at all by k_march_rays: no sample either way)
+    if (near < far && dlen > 0.0f && __builtin_isfinite(far) && __builtin_isfinite(dlen)) {
+        float t = near;
+        for (uint32_t it = 0; it < 4096u && !keep; it++) {      // (bounded: a degenerate ray is kept, never spun on)
+            const float tc = fminf(t, far);
+            const float x = clampf(__builtin_fmaf(tc, dx, ox), -bound, bound);
+            const float y = clampf(__builtin_fmaf(tc, dy, oy), -bound, bound);
+            const float z = clampf(__builtin_fmaf(tc, dz, oz), -bound, bound);
+            int lp = 0;
+            if (C > 1u) lp = mip_exponent(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), Cm1);
+            // (from one cascade BELOW the sample's own: a point of the next half cell may already lie inside that finer cascade's box; the
+            // sample itself is outside it and clamps to its boundary cell, which is the neighbour of that point's cell)
+            for (int c = lp > 0 ? lp - 1 : 0; c < (int)C && !keep; c++) {
+                const float mb = fminf(scalbnf(1.0f, c), bound), rmb = 1.0f / mb;
+                const int ix = (int)clampf((0.5f * __builtin_fmaf(x, rmb, 1.0f)) * Rf, 0.0f, Rf - 1.0f);
+                const int iy = (int)clampf((0.5f * __builtin_fmaf(y, rmb, 1.0f)) * Rf, 0.0f, Rf - 1.0f);
+                const int iz = (int)clampf((0.5f * __builtin_fmaf(z, rmb, 1.0f)) * Rf, 0.0f, Rf - 1.0f);
+                keep = coarse[(size_t)c * cells + ((uint32_t)iz * R + (uint32_t)iy) * R + (uint32_t)ix] != 0u;
+            }
+            if (!(t < far)) break;
+            // half a coarse cell of the finest cascade that holds this point, as a step of the ray parameter (0.45: a little under half)
+            t += 0.45f * (2.0f * fminf(scalbnf(1.0f, lp), bound) / Rf) / dlen;
+            if (it == 4095u) keep = true;
+        }
+    }
+    rays_alive[n] = keep ? (int32_t)n : -1;
+}
+
 }  // namespace ngp
 
 using namespace ngp;
@@ -1505,6 +1580,24 @@ extern "C" int ngp_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thr
     RM_LAUNCH_1D(k_composite_rays, n_alive, as_stream(stream), n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
                  weights_sum, depth, image, (const int32_t*)nullptr, 0u, 0u);
     return check_launch("composite_rays");
+}
+
+extern "C" size_t ngp_coarse_occupancy_bytes(uint32_t C, uint32_t H) { const size_t R = H >> COARSE_SHIFT; return (size_t)C * R * R * R; }
+
+extern "C" int ngp_coarse_occupancy(const uint8_t* grid, uint32_t C, uint32_t H, uint8_t* coarse, ngp_stream_t stream) {
+    NGP_REQUIRE(grid && coarse, NGP_ERR_INVALID, "coarse_occupancy: NULL tensor");
+    NGP_REQUIRE(C >= 1 && C <= 8 && H >= 16 && (H & (H - 1)) == 0, NGP_ERR_INVALID, "coarse_occupancy: needs 1..8 cascades and a power-of-two grid >= 16 (got %u, %u)", C, H);
+    RM_LAUNCH_1D(k_coarse_occupancy, (uint32_t)ngp_coarse_occupancy_bytes(C, H), as_stream(stream), grid, C, H, coarse);
+    return check_launch("coarse_occupancy");
+}
+
+extern "C" int ngp_cull_rays(const float* rays_o, const float* rays_d, const float* nears, const float* fars, uint32_t N, float bound, uint32_t C,
+                             uint32_t H, const uint8_t* coarse, int32_t* rays_alive, ngp_stream_t stream) {
+    if (N == 0) return NGP_OK;
+    NGP_REQUIRE(rays_o && rays_d && nears && fars && coarse && rays_alive, NGP_ERR_INVALID, "cull_rays: NULL tensor");
+    NGP_REQUIRE(C >= 1 && C <= 8 && H >= 16 && (H & (H - 1)) == 0 && bound > 0.0f, NGP_ERR_INVALID, "cull_rays: bad grid description");
+    RM_LAUNCH_1D(k_cull_rays, N, as_stream(stream), rays_o, rays_d, nears, fars, N, bound, C, H, coarse, rays_alive);
+    return check_launch("cull_rays");
 }
 
 extern "C" size_t ngp_compact_rays_workspace_bytes(uint32_t n_alive) { return sizeof(uint32_t) * (size_t)cdiv(n_alive ? n_alive : 1, RM_THREADS); }

@@ -150,6 +150,23 @@ def compact_rays(rays_alive, n_alive, out_alive, out_count):
                                          capi.stream()))
 
 
+def coarse_occupancy(grid, C, H, coarse):
+    """extension (include/ngp_hip.h): dilated (H/4)^3 occupancy per cascade, for cull_rays"""
+    capi.dense(grid, 'grid'); capi.dense(coarse, 'coarse')
+    if coarse.numel() * coarse.element_size() < capi.lib.ngp_coarse_occupancy_bytes(C, H):
+        raise RuntimeError('coarse_occupancy: `coarse` is too small')
+    capi.check(capi.lib.ngp_coarse_occupancy(capi.ptr(grid), C, H, capi.ptr(coarse), capi.stream()))
+
+
+def cull_rays(rays_o, rays_d, nears, fars, N, bound, C, H, coarse, rays_alive):
+    """extension: rays_alive[n] = n, or -1 for a ray whose [near, far] segment provably meets no occupied voxel"""
+    for t, n in ((rays_o, 'rays_o'), (rays_d, 'rays_d'), (nears, 'nears'), (fars, 'fars')):
+        _f32(t, n)
+    _i32(rays_alive, 'rays_alive'); capi.dense(coarse, 'coarse')
+    capi.check(capi.lib.ngp_cull_rays(capi.ptr(rays_o), capi.ptr(rays_d), capi.ptr(nears), capi.ptr(fars), N, float(bound), C, H, capi.ptr(coarse),
+                                      capi.ptr(rays_alive), capi.stream()))
+
+
 def march_rays_dev(state, alive_bound, n_total, n_step_cap, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars,
                    xyzs, dirs, deltas, noises, rows):
     """extension (include/ngp_hip.h, on-device inference loop): march_rays with the alive count / n_step taken from the device `state`"""
@@ -206,6 +223,7 @@ composite_rays_train_backward = _accept_half(composite_rays_train_backward)
 
 _backend = types.SimpleNamespace(
     march_rays_dev=march_rays_dev, composite_rays_dev=composite_rays_dev, compact_rays_dev=compact_rays_dev,
+    coarse_occupancy=coarse_occupancy, cull_rays=cull_rays,
     near_far_from_aabb=near_far_from_aabb, sph_from_ray=sph_from_ray, morton3D=morton3D, morton3D_invert=morton3D_invert,
     packbits=packbits, packbits_capped=packbits_capped, density_grid_update=density_grid_update,
     density_grid_update_workspace_bytes=density_grid_update_workspace_bytes, march_rays_train=march_rays_train, composite_rays_train_forward=composite_rays_train_forward,

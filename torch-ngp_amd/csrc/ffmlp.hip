@@ -250,6 +250,30 @@ __device__ __forceinline__ void pack_hidden(const float16_t (&acc)[Shape<WIDTH>:
     }
 }
 
+// ReLU + pack in two instructions per PAIR of accumulators: round the pair to fp16 (v_cvt_pk_f16_f32, the rounding of pack_hidden), then
+// a packed SIGNED-INTEGER max with 0 on the fp16 bit patterns -- every pattern with the sign bit set (negative values, -0) becomes +0,
+// every other one is kept: relu(half(x)) = half(relu(x)) bit for bit (rounding is monotonic and keeps the sign).  The fp32 form
+// `fmaxf(acc, 0)` costs FOUR per pair (the compiler quiets a possible signalling NaN with a v_max(x, x) of its own before the max with 0)
+// plus the conversion: 88 vector instructions per 64-wide layer and tile against 32 here -- more than half of the network forward's
+// vector stream was this (SQ_INSTS_VALU 808 per tile, EXPERIMENTS.md round 5).  NaN: a positive NaN now propagates (fmaxf returned 0).
+__device__ __forceinline__ uint32_t relu_pack2(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    const half2_t hv = __builtin_convertvector(f32x2{a, b}, half2_t);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, hv), i16x2{0, 0}));
+}
+template <int WIDTH>
+__device__ __forceinline__ void pack_hidden_relu(const float16_t (&acc)[Shape<WIDTH>::NIB], half8_t (&frag)[Shape<WIDTH>::NKB]) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int kb = 0; kb < Shape<WIDTH>::NKB; kb++) {
+        u32x4 w;
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = relu_pack2(acc[kb >> 1][(kb & 1) * 8 + 2 * q], acc[kb >> 1][(kb & 1) * 8 + 2 * q + 1]);
+        frag[kb] = __builtin_bit_cast(half8_t, w);
+    }
+}
+
 
 // 8 consecutive input features f0 .. f0+7 (f0 a multiple of 8) of sample s.
 //   row-major: inputs[s][in_dim]                      (the reference layout)
@@ -316,17 +340,16 @@ __device__ __forceinline__ void ffmlp_forward_body(const half_t* __restrict__ in
         for (uint32_t l = 0;; l++) {
             // activation of hidden layer l (fp32), then round to fp16 operand fragments
             if (PLAIN || act == ACT_RELU) {
+                pack_hidden_relu<WIDTH>(acc, hid);
+            } else {
+                if (act != ACT_NONE) {
 #pragma unroll
-                for (int ib = 0; ib < NIB; ib++)
+                    for (int ib = 0; ib < NIB; ib++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
-            } else if (act != ACT_NONE) {
-#pragma unroll
-                for (int ib = 0; ib < NIB; ib++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[ib][r] = act_forward(act, acc[ib][r]);
+                        for (int r = 0; r < 16; r++) acc[ib][r] = act_forward(act, acc[ib][r]);
+                }
+                pack_hidden<WIDTH>(acc, hid);
             }
-            pack_hidden<WIDTH>(acc, hid);
             if (TRAIN && !(diag & 1u)) {
                 half8_t* dst = reinterpret_cast<half8_t*>(forward_buffer) + l * layer_stride + (size_t)tile * NKB * 64 + lane;
 #pragma unroll
@@ -387,41 +410,75 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 // Same MFMA sequence and the same fp16 rounding points as the separate kernels: bit-identical sigma / rgb / stored activations.
 // TRAIN additionally stores what the backward kernels read: both forward buffers (fragment order), h16 and the colour input (row-major).
 // ------------------------------------------------------------------------------------------------
-// hidden layers + output layer of a 64-wide ReLU network for one tile: first-layer accumulators in, output accumulators out; the hidden
-// post-activations are streamed to `fb` (fragment order) when TRAIN
-template <bool TRAIN>
-__device__ __forceinline__ float16_t relu_network_tail(float16_t (&acc)[2], const half8_t* __restrict__ hid_img, const half8_t* __restrict__ out_img,
-                                                       uint32_t nl, half_t* __restrict__ fb, size_t layer_stride, uint32_t tile, int lane) {
+#ifdef NGP_NETFWD_DIAG  // timing experiments of tools/netfwd_probe.py (compile-time only, results are garbage): bit 0: no MFMA (one dependent vector
+                        // instruction instead), bit 1: no ReLU / pack, bit 2: no SH polynomials, bit 3: no exp / sigmoid epilogue
+__device__ __forceinline__ float16_t net_mfma(half8_t a, half8_t b, float16_t c) {
+    if (NGP_NETFWD_DIAG & 1) { c[0] += (float)a[0] * (float)b[0]; return c; }
+    return mfma(a, b, c);
+}
+template <int WIDTH>
+__device__ __forceinline__ void net_pack(const float16_t (&acc)[Shape<WIDTH>::NIB], half8_t (&frag)[Shape<WIDTH>::NKB]) {
+    if (NGP_NETFWD_DIAG & 2) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int kb = 0; kb < Shape<WIDTH>::NKB; kb++) {
+            f32x4 w = {acc[kb >> 1][(kb & 1) * 8], acc[kb >> 1][(kb & 1) * 8 + 2], acc[kb >> 1][(kb & 1) * 8 + 4], acc[kb >> 1][(kb & 1) * 8 + 6]};
+            frag[kb] = __builtin_bit_cast(half8_t, w);
+        }
+        return;
+    }
+    pack_hidden_relu<WIDTH>(acc, frag);
+}
+#else
+#define net_mfma mfma
+#define net_pack pack_hidden_relu
+#endif
+// hidden layers + output layer of a 64-wide ReLU network for the NT tiles a wave works on together: first-layer accumulators in, output
+// accumulators out; the hidden post-activations are streamed to `fb` (fragment order) when TRAIN.  Every weight fragment is read from
+// the LDS image ONCE and multiplied into all NT tiles: NT independent accumulator chains per wave (the vector work of one tile issues
+// under the matrix work of the other), half the LDS reads per MFMA at NT = 2.
+template <bool TRAIN, int NT>
+__device__ __forceinline__ void relu_network_tail(float16_t (&acc)[NT][2], float16_t (&o)[NT], const half8_t* __restrict__ hid_img,
+                                                  const half8_t* __restrict__ out_img, uint32_t nl, half_t* __restrict__ fb, size_t layer_stride,
+                                                  const uint32_t (&tile)[NT], const bool (&live)[NT], int lane) {
     constexpr int WIDTH = 64, NIB = 2, NKB = 4;
-    half8_t hid[NKB];
+    half8_t hid[NT][NKB];
     for (uint32_t l = 0;; l++) {
 #pragma unroll
-        for (int ib = 0; ib < NIB; ib++)
+        for (int t = 0; t < NT; t++) {
+            net_pack<WIDTH>(acc[t], hid[t]);
+            if (TRAIN && fb && live[t]) {  // (fb == NULL: the backward recomputes the activations, NGP_FF_RECOMPUTE)
+                half8_t* dst = reinterpret_cast<half8_t*>(fb) + l * layer_stride + (size_t)tile[t] * NKB * 64 + lane;
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
-        pack_hidden<WIDTH>(acc, hid);
-        if (TRAIN && fb) {  // (fb == NULL: the backward recomputes the activations, NGP_FF_RECOMPUTE)
-            half8_t* dst = reinterpret_cast<half8_t*>(fb) + l * layer_stride + (size_t)tile * NKB * 64 + lane;
-#pragma unroll
-            for (int kb = 0; kb < NKB; kb++) stream_store(dst + kb * 64, hid[kb]);
+                for (int kb = 0; kb < NKB; kb++) stream_store(dst + kb * 64, hid[t][kb]);
+            }
         }
         if (l + 1 == nl) break;
         const half8_t* wl = hid_img + (size_t)l * NIB * NKB * 64;
 #pragma unroll
         for (int ib = 0; ib < NIB; ib++) {
-            acc[ib] = zero16();
 #pragma unroll
-            for (int kb = 0; kb < NKB; kb++) acc[ib] = mfma(wl[(ib * NKB + kb) * 64], hid[kb], acc[ib]);
+            for (int t = 0; t < NT; t++) acc[t][ib] = zero16();
+#pragma unroll
+            for (int kb = 0; kb < NKB; kb++) {
+                const half8_t a = wl[(ib * NKB + kb) * 64];
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t][ib] = net_mfma(a, hid[t][kb], acc[t][ib]);
+            }
         }
     }
-    float16_t o = zero16();
 #pragma unroll
-    for (int kb = 0; kb < NKB; kb++) o = mfma(out_img[kb * 64], hid[kb], o);
-    return o;
+    for (int t = 0; t < NT; t++) o[t] = zero16();
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++) {
+        const half8_t a = out_img[kb * 64];
+#pragma unroll
+        for (int t = 0; t < NT; t++) o[t] = net_mfma(a, hid[t][kb], o[t]);
+    }
 }
 
-template <bool TRAIN>
-__global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_network_forward(
+template <bool TRAIN, int WAVES /* per workgroup: they share one pair of weight images */, int NT /* tiles a wave works on together */>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 4 : 2, NT == 1 ? 4 : 3))) void k_network_forward(
     const half_t* __restrict__ enc, bool enc_planar, const float* __restrict__ dirs, uint32_t M_valid, const half_t* __restrict__ w_sigma,
     const half_t* __restrict__ w_color, half_t* __restrict__ fb_s, half_t* __restrict__ h16, float* __restrict__ sigma,
     half_t* __restrict__ color_in, half_t* __restrict__ fb_c, float* __restrict__ rgb, uint32_t n_tiles, uint32_t nl_s, uint32_t nl_c,
@@ -435,20 +492,27 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const size_t rows = (size_t)n_tiles * FF_TILE;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = lane & 31, h = lane >> 5;
-    // a tile's inputs (encoder features, direction) are requested one tile ahead -- the first tile's before the weight images are built, so
-    // that round trip runs under the build, the later ones under the previous tile's arithmetic
-    half8_t x_next[in_kb];
-    float dir_next[3] = {0.0f, 0.0f, 0.0f};
-    auto request = [&](uint32_t tile) {
-        if (tile < n_tiles) {
-            const size_t srow = (size_t)tile * FF_TILE + n;
+    const uint32_t n_groups = (n_tiles + NT - 1) / NT;   // a wave iteration = NT consecutive tiles (the last group repeats the last tile)
+    // a group's inputs (encoder features, direction) are requested one group ahead -- the first one's before the weight images are built,
+    // so that round trip runs under the build, the later ones under the previous group's arithmetic
+    half8_t x_next[NT][in_kb];
+    float dir_next[NT][3];
 #pragma unroll
-            for (uint32_t kb = 0; kb < in_kb; kb++) x_next[kb] = load_features8(enc, enc_planar, rows, srow, 32, 16 * kb + 8 * h);
-            dir_next[0] = dir_next[1] = dir_next[2] = 0.0f;
-            if (srow < M_valid) { dir_next[0] = dirs[srow * 3]; dir_next[1] = dirs[srow * 3 + 1]; dir_next[2] = dirs[srow * 3 + 2]; }
+    for (int t = 0; t < NT; t++) dir_next[t][0] = dir_next[t][1] = dir_next[t][2] = 0.0f;
+    auto request = [&](uint32_t group) {
+        if (group < n_groups) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const uint32_t tl = group * NT + t < n_tiles ? group * NT + t : n_tiles - 1;
+                const size_t srow = (size_t)tl * FF_TILE + n;
+#pragma unroll
+                for (uint32_t kb = 0; kb < in_kb; kb++) x_next[t][kb] = load_features8(enc, enc_planar, rows, srow, 32, 16 * kb + 8 * h);
+                dir_next[t][0] = dir_next[t][1] = dir_next[t][2] = 0.0f;
+                if (srow < M_valid) { dir_next[t][0] = dirs[srow * 3]; dir_next[t][1] = dirs[srow * 3 + 1]; dir_next[t][2] = dirs[srow * 3 + 2]; }
+            }
         }
     };
-    request(blockIdx.x * FF_WAVES + wid);
+    request(blockIdx.x * WAVES + wid);
     build_forward_image<WIDTH>(img_s, w_sigma, 32, nl_s);
     build_forward_image<WIDTH>(img_c, w_color, 32, nl_c);
     __syncthreads();
@@ -461,45 +525,77 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     const half8_t* c_hid = c_l0 + (size_t)NIB * in_kb * 64;
     const half8_t* c_out = c_hid + (size_t)(nl_c - 1) * NIB * NKB * 64;
 
-    for (uint32_t tile = blockIdx.x * FF_WAVES + wid; tile < n_tiles; tile += gridDim.x * FF_WAVES) {
-        const size_t srow = (size_t)tile * FF_TILE + n;
-        half8_t x_cur[in_kb];
+    for (uint32_t group = blockIdx.x * WAVES + wid; group < n_groups; group += gridDim.x * WAVES) {
+        uint32_t tile[NT];
+        bool live[NT];
+        size_t srow[NT];
+        half8_t x_cur[NT][in_kb];
+        float dir_x[NT], dir_y[NT], dir_z[NT];
 #pragma unroll
-        for (uint32_t kb = 0; kb < in_kb; kb++) x_cur[kb] = x_next[kb];
-        const float dir_x = dir_next[0], dir_y = dir_next[1], dir_z = dir_next[2];
-        request(tile + gridDim.x * FF_WAVES);
+        for (int t = 0; t < NT; t++) {
+            live[t] = NT == 1 || group * NT + t < n_tiles;
+            tile[t] = live[t] ? group * NT + t : n_tiles - 1;
+            srow[t] = (size_t)tile[t] * FF_TILE + n;
+#pragma unroll
+            for (uint32_t kb = 0; kb < in_kb; kb++) x_cur[t][kb] = x_next[t][kb];
+            dir_x[t] = dir_next[t][0]; dir_y[t] = dir_next[t][1]; dir_z[t] = dir_next[t][2];
+        }
+        request(group + gridDim.x * WAVES);
         // ---- sigma network ----
-        float16_t acc[NIB];
+        float16_t acc[NT][NIB], o[NT];
 #pragma unroll
-        for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
+        for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (uint32_t kb = 0; kb < in_kb; kb++) {
-            const half8_t x = x_cur[kb];
+            for (int ib = 0; ib < NIB; ib++) acc[t][ib] = zero16();
 #pragma unroll
-            for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(s_l0[(ib * in_kb + kb) * 64], x, acc[ib]);
-        }
-        const float16_t o = relu_network_tail<TRAIN>(acc, s_hid, s_out, nl_s, fb_s, layer_stride, tile, lane);
-        // h16 = half(o): this lane owns output features 4h + c (lo) and 8 + 4h + c (hi) of its sample
-        half4_t lo, hi;
+        for (uint32_t kb = 0; kb < in_kb; kb++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) { lo[c] = (half_t)o[c]; hi[c] = (half_t)o[4 + c]; }
-        if (TRAIN) {
-            half_t* hrow = h16 + srow * 16 + 4 * h;
-            *reinterpret_cast<half4_t*>(hrow) = lo;
-            *reinterpret_cast<half4_t*>(hrow + 8) = hi;
-        }
-        if (h == 0) sigma[srow] = density_scale * expf((float)lo[0]);  // trunc_exp forward on the fp16 output (activation.py:9-10)
-        // ---- colour-net input: k block 0 = half(SH_4(dir))[8h .. 8h+7], k block 1 = h16[1 + 8h + j] (j < 8; feature 16 -> the zero pad) ----
-        half8_t cin[2];
-        {
-            const float x = dir_x, y = dir_y, z = dir_z;
-            // component i goes to half-wave i >> 3, slot i & 7 (no array: the polynomial values are consumed as they are produced)
-#define SH_OUT(i, v) { const float sh_v_ = (v); if (((i) >> 3) == h) cin[0][(i) & 7] = to_half_rne(sh_v_); }
+            for (int ib = 0; ib < NIB; ib++) {
+                const half8_t a = s_l0[(ib * in_kb + kb) * 64];
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t][ib] = net_mfma(a, x_cur[t][kb], acc[t][ib]);
+            }
+        relu_network_tail<TRAIN, NT>(acc, o, s_hid, s_out, nl_s, fb_s, layer_stride, tile, live, lane);
+        half8_t cin[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            // h16 = half(o): this lane owns output features 4h + c (lo) and 8 + 4h + c (hi) of its sample
+            half4_t lo, hi;
+#pragma unroll
+            for (int c = 0; c < 4; c++) { lo[c] = (half_t)o[t][c]; hi[c] = (half_t)o[t][4 + c]; }
+            if (TRAIN && live[t]) {
+                half_t* hrow = h16 + srow[t] * 16 + 4 * h;
+                *reinterpret_cast<half4_t*>(hrow) = lo;
+                *reinterpret_cast<half4_t*>(hrow + 8) = hi;
+            }
+#if defined(NGP_NETFWD_DIAG) && (NGP_NETFWD_DIAG & 8)
+            if (h == 0 && live[t]) sigma[srow[t]] = density_scale * (float)lo[0];
+#else
+            if (h == 0 && live[t]) sigma[srow[t]] = density_scale * expf((float)lo[0]);
+#endif  // trunc_exp forward on the fp16 output (activation.py:9-10)
+            // ---- colour-net input: k block 0 = half(SH_4(dir))[8h .. 8h+7], k block 1 = h16[1 + 8h + j] (j < 8; feature 16 -> the zero pad) ----
+            const float x = dir_x[t], y = dir_y[t], z = dir_z[t];
+            // component i goes to half-wave i >> 3, slot i & 7: all 16 polynomials as fp32 values (pinned: the conversion must round the
+            // fp32 VALUE, see to_half_rne), then one select per slot and four packed conversions.  (A conditional store per component --
+            // the first version -- compiled to sixteen divergent branches per tile, both sides taken by every wave.)
+            float sh_0, sh_1, sh_2, sh_3, sh_4, sh_5, sh_6, sh_7, sh_8, sh_9, sh_10, sh_11, sh_12, sh_13, sh_14, sh_15;
+#define SH_OUT(i, v) { sh_##i = (v); asm volatile("" : "+v"(sh_##i)); }
+#if defined(NGP_NETFWD_DIAG) && (NGP_NETFWD_DIAG & 4)
+            sh_0 = sh_1 = sh_2 = sh_3 = sh_4 = sh_5 = sh_6 = sh_7 = x; sh_8 = sh_9 = sh_10 = sh_11 = sh_12 = sh_13 = sh_14 = sh_15 = y + z;
+#else
             SH_BAND_0_VALUES;
             SH_BAND_1_VALUES;
             SH_BAND_2_VALUES;
             SH_BAND_3_VALUES;
+#endif
 #undef SH_OUT
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define SH_PAIR(q, a0, a1, b0, b1) { const half2_t pr = __builtin_convertvector(f32x2{h ? b0 : a0, h ? b1 : a1}, half2_t); cin[t][0][2 * (q)] = pr.x; cin[t][0][2 * (q) + 1] = pr.y; }
+            SH_PAIR(0, sh_0, sh_1, sh_8, sh_9);
+            SH_PAIR(1, sh_2, sh_3, sh_10, sh_11);
+            SH_PAIR(2, sh_4, sh_5, sh_12, sh_13);
+            SH_PAIR(3, sh_6, sh_7, sh_14, sh_15);
+#undef SH_PAIR
             // exchange the eight fp16 outputs with the partner half-wave (lane ^ 32): mine[q] = feature (q < 4 ? 4h + q : 8 + 4h + q - 4)
             const uint32_t m0 = __builtin_bit_cast(uint32_t, half2_t{lo[0], lo[1]}), m1 = __builtin_bit_cast(uint32_t, half2_t{lo[2], lo[3]});
             const uint32_t m2 = __builtin_bit_cast(uint32_t, half2_t{hi[0], hi[1]}), m3 = __builtin_bit_cast(uint32_t, half2_t{hi[2], hi[3]});
@@ -510,34 +606,47 @@ __global__ __launch_bounds__(FF_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             // h == 0 wants features 1..8 : mine lo[1..3], partner lo[0..3] (4..7), mine hi[0] (8)
             // h == 1 wants features 9..15, pad: partner hi[1..3] (9..11), mine hi[0..3] (12..15), 0
             if (h == 0) {
-                cin[1][0] = lo[1]; cin[1][1] = lo[2]; cin[1][2] = lo[3];
-                cin[1][3] = p0.x; cin[1][4] = p0.y; cin[1][5] = p1.x; cin[1][6] = p1.y;
-                cin[1][7] = hi[0];
+                cin[t][1][0] = lo[1]; cin[t][1][1] = lo[2]; cin[t][1][2] = lo[3];
+                cin[t][1][3] = p0.x; cin[t][1][4] = p0.y; cin[t][1][5] = p1.x; cin[t][1][6] = p1.y;
+                cin[t][1][7] = hi[0];
             } else {
-                cin[1][0] = p2.y; cin[1][1] = p3.x; cin[1][2] = p3.y;
-                cin[1][3] = hi[0]; cin[1][4] = hi[1]; cin[1][5] = hi[2]; cin[1][6] = hi[3];
-                cin[1][7] = (half_t)0.0f;
+                cin[t][1][0] = p2.y; cin[t][1][1] = p3.x; cin[t][1][2] = p3.y;
+                cin[t][1][3] = hi[0]; cin[t][1][4] = hi[1]; cin[t][1][5] = hi[2]; cin[t][1][6] = hi[3];
+                cin[t][1][7] = (half_t)0.0f;
             }
-        }
-        if (TRAIN) {
-            half_t* crow = color_in + srow * 32 + 8 * h;
-            stream_store(reinterpret_cast<half8_t*>(crow), cin[0]);
-            stream_store(reinterpret_cast<half8_t*>(crow + 16), cin[1]);
+            if (TRAIN && live[t]) {
+                half_t* crow = color_in + srow[t] * 32 + 8 * h;
+                stream_store(reinterpret_cast<half8_t*>(crow), cin[t][0]);
+                stream_store(reinterpret_cast<half8_t*>(crow + 16), cin[t][1]);
+            }
         }
         // ---- colour network ----
 #pragma unroll
-        for (int ib = 0; ib < NIB; ib++) acc[ib] = zero16();
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int ib = 0; ib < NIB; ib++) acc[t][ib] = zero16();
 #pragma unroll
         for (uint32_t kb = 0; kb < in_kb; kb++)
 #pragma unroll
-            for (int ib = 0; ib < NIB; ib++) acc[ib] = mfma(c_l0[(ib * in_kb + kb) * 64], cin[kb], acc[ib]);
-        const float16_t oc = relu_network_tail<TRAIN>(acc, c_hid, c_out, nl_c, fb_c, layer_stride, tile, lane);
-        if (h == 0) {  // rgb = fp16-rounded sigmoid of the fp16-rounded outputs 0..2 (network_ff.py:72)
-            float* prgb = rgb + srow * 3;
+            for (int ib = 0; ib < NIB; ib++) {
+                const half8_t a = c_l0[(ib * in_kb + kb) * 64];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float v = (float)(half_t)oc[c];
-                prgb[c] = (float)to_half_rne(1.0f / (1.0f + expf(-v)));
+                for (int t = 0; t < NT; t++) acc[t][ib] = net_mfma(a, cin[t][kb], acc[t][ib]);
+            }
+        relu_network_tail<TRAIN, NT>(acc, o, c_hid, c_out, nl_c, fb_c, layer_stride, tile, live, lane);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (h == 0 && live[t]) {  // rgb = fp16-rounded sigmoid of the fp16-rounded outputs 0..2 (network_ff.py:72)
+                float* prgb = rgb + srow[t] * 3;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float v = (float)(half_t)o[t][c];
+#if defined(NGP_NETFWD_DIAG) && (NGP_NETFWD_DIAG & 8)
+                    prgb[c] = v;
+#else
+                    prgb[c] = (float)to_half_rne(1.0f / (1.0f + expf(-v)));
+#endif
+                }
             }
         }
     }
@@ -1069,11 +1178,7 @@ __device__ __forceinline__ void recompute_hidden(const half8_t* __restrict__ fim
     half8_t hid[NKB];
 #pragma unroll
     for (int l = 0; l <= NHM; l++) {
-#pragma unroll
-        for (int ib = 0; ib < NIB; ib++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[ib][r] = fmaxf(acc[ib][r], 0.0f);
-        pack_hidden<WIDTH>(acc, hid);
+        pack_hidden_relu<WIDTH>(acc, hid);
         sink(l, hid);
         if (l == NHM) break;
         const half8_t* wl = fhid + (size_t)l * NIB * NKB * 64;
@@ -2185,25 +2290,42 @@ extern "C" int ngp_network_forward(const void* enc, const float* dirs, uint32_t 
                 "network_forward: the training variant needs h16 and color_in, and both forward buffers or (NGP_FF_RECOMPUTE backward) neither");
     const size_t lds = forward_image_bytes<64>(32, num_layers_sigma) + forward_image_bytes<64>(32, num_layers_color);
     NGP_REQUIRE(lds <= 152 * 1024, NGP_ERR_INVALID, "network_forward: weights (%zu B) exceed the LDS of a CU", lds);
-    const void* kern = training ? reinterpret_cast<const void*>(k_network_forward<true>) : reinterpret_cast<const void*>(k_network_forward<false>);
+#ifndef NGP_NETFWD_TRAIN_WAVES
+#define NGP_NETFWD_TRAIN_WAVES 4
+#endif
+#ifndef NGP_NETFWD_INFER_WAVES
+#define NGP_NETFWD_INFER_WAVES 4
+#endif
+#ifndef NGP_NETFWD_TRAIN_TILES
+#define NGP_NETFWD_TRAIN_TILES 1
+#endif
+#ifndef NGP_NETFWD_INFER_TILES
+#define NGP_NETFWD_INFER_TILES 1
+#endif
+    constexpr int TW = NGP_NETFWD_TRAIN_WAVES, IW = NGP_NETFWD_INFER_WAVES, TT = NGP_NETFWD_TRAIN_TILES, IT = NGP_NETFWD_INFER_TILES;
+    const void* kern = training ? reinterpret_cast<const void*>(k_network_forward<true, TW, TT>) : reinterpret_cast<const void*>(k_network_forward<false, IW, IT>);
     int rc = raise_lds(kern, lds, "network_forward");
     if (rc) return rc;
     const uint32_t n_tiles = M / FF_TILE;
-    const uint32_t per_cu = (uint32_t)((160 * 1024) / (lds + 1024));
+    const uint32_t waves = training ? TW : IW, nt = training ? TT : IT;
+    // workgroups per CU: what the LDS holds, at most 16 waves per CU (four per SIMD at one tile per wave iteration; 12 at two: more registers)
+    const uint32_t by_lds = (uint32_t)((160 * 1024) / (lds + 1024)), by_waves = (nt == 1 ? 16u : 12u) / waves;
 #ifndef NGP_NETFWD_PER_CU
-#define NGP_NETFWD_PER_CU 4u   // workgroups per CU; 1 / 2 / 3 measured slower for training (60 / 55 / 56 vs 55 us) and inference (26 / 21 / 20 vs 20 us)
+#define NGP_NETFWD_PER_CU 4u   // cap; 1 / 2 / 3 measured slower for training (60 / 55 / 56 vs 55 us) and inference (26 / 21 / 20 vs 20 us) at 4 waves
 #endif
-    uint32_t blocks = (uint32_t)device_info().cus * (per_cu < 1 ? 1 : (per_cu > NGP_NETFWD_PER_CU ? NGP_NETFWD_PER_CU : per_cu));
-    const uint32_t need = cdiv(n_tiles, FF_WAVES);
+    uint32_t per_cu = by_lds < by_waves ? by_lds : by_waves;
+    per_cu = per_cu < 1 ? 1 : (per_cu > NGP_NETFWD_PER_CU ? NGP_NETFWD_PER_CU : per_cu);
+    uint32_t blocks = (uint32_t)device_info().cus * per_cu;
+    const uint32_t need = cdiv(cdiv(n_tiles, nt), waves);
     if (blocks > need) blocks = need;
     hipStream_t st = as_stream(stream);
     const bool planar = (flags & NGP_FF_INPUT_PLANAR) != 0;
     if (training)
-        hipLaunchKernelGGL(k_network_forward<true>, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)enc, planar, dirs, M_valid, (const half_t*)w_sigma,
+        hipLaunchKernelGGL((k_network_forward<true, TW, TT>), dim3(blocks), dim3(TW * 64), lds, st, (const half_t*)enc, planar, dirs, M_valid, (const half_t*)w_sigma,
                            (const half_t*)w_color, (half_t*)forward_buffer_sigma, (half_t*)h16, sigma, (half_t*)color_in, (half_t*)forward_buffer_color, rgb,
                            n_tiles, num_layers_sigma, num_layers_color, density_scale);
     else
-        hipLaunchKernelGGL(k_network_forward<false>, dim3(blocks), dim3(FF_THREADS), lds, st, (const half_t*)enc, planar, dirs, M_valid, (const half_t*)w_sigma,
+        hipLaunchKernelGGL((k_network_forward<false, IW, IT>), dim3(blocks), dim3(IW * 64), lds, st, (const half_t*)enc, planar, dirs, M_valid, (const half_t*)w_sigma,
                            (const half_t*)w_color, (half_t*)nullptr, (half_t*)nullptr, sigma, (half_t*)nullptr, (half_t*)nullptr, rgb, n_tiles,
                            num_layers_sigma, num_layers_color, density_scale);
     return check_launch("network_forward");

@@ -224,7 +224,8 @@ struct Ray {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
 };
 struct MarchParams {  // wave-uniform
-    float bound, dt_gamma, dt_min, dt_max, Hf, rH, H3f, Hm1, Cm1;
+    float bound, rbound, dt_gamma, dt_min, dt_max, Hf, rH, H3f, Hm1, Cm1;
+    uint32_t H3;
     const uint8_t* grid;
 };
 
@@ -237,6 +238,8 @@ __device__ __forceinline__ MarchParams make_params(float bound, float dt_gamma, 
     p.Hf = (float)H;
     p.rH = 1.0f / p.Hf;
     p.H3f = (float)(H * H * H);
+    p.H3 = H * H * H;
+    p.rbound = 1.0f / bound;
     p.Hm1 = (float)(H - 1);
     p.Cm1 = (float)C - 1.0f;
     p.dt_min = 2.0f * SQRT3 / (float)max_steps;
@@ -253,10 +256,15 @@ __device__ __forceinline__ Ray load_ray(const float* __restrict__ rays_o, const 
     return r;
 }
 
+// clamp of a value to [lo, hi] with lo <= hi as ONE instruction (v_med3_f32).  `fminf(hi, fmaxf(lo, x))` is two, plus a v_max(x, x) per
+// operand the compiler cannot prove quiet (IEEE mode) -- recomputed in every iteration of the march loop for the loop-invariant bounds too.
+// Same result for every x incl. NaN (both forms return lo); NOT for lo > hi, which is why step_dt keeps the two-instruction form.
+__device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+
 __device__ __forceinline__ int mip_exponent(float mx, float Cm1) {
     int e;
     (void)frexpf(mx, &e);
-    return (int)fminf(Cm1, fmaxf(0.0f, (float)e));
+    return (int)clamp_med3((float)e, 0.0f, Cm1);
 }
 
 __device__ __forceinline__ float step_dt(const MarchParams& p, float t) { return clampf(t * p.dt_gamma, p.dt_min, p.dt_max); }
@@ -272,9 +280,9 @@ struct ProbeGeom {
 
 __device__ __forceinline__ ProbeGeom probe_geom(const MarchParams& p, const Ray& r, float t) {
     ProbeGeom g;
-    g.x = clampf(__builtin_fmaf(t, r.dx, r.ox), -p.bound, p.bound);
-    g.y = clampf(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
-    g.z = clampf(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
+    g.x = clamp_med3(__builtin_fmaf(t, r.dx, r.ox), -p.bound, p.bound);
+    g.y = clamp_med3(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
+    g.z = clamp_med3(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
     g.dt = step_dt(p, t);
     int level = 0;  // a single cascade: both mip exponents clamp to 0 (min(C - 1, .) in raymarching.cu:367-369), skip the frexp work
     if (p.Cm1 > 0.0f) {
@@ -283,12 +291,16 @@ __device__ __forceinline__ ProbeGeom probe_geom(const MarchParams& p, const Ray&
         const int ld = mip_exponent((g.dt * p.Hf) * 0.5f, p.Cm1);
         level = lp > ld ? lp : ld;
     }
-    g.mip_bound = fminf(scalbnf(1.0f, level), p.bound);
-    const float mip_rbound = 1.0f / g.mip_bound;
-    g.nx = (int)clampf((0.5f * __builtin_fmaf(g.x, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
-    g.ny = (int)clampf((0.5f * __builtin_fmaf(g.y, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
-    g.nz = (int)clampf((0.5f * __builtin_fmaf(g.z, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
-    g.index = (uint32_t)((float)level * p.H3f + (float)morton3D_1((uint32_t)g.nx, (uint32_t)g.ny, (uint32_t)g.nz));
+    // mip_bound = min(2^level, bound) and its reciprocal (raymarching.cu:371-372: `1 / mip_bound`, an IEEE division -- a dozen
+    // instructions per term) without dividing: 1 / 2^level IS 2^-level, 1 / bound is loop-invariant
+    const float pw = scalbnf(1.0f, level);
+    const bool capped = !(pw < p.bound);
+    g.mip_bound = capped ? p.bound : pw;
+    const float mip_rbound = capped ? p.rbound : scalbnf(1.0f, -level);
+    g.nx = (int)clamp_med3((0.5f * __builtin_fmaf(g.x, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
+    g.ny = (int)clamp_med3((0.5f * __builtin_fmaf(g.y, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
+    g.nz = (int)clamp_med3((0.5f * __builtin_fmaf(g.z, mip_rbound, 1.0f)) * p.Hf, 0.0f, p.Hm1);
+    g.index = (uint32_t)level * p.H3 + morton3D_1((uint32_t)g.nx, (uint32_t)g.ny, (uint32_t)g.nz);
     return g;
 }
 
@@ -318,6 +330,30 @@ __device__ __forceinline__ float skip_to(const MarchParams& p, float t, float tt
         t += step_dt(p, t);
     } while (t < tt && t < far);
     return t;
+}
+
+// The same walk for the lane-per-ray marcher, eight steps per trip: the partial sums t + dt, (t + dt) + dt, ... are the SAME sequence of
+// fp32 additions (a closed form t + k dt rounds differently), the first one that is not below min(tt, far) is selected.  One step per trip
+// was 6 vector + 4 scalar instructions and a taken branch; a cascade-0 voxel is ~5 steps wide, and a wave leaves the loop with its
+// slowest lane.  CONST_DT: dt_gamma == 0, dt(t) is the constant clamp(0, dt_min, dt_max).
+template <bool CONST_DT>
+__device__ __forceinline__ float skip_to_unrolled(const MarchParams& p, float t, float tt, float far, float dt_const) {
+    const float stop = fminf(tt, far);   // (t < tt && t < far) == (t < min(tt, far)); a NaN tt cannot occur: it is t + max(0, .)
+    constexpr int U = 8;
+    for (;;) {
+        float s[U];
+        float c = t;
+#pragma unroll
+        for (int i = 0; i < U; i++) {
+            c += CONST_DT ? dt_const : step_dt(p, c);
+            s[i] = c;
+        }
+        float pick = s[U - 1];
+#pragma unroll
+        for (int i = U - 2; i >= 0; i--) pick = (s[i] < stop) ? pick : s[i];
+        t = pick;
+        if (!(t < stop)) return t;
+    }
 }
 
 // block-wide sum of one uint32 per thread (RM_THREADS threads); result valid in every thread
@@ -781,6 +817,8 @@ __global__ __launch_bounds__(RM_THREADS) void k_march_rays(uint32_t n_alive, uin
     float* de = deltas + (size_t)n * n_step * 2;
     uint32_t step = 0;
     float x, y, z, dt, tt;
+    const bool const_dt = dt_gamma == 0.0f;
+    const float dt_const = step_dt(p, 0.0f);
     while (t < far && step < n_step) {
         if (probe(p, r, t, x, y, z, dt, tt)) {
             xo[0] = x; xo[1] = y; xo[2] = z;
@@ -791,7 +829,7 @@ __global__ __launch_bounds__(RM_THREADS) void k_march_rays(uint32_t n_alive, uin
             xo += 3; dd += 3; de += 2;
             step++;
         } else {
-            t = skip_to(p, t, tt, far);
+            t = const_dt ? skip_to_unrolled<true>(p, t, tt, far, dt_const) : skip_to_unrolled<false>(p, t, tt, far, dt_const);
         }
     }
     if (zero_rows > 0) {

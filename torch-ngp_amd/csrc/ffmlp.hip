@@ -477,59 +477,6 @@ __device__ __forceinline__ void relu_network_tail(float16_t (&acc)[NT][2], float
     }
 }
 
-// The two-tile form with the tiles half a layer apart: while the matrix pipe multiplies tile A's layer, the vector pipe rounds and packs
-// tile B's previous one, and vice versa (tools/overlap_mfma_valu.hip: the two pipes of a SIMD overlap almost completely when MFMAs and
-// vector instructions alternate in ONE instruction stream -- 8 MFMAs + 32 packed ops: 333 cycles against 319 for the MFMAs alone, 454 when
-// the 32 follow the 8 -- and only partly across waves that each alternate whole phases, which is what the one-tile kernel relies on).
-// The order is requested from the scheduler with sched_group_barrier: (1 LDS read, 1 MFMA, 4 vector) x 8 per half layer.
-// Same arithmetic per tile as relu_network_tail: bit-identical outputs.
-#define NGP_SCHED_MFMA_VALU(n_valu)                                   \
-    _Pragma("unroll") for (int sgb_ = 0; sgb_ < 8; sgb_++) {          \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            \
-        __builtin_amdgcn_sched_group_barrier(0x002, n_valu, 0);       \
-    }
-template <bool TRAIN>
-__device__ __forceinline__ void relu_network_tail_skewed(float16_t (&acc)[2][2], float16_t (&o)[2], const half8_t* __restrict__ hid_img,
-                                                         const half8_t* __restrict__ out_img, uint32_t nl, half_t* __restrict__ fb,
-                                                         size_t layer_stride, const uint32_t (&tile)[2], const bool (&live)[2], int lane) {
-    constexpr int WIDTH = 64, NIB = 2, NKB = 4;
-    half8_t hid[2][NKB];
-    auto pack = [&](int t, uint32_t l) {
-        net_pack<WIDTH>(acc[t], hid[t]);
-        if (TRAIN && fb && live[t]) {
-            half8_t* dst = reinterpret_cast<half8_t*>(fb) + l * layer_stride + (size_t)tile[t] * NKB * 64 + lane;
-#pragma unroll
-            for (int kb = 0; kb < NKB; kb++) stream_store(dst + kb * 64, hid[t][kb]);
-        }
-    };
-    auto layer = [&](int t, const half8_t* wl) {
-#pragma unroll
-        for (int ib = 0; ib < NIB; ib++) {
-            acc[t][ib] = zero16();
-#pragma unroll
-            for (int kb = 0; kb < NKB; kb++) acc[t][ib] = net_mfma(wl[(ib * NKB + kb) * 64], hid[t][kb], acc[t][ib]);
-        }
-    };
-    pack(0, 0);
-    for (uint32_t l = 0; l + 1 < nl; l++) {
-        const half8_t* wl = hid_img + (size_t)l * NIB * NKB * 64;
-        layer(0, wl);       // matrix pipe: tile A, hidden matmul l     | vector pipe: tile B, activation l
-        pack(1, l);
-        NGP_SCHED_MFMA_VALU(4)
-        layer(1, wl);       // matrix pipe: tile B, hidden matmul l     | vector pipe: tile A, activation l + 1
-        pack(0, l + 1);
-        NGP_SCHED_MFMA_VALU(4)
-    }
-    o[0] = zero16();
-#pragma unroll
-    for (int kb = 0; kb < NKB; kb++) o[0] = net_mfma(out_img[kb * 64], hid[0][kb], o[0]);   // tile A's output layer | tile B's last activation
-    pack(1, nl - 1);
-    o[1] = zero16();
-#pragma unroll
-    for (int kb = 0; kb < NKB; kb++) o[1] = net_mfma(out_img[kb * 64], hid[1][kb], o[1]);
-}
-
 template <bool TRAIN, int WAVES /* per workgroup: they share one pair of weight images */, int NT /* tiles a wave works on together */>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 4 : 2, NT == 1 ? 4 : 3))) void k_network_forward(
     const half_t* __restrict__ enc, bool enc_planar, const float* __restrict__ dirs, uint32_t M_valid, const half_t* __restrict__ w_sigma,
@@ -608,8 +555,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(NT =
 #pragma unroll
                 for (int t = 0; t < NT; t++) acc[t][ib] = net_mfma(a, x_cur[t][kb], acc[t][ib]);
             }
-        if constexpr (NT == 2) relu_network_tail_skewed<TRAIN>(acc, o, s_hid, s_out, nl_s, fb_s, layer_stride, tile, live, lane);
-        else relu_network_tail<TRAIN, NT>(acc, o, s_hid, s_out, nl_s, fb_s, layer_stride, tile, live, lane);
+        relu_network_tail<TRAIN, NT>(acc, o, s_hid, s_out, nl_s, fb_s, layer_stride, tile, live, lane);
         half8_t cin[NT][2];
 #pragma unroll
         for (int t = 0; t < NT; t++) {
@@ -687,8 +633,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(NT =
 #pragma unroll
                 for (int t = 0; t < NT; t++) acc[t][ib] = net_mfma(a, cin[t][kb], acc[t][ib]);
             }
-        if constexpr (NT == 2) relu_network_tail_skewed<TRAIN>(acc, o, c_hid, c_out, nl_c, fb_c, layer_stride, tile, live, lane);
-        else relu_network_tail<TRAIN, NT>(acc, o, c_hid, c_out, nl_c, fb_c, layer_stride, tile, live, lane);
+        relu_network_tail<TRAIN, NT>(acc, o, c_hid, c_out, nl_c, fb_c, layer_stride, tile, live, lane);
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             if (h == 0 && live[t]) {  // rgb = fp16-rounded sigmoid of the fp16-rounded outputs 0..2 (network_ff.py:72)
@@ -2363,8 +2308,8 @@ extern "C" int ngp_network_forward(const void* enc, const float* dirs, uint32_t 
     if (rc) return rc;
     const uint32_t n_tiles = M / FF_TILE;
     const uint32_t waves = training ? TW : IW, nt = training ? TT : IT;
-    // workgroups per CU: what the LDS holds, at most 16 waves per CU (four per SIMD at one tile per wave iteration; 8 at two: 190 registers)
-    const uint32_t by_lds = (uint32_t)((160 * 1024) / (lds + 1024)), by_waves = (nt == 1 ? 16u : 8u) / waves;
+    // workgroups per CU: what the LDS holds, at most 16 waves per CU (four per SIMD at one tile per wave iteration; 12 at two: 166 registers)
+    const uint32_t by_lds = (uint32_t)((160 * 1024) / (lds + 1024)), by_waves = (nt == 1 ? 16u : 12u) / waves;
 #ifndef NGP_NETFWD_PER_CU
 #define NGP_NETFWD_PER_CU 4u   // cap; 1 / 2 / 3 measured slower for training (60 / 55 / 56 vs 55 us) and inference (26 / 21 / 20 vs 20 us) at 4 waves
 #endif

@@ -57,9 +57,11 @@ class _ffmlp_forward(Function):
         input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.net
         grad = grad.contiguous()
         batch = grad.shape[0]
-        grad_inputs = torch.zeros_like(inputs) if calc_grad_inputs else torch.zeros(1, device=grad.device, dtype=grad.dtype)
-        grad_weights = torch.zeros_like(weights)
-        backward_buffer = torch.zeros(num_layers, batch, hidden_dim, device=grad.device, dtype=grad.dtype)
+        # (the reference zero-fills these three, ffmlp.py:66-71; every kernel behind ffmlp_backward OVERWRITES what it is handed --
+        # include/ngp_hip.h -- so the fills, one of them [num_layers, B, hidden], would be three launches per network for nothing)
+        grad_inputs = torch.empty_like(inputs) if calc_grad_inputs else torch.empty(1, device=grad.device, dtype=grad.dtype)
+        grad_weights = torch.empty_like(weights)
+        backward_buffer = torch.empty(num_layers, batch, hidden_dim, device=grad.device, dtype=grad.dtype)
         _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, batch, input_dim, output_dim, hidden_dim, num_layers,
                                 activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights)
         return (grad_inputs if calc_grad_inputs else None), grad_weights, None, None, None, None, None, None, None, None

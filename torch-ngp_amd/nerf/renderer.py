@@ -147,7 +147,11 @@ class NeRFRenderer(nn.Module):
     def _background(self, rays_o, rays_d, bg_color):
         if self.bg_radius > 0:
             sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
-            return self.background(sph, rays_d)
+            # .float(): under autocast the background network returns fp16, and PyTorch-ROCm's same-shape MIXED-dtype elementwise kernel
+            # (fp32 gradient x fp16 colour in the backward of the blend below) runs [4096, 3] in ONE workgroup for 45-170 us (4 us for
+            # fp32 x fp32; measured in isolation and in the config-5 step, EXPERIMENTS.md round 5).  Same values: the blend promotes to fp32
+            # either way, and the gradient is rounded to fp16 once on the way back in both forms.
+            return self.background(sph, rays_d).float()
         return 1 if bg_color is None else bg_color
 
     def _finish(self, image, depth, weights_sum, bg_color, nears, fars, lead):

@@ -325,6 +325,56 @@ def test_inference_loop_matches_oracle_loop():
     assert step > 8
 
 
+@pytest.mark.parametrize('bound,cascade,dt_gamma', [(1.0, 1, 0.0), (2.0, 2, 0.0), (4.0, 3, 1.0 / 128), (8.0, 4, 1.0 / 128), (1.5, 2, 1.0 / 256), (3.0, 3, 0.0)])
+def test_march_rays_inference_bit_exact_across_cascades(bound, cascade, dt_gamma):
+    """the lane-per-ray marcher against the oracle AND the reference's own kernel (compiled for the host, when present): several cascades, bounds
+    that are not powers of two (the coarsest cascade is capped at `bound`: its reciprocal is the precomputed 1 / bound), dt_gamma != 0 (the
+    eight-steps-per-trip walk re-evaluates dt(t) per step) -- three consecutive iterations of 1, 4 and 8 samples per ray, sparse occupancy
+    (long walks through empty cells of every cascade)."""
+    rm = _rm()
+    H = 128
+    rng = np.random.default_rng(23)
+    dens = np.zeros((cascade, H ** 3), np.float32)
+    for c in range(cascade):
+        dens[c, rng.integers(0, H ** 3, size=6000)] = 1.0
+        ctr = rng.integers(20, 108, size=(12, 3))                       # a few solid 6^3 blobs: rays emit runs of samples, not single ones
+        for cx, cy, cz in ctr:
+            g = np.stack(np.meshgrid(np.arange(cx, cx + 6), np.arange(cy, cy + 6), np.arange(cz, cz + 6), indexing='ij'), -1).reshape(-1, 3)
+            dens[c, oracle.morton3D(g.astype(np.int32))] = 1.0
+    bits = oracle.packbits(dens.reshape(-1), 0.5)
+    N = 12000
+    o, d = _random_rays(N, 9, radius=2.6 * bound, spread=0.9 * bound)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    keep = nears < fars
+    alive = np.nonzero(keep)[0].astype(np.int32)
+    n_alive = len(alive)
+    assert n_alive > N // 2
+    to, td, tn, tf, tb = cu(o), cu(d), cu(nears), cu(fars), cu(bits)
+    rt = nears.copy()
+    from oracle import ref as oref
+    have_ref = oref.available('fma')     # the reference's kernel compiled for the host with contraction, as nvcc compiles it (tests/test_gpu_vs_ref.py)
+    total = 0
+    for n_step in (1, 4, 8):
+        noises = np.zeros(n_alive, np.float32)
+        x, dd, de = oracle.march_rays(n_alive, n_step, alive, rt, o, d, bound, bits, cascade, H, nears, fars, noises, dt_gamma=dt_gamma, align=128)
+        gx, gd, gde = rm.march_rays(n_alive, n_step, cu(alive), cu(rt).clone(), to, td, bound, tb, cascade, H, tn, tf, 128, False, dt_gamma, 1024)
+        assert np.array_equal(gx.cpu().numpy(), x) and np.array_equal(gde.cpu().numpy(), de) and np.array_equal(gd.cpu().numpy(), dd)
+        if have_ref:
+            rx, rd, rde = oref.march_rays(n_alive, n_step, alive, rt, o, d, bound, bits, cascade, H, nears, fars, noises, dt_gamma=dt_gamma, variant='fma')
+            m = rx.shape[0]
+            assert np.array_equal(gx.cpu().numpy()[:m], rx) and np.array_equal(gde.cpu().numpy()[:m], rde) and np.array_equal(gd.cpu().numpy()[:m], rd)
+        total += int((de[:, 0] > 0).sum())
+        # advance every ray as the compositor would (all samples kept: t moves past the last sample of the slot)
+        for i, r in enumerate(alive):
+            k = de[i * n_step:(i + 1) * n_step]
+            if (k[:, 0] > 0).any():
+                rt[r] += k[:, 1].sum()
+            else:
+                rt[r] = fars[r]
+    assert total > n_alive // 4
+
+
 def test_marcher_survives_degenerate_rays():
     # zero direction, NaN origin, far = inf must not hang the device
     bits = np.zeros(128 ** 3 // 8, np.uint8)

@@ -22,7 +22,7 @@ REFERENCE_TABLES = {
 EXTENSIONS = {
     '_gridencoder': ['grid_corner_indices'],
     '_raymarching': ['packbits_capped', 'march_rays_ex', 'compact_rays', 'march_rays_dev', 'composite_rays_dev', 'compact_rays_dev',
-                     'density_grid_update', 'density_grid_update_workspace_bytes'],
+                     'density_grid_update', 'density_grid_update_workspace_bytes', 'coarse_occupancy', 'cull_rays'],
 }
 
 

@@ -36,8 +36,10 @@ def _check(rc):
 
 class _fused_ngp(Function):
     @staticmethod
-    def forward(ctx, x, d, embeddings, w_sigma, w_color, offsets, cfg, bufs):
-        """x [M,3] fp32 in [-bound,bound], d [M,3] fp32; embeddings [n,2] fp32 param; w_* flat fp32 params -> sigma [M] fp32, rgb [M,3] fp32"""
+    def forward(ctx, x, d, embeddings, w_sigma, w_color, offsets, cfg, bufs, density_scale=1.0):
+        """x [M,3] fp32 in [-bound,bound], d [M,3] fp32; embeddings [n,2] fp32 param; w_* flat fp32 params -> sigma [M] fp32, rgb [M,3] fp32.
+        density_scale (inference only): sigma comes out multiplied by it -- the kernel's `scale * exp(h)` is the fp32 product the renderer's
+        `self.density_scale * sigmas` would compute in a launch of its own"""
         (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, training) = cfg
         M = x.shape[0]
         dev = x.device
@@ -63,7 +65,8 @@ class _fused_ngp(Function):
             fb_c = torch.empty(nl_color, M, 64, **half)
         else:
             fb_s = fb_c = None
-        _network_forward(enc, d, d_valid, ws16, wc16, nl_sigma, nl_color, 1.0, training, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M, st)
+        assert not training or density_scale == 1.0, 'the backward of _fused_ngp knows no density scale (the fused training render folds it itself)'
+        _network_forward(enc, d, d_valid, ws16, wc16, nl_sigma, nl_color, float(density_scale), training, fb_s, h16, sigma, color_in, fb_c, out16, rgb, M, st)
         if training:
             ctx.save_for_backward(x, offsets, enc, ws16, wc16, fb_s, fb_c, h16, color_in, rgb)
             ctx.cfg = cfg
@@ -97,8 +100,8 @@ class _fused_ngp(Function):
                                               0, 6, 1, scratch_s.data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(), _PLANAR_IN | _PLANAR_DX, st))
         _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st)
         if deposited:
-            return None, None, None, None, None, None, None, None
-        return None, None, g_emb, g_ws, g_wc, None, None, None
+            return None, None, None, None, None, None, None, None, None
+        return None, None, g_emb, g_ws, g_wc, None, None, None, None
 
 
 USE_FUSED_NETWORK = True  # one launch for the whole network behind the encoder (False: the four kernels it replaces, for comparison)
@@ -184,7 +187,7 @@ def _resync_stale_shadows(params):
             p._ngp_version = p._version
 
 
-def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
+def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training, density_scale=1.0):
     cfg = network_cfg(encoder, sigma_net, color_net, bound, training)
     params = (encoder.embeddings, sigma_net.weights, color_net.weights)
     bufs = _optimizer_buffers(params) if training else None
@@ -196,7 +199,7 @@ def fused_ngp(x, d, encoder, sigma_net, color_net, bound, training):
             sh = [getattr(p, '_ngp_fp16', None) for p in params]
         if all(t is not None for t in sh):
             bufs = tuple(sh) + (None, None, None)
-    return _fused_ngp.apply(x, d, encoder.embeddings, sigma_net.weights, color_net.weights, encoder.offsets, cfg, bufs)
+    return _fused_ngp.apply(x, d, encoder.embeddings, sigma_net.weights, color_net.weights, encoder.offsets, cfg, bufs, density_scale)
 
 
 # ------------------------------------------------------------------------------------------------------------------

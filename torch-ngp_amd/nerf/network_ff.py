@@ -59,6 +59,14 @@ class NeRFNetwork(NeRFRenderer):
         sigma, geo_feat = self._density_head(x)
         return sigma, self._color_head(d, geo_feat)
 
+    def forward_scaled(self, x, d, density_scale):
+        """-> (density_scale * sigma, rgb) (extension, used by the on-device eval loop): the scale rides in the network kernel instead of a
+        multiply launch per loop iteration; the same fp32 product"""
+        if not torch.is_grad_enabled() and self._fused_ok(x, d):
+            return fused_ngp(x, d, self.encoder, self.sigma_net, self.color_net, self.bound, False, density_scale)
+        sigma, rgb = self(x, d)
+        return density_scale * sigma, rgb
+
     def density(self, x):
         if not torch.is_grad_enabled() and x.dim() == 2 and self._fused_ok(x, x):
             sigma, geo_feat = fused_density(x, self.encoder, self.sigma_net, self.bound)

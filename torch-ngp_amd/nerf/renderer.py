@@ -339,8 +339,12 @@ class NeRFRenderer(nn.Module):
             deltas = torch.empty(rows, 2, dtype=torch.float32, device=dev)
             stage('march_rays', lambda: rb.march_rays_dev(state[cur], lanes, n_total, cap, alive[cur], s_t, s_o, s_d, self.bound, dt_gamma, max_steps,
                                                           self.cascade, self.grid_size, bits, s_near, s_far, xyzs, dirs, deltas, noises, rows))
-            sigmas, rgbs = stage('network (encoder + MLPs + glue)', lambda: self(xyzs, dirs))
-            sigmas, rgbs32 = stage('casts (density_scale, fp32 copies)', lambda: ((self.density_scale * sigmas).float().contiguous(), rgbs.float().contiguous()))
+            if hasattr(self, 'forward_scaled'):   # (the fused network folds the density scale: one launch less per iteration)
+                sigmas, rgbs = stage('network (encoder + MLPs + glue)', lambda: self.forward_scaled(xyzs, dirs, self.density_scale))
+                sigmas, rgbs32 = stage('casts (density_scale, fp32 copies)', lambda: (sigmas.float().contiguous(), rgbs.float().contiguous()))
+            else:
+                sigmas, rgbs = stage('network (encoder + MLPs + glue)', lambda: self(xyzs, dirs))
+                sigmas, rgbs32 = stage('casts (density_scale, fp32 copies)', lambda: ((self.density_scale * sigmas).float().contiguous(), rgbs.float().contiguous()))
             stage('composite_rays', lambda: rb.composite_rays_dev(state[cur], lanes, n_total, cap, T_thresh, alive[cur], s_t, sigmas, rgbs32, deltas, s_ws,
                                                                   s_depth, s_image))
             stage('compact_rays', lambda: rb.compact_rays_dev(state[cur], lanes, n_total, cap, max_steps, alive[cur], alive[1 - cur], state[1 - cur], ws))

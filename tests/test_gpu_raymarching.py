@@ -387,6 +387,19 @@ def test_marcher_survives_degenerate_rays():
     assert counter[1].item() == 3
 
 
+def test_inference_marcher_survives_degenerate_rays():
+    """zero direction / far = +inf in an EMPTY grid: the walk to the far face has no finite target (tt = far = +inf); the lane-per-ray marcher
+    must come back (t stops growing once t + dt == t) instead of spinning as the reference's do-while would"""
+    bits = np.zeros(128 ** 3 // 8, np.uint8)
+    o = np.array([[0, 0, -3], [0.1, 0.2, 0.3], [0, 0, 0]], np.float32)
+    d = np.array([[0, 0, 0], [0, 0, 0], [1, 0, 0]], np.float32)
+    nears = np.array([0.2, 0.2, 0.2], np.float32); fars = np.array([np.inf, np.inf, 3.0], np.float32)
+    alive = torch.arange(3, dtype=torch.int32, device='cuda')
+    x, dd, de = _rm().march_rays(3, 2, alive, cu(nears).clone(), cu(o), cu(d), 1.0, cu(bits), 1, 128, cu(nears), cu(fars), 128, False, 0, 4)
+    torch.cuda.synchronize()
+    assert float(de.abs().sum()) == 0.0   # nothing is occupied: no sample
+
+
 def test_time_indexed_bitfields_dnerf_layout():
     """D-NeRF keeps one occupancy grid per time slot -- density_grid [T, cascade, H^3], density_bitfield [T, cascade*H^3/8]
     (dnerf/renderer.py:91-95) -- packs every slot in place with `packbits(density_grid[t], thresh, density_bitfield[t])` (:546-547) and

@@ -351,6 +351,9 @@ __device__ __forceinline__ float skip_to_unrolled(const MarchParams& p, float t,
         float pick = s[U - 1];
 #pragma unroll
         for (int i = U - 2; i >= 0; i--) pick = (s[i] < stop) ? pick : s[i];
+        // no progress over a whole trip (t has grown until t + dt == t: only a ray with tt = far = +inf gets here, the reference's loop would
+        // spin forever): leave with `stop`, which ends the caller's `t < far` loop as well
+        if (!(pick > t)) return stop;
         t = pick;
         if (!(t < stop)) return t;
     }

@@ -470,9 +470,16 @@ def test_culled_rays_never_emit_a_sample(bound, cascade, dt_gamma, fill):
     import _ngp_capi as capi
     coarse = torch.empty(int(capi.lib.ngp_coarse_occupancy_bytes(cascade, H)), dtype=torch.uint8, device='cuda')
     rb.coarse_occupancy(tb, cascade, H, coarse)
+    if fill == 'scene':   # degenerate rays the marcher still takes up (zero direction inside the object, far = +inf) are kept, not judged
+        o[0] = [0.0, 0.0, 0.0]; d[0] = [0.0, 0.0, 0.0]; nears[0], fars[0] = 0.2, 3.0
+        fars[1] = np.inf
+        to, td, tn, tf = cu(o), cu(d), cu(nears), cu(fars)
     flags = torch.full((N,), 7, dtype=torch.int32, device='cuda')
     rb.cull_rays(to, td, tn, tf, N, bound, cascade, H, coarse, flags)
     flags = flags.cpu().numpy()
+    if fill == 'scene':
+        assert flags[0] == 0 and flags[1] == 1
+        fars[1] = 3.0; tf = cu(fars)      # (the ground-truth march below gets a finite far for that ray)
     assert set(np.unique(flags[flags >= 0] - np.arange(N)[flags >= 0])) <= {0}, 'a kept ray carries its own index'
     # ground truth from the marcher: one sample slot per ray, all rays alive, t starting at near
     alive = torch.arange(N, dtype=torch.int32, device='cuda')

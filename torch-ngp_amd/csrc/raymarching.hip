@@ -1314,9 +1314,11 @@ __global__ __launch_bounds__(RM_THREADS) void k_cull_rays(const float* __restric
     const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
     const float near = nears[n], far = fars[n];
     const float dlen = sqrtf(dx * dx + dy * dy + dz * dz);
-    bool keep = false;
-    // (a ray with near >= far -- it misses the box -- is not marched at all by k_march_rays: no sample either way)
-    if (near < far && dlen > 0.0f && __builtin_isfinite(far) && __builtin_isfinite(dlen)) {
+    // (a ray with near >= far -- it misses the box -- is not marched at all by k_march_rays: no sample either way; a DEGENERATE ray that the
+    // marcher would still take up -- zero or non-finite direction, far = +inf -- is kept, not judged)
+    const bool regular = dlen > 0.0f && __builtin_isfinite(far) && __builtin_isfinite(dlen);
+    bool keep = (near < far) && !regular;
+    if (near < far && regular) {
         float t = near;
         for (uint32_t it = 0; it < 4096u && !keep; it++) {      // (bounded: a degenerate ray is kept, never spun on)
             const float tc = fminf(t, far);

@@ -11,6 +11,7 @@ quarter-occupied resampling afterwards; packbits against min(mean_density, densi
 import math
 
 import numpy as np
+import os
 import torch
 import torch.nn as nn
 
@@ -353,10 +354,18 @@ class NeRFRenderer(nn.Module):
             return rows + 128 - rows % 128  # the marchers' padding rule (raymarching.py:328-331); the fused network wants multiples of 128
 
         # the first two iterations: full-frame sized, kernel-bound, the only ones that may perturb -- issued eagerly
-        full = pad(n_rays)
+        # Row budget of this first pair: `loop_initial_boost` x N (default 2; 1 = the reference's n_step rule).  With N rows the opaque frame's
+        # first iterations march 1 and 2 samples per ray (n_step = N // alive) although every surviving ray has 5-10 to give: twice the
+        # rows (n_step 3 and 4 after the empty-ray culling) finish the frame in two iterations less -- 1.62 -> 1.40 ms; 3 x N evaluates
+        # too many rows of rays that end early (1.55 ms); the transparent frame does not care (14.45 -> 14.3 ms).  Same image -- EXCEPT with
+        # perturb: the start offset is added to the marcher's t of the first call only, while the compositor advances rays_t by the
+        # summed deltas from the UN-offset start (the reference's behaviour), so the samples of the first call are the offset ones and how
+        # many they are must follow the reference's rule (tests/test_gpu_pipeline.py caught it): no boost then.
+        ib = 1 if perturb else max(1, int(os.environ.get('NGP_LOOP_INITIAL_BOOST', getattr(self, 'loop_initial_boost', 2))))
+        full = pad(ib * n_rays)
         noises = torch.rand(n_rays, dtype=torch.float32, device=dev) if perturb else None
-        iteration(0, n_rays, full, noises)
-        iteration(1, n_rays, full, None)
+        iteration(0, n_rays, full, noises, ib * n_rays)
+        iteration(1, n_rays, full, None, ib * n_rays)
         done = 2
         use_graphs = getattr(self, 'graph_loop', False) and not cache['failed']
         adaptive = getattr(self, 'adaptive_n_step', True) and not use_graphs
@@ -378,7 +387,6 @@ class NeRFRenderer(nn.Module):
         # 26 -> 8 iterations on that frame, 3.1 -> 2.1 ms.  Same image, bit for bit (chunking does not change a ray's samples or their
         # compositing order); the max_steps caveat of the docstring applies unchanged.  loop_tail_cap = 8 / adaptive_n_step = False: the
         # reference sequence.
-        import os
         tail_cap = int(getattr(self, 'loop_tail_cap', os.environ.get('NGP_LOOP_TAIL_CAP', 64))) if adaptive else 8
         tail_cap = max(8, min(tail_cap, 1024))
         boost, prev_alive, prev_iters = 1, n_rays, 2

@@ -34,6 +34,8 @@ Requirements: a torch optimizer constructed with `capturable=True` (and preferab
 one `update_extra_state` after 16 eager steps (`model.mean_count > 0`) -- before that the sample buffer is sized for the
 worst case and read back, which cannot be captured, and `step()` simply runs eagerly.
 """
+import os
+
 import torch
 
 
@@ -109,7 +111,6 @@ class GraphedTrainStep:
         self.occupancy_epoch = 0
         self.la_presampled = None           # refresh mode (full sweep?) whose cell sampling already ran on the side stream
         self.la_presample_hits = 0
-        import os
         # sharded lookahead only: capture the two RCCL collectives INSIDE the rest graph (one replay per step on the main stream) instead of
         # issuing them eagerly between two replays.  Off by default: measurable here only over a 1-rank group (bench.py ddp_overhead_1rank)
         self.graph_collectives = os.environ.get('NGP_GRAPH_COLLECTIVES', '0') == '1'

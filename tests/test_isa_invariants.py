@@ -1,0 +1,91 @@
+"""Instruction-level invariants of the hot kernels, read off the BUILT objects (torch-ngp_amd/csrc/_obj/*.o -> device code object ->
+llvm-objdump; ~2 s per file, no GPU).  Round 5 found more than half of the network forward's vector instructions and a third of the
+inference marcher's in compiler artefacts that no source review shows -- `fmaxf(x, 0)` as two v_max_f32, a private array in scratch memory,
+an IEEE division by a power of two per marcher term, sixteen divergent branches around the SH components.  These checks keep the fixes from
+silently regressing with a compiler update or an innocent-looking edit (EXPERIMENTS.md, "Reading the assembly ...")."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJ = os.path.join(ROOT, 'torch-ngp_amd', 'csrc', '_obj')
+LLVM = '/opt/rocm/lib/llvm/bin'
+
+
+def _disassemble(unit, tmp_path_factory, _cache={}):
+    """{mangled kernel name: [instruction lines]} of csrc/_obj/<unit>.o's gfx950 code object"""
+    if unit in _cache:
+        return _cache[unit]
+    obj = os.path.join(OBJ, unit + '.o')
+    tools = [os.path.join(LLVM, t) for t in ('llvm-objcopy', 'clang-offload-bundler', 'llvm-objdump')]
+    if not os.path.exists(obj) or not all(os.path.exists(t) for t in tools):
+        pytest.skip(f'{obj} (run __graft_entry__.build()) or the LLVM tools are missing')
+    d = tmp_path_factory.mktemp('isa_' + unit)
+    fat, co = str(d / 'fat.bin'), str(d / 'dev.co')
+    subprocess.check_call([tools[0], '-O', 'binary', '--only-section=.hip_fatbin', obj, fat])
+    subprocess.check_call([tools[1], '--unbundle', '--type=o', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--input=' + fat, '--output=' + co])
+    text = subprocess.check_output([tools[2], '-d', co], text=True)
+    kernels, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r'^[0-9a-f]+ <(\S+)>:$', line)
+        if m:
+            cur = kernels.setdefault(m.group(1), [])
+        elif cur is not None and line.startswith('\t'):
+            cur.append(line.split('//')[0].strip())
+    shutil.rmtree(d, ignore_errors=True)
+    _cache[unit] = kernels
+    return kernels
+
+
+def _one(kernels, *parts):
+    hit = [k for k in kernels if all(p in k for p in parts) and not k.endswith('.kd')]
+    assert len(hit) == 1, (parts, hit[:4])
+    return kernels[hit[0]]
+
+
+def _count(ins, prefix):
+    return sum(1 for i in ins if i.startswith(prefix))
+
+
+@pytest.mark.parametrize('train', ['Lb1E', 'Lb0E'])
+def test_network_forward_relu_is_packed_and_nothing_spills(train, tmp_path_factory):
+    ins = _one(_disassemble('ffmlp', tmp_path_factory), 'k_network_forwardI' + train + 'Li4ELi1E')
+    assert _count(ins, 'scratch_') == 0, 'private memory in the network forward (round 5: a `float sh[16]` went to scratch)'
+    # ReLU + pack: one v_cvt_pk_f16_f32 + one v_pk_max_i16 per accumulator PAIR: 16 each per layer, two layer bodies in the listing
+    assert _count(ins, 'v_pk_max_i16') >= 32 and _count(ins, 'v_cvt_pk_f16_f32') >= 32
+    quiet = [i for i in ins if re.match(r'v_max_f32(_e32|_e64)? (v\d+), \2, \2$', i)]
+    assert len(quiet) <= 4, f'{len(quiet)} v_max_f32 x, x, x: fmaxf() is back in the layer loop (two instructions per element)'
+    assert _count(ins, 'v_max_f32') <= 16
+    assert _count(ins, 'v_mfma_f32_32x32x16_f16') == 32
+
+
+def test_plain_ffmlp_forward_uses_the_packed_relu(tmp_path_factory):
+    ins = _one(_disassemble('ffmlp', tmp_path_factory), 'k_ffmlp_forwardILi64ELb1ELb1E')
+    assert _count(ins, 'v_pk_max_i16') >= 16 and _count(ins, 'scratch_') == 0
+
+
+def test_inference_marcher_term_has_no_division_left(tmp_path_factory):
+    ins = _one(_disassemble('raymarching', tmp_path_factory), 'k_march_raysE')
+    assert _count(ins, 'scratch_') == 0
+    # clamps as v_med3_f32 (position x 3, cell index x 3, mip exponents x 2)
+    assert _count(ins, 'v_med3_f32') >= 8
+    # IEEE divisions: 1 / d (x 3) and 1 / bound in the prologue only -- the per-term 1 / mip_bound is ldexp(1, -level) or the precomputed one
+    assert _count(ins, 'v_div_fixup_f32') <= 8, _count(ins, 'v_div_fixup_f32')
+    # the bit index is integer arithmetic: the one float -> uint conversion left belongs to the unsigned division n_total / n_alive of the prologue
+    assert _count(ins, 'v_cvt_u32_f32') <= 1
+    # eight additions per trip of the empty-voxel walk: a run of >= 8 consecutive v_add_f32
+    run = best = 0
+    for i in ins:
+        run = run + 1 if i.startswith('v_add_f32') else 0
+        best = max(best, run)
+    assert best >= 8
+
+
+@pytest.mark.parametrize('unit,parts', [('gridencoder', ('k_grid_forward_fastILb0ELb0E',)), ('gridencoder', ('k_grid_backward_binILi3ELi3ELi2E',)),
+                                        ('gridencoder', ('k_grid_backward_accumulateILi3E',)), ('optim', ('k_adam',)),
+                                        ('raymarching', ('k_composite_train_loss_bwd',)), ('ffmlp', ('k_ffmlp_backward_pairedILi64ELi1ELi2ELb1ELb0E',))])
+def test_hot_kernels_keep_out_of_scratch_memory(unit, parts, tmp_path_factory):
+    assert _count(_one(_disassemble(unit, tmp_path_factory), *parts), 'scratch_') == 0

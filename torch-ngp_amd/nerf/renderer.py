@@ -292,10 +292,17 @@ class NeRFRenderer(nn.Module):
                      'bufs': [torch.empty_like(t) for t in (rays_o, rays_d, nears, fars, rays_t, weights_sum, depth, image)],
                      'arange': torch.arange(n_rays, dtype=torch.int32, device=dev)}
             self._loop_cache = cache
-        # static buffers (the graphs hold their addresses): this frame's inputs and accumulators are copied in, the results copied out
-        s_o, s_d, s_near, s_far, s_t, s_ws, s_depth, s_image = cache['bufs']
-        for dst, src in zip(cache['bufs'], (rays_o, rays_d, nears, fars, rays_t, weights_sum, depth, image)):
-            dst.copy_(src)
+        # static buffers (the graphs hold their addresses): this frame's inputs and accumulators are copied in, the results copied out --
+        # only with graph_loop; the eager loop works on the caller's tensors (eleven 4-us copy launches per frame less)
+        static = bool(getattr(self, 'graph_loop', False)) and not cache['failed']
+        frame = tuple(t.contiguous() for t in (rays_o, rays_d, nears, fars, rays_t, weights_sum, depth, image))
+        static = static or any(a is not b for a, b in zip(frame[5:], (weights_sum, depth, image)))   # (accumulators must be updated in place)
+        if static:
+            for dst, src in zip(cache['bufs'], (rays_o, rays_d, nears, fars, rays_t, weights_sum, depth, image)):
+                dst.copy_(src)
+            s_o, s_d, s_near, s_far, s_t, s_ws, s_depth, s_image = cache['bufs']
+        else:
+            s_o, s_d, s_near, s_far, s_t, s_ws, s_depth, s_image = frame
         alive, state, ws = cache['alive'], cache['state'], cache['ws']
         state.zero_()
         # Empty-ray culling (round 5, `cull_empty_rays`, default on): in the first iteration every ray is alive and more than half of them
@@ -435,9 +442,10 @@ class NeRFRenderer(nn.Module):
             bound_alive = int(state[0, 0].item())
             if adaptive and tail_cap > 8 and bound_alive * 16 <= n_rays:
                 batch = 2          # the tail: a pair of iterations now marches up to 2 x cap samples per ray -- look before launching more
-        weights_sum.copy_(s_ws)
-        depth.copy_(s_depth)
-        image.copy_(s_image)
+        if static:
+            weights_sum.copy_(s_ws)
+            depth.copy_(s_depth)
+            image.copy_(s_image)
 
     # -- occupancy grid maintenance -------------------------------------------------------------
     def _cascade_points(self, coords, cas):

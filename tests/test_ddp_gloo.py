@@ -1,5 +1,6 @@
 """N>1 path on CPU: two gloo ranks average gradients / broadcast parameters / shard rays exactly as the RCCL path does
 (the collectives are backend-agnostic; only the reduce op differs: AVG on RCCL, SUM+scale on gloo)."""
+import math
 import os
 import socket
 
@@ -73,11 +74,12 @@ def _make_double():
                     if not torch.isfinite(e[4].float()).all():
                         s[2] = 1.0
             if phases & capi.NGP_OPT_PHASE_UPDATE:
-                skip = bool(s[2] != 0)
+                dead = not math.isfinite(1.0 / float(s[0])) if float(s[0]) != 0.0 else True   # underflowed loss scale: skipped (optim.hip k_adam)
+                skip = bool(s[2] != 0) or dead
                 t = float(s[3]) + 1.0
                 b1, b2 = self.betas
                 for n, p, m, v, g, p16, is_half, lr, ema in entries:
-                    gf = g.float().reshape(-1) / float(s[0])
+                    gf = g.float().reshape(-1) * (0.0 if dead else 1.0 / float(s[0]))
                     g.zero_()
                     if skip:
                         continue
@@ -88,7 +90,7 @@ def _make_double():
                     if p16 is not None:
                         p16.reshape(-1).copy_(p.reshape(-1))
             if phases & capi.NGP_OPT_PHASE_COMMIT:
-                if s[2] != 0:
+                if s[2] != 0 or float(s[0]) == 0.0 or not math.isfinite(1.0 / float(s[0])):
                     s[0] *= self.backoff_factor
                     s[1] = 0.0
                 else:

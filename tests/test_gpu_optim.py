@@ -61,6 +61,28 @@ def test_matches_torch_adam_and_gradscaler(deposit):
     assert float(opt.scalars[3].item()) == 7.0   # 9 iterations, 2 skipped
 
 
+@pytest.mark.parametrize('scale', [0.0, 1e-42])
+def test_underflowed_loss_scale_skips_instead_of_poisoning_the_weights(scale):
+    """after a long run of overflowing steps the loss scale is a denormal, then 0 (GradScaler has no lower bound either).  GradScaler unscales
+    before it checks: 1 / scale = inf makes every gradient non-finite and the step is skipped.  A finite -- e.g. all-zero -- SCALED gradient
+    must not get through here as 0 * inf = NaN (tools/soak_train.py found exactly that after 38 000 steps of the bench workload)."""
+    dev = torch.device('cuda')
+    shapes = [(5001, 2), (256,)]
+    ours, ref, opt, topt, scaler = _pair(shapes, dev, True)
+    before = [p.detach().clone() for p in ours]
+    opt.scalars[0] = scale
+    for p in ours:
+        p._ngp_grad16.zero_()
+    ours[1]._ngp_grad16[3] = 1.0
+    t0 = float(opt.scalars[3].item())
+    opt.step()
+    torch.cuda.synchronize()
+    for p, b in zip(ours, before):
+        assert torch.isfinite(p).all() and torch.equal(p.detach(), b)
+        assert torch.equal(p._ngp_fp16, p.detach().half())
+    assert float(opt.scalars[3].item()) == t0 and float(opt.scalars[0].item()) <= scale and float(opt.scalars[2].item()) == 0.0
+
+
 def test_training_loop_with_fused_optimizer_and_graph():
     import oracle
     import raymarching

@@ -67,8 +67,13 @@ __global__ __launch_bounds__(OPT_THREADS) void k_check_finite(OptTensors ts, flo
 // presumably the 2048 workgroups, which finish together, queueing on ONE device-scope atomic -- for 4 us of launch saved.)
 __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float* __restrict__ state, float beta1, float beta2, float eps,
                                                       float grad_mult, float ema_omd) {
-    const bool skip = state[2] != 0.0f;
-    const float inv_scale = grad_mult / state[0];
+    // A loss scale that has underflowed (a long run of overflowing steps halves it to a denormal, then to 0): GradScaler unscales BEFORE it
+    // checks, so its 1 / scale = inf turns every gradient into inf or NaN and the step is skipped -- for good, the run is dead, but the weights
+    // stay what they were.  Checking the SCALED gradient (the producers do) would let a zero gradient through and 0 * inf = NaN into every
+    // parameter (seen in a 200 000-step soak of the bench workload, tools/soak_train.py): the unusable scale is an overflow of its own.
+    const bool scale_dead = !__builtin_isfinite(1.0f / state[0]);
+    const bool skip = state[2] != 0.0f || scale_dead;
+    const float inv_scale = scale_dead ? 0.0f : grad_mult / state[0];
     const float t = state[3] + 1.0f;  // this step's count (k_update_scale commits it)
     const float bc1 = 1.0f - powf(beta1, t);
     const float bc2_sqrt = sqrtf(1.0f - powf(beta2, t));
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
 // torch.amp.GradScaler.update (_amp_update_scale_): found_inf -> scale *= backoff, tracker = 0; else tracker += 1 and, when it reaches
 // growth_interval, scale *= growth (only if the result is finite) and tracker = 0.  Also commits the Adam step count.
 __device__ __forceinline__ void update_scale(float* state, float growth, float backoff, float growth_interval) {
-    if (state[2] != 0.0f) {
+    if (state[2] != 0.0f || !__builtin_isfinite(1.0f / state[0])) {   // (an underflowed scale counts as an overflow: see k_adam)
         state[0] *= backoff;
         state[1] = 0.0f;
     } else {

@@ -74,7 +74,7 @@ def _make_double():
                     if not torch.isfinite(e[4].float()).all():
                         s[2] = 1.0
             if phases & capi.NGP_OPT_PHASE_UPDATE:
-                dead = not math.isfinite(1.0 / float(s[0])) if float(s[0]) != 0.0 else True   # underflowed loss scale: skipped (optim.hip k_adam)
+                dead = not bool(torch.isfinite(1.0 / s[0].float()))   # underflowed loss scale (fp32: 1 / denormal = inf): skipped (optim.hip k_adam)
                 skip = bool(s[2] != 0) or dead
                 t = float(s[3]) + 1.0
                 b1, b2 = self.betas
@@ -90,7 +90,7 @@ def _make_double():
                     if p16 is not None:
                         p16.reshape(-1).copy_(p.reshape(-1))
             if phases & capi.NGP_OPT_PHASE_COMMIT:
-                if s[2] != 0 or float(s[0]) == 0.0 or not math.isfinite(1.0 / float(s[0])):
+                if s[2] != 0 or not bool(torch.isfinite(1.0 / s[0].float())):
                     s[0] *= self.backoff_factor
                     s[1] = 0.0
                 else:
@@ -407,3 +407,23 @@ def test_kept_deposit_buffer_protocol_on_the_host():
         opt.all_reduce()
     opt.world_size = 1
     opt.clean_deposits(params)
+
+
+def test_underflowed_loss_scale_is_an_overflow_of_its_own_on_the_host_double():
+    """the documented semantics of ngp_optim_adam_step_ex for a loss scale that has underflowed (include/ngp_hip.h; csrc/optim.hip k_adam):
+    1 / scale is not finite -> the step is skipped whatever the gradient holds, the scale backs off (stays 0), the step count does not move.
+    (GPU: tests/test_gpu_optim.py; found by a 200 000-step soak, EXPERIMENTS.md.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "torch-ngp_amd"))
+    Double = _make_double()
+    torch.manual_seed(0)
+    for scale in (0.0, 1e-42):
+        params = [torch.nn.Parameter(torch.randn(64, 2) * 0.1), torch.nn.Parameter(torch.randn(128) * 0.1)]
+        opt = Double([{'params': params, 'lr': 1e-2}], betas=(0.9, 0.99), eps=1e-15, init_scale=1.0)
+        before = [p.detach().clone() for p in params]
+        opt.scalars[0] = scale
+        params[1]._ngp_grad16[3] = 1.0          # a finite scaled gradient: the producers' checks see nothing wrong
+        opt.step()
+        for p, b in zip(params, before):
+            assert torch.isfinite(p).all() and torch.equal(p.detach(), b)
+        assert float(opt.scalars[3]) == 0.0 and float(opt.scalars[0]) <= scale and float(opt.scalars[2]) == 0.0

@@ -484,7 +484,10 @@ int ngp_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
  * state = device float[8]: {loss scale, growth tracker, found_inf, Adam step count, lr multiplier, -, -, -}; no host sync.
  * grad_mult: extra factor on the gradients (1 / world_size after a SUM all-reduce).  A step over more than 8 tensors uses
  * ngp_optim_adam_step_ex below (phases), which keeps "a non-finite gradient anywhere skips the whole step" across calls; for
- * compatibility growth_interval < 0 here still means "CHECK + UPDATE of this chunk, no COMMIT". */
+ * compatibility growth_interval < 0 here still means "CHECK + UPDATE of this chunk, no COMMIT".
+ * A loss scale that has underflowed (1 / scale not finite in fp32: 0 or a denormal, after a long run of overflowing steps) counts as an
+ * overflow of its own: UPDATE skips, COMMIT backs off -- GradScaler's unscale-then-check order, so that a zero gradient is never
+ * multiplied by 1 / 0 into the weights. */
 int ngp_optim_adam_step(int count, const uint64_t* n, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
                         void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
                         float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,

@@ -84,6 +84,12 @@ def test_inference_marcher_term_has_no_division_left(tmp_path_factory):
     assert best >= 8
 
 
+def test_cull_kernel_divides_only_in_its_prologue(tmp_path_factory):
+    ins = _one(_disassemble('raymarching', tmp_path_factory), 'k_cull_raysE')
+    # 1 / |d|, 1 / bound and the launch-uniform step: the per-sample, per-cascade `1 / min(2^c, bound)` is ldexp(1, -c) or the precomputed one
+    assert _count(ins, 'v_div_fixup_f32') <= 3 and _count(ins, 'v_med3_f32') >= 6 and _count(ins, 'scratch_') == 0
+
+
 @pytest.mark.parametrize('unit,parts', [('gridencoder', ('k_grid_forward_fastILb0ELb0E',)), ('gridencoder', ('k_grid_backward_binILi3ELi3ELi2E',)),
                                         ('gridencoder', ('k_grid_backward_accumulateILi3E',)), ('optim', ('k_adam',)),
                                         ('raymarching', ('k_composite_train_loss_bwd',)), ('ffmlp', ('k_ffmlp_backward_pairedILi64ELi1ELi2ELb1ELb0E',))])

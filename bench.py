@@ -67,10 +67,17 @@ TIMED = {
     'ngp_ffmlp_backward': ('ffmlp_backward', 4, lambda a: _ff_bwd_bytes(a[8]), lambda a: 2.0 * _ff_flops(a[8]), 'sample'),
     'ngp_grid_encode_forward_ex': ('grid_encode_forward', 4, lambda a: 588.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_forward_sched': ('grid_encode_forward', 4, lambda a: 588.0, lambda a: 0.0, 'point'),
+    'ngp_grid_encode_forward_sel': ('grid_encode_forward', 6, lambda a: 588.0, lambda a: 0.0, 'point'),   # (double-buffered table: optim.NGPAdam.enable_table_fusion)
     'ngp_grid_encode_backward_ex': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_ws': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_checked': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
-    'ngp_grid_encode_backward_checked_slabs': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),   # (+ the MLPs' slab reduction in its last launch)
+    # (+ the MLPs' slab reduction in its last launch; + 26 B per table parameter when the table's Adam sweep rides in the accumulate's flush:
+    # master weight and two moments read and written, fp16 shadow written -- the gradient's store and re-read are gone)
+    'ngp_grid_encode_backward_checked_slabs': ('grid_encode_backward', 5, lambda a: 1100.0 + 26.0 * _table_adam_params(a) / max(int(a[5]), 1),
+                                               lambda a: 0.0, 'point'),
+    # what is left of the optimizer step when the table is updated in the grid backward: Adam on the MLP weights + commit, one workgroup
+    'ngp_optim_adam_small_commit': ('k_adam_small_commit (MLP weights + scaler commit + parity flip)', lambda a: _small_params(a), lambda a: 30.0,
+                                    lambda a: 0.0, 'parameter'),
     'ngp_ffmlp_forward_ex': ('ffmlp_forward', 2, lambda a: _ff_fwd_bytes(a[6]), lambda a: _ff_flops(a[6]), 'sample'),
     # the whole network behind the encoder in one launch: enc 64 B + dir 12 B in, both forward buffers (when they are stored: not with the
     # recomputing backward) + h16 32 B + colour input 64 B + sigma 4 B + rgb 12 B out per sample; flops of both MLPs
@@ -91,6 +98,28 @@ TIMED = {
     # per parameter.  Only the calls that UPDATE are rows.
     'ngp_optim_adam_step_ex': ('k_adam (Adam + scaler + shadows + gradient zeroing)', lambda a: _adam_params(a), lambda a: _adam_bytes(a), lambda a: 0.0, 'parameter'),
 }
+
+
+def _table_adam_params(a):
+    """table parameters whose Adam sweep one ngp_grid_encode_backward_checked_slabs call carries (0: none)"""
+    import ctypes
+    import _ngp_capi as capi
+    ss, oh = a[23], a[18]
+    if not ss or not oh:
+        return 0
+    sets = ctypes.cast(ss, ctypes.POINTER(capi.SlabSets)).contents
+    if not sets.table_adam:
+        return 0
+    return int(ctypes.cast(oh, ctypes.POINTER(ctypes.c_int32))[int(a[8])]) * int(a[7])
+
+
+def _small_params(a):
+    import ctypes
+    k = int(a[0])
+    if k == 0 or not a[1]:
+        return 0
+    n = ctypes.cast(a[1], ctypes.POINTER(ctypes.c_uint64))
+    return int(sum(n[i] for i in range(k)))
 
 
 def _adam_bytes(a):
@@ -388,8 +417,11 @@ class TrainingRun:
         graphed = bool(getattr(args, 'graph_collectives', False)) or os.environ.get('NGP_GRAPH_COLLECTIVES', '0') == '1'
         self.lookahead = (graph and fused and not torch_optim and not autograd and not getattr(args, 'no_lookahead', False)
                           and (not ddp_on or bool(getattr(optimizer, 'shard', False))))
+        # single GPU: the hash table's Adam sweep rides in the grid backward's slice accumulate (speculative double buffer + parity word)
+        self.fused_adam = (graph and fused and not torch_optim and not autograd and not ddp_on and not config5
+                           and not getattr(args, 'no_fused_adam', False))
         self.stepper = GraphedTrainStep(model, optimizer, scaler, self.rays, self.opt_kwargs, loss_fn=mse_loss, averager=averager,
-                                        after_update=keep_scene, direct=not autograd, lookahead=self.lookahead)
+                                        after_update=keep_scene, direct=not autograd, lookahead=self.lookahead, fused_table_adam=self.fused_adam)
         if ddp_on:
             self.stepper.graph_collectives = graphed
         self.step_no = 0
@@ -807,6 +839,8 @@ def main():
     ap.add_argument('--no-render', action='store_true', help='skip the 800x800 inference-frame timing')
     ap.add_argument('--no-lookahead', action='store_true', help='do not march the next batch on a side stream under the current iteration '
                     '(graph.GraphedTrainStep(lookahead=True): single rank, fused + graph + NGPAdam only)')
+    ap.add_argument('--no-fused-adam', action='store_true', help="N = 1: keep the table's Adam sweep a launch of its own (k_adam) instead of the "
+                    "speculative sweep inside the grid backward's slice accumulate (optim.NGPAdam.enable_table_fusion)")
     ap.add_argument('--no-dropin', action='store_true', help='skip the second, drop-in-surface-only measurement')
     ap.add_argument('--ab-off', default='', help='A/B measurement: comma-separated optional launch fusions of fused.py to switch OFF '
                     '(USE_FUSED_NETWORK, USE_FUSED_COMPOSITE, USE_FUSED_MID, USE_FUSED_SCAN, USE_FUSED_CHECK, USE_SLABS_IN_ACCUMULATE, USE_OVERWRITE_TABLE, ...); '
@@ -1184,6 +1218,7 @@ def main():
                        'captures_in_timed_region': res['captures'],
                        'host_issue_ms_per_step': round(res['issued'] / args.steps * 1e3, 4), 'host_ms_per_step_unblocked': res.get('host_first'),
                        'autograd_free_iteration': bool(stepper.used_direct), 'fused_pipeline': bool(model.fused),
+                       'table_adam_in_grid_backward': bool(getattr(stepper, 'table_fused', False)),
                        'optimizer': 'torch.optim.Adam(fused)+GradScaler' if args.torch_optim else 'optim.NGPAdam (fused Adam + loss scaling)',
                        'final_loss': res['final_loss']},
             'roofline': roof, 'rooflines': roofs, 'cpu_baseline': cpu, 'dropin_path': dropin, 'render_800x800_ms': render,

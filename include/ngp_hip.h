@@ -219,6 +219,15 @@ int ngp_grid_encode_forward_sched(const float* inputs, const void* embeddings, c
                                   uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
                                   const float* level_cost_host, ngp_stream_t stream);
 
+/* ngp_grid_encode_forward_sched for a DOUBLE-BUFFERED fp16 table (ngp_table_adam_t): the kernel reads *parity (a device float: the
+ * optimizer's state[5]) at entry and gathers from `embeddings` when it is 0, from `embeddings_alt` otherwise -- the selection is made on the
+ * device, so a captured HIP graph follows the commit / skip decisions of the steps replayed before it.  embeddings_alt == NULL or parity ==
+ * NULL: ngp_grid_encode_forward_sched.  dy_dx must be NULL (the inference / fused-training forward). */
+int ngp_grid_encode_forward_sel(const float* inputs, const void* embeddings, const void* embeddings_alt, const float* parity,
+                                const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound, const float* level_cost_host,
+                                ngp_stream_t stream);
+
 /* diagnostic: the per-XCD work lists ngp_grid_encode_forward_sched would launch for L levels of `tiles` tiles each (host computation):
  * 8 x 8 segments (level, first tile, cumulative slot end; level 0xffff = unused); returns the slots of the longest list (0 on bad arguments) */
 uint32_t ngp_grid_forward_work_lists(uint32_t L, uint32_t tiles, const float* level_cost_host, uint16_t* level_out, uint32_t* tile0_out,
@@ -248,6 +257,28 @@ int ngp_grid_encode_backward_checked(const void* grad, const float* inputs, cons
  * behind it: the two are independent, the reduction fills slots the last table slices leave idle (training step: -1 launch, ~6 us).
  * slab_sets == NULL: plain ngp_grid_encode_backward_checked.  When this call has no such launch (few samples, no workspace, B == 0) the
  * reduction is launched on its own: the reduced gradients are there when the call returns either way (stream order). */
+/* Adam on the hash table INSIDE the slice accumulate of the grid backward (round 6).  torch.optim.Adam + GradScaler.step
+ * (nerf/utils.py:751-753) need the global "any gradient non-finite?" verdict before the first weight moves; the accumulate produces the final
+ * gradient of a 4096-entry slice in LDS while most of the chip waits on its record walk, and a separate 28 B/parameter Adam sweep over the
+ * 12 M-entry table follows.  Here the flush of every slice applies Adam at once -- SPECULATIVELY: it reads the parameters, moments of buffer
+ * set state[5] (the parity: 0 or 1) and writes the updated parameters, moments and fp16 shadow into the OTHER set.  The commit
+ * (ngp_optim_adam_small_commit / NGP_OPT_PHASE_FLIP) flips the parity only when the step stands; a skipped step leaves the current set
+ * untouched -- GradScaler's semantics, exactly.  Readers of the fp16 table select the current set at kernel entry
+ * (ngp_grid_encode_forward_sel).  Needs overwrite_table with every level on the record-sort path (else NGP_ERR_INVALID: nothing was
+ * launched); the fp16 gradient is rounded exactly as when it is stored, so the result equals ngp_optim_adam_step_ex on the stored gradient
+ * bit for bit.  The DENSE levels at the start of the table (their entries are dealt round-robin to the accumulate's workgroups: 8-byte
+ * accesses 1 KiB apart would be all the flush could do for them) are left out: their gradient is stored to grad_embeddings as usual and
+ * ngp_optim_adam_small_commit sweeps that prefix contiguously (same double buffer, verdict already known) -- ngp_grid_table_adam_prefix()
+ * entries.  Behind the prefix grad_embeddings is not written (it may be NULL when the prefix is empty). */
+typedef struct ngp_table_adam {
+    float* param[2]; float* exp_avg[2]; float* exp_avg_sq[2]; void* param_fp16[2];   /* [n_entries, C] each; set index = parity */
+    const float* state;          /* the optimizer's scalars (ngp_optim_adam_step: state[0] scale, [3] step count, [4] lr multiplier, [5] parity) */
+    float lr, beta1, beta2, eps;
+} ngp_table_adam_t;
+/* entries (whole levels) at the start of the table that a backward with table_adam leaves to ngp_optim_adam_small_commit; 0xffffffff: this
+ * batch / table shape cannot carry the sweep at all (the backward would refuse table_adam).  Host computation, same plan as the backward. */
+uint32_t ngp_grid_table_adam_prefix(const int32_t* offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                    uint32_t gridtype, int align_corners, int dtype);
 typedef struct ngp_slab_sets {
     const void* slabs_a; uint32_t n_slabs_a, n_params_a; void* grad_weights_a;
     const void* slabs_b; uint32_t n_slabs_b, n_params_b; void* grad_weights_b;
@@ -258,6 +289,8 @@ typedef struct ngp_slab_sets {
      * read): for a caller whose optimizer then does not zero the buffer (ngp_optim_adam_step*: grad_is_half & 2).  Same bits as adding into
      * a zeroed buffer.  Calls that cannot write every entry from the sort (levels on the atomic path) zero the table first. */
     uint32_t overwrite_table;
+    /* optional (NULL: none): the table's Adam sweep rides in the accumulate's flush, see ngp_table_adam_t */
+    const ngp_table_adam_t* table_adam;
 } ngp_slab_sets_t;
 int ngp_grid_encode_backward_checked_slabs(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
                                            void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
@@ -481,7 +514,9 @@ int ngp_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
  * grad_is_half[k] & 2: the producer of that buffer overwrites ALL of it every step (ngp_grid_encode_backward_checked_slabs with
  * overwrite_table), so it is left as it is (and a skipped step does not touch the tensor at all); params_fp16[k]
  * (optional, may be NULL per tensor or as a whole) receives the fp16 copy of the updated weights.
- * state = device float[8]: {loss scale, growth tracker, found_inf, Adam step count, lr multiplier, -, -, -}; no host sync.
+ * state = device float[8]: {loss scale, growth tracker, found_inf, Adam step count, lr multiplier, table parity (ngp_table_adam_t), ticket of
+ * ngp_optim_adam_small_commit (0 between launches), -};
+ * no host sync.
  * grad_mult: extra factor on the gradients (1 / world_size after a SUM all-reduce).  A step over more than 8 tensors uses
  * ngp_optim_adam_step_ex below (phases), which keeps "a non-finite gradient anywhere skips the whole step" across calls; for
  * compatibility growth_interval < 0 here still means "CHECK + UPDATE of this chunk, no COMMIT".
@@ -504,10 +539,25 @@ int ngp_optim_adam_step(int count, const uint64_t* n, float* const* params, floa
 #define NGP_OPT_PHASE_CHECK 1u
 #define NGP_OPT_PHASE_UPDATE 2u
 #define NGP_OPT_PHASE_COMMIT 4u
+/* with COMMIT: a step that stands also flips state[5], the parity of a speculatively updated table (ngp_table_adam_t) */
+#define NGP_OPT_PHASE_FLIP 8u
 int ngp_optim_adam_step_ex(int count, const uint64_t* n, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
                            void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
                            float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
                            float* state, float* const* ema, float ema_one_minus_decay, uint32_t phases, ngp_stream_t stream);
+/* The rest of a step whose hash table was updated inside the grid backward (ngp_table_adam_t): Adam (same rule, same arithmetic, the
+ * skip-as-a-whole verdict read from state[2]) on what is left -- the few SMALL tensors (the two MLPs' weights, updated in place) and,
+ * table != NULL, the first table_prefix_params parameters of the double-buffered table (the dense levels: read from buffer set state[5]
+ * with the stored fp16 gradient table_grad_fp16, written to the other set; nothing is written when the step is skipped) -- followed by
+ * the COMMIT of the loss scale / step count and, flip_parity != 0, the parity flip that makes the speculatively written table current.
+ * ONE launch of a few workgroups; the last one to finish (a ticket in state[6]) commits.  count may be 0.  At most 8 tensors and 4 M
+ * parameters in total; table_prefix_params a multiple of 4. */
+struct ngp_table_adam;
+int ngp_optim_adam_small_commit(int count, const uint64_t* n, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                                void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
+                                float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
+                                float* state, int flip_parity, const struct ngp_table_adam* table, const void* table_grad_fp16,
+                                uint64_t table_prefix_params, ngp_stream_t stream);
 /* Data-parallel sharded update (one process per GPU, reduce-scatter -> Adam on 1/world -> all-gather; the reference's dormant DDP hook,
  * nerf/utils.py:364-366, all-reduces everything): the global "skip this step" verdict without a collective of its own.
  * ngp_optim_poison_shards: when state[2] (found_inf of THIS rank's local gradient) is set, writes NaN into element 0 of each of the `shards`

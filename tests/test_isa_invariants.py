@@ -91,7 +91,8 @@ def test_cull_kernel_divides_only_in_its_prologue(tmp_path_factory):
 
 
 @pytest.mark.parametrize('unit,parts', [('gridencoder', ('k_grid_forward_fastILb0ELb0E',)), ('gridencoder', ('k_grid_backward_binILi3ELi3ELi2E',)),
-                                        ('gridencoder', ('k_grid_backward_accumulateILi3E',)), ('optim', ('k_adam',)),
+                                        ('gridencoder', ('k_grid_backward_accumulateILi3ELb0E',)), ('gridencoder', ('k_grid_backward_accumulateILi3ELb1E',)),
+                                        ('optim', ('6k_adamE',)), ('optim', ('k_adam_small_commitE',)),
                                         ('raymarching', ('k_composite_train_loss_bwd',)), ('ffmlp', ('k_ffmlp_backward_pairedILi64ELi1ELi2ELb1ELb0E',))])
 def test_hot_kernels_keep_out_of_scratch_memory(unit, parts, tmp_path_factory):
     assert _count(_one(_disassemble(unit, tmp_path_factory), *parts), 'scratch_') == 0

@@ -22,8 +22,8 @@ LIB_PATH = os.environ.get('NGP_HIP_LIBRARY') or os.path.join(_HERE, 'libngp_hip.
 NGP_F32, NGP_F16 = 0, 1
 NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR, NGP_FF_LAYERED, NGP_FF_SINGLE_WAVE, NGP_FF_DEFER_REDUCE, NGP_FF_RECOMPUTE = 1, 2, 4, 8, 16, 32
 NGP_MARCH_RESET_COUNTER, NGP_MARCH_ZERO_TAIL, NGP_MARCH_NOISE_FROM_SEED, NGP_MARCH_SCAN_LAUNCH = 1, 2, 4, 8
-NGP_OPT_PHASE_CHECK, NGP_OPT_PHASE_UPDATE, NGP_OPT_PHASE_COMMIT = 1, 2, 4
-ABI_VERSION = 7
+NGP_OPT_PHASE_CHECK, NGP_OPT_PHASE_UPDATE, NGP_OPT_PHASE_COMMIT, NGP_OPT_PHASE_FLIP = 1, 2, 4, 8
+ABI_VERSION = 8
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -67,6 +67,7 @@ _SIGNATURES = {
     'ngp_ffmlp_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
     'ngp_grid_encode_forward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
     'ngp_grid_encode_forward_sched': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _f32, _vp, _vp],
+    'ngp_grid_encode_forward_sel': [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _u32, _i32, _f32, _vp, _vp],
     'ngp_grid_encode_backward_ex': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
     'ngp_grid_encode_backward_ws': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp, _vp,
                                     _sz, _vp],
@@ -98,6 +99,8 @@ _SIGNATURES = {
     'ngp_ffmlp_reduce_slabs_pair': [_vp, _u32, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp],
     'ngp_optim_adam_step': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp],
     'ngp_optim_adam_step_ex': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _f32, _u32, _vp],
+    'ngp_optim_adam_small_commit': [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _i32, _vp, _vp,
+                                    ctypes.c_uint64, _vp],
     'ngp_optim_ema_update': [_i32, _vp, _vp, _vp, _f32, _vp],
     'ngp_optim_poison_shards': [_vp, _u32, ctypes.c_uint64, _vp, _vp],
     'ngp_optim_shard_verdict': [_vp, _vp, _vp, _u32, ctypes.c_uint64, _vp],
@@ -121,6 +124,8 @@ lib.ngp_ffmlp_backward_workspace_bytes.restype = _sz
 lib.ngp_grid_backward_workspace_bytes.argtypes = [_vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _i32]
 lib.ngp_grid_backward_workspace_bytes.restype = _sz
 lib.ngp_compact_rays_workspace_bytes.restype = _sz
+lib.ngp_grid_table_adam_prefix.argtypes = [_vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _i32]
+lib.ngp_grid_table_adam_prefix.restype = _u32
 lib.ngp_coarse_occupancy_bytes.argtypes = [_u32, _u32]
 lib.ngp_coarse_occupancy_bytes.restype = _sz
 lib.ngp_grid_forward_work_lists.argtypes = [_u32, _u32, _vp, _vp, _vp, _vp]
@@ -134,7 +139,8 @@ if lib.ngp_abi_version() != ABI_VERSION:
 EXPORTED = sorted(list(_SIGNATURES) + ['ngp_last_error', 'ngp_target_arch', 'ngp_abi_version',
                                        'ngp_march_rays_train_workspace_bytes', 'ngp_compact_rays_workspace_bytes',
                                        'ngp_grid_backward_workspace_bytes', 'ngp_ffmlp_backward_workspace_bytes',
-                                       'ngp_ffmlp_backward_slab_count', 'ngp_density_grid_update_workspace_bytes', 'ngp_grid_forward_work_lists', 'ngp_coarse_occupancy_bytes'])
+                                       'ngp_ffmlp_backward_slab_count', 'ngp_density_grid_update_workspace_bytes', 'ngp_grid_forward_work_lists', 'ngp_coarse_occupancy_bytes',
+                                       'ngp_grid_table_adam_prefix'])
 
 
 def check(rc):
@@ -147,7 +153,14 @@ class SlabSets(ctypes.Structure):
     """ngp_slab_sets_t (include/ngp_hip.h): two sets of deferred FFMLP weight-gradient slabs for ngp_grid_encode_backward_checked_slabs"""
     _fields_ = [('slabs_a', ctypes.c_void_p), ('n_slabs_a', ctypes.c_uint32), ('n_params_a', ctypes.c_uint32), ('grad_weights_a', ctypes.c_void_p),
                 ('slabs_b', ctypes.c_void_p), ('n_slabs_b', ctypes.c_uint32), ('n_params_b', ctypes.c_uint32), ('grad_weights_b', ctypes.c_void_p),
-                ('ray_err', ctypes.c_void_p), ('n_rays', ctypes.c_uint32), ('loss', ctypes.c_void_p), ('overwrite_table', ctypes.c_uint32)]
+                ('ray_err', ctypes.c_void_p), ('n_rays', ctypes.c_uint32), ('loss', ctypes.c_void_p), ('overwrite_table', ctypes.c_uint32),
+                ('table_adam', ctypes.c_void_p)]
+
+
+class TableAdam(ctypes.Structure):
+    """ngp_table_adam_t (include/ngp_hip.h): the two buffer sets of a table whose Adam sweep rides in the grid backward's accumulate launch"""
+    _fields_ = [('param', ctypes.c_void_p * 2), ('exp_avg', ctypes.c_void_p * 2), ('exp_avg_sq', ctypes.c_void_p * 2), ('param_fp16', ctypes.c_void_p * 2),
+                ('state', ctypes.c_void_p), ('lr', ctypes.c_float), ('beta1', ctypes.c_float), ('beta2', ctypes.c_float), ('eps', ctypes.c_float)]
 
 
 def ptr(t):

@@ -23,6 +23,7 @@ def save_checkpoint(path, model, epoch=0, global_step=0, stats=None, optimizer=N
     if write is None:
         write = (not in_group) or dist.get_rank() == 0
     state = {'epoch': epoch, 'global_step': global_step, 'stats': stats if stats is not None else {}}
+    _materialize(model)
     if optimizer is not None and getattr(optimizer, 'shard', False):
         # optim.NGPAdam(shard=True): a rank keeps only its own 1/world of the fp32 master weights current between steps -- complete them
         # from their owners before ANY state_dict (also the model-only "best" checkpoints); a collective: every rank calls save_checkpoint
@@ -91,6 +92,7 @@ def load_checkpoint(checkpoint, model, optimizer=None, scaler=None, lr_scheduler
     ck = torch.load(checkpoint, map_location=map_location, weights_only=False) if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, 'read') \
         else checkpoint
     info = {'missing_keys': [], 'unexpected_keys': [], 'epoch': None, 'global_step': None, 'stats': None}
+    _materialize(model)   # (before the load: a table whose current copy is buffer set B would otherwise be copied OVER the loaded weights)
     if 'model' not in ck:  # a bare state_dict (nerf/utils.py:1089-1092)
         model.load_state_dict(ck)
         _after_model_load(model, optimizer)
@@ -119,6 +121,15 @@ def load_checkpoint(checkpoint, model, optimizer=None, scaler=None, lr_scheduler
     if scaler is not None and 'scaler' in ck:
         scaler.load_state_dict(ck['scaler'])
     return info
+
+
+def _materialize(model):
+    """a hash table whose Adam sweep rides in the grid backward (optim.NGPAdam.enable_table_fusion) lives in two buffer sets; the torch
+    Parameter is one of them -- make it the current one before the parameters are read or written from outside"""
+    for p in model.parameters():
+        fn = getattr(p, '_ngp_materialize', None)
+        if fn is not None:
+            fn()
 
 
 def _after_model_load(model, optimizer):

@@ -122,6 +122,48 @@ __device__ __forceinline__ void loss_sum_block(const float* err, uint32_t N, flo
     }
 }
 
+// ---- Adam + loss-scale arithmetic shared by optim.hip (k_adam, k_adam_small_commit) and the slice accumulate of the grid backward that
+// carries the table's Adam sweep in its flush (gridencoder.hip): ONE statement of the update, so the fused and the separate form produce the
+// same bits (the library is built with -ffp-contract=off).
+// state[0] = loss scale, [1] = growth tracker, [2] = found_inf, [3] = Adam step count t, [4] = lr multiplier, [5] = table parity (0 / 1: which of
+// the two buffer sets of a speculatively updated table is current, ngp_table_adam_t)
+struct AdamConsts {
+    float inv_scale, bc1, bc2_sqrt, lr_mult;
+    bool skip;  // found_inf already raised, or the loss scale is unusable (underflowed to 0 / denormal: GradScaler's 1 / scale = inf)
+};
+__device__ __forceinline__ AdamConsts adam_consts(const float* state, float beta1, float beta2, float grad_mult) {
+    AdamConsts a;
+    const bool scale_dead = !__builtin_isfinite(1.0f / state[0]);
+    a.skip = state[2] != 0.0f || scale_dead;
+    a.inv_scale = scale_dead ? 0.0f : grad_mult / state[0];
+    const float t = state[3] + 1.0f;  // this step's count (the commit stores it)
+    a.bc1 = 1.0f - powf(beta1, t);
+    a.bc2_sqrt = sqrtf(1.0f - powf(beta2, t));
+    a.lr_mult = state[4];
+    return a;
+}
+// one element: g = the (already unscaled) gradient; PyTorch's Adam (amsgrad = False, weight_decay = 0)
+__device__ __forceinline__ void adam_element(float g, float& pm, float& pv, float& pp, float beta1, float beta2, float eps, float step_size,
+                                             float bc2_sqrt) {
+    pm = beta1 * pm + (1.0f - beta1) * g;
+    pv = beta2 * pv + (1.0f - beta2) * g * g;
+    pp -= step_size * pm / (sqrtf(pv) / bc2_sqrt + eps);
+}
+// the table's Adam sweep inside the grid backward (device-side copy of ngp_table_adam_t)
+struct TableAdam {
+    float* p[2];
+    float* m[2];
+    float* v[2];
+    _Float16* p16[2];
+    const float* state;
+    float lr, beta1, beta2, eps;
+};
+// which copy of a double-buffered fp16 table a reader takes (device-side copy of the (embeddings_alt, parity) pair of the *_sel entry points)
+struct TableSel {
+    const _Float16* alt;
+    const float* parity;
+};
+
 // ---- fixed-order sum of per-workgroup fp32 weight-gradient slabs (the FFMLP backward's deferred reduction), TWO sets per launch ----
 // One block of RS_PARAMS x RS_GROUPS threads sums RS_PARAMS parameters of one set: group g adds slabs g, g + RS_GROUPS, ..., the groups'
 // partial sums are added in group order and rounded once to fp16 -- the same order for every launch shape, so the same bits whether the

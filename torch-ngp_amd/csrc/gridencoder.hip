@@ -372,11 +372,13 @@ __device__ __forceinline__ void forward_pair_block(const float* __restrict__ inp
 }
 
 template <typename T, int D, int C>
-__global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid,
+__global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid_a,
                                                                    const int32_t* __restrict__ offsets, T* __restrict__ outputs,
                                                                    uint32_t B, uint32_t L, GridLevels lv, uint32_t gridtype,
                                                                    bool align_corners, uint32_t interp, FwdSchedule sched,
-                                                                   uint32_t points_per_block, InputMap im) {
+                                                                   uint32_t points_per_block, InputMap im, TableSel sel) {
+    // double-buffered table (ngp_grid_encode_forward_sel): which copy is current is a device word, read once per workgroup (scalar load)
+    const T* __restrict__ grid = sel.parity && sel.parity[0] != 0.0f ? reinterpret_cast<const T*>(sel.alt) : grid_a;
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     uint32_t level = 0xffffu, tile = 0u, begin = 0u;
 #pragma unroll
@@ -442,11 +444,13 @@ struct FwdPos3 {
 #endif
 // (measured and dropped, EXPERIMENTS.md round 5: non-temporal table gathers on the fine hashed levels -- no effect: 58.0 / 58.1 vs 57.5 us)
 template <bool SMOOTH /* interp == 1 (smoothstep) */, bool MAPPED /* inputs are world coordinates: InputMap */>
-__global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_fast(const float* __restrict__ inputs, const half_t* __restrict__ grid,
+__global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_fast(const float* __restrict__ inputs, const half_t* __restrict__ grid_a,
                                                                    const int32_t* __restrict__ offsets, half_t* __restrict__ outputs, uint32_t B,
                                                                    uint32_t L, GridLevels lv, uint32_t gridtype, uint32_t interp, FwdSchedule sched,
-                                                                   uint32_t points_per_block, InputMap im) {
+                                                                   uint32_t points_per_block, InputMap im, TableSel sel) {
     constexpr int D = 3, C = 2;
+    // double-buffered table (ngp_grid_encode_forward_sel): which copy is current is a device word, read once per workgroup (scalar load)
+    const half_t* __restrict__ grid = sel.parity && sel.parity[0] != 0.0f ? sel.alt : grid_a;
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     uint32_t level = 0xffffu, tile = 0u, begin = 0u;
 #pragma unroll
@@ -977,6 +981,7 @@ struct BinPlan {
     uint32_t lc[NGP_MAX_LEVELS][BIN_LC_WORDS];
     uint32_t n_chunks;                   // chunks (BIN_PPB samples) per level
     uint32_t n_levels;                   // binned levels
+    uint8_t acc_order[NGP_MAX_LEVELS];   // accumulate launch: grid row r serves binned level acc_order[r]
     // interleaved = 0: bin = index >> 12 (contiguous slices); 1: bin = index & 127 (dense levels, see above)
     __host__ __device__ __forceinline__ uint32_t level(uint32_t li) const { return lc[li][0]; }
     __host__ __device__ __forceinline__ uint32_t n_bins(uint32_t li) const { return lc[li][1]; }
@@ -1460,11 +1465,19 @@ void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restric
 // a time: lane l of window w handles pair 64 w + l.  Which run a pair belongs to comes from a scatter of the run heads that fall into
 // the window (one LDS byte array per wave) followed by a DPP max-scan over the lanes -- about 15 VALU per window of 128 records, whatever
 // the run lengths.  Non-finite and scaled records (rare) leave the straight-line addend behind one wave-uniform branch.
-template <int D>
+// ADAM (round 6): the flush of a slice is also the table's Adam sweep for that slice (ngp_table_adam_t, include/ngp_hip.h): the final
+// gradient of 4096 entries sits in LDS, most of the chip is waiting on record walks, and the separate 28 B/parameter sweep over the whole
+// table that used to follow (k_adam: 61 us, HBM-bound) is exactly the kind of stream that fits under a latency-bound kernel.  The update is
+// speculative -- parameters / moments of buffer set state[5] are read, the OTHER set is written; the commit flips the parity only when no
+// gradient of the step was non-finite -- and uses the fp16-rounded gradient, i.e. the bits k_adam would have read from the stored table.
+#ifndef NGP_TADAM_PROBE
+#define NGP_TADAM_PROBE 0   // timing probes only (tools/table_adam_probe.py): 1 = no Adam on the round-robin bins of the dense levels, 2 = no stores, 4 = no loads
+#endif
+template <int D, bool ADAM>
 __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_grid_backward_accumulate(const int32_t* __restrict__ offsets, half_t* __restrict__ grad_grid,
                                                                           BinPlan plan, const uint32_t* __restrict__ descriptors,
                                                                           const uint2* __restrict__ records, float* __restrict__ found_inf,
-                                                                          SlabSets slabs, bool overwrite) {
+                                                                          SlabSets slabs, bool overwrite, TableAdam ta) {
     constexpr int MAX_REC = BIN_PPB * (1 << D);
     constexpr int WAVES = ACC_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char acc_smem[];
@@ -1481,7 +1494,7 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     uint32_t* head_at = reinterpret_cast<uint32_t*>(run_table + WAVES * 64);                                // [WAVES][64] run (1-based) whose first pair sits at this lane of the window
     // levels in REVERSE order: the sort wrote the last level's records last, so they are the ones still in the memory-side cache
     // (same-box A/B: -4 us per iteration)
-    const uint32_t li = plan.n_levels - 1u - (blockIdx.y - slab_row), bin = blockIdx.x;
+    const uint32_t li = plan.acc_order[blockIdx.y - slab_row], bin = blockIdx.x;
     if (bin >= plan.n_bins(li)) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 2 * BIN_SLICE; i += ACC_THREADS) acc[i] = 0ull;
@@ -1491,6 +1504,50 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     const uint32_t* __restrict__ desc = descriptors + plan.desc_base(li) + (size_t)bin * n_chunks;
     const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(records + (size_t)li * n_chunks * MAX_REC);  // 2 words per record
     const bool interleaved = plan.interleaved(li);
+    // ADAM: the slice's master weights and moments are REQUESTED HERE, in front of the record walk, and consumed by the flush behind it --
+    // the walk is bound by latency (descriptors -> record windows), the requests ride under it; the step's constants (two powf, a sqrt,
+    // a division) are computed under the same latency and parked in LDS.  The round-robin bins of the dense levels (entries 128 apart: 8-byte
+    // accesses at a stride of 1 KiB) do NOT take part: their flush stores the gradient as usual and the step's closing launch
+    // (ngp_optim_adam_small_commit) sweeps that prefix of the table contiguously -- measured: 45 of the fused flush's 94 us were those bins.
+    constexpr int TRIPS = BIN_SLICE / (2 * ACC_THREADS);
+    static_assert(BIN_SLICE % (2 * ACC_THREADS) == 0, "slice entries divide evenly over lane pairs");
+    float* adam_lds = reinterpret_cast<float*>(head_at + WAVES * 64);   // [4]: inv_scale, step_size, bc2_sqrt, source set
+    const bool adam_here = ADAM && !interleaved;
+    float4_t pp[TRIPS], pm[TRIPS], pv[TRIPS];
+    bool wide[TRIPS];
+    // (requested in FRONT of the walk, straight-line.  Requesting behind the first two record windows -- so that the descriptors and those
+    // windows are not queued behind the burst: vector-memory returns are in order -- needs the values live across a branchy region: the
+    // compiler spilled 65 registers and the kernel went from 95 to 125 us, EXPERIMENTS.md round 6)
+    if constexpr (ADAM) {
+        if (adam_here) {
+            const uint32_t level_ = plan.level(li);
+            const uint32_t off0_ = (uint32_t)offsets[level_], size_ = (uint32_t)offsets[level_ + 1] - off0_;
+            const uint32_t src = ta.state[5] != 0.0f ? 1u : 0u;
+            const float* __restrict__ p_in = ta.p[src] + (size_t)off0_ * 2;
+            const float* __restrict__ m_in = ta.m[src] + (size_t)off0_ * 2;
+            const float* __restrict__ v_in = ta.v[src] + (size_t)off0_ * 2;
+#pragma unroll
+            for (int k = 0; k < TRIPS; k++) {
+                const uint32_t e0 = bin * BIN_SLICE + 2u * ((uint32_t)tid + (uint32_t)k * ACC_THREADS);
+                wide[k] = e0 + 1u < size_ && ((off0_ + e0) & 1u) == 0u;   // a 16-byte aligned pair of entries inside the level
+                pp[k] = pm[k] = pv[k] = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
+                if (wide[k] && !(NGP_TADAM_PROBE & 4)) {
+                    pp[k] = __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(p_in + (size_t)e0 * 2));
+                    pm[k] = __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(m_in + (size_t)e0 * 2));
+                    pv[k] = __builtin_nontemporal_load(reinterpret_cast<const float4_t*>(v_in + (size_t)e0 * 2));
+                }
+            }
+            if (wid == 0) {   // one wave computes the constants (every lane the same values), one lane parks them
+                const AdamConsts ac = adam_consts(ta.state, ta.beta1, ta.beta2, 1.0f);
+                if (lane == 0) {
+                    adam_lds[0] = ac.inv_scale;
+                    adam_lds[1] = ta.lr * ac.lr_mult / ac.bc1;
+                    adam_lds[2] = ac.bc2_sqrt;
+                    adam_lds[3] = (float)src;
+                }
+            }
+        }
+    }
     // Exact fixed-point addend of a finite fp16 value v (11 significant bits), straight-line for BOTH magnitude ranges:
     //   |v| <  128: v * 2^24 is an integer below 2^31                      -> q = (int32) (v * 2^24), addend = q
     //   |v| >= 128: v is a multiple of 2^-3 (ulp of the binade of 128)     -> q = (int32) (v * 8) (<= 524032), addend = q << 21
@@ -1610,6 +1667,81 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off0;
     half2_t* __restrict__ gtable = reinterpret_cast<half2_t*>(grad_grid + (size_t)off0 * 2);
     bool nonfinite = false;
+    if constexpr (ADAM) {
+        if (adam_here) {
+            // Two ADJACENT entries per lane and trip: 16-byte accesses on the fp32 streams (8-byte global accesses run at 0.5-0.7x that rate
+            // on this chip, optim.hip).  The pairs that were not requested ahead (a level whose end is not pair-aligned) are fetched here.
+            const float inv_scale = adam_lds[0], step_size = adam_lds[1], bc2_sqrt = adam_lds[2];
+            const uint32_t src = adam_lds[3] != 0.0f ? 1u : 0u, dst = src ^ 1u;
+            float* __restrict__ p_out = ta.p[dst] + (size_t)off0 * 2;
+            float* __restrict__ m_out = ta.m[dst] + (size_t)off0 * 2;
+            float* __restrict__ v_out = ta.v[dst] + (size_t)off0 * 2;
+            half_t* __restrict__ h_out = ta.p16[dst] + (size_t)off0 * 2;
+#pragma unroll
+            for (int k = 0; k < TRIPS; k++) {
+                const uint32_t i = 2u * ((uint32_t)tid + (uint32_t)k * ACC_THREADS);
+                const uint32_t e0 = bin * BIN_SLICE + i;
+                const bool ok0 = e0 < hashmap_size, ok1 = e0 + 1u < hashmap_size;
+                if (!wide[k]) {
+                    const float* __restrict__ p_in = ta.p[src] + (size_t)off0 * 2;
+                    const float* __restrict__ m_in = ta.m[src] + (size_t)off0 * 2;
+                    const float* __restrict__ v_in = ta.v[src] + (size_t)off0 * 2;
+                    if (ok0) {
+                        const float2_t a = *reinterpret_cast<const float2_t*>(p_in + (size_t)e0 * 2), b = *reinterpret_cast<const float2_t*>(m_in + (size_t)e0 * 2),
+                                       c = *reinterpret_cast<const float2_t*>(v_in + (size_t)e0 * 2);
+                        pp[k].x = a.x; pp[k].y = a.y; pm[k].x = b.x; pm[k].y = b.y; pv[k].x = c.x; pv[k].y = c.y;
+                    }
+                    if (ok1) {
+                        const float2_t a = *reinterpret_cast<const float2_t*>(p_in + (size_t)e0 * 2 + 2), b = *reinterpret_cast<const float2_t*>(m_in + (size_t)e0 * 2 + 2),
+                                       c = *reinterpret_cast<const float2_t*>(v_in + (size_t)e0 * 2 + 2);
+                        pp[k].z = a.x; pp[k].w = a.y; pm[k].z = b.x; pm[k].w = b.y; pv[k].z = c.x; pv[k].w = c.y;
+                    }
+                }
+                const float nan = __builtin_nanf("");
+                half4_t g16, h16;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t ii = i + (uint32_t)(c >> 1);
+                    const long long sum = (long long)acc[2 * ii + (c & 1)];
+                    const uint32_t bad = (poison[ii >> 4] >> ((ii & 15u) * 2u + (uint32_t)(c & 1))) & 1u;
+                    // the gradient as it would be stored: the exact sum rounded once to fp16 (0 + sum: what adding into a zeroed entry gives)
+                    g16[c] = (half_t)(0.0f + (bad ? nan : (float)sum * 0x1p-24f));
+                    const bool live = (c >> 1) ? ok1 : ok0;
+                    nonfinite = nonfinite || (live && !__builtin_isfinite((float)g16[c]));
+                    const float g = (float)g16[c] * inv_scale;
+                    float m_ = pm[k][c], v_ = pv[k][c], p_ = pp[k][c];
+                    adam_element(g, m_, v_, p_, ta.beta1, ta.beta2, ta.eps, step_size, bc2_sqrt);
+                    pm[k][c] = m_; pv[k][c] = v_; pp[k][c] = p_;
+                    h16[c] = (half_t)p_;
+                }
+                if ((NGP_TADAM_PROBE & 2) && pp[k][0] != 123.456f) continue;
+                if (wide[k]) {
+                    __builtin_nontemporal_store(pm[k], reinterpret_cast<float4_t*>(m_out + (size_t)e0 * 2));
+                    __builtin_nontemporal_store(pv[k], reinterpret_cast<float4_t*>(v_out + (size_t)e0 * 2));
+                    __builtin_nontemporal_store(pp[k], reinterpret_cast<float4_t*>(p_out + (size_t)e0 * 2));
+                    *reinterpret_cast<half4_t*>(h_out + (size_t)e0 * 2) = h16;
+                    if (grad_grid) *reinterpret_cast<half4_t*>(gtable + e0) = g16;
+                } else {
+                    if (ok0) {
+                        *reinterpret_cast<float2_t*>(m_out + (size_t)e0 * 2) = float2_t{pm[k].x, pm[k].y};
+                        *reinterpret_cast<float2_t*>(v_out + (size_t)e0 * 2) = float2_t{pv[k].x, pv[k].y};
+                        *reinterpret_cast<float2_t*>(p_out + (size_t)e0 * 2) = float2_t{pp[k].x, pp[k].y};
+                        *reinterpret_cast<half2_t*>(h_out + (size_t)e0 * 2) = half2_t{h16[0], h16[1]};
+                        if (grad_grid) gtable[e0] = half2_t{g16[0], g16[1]};
+                    }
+                    if (ok1) {
+                        *reinterpret_cast<float2_t*>(m_out + (size_t)e0 * 2 + 2) = float2_t{pm[k].z, pm[k].w};
+                        *reinterpret_cast<float2_t*>(v_out + (size_t)e0 * 2 + 2) = float2_t{pv[k].z, pv[k].w};
+                        *reinterpret_cast<float2_t*>(p_out + (size_t)e0 * 2 + 2) = float2_t{pp[k].z, pp[k].w};
+                        *reinterpret_cast<half2_t*>(h_out + (size_t)e0 * 2 + 2) = half2_t{h16[2], h16[3]};
+                        if (grad_grid) gtable[e0 + 1u] = half2_t{g16[2], g16[3]};
+                    }
+                }
+            }
+            if (found_inf && __any(nonfinite) && (tid & 63) == 0) found_inf[0] = 1.0f;
+            return;
+        }
+    }
     // every thread owns BIN_SLICE / ACC_THREADS entries: their old values are loaded TOGETHER, then added to and stored (written as one
     // load-add-store per loop trip the compiler has to order each load behind the previous store -- it cannot see that the entries
     // differ -- and the tail of every workgroup became that many dependent round trips to memory)
@@ -1811,8 +1943,12 @@ static uint32_t build_forward_schedule(FwdSchedule& sc, uint32_t L, uint32_t til
 template <typename T, int D, int C>
 static int launch_forward(const float* inputs, const void* emb, const int32_t* offsets, void* outputs, uint32_t B,
                           uint32_t L, const GridLevels& lv, void* dy_dx, uint32_t gridtype, bool ac, uint32_t interp,
-                          InputMap im, const float* level_cost, hipStream_t st) {
+                          InputMap im, const float* level_cost, TableSel sel, hipStream_t st) {
     if (dy_dx) {
+        if (sel.parity) {
+            set_error("grid_encode_forward: the double-buffered table selection does not serve the dy_dx kernel");
+            return NGP_ERR_INVALID;
+        }
         dim3 grid(fwd_blocks(B), L, 1);
         hipLaunchKernelGGL((k_grid_forward<T, D, C, true>), grid, dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
                            (T*)outputs, B, L, lv, (T*)dy_dx, gridtype, ac, interp);
@@ -1829,7 +1965,7 @@ static int launch_forward(const float* inputs, const void* emb, const int32_t* o
             const bool smooth = interp == 1u, mapped = im.scale != 0.0f;
 #define NGP_FWD_FAST_LAUNCH(S, M)                                                                                                        \
             hipLaunchKernelGGL((k_grid_forward_fast<S, M>), dim3(8u * max_slots), dim3(FWD_THREADS), 0, st, inputs, (const half_t*)emb, \
-                               offsets, (half_t*)outputs, B, L, lv, gridtype, interp, sched, ppb, im)
+                               offsets, (half_t*)outputs, B, L, lv, gridtype, interp, sched, ppb, im, sel)
             if (smooth && mapped) NGP_FWD_FAST_LAUNCH(true, true);
             else if (smooth) NGP_FWD_FAST_LAUNCH(true, false);
             else if (mapped) NGP_FWD_FAST_LAUNCH(false, true);
@@ -1839,7 +1975,7 @@ static int launch_forward(const float* inputs, const void* emb, const int32_t* o
         }
     }
     hipLaunchKernelGGL((k_grid_forward_pair<T, D, C>), dim3(8u * max_slots), dim3(FWD_THREADS), 0, st, inputs, (const T*)emb, offsets,
-                       (T*)outputs, B, L, lv, gridtype, ac, interp, sched, ppb, im);
+                       (T*)outputs, B, L, lv, gridtype, ac, interp, sched, ppb, im, sel);
     return check_launch("grid_encode_forward");
 }
 
@@ -1867,6 +2003,8 @@ struct BackwardPlan {
     float* found_inf = nullptr;  // optional: set to 1 when a gradient value this call produced is not finite
     bool overwrite = false;      // the table gradient is written, not added to (every entry: needs every level on the record-sort path)
     SlabSets slabs = {};         // optional: slab reduction carried by the accumulate launch (blocks[] = 0: none)
+    bool adam = false;           // the accumulate's flush applies Adam to the table (needs overwrite; ngp_table_adam_t)
+    TableAdam table_adam = {};
     mutable bool slabs_done = false;  // set by the launch that carried them
     size_t desc_bytes() const { return ((size_t)total_desc * sizeof(uint32_t) + 255) & ~(size_t)255; }
     // (+64: the 16-byte load of a one-record run at the very end of the last chunk reads 8 bytes past it)
@@ -1937,13 +2075,15 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
                                 const GridLevels& lv, uint32_t gridtype, bool ac, uint32_t interp, InputMap im, const BackwardPlan& p,
                                 void* workspace, bool with_atomic_levels, hipStream_t st) {
     constexpr size_t acc_smem = sizeof(unsigned long long) * 2 * BIN_SLICE + sizeof(uint32_t) * (BIN_SLICE / 16) +
-                                (ACC_THREADS / 64) * 64 * (sizeof(uint2) + sizeof(uint32_t));
+                                (ACC_THREADS / 64) * 64 * (sizeof(uint2) + sizeof(uint32_t)) + 4 * sizeof(float);
     const uint32_t bins_cap = p.max_bins <= 128u ? 128u : (uint32_t)BIN_MAX_BINS;
     constexpr size_t bin_smem_max = sizeof(uint2) * (BIN_PPB * (1 << D) + BIN_MAX_BINS) + sizeof(uint32_t) * 2 * (BIN_THREADS / 64) * BIN_MAX_BINS;
     const size_t bin_smem = sizeof(uint2) * (BIN_PPB * (1 << D) + bins_cap) + sizeof(uint32_t) * 2 * (BIN_THREADS / 64) * bins_cap;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_accumulate<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_accumulate<D, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)acc_smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_accumulate<D, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)acc_smem) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_grid_backward_bin<D, AMERGE, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)bin_smem_max) != hipSuccess ||
@@ -1978,6 +2118,24 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     const uint32_t blocks = persistent + ap.n_blocks;
     BinPlan bins = p.bins;
     bins.n_levels = p.n_binned;
+    {   // row order of the accumulate launch.  Default: levels in REVERSE (the sort wrote the last level's records last: still in the memory-side cache)
+        static const int order_mode = getenv("NGP_ACC_ORDER") ? atoi(getenv("NGP_ACC_ORDER")) : 0;   // experiment knob (EXPERIMENTS.md round 6)
+        uint32_t r = 0;
+        std::vector<uint32_t> dense, hashed;
+        for (uint32_t i = p.n_binned; i-- > 0;) (bins.interleaved(i) ? dense : hashed).push_back(i);
+        if (order_mode == 1) {          // dense levels first (short workgroups of unequal length: the hashed rounds behind them start staggered)
+            for (uint32_t i : dense) bins.acc_order[r++] = (uint8_t)i;
+            for (uint32_t i : hashed) bins.acc_order[r++] = (uint8_t)i;
+        } else if (order_mode == 2) {   // alternate hashed / dense
+            size_t a = 0, b = 0;
+            while (a < hashed.size() || b < dense.size()) {
+                if (a < hashed.size()) bins.acc_order[r++] = (uint8_t)hashed[a++];
+                if (b < dense.size()) bins.acc_order[r++] = (uint8_t)dense[b++];
+            }
+        } else {
+            for (uint32_t i = p.n_binned; i-- > 0;) bins.acc_order[r++] = (uint8_t)i;
+        }
+    }
     if (bins_cap <= 128u)
         hipLaunchKernelGGL((k_grid_backward_bin<D, AMERGE, 2>), dim3(blocks), dim3(BIN_THREADS), bin_smem, st, (const half_t*)grad, inputs, offsets,
                            (half_t*)grad_emb, B, lv, gridtype, ac, interp, im, bins, descriptors, records, ap);
@@ -1988,9 +2146,13 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     if (rc) return rc;
     static_assert(ACC_THREADS == RS_PARAMS * RS_GROUPS, "the slab reduction's blocks have the accumulate's shape");
     const uint32_t slab_blocks = p.slabs.total_blocks();
-    hipLaunchKernelGGL((k_grid_backward_accumulate<D>), dim3(std::max(p.max_bins, slab_blocks), p.n_binned + (slab_blocks ? 1u : 0u)), dim3(ACC_THREADS),
-                       acc_smem, st, offsets, (half_t*)grad_emb, bins, (const uint32_t*)descriptors, (const uint2*)records, p.found_inf, p.slabs,
-                       p.overwrite);
+    const dim3 acc_grid(std::max(p.max_bins, slab_blocks), p.n_binned + (slab_blocks ? 1u : 0u));
+    if (p.adam)
+        hipLaunchKernelGGL((k_grid_backward_accumulate<D, true>), acc_grid, dim3(ACC_THREADS), acc_smem, st, offsets, (half_t*)grad_emb, bins,
+                           (const uint32_t*)descriptors, (const uint2*)records, p.found_inf, p.slabs, p.overwrite, p.table_adam);
+    else
+        hipLaunchKernelGGL((k_grid_backward_accumulate<D, false>), acc_grid, dim3(ACC_THREADS), acc_smem, st, offsets, (half_t*)grad_emb, bins,
+                           (const uint32_t*)descriptors, (const uint2*)records, p.found_inf, p.slabs, p.overwrite, p.table_adam);
     p.slabs_done = slab_blocks != 0;
     return check_launch("grid_encode_backward(accumulate)");
 }
@@ -2153,10 +2315,10 @@ extern "C" uint32_t ngp_grid_forward_work_lists(uint32_t L, uint32_t tiles, cons
     return max_slots;
 }
 
-extern "C" int ngp_grid_encode_forward_sched(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
-                                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
-                                             uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
-                                             const float* level_cost_host, ngp_stream_t stream) {
+static int grid_encode_forward_impl(const float* inputs, const void* embeddings, TableSel sel, const int32_t* offsets, void* outputs,
+                                    uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                    uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
+                                    const float* level_cost_host, ngp_stream_t stream) {
     int rc = check_grid_args("grid_encode_forward", B, D, C, L, dtype);
     NGP_REQUIRE(!(bound > 0.0f && dy_dx), NGP_ERR_INVALID, "grid_encode_forward: the fused input mapping does not provide dy_dx");
     const InputMap im = make_input_map(bound);
@@ -2171,12 +2333,30 @@ extern "C" int ngp_grid_encode_forward_sched(const float* inputs, const void* em
     for (uint32_t l = 0; level_cost && l < L; l++)
         NGP_REQUIRE(level_cost[l] > 0.0f && level_cost[l] < 1e6f, NGP_ERR_INVALID, "grid_encode_forward: level_cost[%u] must be positive and finite", l);
     if (dtype == NGP_F16) {
-        NGP_DISPATCH_DC(launch_forward, half_t, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, im, level_cost, st)
+        NGP_DISPATCH_DC(launch_forward, half_t, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, im, level_cost, sel, st)
     } else {
-        NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, im, level_cost, st)
+        NGP_DISPATCH_DC(launch_forward, float, inputs, embeddings, offsets, outputs, B, L, lv, dy_dx, gridtype, ac, interp, im, level_cost, sel, st)
     }
     set_error("grid_encode_forward: unsupported (D=%u, C=%u)", D, C);
     return NGP_ERR_INVALID;
+}
+
+extern "C" int ngp_grid_encode_forward_sched(const float* inputs, const void* embeddings, const int32_t* offsets, void* outputs,
+                                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
+                                             uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
+                                             const float* level_cost_host, ngp_stream_t stream) {
+    return grid_encode_forward_impl(inputs, embeddings, TableSel{nullptr, nullptr}, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
+                                    interp, dtype, bound, level_cost_host, stream);
+}
+
+extern "C" int ngp_grid_encode_forward_sel(const float* inputs, const void* embeddings, const void* embeddings_alt, const float* parity,
+                                           const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                           uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
+                                           const float* level_cost_host, ngp_stream_t stream) {
+    NGP_REQUIRE(dtype == NGP_F16 || !(embeddings_alt && parity), NGP_ERR_INVALID, "grid_encode_forward_sel: the double-buffered table is fp16");
+    const TableSel sel = embeddings_alt && parity ? TableSel{reinterpret_cast<const _Float16*>(embeddings_alt), parity} : TableSel{nullptr, nullptr};
+    return grid_encode_forward_impl(inputs, embeddings, sel, offsets, outputs, B, D, C, L, S, H, nullptr, gridtype, align_corners, interp, dtype,
+                                    bound, level_cost_host, stream);
 }
 
 #ifdef NGP_DEBUG_BOUNDS
@@ -2196,7 +2376,7 @@ extern "C" int ngp_debug_forward_bad_tile(const float* inputs, const void* embed
     sc.level[0][0] = 0;
     sc.tile0[0][0] = cdiv(B, 1024u);  // one past the last tile
     hipLaunchKernelGGL((k_grid_forward_pair<half_t, 3, 2>), dim3(8u), dim3(FWD_THREADS), 0, as_stream(stream), inputs, (const half_t*)embeddings,
-                       offsets, (half_t*)outputs, B, 2u, lv, 0u, false, 0u, sc, 1024u, InputMap{0.0f, 0.0f});
+                       offsets, (half_t*)outputs, B, 2u, lv, 0u, false, 0u, sc, 1024u, InputMap{0.0f, 0.0f}, TableSel{nullptr, nullptr});
     return check_launch("debug_forward_bad_tile");
 }
 #endif
@@ -2224,6 +2404,21 @@ extern "C" size_t ngp_grid_backward_workspace_bytes(const int32_t* offsets_host,
     BackwardPlan plan;
     plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0, true);
     return plan.workspace_bytes();
+}
+
+extern "C" uint32_t ngp_grid_table_adam_prefix(const int32_t* offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                               uint32_t gridtype, int align_corners, int dtype) {
+    if (!offsets_host || L < 1 || L > NGP_MAX_LEVELS || D < 2 || D > 5) return 0xffffffffu;
+    GridLevels lv;
+    fill_levels(lv, L, S, H);
+    BackwardPlan plan;
+    plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0, true);
+    if (plan.n_atomic != 0 || plan.n_binned != L || dtype != NGP_F16 || C != 2) return 0xffffffffu;
+    uint32_t k = 0;
+    while (k < L && plan.bins.interleaved(k)) k++;
+    for (uint32_t j = k; j < L; j++)
+        if (plan.bins.interleaved(j)) return 0xffffffffu;
+    return (uint32_t)offsets_host[k];   // (binned levels are listed in level order when every level is binned: index == level)
 }
 
 template <typename T>
@@ -2280,6 +2475,7 @@ extern "C" int ngp_grid_encode_backward_checked_slabs(const void* grad, const fl
     int rc = check_grid_args("grid_encode_backward", B, D, C, L, dtype);
     if (rc) return rc;
     if (B == 0) {
+        NGP_REQUIRE(!(slab_sets && slab_sets->table_adam), NGP_ERR_INVALID, "grid_encode_backward: table_adam with an empty batch");
         if (slab_sets && slab_sets->overwrite_table) {
             NGP_REQUIRE(offsets_host && grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: overwrite_table needs the table and the host copy of the offsets");
             hipError_t e = hipMemsetAsync(grad_embeddings, 0, (size_t)offsets_host[L] * C * (dtype == NGP_F16 ? 2 : 4), as_stream(stream));
@@ -2287,13 +2483,41 @@ extern "C" int ngp_grid_encode_backward_checked_slabs(const void* grad, const fl
         }
         return reduce_alone();
     }
-    NGP_REQUIRE(grad && inputs && offsets && grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: NULL tensor");
+    const ngp_table_adam_t* tadam = slab_sets ? slab_sets->table_adam : nullptr;
+    NGP_REQUIRE(grad && inputs && offsets && (grad_embeddings || tadam), NGP_ERR_INVALID, "grid_encode_backward: NULL tensor");
     GridLevels lv;
     fill_levels(lv, L, S, H);
     BackwardPlan plan;
     plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0, workspace != nullptr);
     plan.found_inf = found_inf;
     plan.slabs = carried;
+    if (tadam) {
+        // the table's Adam sweep rides in the accumulate's flush: only when EVERY entry of the table comes out of a flush (all levels on the
+        // record-sort path, overwrite mode) -- refused otherwise, before anything is launched (the caller falls back to ngp_optim_adam_step_ex)
+        NGP_REQUIRE(slab_sets->overwrite_table && plan.n_atomic == 0 && plan.n_binned == L && dtype == NGP_F16 && C == 2, NGP_ERR_INVALID,
+                    "grid_encode_backward: table_adam needs overwrite_table and every level on the record-sort path (fp16, C = 2, >= %u samples, "
+                    "a workspace and the host offsets)", BIN_MIN_SAMPLES);
+        NGP_REQUIRE(tadam->state, NGP_ERR_INVALID, "grid_encode_backward: table_adam without the optimizer's state");
+        {   // the dense levels' round-robin bins leave their entries to ngp_optim_adam_small_commit: they must form a prefix of the table
+            // (ngp_grid_table_adam_prefix tells the caller how long it is), and their gradient has to be stored for it
+            uint32_t k = 0;
+            while (k < plan.n_binned && plan.bins.interleaved(k)) k++;
+            for (uint32_t j = k; j < plan.n_binned; j++)
+                NGP_REQUIRE(!plan.bins.interleaved(j), NGP_ERR_INVALID, "grid_encode_backward: table_adam: a dense level behind a hashed one (level %u)",
+                            plan.bins.level(j));
+            NGP_REQUIRE(k == 0 || grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: table_adam: the dense levels' gradient needs grad_embeddings");
+        }
+        for (int k = 0; k < 2; k++)
+            NGP_REQUIRE(tadam->param[k] && tadam->exp_avg[k] && tadam->exp_avg_sq[k] && tadam->param_fp16[k], NGP_ERR_INVALID,
+                        "grid_encode_backward: table_adam: NULL buffer in set %d", k);
+        plan.adam = true;
+        for (int k = 0; k < 2; k++) {
+            plan.table_adam.p[k] = tadam->param[k]; plan.table_adam.m[k] = tadam->exp_avg[k]; plan.table_adam.v[k] = tadam->exp_avg_sq[k];
+            plan.table_adam.p16[k] = reinterpret_cast<_Float16*>(tadam->param_fp16[k]);
+        }
+        plan.table_adam.state = tadam->state;
+        plan.table_adam.lr = tadam->lr; plan.table_adam.beta1 = tadam->beta1; plan.table_adam.beta2 = tadam->beta2; plan.table_adam.eps = tadam->eps;
+    }
     if (slab_sets && slab_sets->overwrite_table) {
         // every entry comes out of the accumulate only when every level is sorted; otherwise: zero the table, then add as usual
         if (plan.n_atomic == 0 && plan.n_binned == L && dtype == NGP_F16) {

@@ -19,8 +19,17 @@
 // fp32 read-modify-write stream instead of a separate pass over every parameter.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace ngp {
+
+// adam_element on components of vector registers (a vector element does not bind to a reference)
+#define NGP_ADAM_EL(G, M, V, P)                                                    \
+    {                                                                              \
+        float m_ = (M), v_ = (V), p_ = (P);                                        \
+        adam_element((G), m_, v_, p_, beta1, beta2, eps, step_size, bc2_sqrt);     \
+        (M) = m_; (V) = v_; (P) = p_;                                              \
+    }
 
 constexpr int OPT_THREADS = 256;
 constexpr int OPT_MAX_TENSORS = 8;
@@ -70,14 +79,11 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
     // A loss scale that has underflowed (a long run of overflowing steps halves it to a denormal, then to 0): GradScaler unscales BEFORE it
     // checks, so its 1 / scale = inf turns every gradient into inf or NaN and the step is skipped -- for good, the run is dead, but the weights
     // stay what they were.  Checking the SCALED gradient (the producers do) would let a zero gradient through and 0 * inf = NaN into every
-    // parameter (seen in a 200 000-step soak of the bench workload, tools/soak_train.py): the unusable scale is an overflow of its own.
-    const bool scale_dead = !__builtin_isfinite(1.0f / state[0]);
-    const bool skip = state[2] != 0.0f || scale_dead;
-    const float inv_scale = scale_dead ? 0.0f : grad_mult / state[0];
-    const float t = state[3] + 1.0f;  // this step's count (k_update_scale commits it)
-    const float bc1 = 1.0f - powf(beta1, t);
-    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, t));
-    const float lr_mult = state[4];
+    // parameter (seen in a 200 000-step soak of the bench workload, tools/soak_train.py): the unusable scale is an overflow of its own
+    // (adam_consts, common.h).
+    const AdamConsts ac = adam_consts(state, beta1, beta2, grad_mult);
+    const bool skip = ac.skip;
+    const float inv_scale = ac.inv_scale, bc1 = ac.bc1, bc2_sqrt = ac.bc2_sqrt, lr_mult = ac.lr_mult;
     for (int k = 0; k < ts.count; k++) {
         const uint64_t n = ts.n[k];
         const float step_size = ts.lr[k] * lr_mult / bc1;
@@ -123,13 +129,9 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const float g0 = (float)x0[c] * inv_scale, g1 = (float)x1[c] * inv_scale;
-                    pm0[c] = beta1 * pm0[c] + (1.0f - beta1) * g0;
-                    pv0[c] = beta2 * pv0[c] + (1.0f - beta2) * g0 * g0;
-                    pp0[c] -= step_size * pm0[c] / (sqrtf(pv0[c]) / bc2_sqrt + eps);
+                    NGP_ADAM_EL(g0, pm0[c], pv0[c], pp0[c]);
                     ph0[c] = (half_t)pp0[c];
-                    pm1[c] = beta1 * pm1[c] + (1.0f - beta1) * g1;
-                    pv1[c] = beta2 * pv1[c] + (1.0f - beta2) * g1 * g1;
-                    pp1[c] -= step_size * pm1[c] / (sqrtf(pv1[c]) / bc2_sqrt + eps);
+                    NGP_ADAM_EL(g1, pm1[c], pv1[c], pp1[c]);
                     ph1[c] = (half_t)pp1[c];
                 }
                 __builtin_nontemporal_store(pm0, reinterpret_cast<float4_t*>(m) + i);
@@ -157,9 +159,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const float g = (float)x[c] * inv_scale;
-                    pm[c] = beta1 * pm[c] + (1.0f - beta1) * g;
-                    pv[c] = beta2 * pv[c] + (1.0f - beta2) * g * g;
-                    pp[c] -= step_size * pm[c] / (sqrtf(pv[c]) / bc2_sqrt + eps);
+                    NGP_ADAM_EL(g, pm[c], pv[c], pp[c]);
                     ph[c] = (half_t)pp[c];
                 }
                 __builtin_nontemporal_store(pm, reinterpret_cast<float4_t*>(m) + i);
@@ -196,10 +196,8 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
             // activation stores of the network forward: -11 us per iteration on one box)
             float2_t pm = __builtin_nontemporal_load(reinterpret_cast<float2_t*>(m) + i), pv = __builtin_nontemporal_load(reinterpret_cast<float2_t*>(v) + i),
                      pp = __builtin_nontemporal_load(reinterpret_cast<float2_t*>(p) + i);
-            pm.x = beta1 * pm.x + (1.0f - beta1) * g0; pm.y = beta1 * pm.y + (1.0f - beta1) * g1;
-            pv.x = beta2 * pv.x + (1.0f - beta2) * g0 * g0; pv.y = beta2 * pv.y + (1.0f - beta2) * g1 * g1;
-            pp.x -= step_size * pm.x / (sqrtf(pv.x) / bc2_sqrt + eps);
-            pp.y -= step_size * pm.y / (sqrtf(pv.y) / bc2_sqrt + eps);
+            NGP_ADAM_EL(g0, pm.x, pv.x, pp.x);
+            NGP_ADAM_EL(g1, pm.y, pv.y, pp.y);
             __builtin_nontemporal_store(pm, reinterpret_cast<float2_t*>(m) + i);
             __builtin_nontemporal_store(pv, reinterpret_cast<float2_t*>(v) + i);
             __builtin_nontemporal_store(pp, reinterpret_cast<float2_t*>(p) + i);
@@ -216,8 +214,8 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
             if (!keep) { if (gh) g16[i] = (half_t)0.0f; else g32[i] = 0.0f; }
             if (!skip) {
                 g0 *= inv_scale;
-                const float nm = beta1 * m[i] + (1.0f - beta1) * g0, nv = beta2 * v[i] + (1.0f - beta2) * g0 * g0;
-                const float np_ = p[i] - step_size * nm / (sqrtf(nv) / bc2_sqrt + eps);
+                float nm = m[i], nv = v[i], np_ = p[i];
+                adam_element(g0, nm, nv, np_, beta1, beta2, eps, step_size, bc2_sqrt);
                 m[i] = nm; v[i] = nv; p[i] = np_;
                 if (p16) p16[i] = (half_t)np_;
             }
@@ -228,7 +226,7 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
 
 // torch.amp.GradScaler.update (_amp_update_scale_): found_inf -> scale *= backoff, tracker = 0; else tracker += 1 and, when it reaches
 // growth_interval, scale *= growth (only if the result is finite) and tracker = 0.  Also commits the Adam step count.
-__device__ __forceinline__ void update_scale(float* state, float growth, float backoff, float growth_interval) {
+__device__ __forceinline__ void update_scale(float* state, float growth, float backoff, float growth_interval, bool flip_parity = false) {
     if (state[2] != 0.0f || !__builtin_isfinite(1.0f / state[0])) {   // (an underflowed scale counts as an overflow: see k_adam)
         state[0] *= backoff;
         state[1] = 0.0f;
@@ -242,12 +240,97 @@ __device__ __forceinline__ void update_scale(float* state, float growth, float b
         } else {
             state[1] = tr;
         }
+        // the step stands: the buffer set the grid backward wrote speculatively (ngp_table_adam_t) becomes the current one.  A skipped
+        // step leaves the parity -- and with it the table, its moments and its fp16 shadow -- exactly as they were.
+        if (flip_parity) state[5] = state[5] != 0.0f ? 0.0f : 1.0f;
     }
     state[2] = 0.0f;
 }
-__global__ void k_update_scale(float* __restrict__ state, float growth, float backoff, float growth_interval) {
+__global__ void k_update_scale(float* __restrict__ state, float growth, float backoff, float growth_interval, int flip_parity) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    update_scale(state, growth, backoff, growth_interval);
+    update_scale(state, growth, backoff, growth_interval, flip_parity != 0);
+}
+
+// The rest of a step whose TABLE was updated inside the grid backward (ngp_table_adam_t): Adam on what is left -- the dense-level prefix of
+// the double-buffered table (contiguous here; the accumulate's round-robin bins could only have reached it 8 bytes at a stride of 1 KiB)
+// and the few small tensors (the two MLPs' weights: 18 k parameters, in place) -- and the commit, in ONE launch of a few workgroups: every
+// workgroup has read the scalars before it draws its ticket (state[6]); the last one commits behind it.  ~8 us where k_adam (60 us over
+// the table) + k_update_scale used to be.  Same arithmetic per element as k_adam.
+constexpr int OPT_SMALL_THREADS = 1024;
+__global__ __launch_bounds__(OPT_SMALL_THREADS) void k_adam_small_commit(OptTensors ts, float* __restrict__ state, float beta1, float beta2, float eps,
+                                                                        float grad_mult, float growth, float backoff, float growth_interval,
+                                                                        int flip_parity, TableAdam ta, const half_t* __restrict__ tgrad,
+                                                                        uint64_t tprefix) {
+    const AdamConsts ac = adam_consts(state, beta1, beta2, grad_mult);
+    const float bc2_sqrt = ac.bc2_sqrt;
+    const float beta1_s = beta1, beta2_s = beta2, eps_s = eps;   // (the small tensors'; the table prefix brings its own in `ta` -- the same values)
+    const uint64_t gtid = (uint64_t)blockIdx.x * OPT_SMALL_THREADS + threadIdx.x, gstride = (uint64_t)gridDim.x * OPT_SMALL_THREADS;
+    if (tprefix && !ac.skip) {   // (a skipped step writes nothing: the current set stays what it is, the other one is never read)
+        const uint32_t src = state[5] != 0.0f ? 1u : 0u, dst = src ^ 1u;
+        const float step_size = ta.lr * ac.lr_mult / ac.bc1;
+        beta1 = ta.beta1; beta2 = ta.beta2; eps = ta.eps;
+        const float4_t* __restrict__ p_in = reinterpret_cast<const float4_t*>(ta.p[src]);
+        const float4_t* __restrict__ m_in = reinterpret_cast<const float4_t*>(ta.m[src]);
+        const float4_t* __restrict__ v_in = reinterpret_cast<const float4_t*>(ta.v[src]);
+        float4_t* __restrict__ p_out = reinterpret_cast<float4_t*>(ta.p[dst]);
+        float4_t* __restrict__ m_out = reinterpret_cast<float4_t*>(ta.m[dst]);
+        float4_t* __restrict__ v_out = reinterpret_cast<float4_t*>(ta.v[dst]);
+        half4_t* __restrict__ h_out = reinterpret_cast<half4_t*>(ta.p16[dst]);
+        const half4_t* __restrict__ g4 = reinterpret_cast<const half4_t*>(tgrad);
+        // two independent 4-element groups per lane and trip (all eight loads in flight before the first dependent instruction)
+        const uint64_t n4 = tprefix / 4;
+        for (uint64_t i = gtid; i < n4; i += 2 * gstride) {
+            const uint64_t j = i + gstride;
+            const bool two = j < n4;
+            const uint64_t jj = two ? j : i;
+            const half4_t x0 = g4[i], x1 = g4[jj];
+            float4_t pm0 = m_in[i], pv0 = v_in[i], pp0 = p_in[i];
+            float4_t pm1 = m_in[jj], pv1 = v_in[jj], pp1 = p_in[jj];
+            half4_t ph0, ph1;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float g0 = (float)x0[c] * ac.inv_scale, g1 = (float)x1[c] * ac.inv_scale;
+                NGP_ADAM_EL(g0, pm0[c], pv0[c], pp0[c]);
+                ph0[c] = (half_t)pp0[c];
+                NGP_ADAM_EL(g1, pm1[c], pv1[c], pp1[c]);
+                ph1[c] = (half_t)pp1[c];
+            }
+            m_out[i] = pm0; v_out[i] = pv0; p_out[i] = pp0; h_out[i] = ph0;
+            if (two) { m_out[j] = pm1; v_out[j] = pv1; p_out[j] = pp1; h_out[j] = ph1; }
+        }
+    }
+    for (int k = 0; k < ts.count; k++) {
+        const uint64_t n = ts.n[k];
+        const float step_size = ts.lr[k] * ac.lr_mult / ac.bc1;
+        float* __restrict__ p = ts.p[k];
+        float* __restrict__ m = ts.m[k];
+        float* __restrict__ v = ts.v[k];
+        half_t* __restrict__ p16 = ts.p16[k];
+        const bool gh = (ts.g_is_half[k] & 1) != 0, keep = (ts.g_is_half[k] & 2) != 0;
+        half_t* g16 = reinterpret_cast<half_t*>(ts.g[k]);
+        float* g32 = reinterpret_cast<float*>(ts.g[k]);
+        for (uint64_t i = gtid; i < n; i += gstride) {
+            float g = gh ? (float)g16[i] : g32[i];
+            if (!keep) { if (gh) g16[i] = (half_t)0.0f; else g32[i] = 0.0f; }
+            if (ac.skip) continue;
+            g *= ac.inv_scale;
+            float nm = m[i], nv = v[i], np_ = p[i];
+            adam_element(g, nm, nv, np_, beta1_s, beta2_s, eps_s, step_size, bc2_sqrt);
+            m[i] = nm; v[i] = nv; p[i] = np_;
+            if (p16) p16[i] = (half_t)np_;
+        }
+    }
+    // every lane of this workgroup has read state[] (adam_consts, parity) before the workgroup draws its ticket; the last ticket commits
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const float old = atomicAdd(&state[6], 1.0f);
+        if (old == (float)(gridDim.x - 1u)) {
+            __threadfence();
+            update_scale(state, growth, backoff, growth_interval, flip_parity != 0);
+            state[6] = 0.0f;
+        }
+    }
 }
 
 // Data-parallel sharded update, the "skipped as a whole" verdict WITHOUT a collective of its own: a rank whose local gradient is not finite
@@ -301,7 +384,8 @@ extern "C" int ngp_optim_adam_step_ex(int count, const uint64_t* n, float* const
                                       float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
                                       float* state, float* const* ema, float ema_one_minus_decay, uint32_t phases, ngp_stream_t stream) {
     NGP_REQUIRE(state, NGP_ERR_INVALID, "optim_adam_step: NULL state");
-    NGP_REQUIRE((phases & ~7u) == 0 && phases != 0, NGP_ERR_INVALID, "optim_adam_step: phases must be a non-empty subset of CHECK|UPDATE|COMMIT");
+    NGP_REQUIRE((phases & ~15u) == 0 && (phases & 7u) != 0, NGP_ERR_INVALID, "optim_adam_step: phases must be a non-empty subset of CHECK|UPDATE|COMMIT (+FLIP)");
+    NGP_REQUIRE(!(phases & NGP_OPT_PHASE_FLIP) || (phases & NGP_OPT_PHASE_COMMIT), NGP_ERR_INVALID, "optim_adam_step: FLIP rides in the COMMIT phase");
     hipStream_t st = as_stream(stream);
     if (phases & (NGP_OPT_PHASE_CHECK | NGP_OPT_PHASE_UPDATE)) {
         NGP_REQUIRE(count >= 1 && count <= OPT_MAX_TENSORS, NGP_ERR_INVALID, "optim_adam_step: between 1 and %d tensors per call (got %d)",
@@ -340,7 +424,8 @@ extern "C" int ngp_optim_adam_step_ex(int count, const uint64_t* n, float* const
         }
     }
     if (phases & NGP_OPT_PHASE_COMMIT) {
-        hipLaunchKernelGGL(k_update_scale, dim3(1), dim3(64), 0, st, state, growth_factor, backoff_factor, growth_interval);
+        hipLaunchKernelGGL(k_update_scale, dim3(1), dim3(64), 0, st, state, growth_factor, backoff_factor, growth_interval,
+                           (phases & NGP_OPT_PHASE_FLIP) ? 1 : 0);
         return check_launch("optim_adam_step(scale)");
     }
     return NGP_OK;
@@ -353,6 +438,59 @@ extern "C" int ngp_optim_adam_step(int count, const uint64_t* n, float* const* p
     const uint32_t phases = NGP_OPT_PHASE_CHECK | NGP_OPT_PHASE_UPDATE | (growth_interval < 0.0f ? 0u : NGP_OPT_PHASE_COMMIT);
     return ngp_optim_adam_step_ex(count, n, params, exp_avg, exp_avg_sq, grads, params_fp16, grad_is_half, lr, beta1, beta2, eps, grad_mult,
                                   growth_factor, backoff_factor, growth_interval, state, nullptr, 0.0f, phases, stream);
+}
+
+extern "C" int ngp_optim_adam_small_commit(int count, const uint64_t* n, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                                           void* const* grads, void* const* params_fp16, const int* grad_is_half, const float* lr, float beta1,
+                                           float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor,
+                                           float growth_interval, float* state, int flip_parity, const ngp_table_adam_t* table,
+                                           const void* table_grad_fp16, uint64_t table_prefix_params, ngp_stream_t stream) {
+    NGP_REQUIRE(state, NGP_ERR_INVALID, "optim_adam_small_commit: NULL state");
+    NGP_REQUIRE(count >= 0 && count <= OPT_MAX_TENSORS, NGP_ERR_INVALID, "optim_adam_small_commit: at most %d tensors per call (got %d)", OPT_MAX_TENSORS,
+                count);
+    NGP_REQUIRE(count == 0 || (n && params && exp_avg && exp_avg_sq && grads && grad_is_half && lr), NGP_ERR_INVALID,
+                "optim_adam_small_commit: NULL argument");
+    OptTensors ts = {};
+    ts.count = count;
+    uint64_t total = 0;
+    for (int k = 0; k < count; k++) {
+        NGP_REQUIRE(grads[k] && params[k] && exp_avg[k] && exp_avg_sq[k], NGP_ERR_INVALID, "optim_adam_small_commit: NULL tensor %d", k);
+        ts.n[k] = n[k];
+        ts.p[k] = params[k];
+        ts.m[k] = exp_avg[k];
+        ts.v[k] = exp_avg_sq[k];
+        ts.g[k] = grads[k];
+        ts.p16[k] = params_fp16 ? reinterpret_cast<half_t*>(params_fp16[k]) : nullptr;
+        ts.g_is_half[k] = grad_is_half[k];
+        ts.lr[k] = lr[k];
+        total += n[k];
+    }
+    TableAdam ta = {};
+    if (table_prefix_params) {
+        NGP_REQUIRE(table && table_grad_fp16 && table->state == state, NGP_ERR_INVALID,
+                    "optim_adam_small_commit: a table prefix needs the table's buffer sets (on the same state) and its stored fp16 gradient");
+        NGP_REQUIRE((table_prefix_params & 3u) == 0, NGP_ERR_INVALID, "optim_adam_small_commit: table_prefix_params must be a multiple of 4");
+        for (int k = 0; k < 2; k++) {
+            NGP_REQUIRE(table->param[k] && table->exp_avg[k] && table->exp_avg_sq[k] && table->param_fp16[k], NGP_ERR_INVALID,
+                        "optim_adam_small_commit: NULL buffer in table set %d", k);
+            ta.p[k] = table->param[k]; ta.m[k] = table->exp_avg[k]; ta.v[k] = table->exp_avg_sq[k];
+            ta.p16[k] = reinterpret_cast<_Float16*>(table->param_fp16[k]);
+        }
+        ta.state = state;
+        ta.lr = table->lr; ta.beta1 = table->beta1; ta.beta2 = table->beta2; ta.eps = table->eps;
+        total += table_prefix_params;
+    }
+    // a few workgroups: meant for what is left when the table is updated elsewhere (the 12 M-entry table itself belongs in ngp_optim_adam_step_ex)
+    NGP_REQUIRE(total <= (1u << 22), NGP_ERR_INVALID, "optim_adam_small_commit: %llu parameters -- this entry serves small tensors (<= 4 M); use "
+                "ngp_optim_adam_step_ex", (unsigned long long)total);
+    // (every workgroup ends with one atomic on the ticket word: ~100 of them keep that queue short)
+    uint32_t blocks = (uint32_t)cdiv64(total, (uint64_t)OPT_SMALL_THREADS * 8);
+    static const uint32_t max_blocks = getenv("NGP_SMALL_COMMIT_BLOCKS") ? (uint32_t)atoi(getenv("NGP_SMALL_COMMIT_BLOCKS")) : 128u;   // experiment knob
+    blocks = blocks < 1u ? 1u : (blocks > max_blocks ? max_blocks : blocks);
+    hipLaunchKernelGGL(k_adam_small_commit, dim3(blocks), dim3(OPT_SMALL_THREADS), 0, as_stream(stream), ts, state, beta1, beta2, eps, grad_mult,
+                       growth_factor, backoff_factor, growth_interval, flip_parity, ta, reinterpret_cast<const half_t*>(table_grad_fp16),
+                       table_prefix_params);
+    return check_launch("optim_adam_small_commit");
 }
 
 extern "C" int ngp_optim_poison_shards(void* flat_grad_fp16, uint32_t shards, uint64_t payload, const float* state, ngp_stream_t stream) {

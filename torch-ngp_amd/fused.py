@@ -34,6 +34,19 @@ def _check(rc):
     capi.check(rc)
 
 
+def _grid_forward(x, emb16, offsets, enc, M, L, S, H, gridtype, align, interp, bound, costs, st):
+    """the encoder launch of the fused paths.  A table that optim.NGPAdam keeps in two buffer sets (enable_table_fusion: the Adam sweep rides
+    in the grid backward and writes the set that is NOT current) carries its second fp16 copy and the device-side parity word on the
+    shadow tensor (`_ngp_sel`): the kernel then picks the current copy itself (ngp_grid_encode_forward_sel) -- valid under graph replay."""
+    sel = getattr(emb16, '_ngp_sel', None)
+    if sel is not None:
+        _check(capi.lib.ngp_grid_encode_forward_sel(x.data_ptr(), emb16.data_ptr(), sel[0].data_ptr(), sel[1].data_ptr(), offsets.data_ptr(),
+                                                    enc.data_ptr(), M, 3, 2, L, S, H, gridtype, align, interp, capi.NGP_F16, float(bound), costs, st))
+    else:
+        _check(capi.lib.ngp_grid_encode_forward_sched(x.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
+                                                      None, gridtype, align, interp, capi.NGP_F16, float(bound), costs, st))
+
+
 class _fused_ngp(Function):
     @staticmethod
     def forward(ctx, x, d, embeddings, w_sigma, w_color, offsets, cfg, bufs, density_scale=1.0):
@@ -55,8 +68,7 @@ class _fused_ngp(Function):
         # step apart, as in training -- the same model (half / twice / four times that spacing: the same frame time); for points without any
         # order it still says "fine hashed levels cost more than dense ones".  800x800 frame: 14.4 -> 13.6 ms / 1.42 -> 1.35 ms, same box.
         costs = capi.ray_level_costs(L, S, H, 3.0 ** 0.5 / (1024.0 * max(float(bound), 1e-6))) if USE_BALANCED_FORWARD else None
-        _check(capi.lib.ngp_grid_encode_forward_sched(x.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
-                                                    None, gridtype, align, interp, capi.NGP_F16, float(bound), costs, st))
+        _grid_forward(x, emb16, offsets, enc, M, L, S, H, gridtype, align, interp, bound, costs, st)
         h16 = torch.empty(M, 16, **half)
         color_in = torch.empty(M, 32, **half)
         out16 = torch.empty(M, 16, **half)
@@ -132,19 +144,28 @@ def _network_forward(enc, dirs, d_valid, ws16, wc16, nl_sigma, nl_color, density
     _check(capi.lib.ngp_pipeline_rgb_forward(out16.data_ptr(), rgb.data_ptr(), M, st))
 
 
-def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf=None, slabs=None, overwrite=False):
+def _grid_backward(g_enc, x, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf=None, slabs=None, overwrite=False,
+                   table_adam=None):
     """hash-grid scatter of the level-major fp16 gradient; large batches take the binned atomic-free path (needs scratch memory).
     found_inf: optional device float that the kernels set when a table gradient comes out non-finite (the optimizer's sweep, done here).
     slabs: optional capi.SlabSets -- the deferred slab reduction of the two MLP backwards rides in this call's last launch.
-    overwrite: g_emb receives the gradient instead of having it added (the optimizer then keeps the buffer: optim.NGPAdam)"""
+    overwrite: g_emb receives the gradient instead of having it added (the optimizer then keeps the buffer: optim.NGPAdam)
+    table_adam: capi.TableAdam (optim.NGPAdam.table_adam()) -- the accumulate's flush applies Adam to the table, speculatively, into the
+    buffer set that is not current; the table gradient itself is then not stored (g_emb is not touched)"""
     arr, ws, nbytes = capi.grid_backward_workspace(offsets, M, 3, 2, L, S, H, gridtype, align, capi.NGP_F16)
     if overwrite:
         slabs = slabs if slabs is not None else capi.SlabSets()
         slabs.overwrite_table = 1
+    if table_adam is not None:   # (the C entry copies the struct before it returns)
+        if not overwrite:
+            raise RuntimeError('fused: table_adam needs overwrite_table')
+        slabs.table_adam = ctypes.cast(ctypes.pointer(table_adam), ctypes.c_void_p)
+        # (g_emb still receives the gradient of the dense levels at the start of the table: the accumulate's round-robin bins leave their
+        # Adam sweep to the optimizer's closing launch, optim.NGPAdam.step; behind that prefix nothing is stored)
     if found_inf is not None and arr is None:
         raise RuntimeError('fused: the in-kernel non-finite sweep needs the host copy of the encoder offsets (call iteration_checks_gradients '
                            'outside stream capture first)')
-    _check(capi.lib.ngp_grid_encode_backward_checked_slabs(g_enc.data_ptr(), x.data_ptr(), None, offsets.data_ptr(), g_emb.data_ptr(), M, 3, 2, L, S,
+    _check(capi.lib.ngp_grid_encode_backward_checked_slabs(g_enc.data_ptr(), x.data_ptr(), None, offsets.data_ptr(), capi.ptr(g_emb), M, 3, 2, L, S,
                                                             H, None, None, gridtype, align, interp, capi.NGP_F16, float(bound),
                                                             None if arr is None else ctypes.cast(arr, ctypes.c_void_p), capi.ptr(ws), nbytes,
                                                             capi.ptr(found_inf), None if slabs is None else ctypes.cast(ctypes.pointer(slabs), ctypes.c_void_p),
@@ -268,9 +289,8 @@ def _render_train_network(marched, emb16, ws16, wc16, bg, offsets, cfg, rcfg, co
     half = dict(device=dev, dtype=torch.half)
     # ---- network ----
     enc = torch.empty(L, M, 2, **half)
-    _check(capi.lib.ngp_grid_encode_forward_sched(xyzs.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,
-                                                None, gridtype, align, interp, capi.NGP_F16, float(bound),
-                                                   capi.ray_level_costs(L, S, H, 3.0 ** 0.5 / (max_steps * max(float(bound), 1e-6))) if USE_BALANCED_FORWARD else None, st))
+    _grid_forward(xyzs, emb16, offsets, enc, M, L, S, H, gridtype, align, interp, bound,
+                  capi.ray_level_costs(L, S, H, 3.0 ** 0.5 / (max_steps * max(float(bound), 1e-6))) if USE_BALANCED_FORWARD else None, st)
     h16 = torch.empty(M, 16, **half)
     color_in = torch.empty(M, 32, **half)
     out16 = torch.empty(M, 16, **half)
@@ -321,7 +341,7 @@ def _render_train_backward(saved, cfg, rcfg, grad_image, grad_ws, g_emb, g_ws, g
     _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf, None, overwrite)
 
 
-def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf=None, loss_job=None, overwrite=False):
+def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, found_inf=None, loss_job=None, overwrite=False, table_adam=None):
     """colour MLP -> exp / feature shuffle -> sigma MLP -> grid scatter, from g_sigma [M] fp32 and g_out16 [M,16] fp16 (CONSUMED: reused as
     the sigma net's output gradient).  loss_job = (ray_err [N], loss [1]): the loss sum the compositor left to a later launch -- only
     accepted where `_carries_reductions` holds (it rides with the slab reduction in the grid backward's last launch)"""
@@ -351,7 +371,7 @@ def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, fou
             err, loss = loss_job if loss_job is not None else (None, None)
             slabs = capi.SlabSets(scratch_c.data_ptr(), n_c, g_wc.numel(), g_wc.data_ptr(), scratch_s.data_ptr(), n_s, g_ws.numel(), g_ws.data_ptr(),
                                   capi.ptr(err), 0 if err is None else err.numel(), capi.ptr(loss))
-            _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf, slabs, overwrite)
+            _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf, slabs, overwrite, table_adam)
             return
         if loss_job is not None:
             raise RuntimeError('fused: a deferred loss sum needs the carried reductions (_carries_reductions)')
@@ -372,7 +392,7 @@ def _network_backward(saved, cfg, rcfg, g_sigma, g_out16, g_emb, g_ws, g_wc, fou
         _check(capi.lib.ngp_ffmlp_backward_ex(g_h16.data_ptr(), enc.data_ptr(), ws16.data_ptr(), fb_s.data_ptr(), M, 32, 16, 64, nl_sigma,
                                               0, 6, 1, scratch[:nl_sigma].data_ptr(), g_enc.data_ptr(), g_ws.data_ptr(),
                                               _PLANAR_IN | _PLANAR_DX, st))
-    _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf, None, overwrite)
+    _grid_backward(g_enc, xyzs, offsets, g_emb, M, L, S, H, gridtype, align, interp, bound, st, found_inf, None, overwrite, table_adam)
 
 
 class _fused_render_train(Function):
@@ -424,7 +444,7 @@ def _render_cfg(model, capacity, bg_color, perturb, dt_gamma, max_steps, T_thres
 
 @torch.no_grad()
 def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity, loss_scale, bg_color=1, perturb=False, dt_gamma=0,
-                          max_steps=1024, T_thresh=1e-4, noise_seed=None, found_inf=None, overwrite_table=False):
+                          max_steps=1024, T_thresh=1e-4, noise_seed=None, found_inf=None, overwrite_table=False, table_adam=None):
     """One training iteration's forward + MSE loss + backward WITHOUT autograd: the launches of `_fused_render_train` forward, the
     Trainer's loss (nerf/utils.py:516,557) and its scaled gradient in one kernel, then the backward launches, depositing the gradients
     into the optimizer's fp16 buffers (optim.NGPAdam with deposit=True must manage the three parameter tensors).  28 launches instead
@@ -436,6 +456,10 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     the next optimizer step keeps the buffer instead of zeroing it (optim.NGPAdam reads the flag this call leaves on the parameter) --
     for a loop that steps the optimizer after every iteration (graph.GraphedTrainStep); gradients do not accumulate across calls in
     this mode, and producers that add (the autograd paths) find the buffer zeroed first (`_optimizer_buffers`).
+    table_adam: an optim.NGPAdam on which `enable_table_fusion(model.encoder.embeddings)` was called -- the grid backward's slice accumulate
+    applies Adam to the table in its flush (speculative double buffer, include/ngp_hip.h ngp_table_adam_t) and the optimizer's next
+    `step(gradients_checked=True)` is one small launch (Adam on the MLP weights, commit, parity flip).  Needs overwrite_table, found_inf
+    and a batch of >= 16 384 samples (else the C entry refuses before launching anything).
     -> (loss [1] fp32, image [N,3], depth [N], weights_sum [N]); same arithmetic as model.render + mse_loss + scaled backward
     (tests/test_gpu_graph.py)."""
     cfg = network_cfg(model.encoder, model.sigma_net, model.color_net, model.bound, True)
@@ -449,10 +473,34 @@ def fused_train_iteration(model, rays_o, rays_d, target, box, counter, capacity,
     if target.shape[0] != rays_o.shape[0] or target.dtype != torch.float32:
         raise RuntimeError('fused_train_iteration: target must be [N,3] float32')
     marched = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed)
-    out = _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf, overwrite_table)
+    ta = _table_adam_of(table_adam, model)
+    out = _train_iteration_rest(marched, bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf, overwrite_table, ta)
     if overwrite_table:
         model.encoder.embeddings._ngp_deposit_overwritten = True   # read (and reset) by the optimizer's next step: it keeps the buffer
+    if ta is not None:
+        _mark_table_adam(model, cfg, capacity)                     # ... and does not sweep the table: this iteration's backward did
     return out
+
+
+def _mark_table_adam(model, cfg, M):
+    """tell the optimizer's next step() that the grid backward swept the table -- except the dense-level prefix (entries), which it does"""
+    (bound, L, S, H, gridtype, align, interp, nl_sigma, nl_color, _) = cfg
+    emb = model.encoder.embeddings
+    arr = capi.host_offsets(model.encoder.offsets)
+    prefix = int(capi.lib.ngp_grid_table_adam_prefix(ctypes.cast(arr, ctypes.c_void_p), int(M), 3, 2, L, S, H, gridtype, align, capi.NGP_F16))
+    if prefix == 0xffffffff:
+        raise RuntimeError('fused: table_adam: this batch / table shape cannot carry the sweep (ngp_grid_table_adam_prefix)')
+    emb._ngp_table_adam_prefix = prefix
+    emb._ngp_table_adam_done = True
+
+
+def _table_adam_of(optimizer, model):
+    """ctypes ngp_table_adam_t of an optimizer whose table fusion is enabled for THIS model's hash table (None: no fusion)"""
+    if optimizer is None:
+        return None
+    if getattr(optimizer, 'fused_table', None) is not model.encoder.embeddings:
+        raise RuntimeError('fused: table_adam: call optimizer.enable_table_fusion(model.encoder.embeddings) first')
+    return optimizer.table_adam()
 
 
 USE_BALANCED_FORWARD = True  # encoder launch of the training step: per-XCD work lists balanced by per-level cost of ray-ordered samples (False: whole levels)
@@ -490,7 +538,9 @@ def iteration_checks_gradients(model):
     return bool(USE_FUSED_CHECK and USE_FUSED_MID and all(n in (2, 3) for n in nl) and capi.host_offsets(model.encoder.offsets) is not None)
 
 
-def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg, rcfg, found_inf=None, overwrite=False):
+def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg, rcfg, found_inf=None, overwrite=False, table_adam=None):
+    if table_adam is not None and not (USE_FUSED_COMPOSITE and found_inf is not None and overwrite):
+        raise RuntimeError('fused: table_adam needs the fused compositor, the in-kernel non-finite sweep (found_inf) and overwrite_table')
     if not USE_FUSED_COMPOSITE:
         image, depth, weights_sum, saved = _render_train_network(marched, bufs[0], bufs[1], bufs[2], bg_t, offsets, cfg, rcfg)
         loss = torch.empty(1, device=image.device, dtype=torch.float32)
@@ -519,13 +569,13 @@ def _train_iteration_rest(marched, bufs, bg_t, offsets, target, loss_scale, cfg,
                                                       ray_err.data_ptr(), g_sigma.data_ptr(), g_out16.data_ptr(), march_ws.data_ptr(),
                                                       march_ws.numel() * march_ws.element_size(), capi.stream()))
     _network_backward(saved, cfg, rcfg, g_sigma, g_out16, bufs[3], bufs[4].view(-1), bufs[5].view(-1), found_inf,
-                      loss_job=(ray_err, loss) if defer else None, overwrite=overwrite)
+                      loss_job=(ray_err, loss) if defer else None, overwrite=overwrite, table_adam=table_adam)
     return loss, image, depth, weights_sum
 
 
 @torch.no_grad()
 def fused_train_iteration_split(model, rays_o, rays_d, target, box, counter, capacity, loss_scale, bg_color=1, perturb=False, dt_gamma=0,
-                                max_steps=1024, T_thresh=1e-4, noise_seed=None, found_inf=None, overwrite_table=False):
+                                max_steps=1024, T_thresh=1e-4, noise_seed=None, found_inf=None, overwrite_table=False, table_adam=None):
     """`fused_train_iteration` in two halves for data-parallel training: returns (march, rest) callables -- `march()` issues the
     parameter-independent launches (near/far, ray marching), `rest()` everything that reads the weights (encode, MLPs, composite, loss,
     backward).  graph.GraphedTrainStep captures them into separate HIP graphs so that the all-gather of the updated fp16 shadow weights
@@ -544,9 +594,12 @@ def fused_train_iteration_split(model, rays_o, rays_d, target, box, counter, cap
         box_['m'] = _render_train_march(rays_o, rays_d, model.density_bitfield, box, counter, cfg, rcfg, noise_seed, into=box_.get('m'))
 
     def rest():
-        out = _train_iteration_rest(box_['m'], bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf, overwrite_table)
+        ta = _table_adam_of(table_adam, model)
+        out = _train_iteration_rest(box_['m'], bufs, bg_t, model.encoder.offsets, target, loss_scale, cfg, rcfg, found_inf, overwrite_table, ta)
         if overwrite_table:
             model.encoder.embeddings._ngp_deposit_overwritten = True
+        if ta is not None:
+            _mark_table_adam(model, cfg, capacity)
         return out
     return march, rest
 
@@ -579,9 +632,8 @@ def fused_density(x, encoder, sigma_net, bound):
     enc = torch.empty(L, M, 2, device=dev, dtype=torch.half)
     S, H = float(np.log2(encoder.per_level_scale)), int(encoder.base_resolution)
     costs = None if density_point_spacing is None else capi.ray_level_costs(L, S, H, float(density_point_spacing))
-    _check(capi.lib.ngp_grid_encode_forward_sched(x.contiguous().data_ptr(), emb16.data_ptr(), encoder.offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L,
-                                                S, H, None, int(encoder.gridtype_id), int(bool(encoder.align_corners)), int(encoder.interp_id),
-                                                capi.NGP_F16, float(bound), costs, st))
+    _grid_forward(x.contiguous(), emb16, encoder.offsets, enc, M, L, S, H, int(encoder.gridtype_id), int(bool(encoder.align_corners)),
+                  int(encoder.interp_id), bound, costs, st)
     h16 = torch.empty(M, 16, device=dev, dtype=torch.half)
     _check(capi.lib.ngp_ffmlp_inference_ex(enc.data_ptr(), w16.data_ptr(), M, 32, 16, 64, int(sigma_net.num_layers), 0, 6, None, h16.data_ptr(),
                                            _PLANAR_IN, st))
@@ -600,6 +652,9 @@ class pinned_half_weights:
     def __enter__(self):
         if all(p is not None and p.is_cuda for p in self.params) and not torch.is_grad_enabled():
             for p in self.params:
+                fn = getattr(p, '_ngp_materialize', None)
+                if fn is not None:
+                    fn()   # a table with two buffer sets (optim.NGPAdam.enable_table_fusion): the Parameter becomes the current one
                 # persistent buffers (same device pointers from frame to frame: the render loop's HIP graphs hold them), refreshed by
                 # one cast kernel per frame
                 buf = getattr(p, '_ngp_fp16_pinbuf', None)

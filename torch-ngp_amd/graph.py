@@ -66,7 +66,8 @@ def mse_loss(out, target):
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, scaler, n_rays, render_kwargs, loss_fn=mse_loss, averager=None, capacity_quantum=8192,
-                 update_interval=16, after_update=None, autocast_dtype=torch.float16, direct=True, capacity_slack=2, lookahead=False):
+                 update_interval=16, after_update=None, autocast_dtype=torch.float16, direct=True, capacity_slack=2, lookahead=False,
+                 fused_table_adam=False):
         self.model, self.optimizer, self.scaler = model, optimizer, scaler
         self.loss_fn, self.averager = loss_fn, averager
         if averager is not None and averager is not optimizer and getattr(optimizer, 'flat_grad16', None) is not None:
@@ -115,6 +116,11 @@ class GraphedTrainStep:
         # issuing them eagerly between two replays.  Off by default: measurable here only over a 1-rank group (bench.py ddp_overhead_1rank)
         self.graph_collectives = os.environ.get('NGP_GRAPH_COLLECTIVES', '0') == '1'
         self.la_apply = None
+        # single GPU, autograd-free iteration, optim.NGPAdam: the hash table's Adam sweep rides in the grid backward's slice accumulate
+        # (speculative double buffer, parity flipped by the commit: optim.NGPAdam.enable_table_fusion) -- k_adam over 12 M parameters and the
+        # scale update become one small launch.  The torch Parameter is then one of two buffer sets: read it through `sync_params()`.
+        self.fused_table_adam = bool(fused_table_adam) and self.direct and averager is None and hasattr(optimizer, 'enable_table_fusion')
+        self.table_fused = False      # what the captured graphs do (decided at capture time: needs the producers' non-finite sweep)
         if self.lookahead:
             self.la_rays_o = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
             self.la_rays_d = [torch.zeros(n_rays, 3, device=dev) for _ in range(2)]
@@ -196,6 +202,16 @@ class GraphedTrainStep:
                 self._capture_update(bool(full))
         return self.captures - before
 
+    def sync_params(self):
+        """make the torch Parameters (and the optimizer's `state`) current after fused-table steps (one host read; optim.NGPAdam.materialize)"""
+        fn = getattr(self.optimizer, 'materialize', None)
+        if fn is not None:
+            fn()
+
+    def _table_adam(self):
+        """the optimizer to hand to the fused iteration as `table_adam` (None: the separate Adam sweep)"""
+        return self.optimizer if self.table_fused else None
+
     def _overwrites_table(self):
         """single-GPU direct iteration: the grid backward WRITES the table gradient and the optimizer keeps the buffer (no zeroing, no
         read of the old value: 49 MB per step).  Not with an averager / sharded exchange (they own the flat buffer's life cycle)."""
@@ -248,7 +264,8 @@ class GraphedTrainStep:
                                                   kw.get('perturb', False), kw.get('dt_gamma', 0), kw.get('max_steps', 1024),
                                                   kw.get('T_thresh', 1e-4), noise_seed=self.optimizer.scalars[3:4],
                                                   found_inf=self.optimizer.scalars[2:3] if self.producers_check else None,
-                                                  overwrite_table=self._overwrites_table())
+                                                  overwrite_table=self._overwrites_table(),
+                                                  table_adam=self._table_adam() if self.producers_check else None)
             self.used_direct = True
             return loss[0]
         self.used_direct = False
@@ -296,6 +313,13 @@ class GraphedTrainStep:
         if self._direct_ok():
             from fused import iteration_checks_gradients
             self._checked_ok = iteration_checks_gradients(self.model)
+        self.sync_params()   # (outside the capture: a re-capture starts from buffer set A)
+        self.table_fused = False
+        if self.fused_table_adam and self._checked_ok and self._overwrites_table() and self.captured_capacity >= 16384:
+            emb = getattr(getattr(self.model, 'encoder', None), 'embeddings', None)
+            if emb is not None and getattr(emb, '_ngp_fp16', None) is not None:
+                self.optimizer.enable_table_fusion(emb)
+                self.table_fused = True
         self.la = None
         self.la_ready = [None, None]
         if self.lookahead and self._direct_ok():
@@ -366,7 +390,7 @@ class GraphedTrainStep:
                                                       kw.get('perturb', False), kw.get('dt_gamma', 0), kw.get('max_steps', 1024),
                                                       kw.get('T_thresh', 1e-4), noise_seed=self.la_seed[p:p + 1],
                                                       found_inf=opt.scalars[2:3] if self._checked_ok else None,
-                                                      overwrite_table=self._overwrites_table())
+                                                      overwrite_table=self._overwrites_table(), table_adam=None if sharded else self._table_adam())
             gm, gr = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with _capture_into(gm, pool=pool_march):
                 march()

@@ -128,6 +128,10 @@ class GridEncoder(nn.Module):
 
     def forward(self, inputs, bound=1):
         # inputs [..., input_dim] in [-bound, bound] -> [..., num_levels * level_dim]
+        fn = getattr(self.embeddings, '_ngp_materialize', None)
+        if fn is not None:
+            fn()   # optim.NGPAdam keeps this table in two buffer sets (enable_table_fusion): the Parameter becomes the current one (a no-op
+                   # unless fused-table steps ran since the last call)
         unit = (inputs + bound) / (2 * bound)
         lead = list(unit.shape[:-1])
         flat = unit.view(-1, self.input_dim)

@@ -118,6 +118,81 @@ class NGPAdam:
         self._keep = []   # ctypes argument arrays of the launches of the current step (kept alive until the next step / building block)
         self._comm_stream = None
         self._shadows_ready = None
+        self.fused_table = None       # the parameter whose Adam sweep rides in the grid backward (enable_table_fusion)
+        self._table_alt = None        # its second buffer set {'p', 'm', 'v', 'p16'}
+        self._maybe_flipped = False   # a fused step was issued since the last materialize(): buffer set B may be the current one
+
+    # -- the table's Adam sweep inside the grid backward (speculative double buffer; include/ngp_hip.h: ngp_table_adam_t) ----------
+    def enable_table_fusion(self, param):
+        """`param` (the hash table: a deposit-managed parameter of this optimizer) gets a SECOND set of master weights, moments and fp16
+        shadow.  A training iteration that passes `table_adam()` to the grid backward (fused.fused_train_iteration(table_adam=...)) has the
+        slice accumulate apply Adam to the table in its flush -- reading the set the device-side parity word `scalars[5]` names, writing the
+        other -- and `step()` then runs one small launch (Adam on the remaining tensors, loss-scale commit, parity flip when the step
+        stands).  GradScaler's skip-the-whole-step rule holds exactly: a skipped step never flips, the current set is never written.
+        Outside a stretch of fused steps set A (the torch Parameter, `state[p]`) is the current one: `materialize()` restores that.
+        Single-process, non-sharded optimizers only.  Idempotent; +14 B per table parameter of device memory."""
+        if self.shard or self.world_size > 1:
+            raise RuntimeError('NGPAdam.enable_table_fusion: the sharded / data-parallel update exchanges the gradient first (not available)')
+        st = self.state.get(param)
+        if st is None or 'fp16' not in st or 'exp_avg' not in st:
+            raise RuntimeError('NGPAdam.enable_table_fusion: the parameter is not a deposit-managed parameter of this optimizer')
+        if self.fused_table is param:
+            return
+        if self.fused_table is not None:
+            raise RuntimeError('NGPAdam.enable_table_fusion: one table per optimizer')
+        self._table_alt = {'p': torch.empty_like(param.data), 'm': torch.empty_like(st['exp_avg']), 'v': torch.empty_like(st['exp_avg_sq']),
+                           'p16': torch.empty_like(st['fp16'])}
+        for t in self._table_alt.values():
+            t.zero_()
+        self.fused_table = param
+        self.scalars[5:6].zero_()
+        # readers of the fp16 table (fused.py: ngp_grid_encode_forward_sel) find the second copy and the parity word on the shadow tensor itself
+        st['fp16']._ngp_sel = (self._table_alt['p16'], self.scalars[5:6])
+        param._ngp_materialize = self.materialize
+
+    def table_adam(self):
+        """ctypes ngp_table_adam_t for the grid backward of this step's iteration (None when no table is fused); marks the step as fused"""
+        p = self.fused_table
+        if p is None:
+            return None
+        st, alt = self.state[p], self._table_alt
+        lr = [g['lr'] for g in self.param_groups if any(q is p for q in g['params'])][0]
+        ta = capi.TableAdam()
+        ta.param[0], ta.param[1] = p.data.data_ptr(), alt['p'].data_ptr()
+        ta.exp_avg[0], ta.exp_avg[1] = st['exp_avg'].data_ptr(), alt['m'].data_ptr()
+        ta.exp_avg_sq[0], ta.exp_avg_sq[1] = st['exp_avg_sq'].data_ptr(), alt['v'].data_ptr()
+        ta.param_fp16[0], ta.param_fp16[1] = st['fp16'].data_ptr(), alt['p16'].data_ptr()
+        ta.state = self.scalars.data_ptr()
+        ta.lr, ta.beta1, ta.beta2, ta.eps = float(lr), self.betas[0], self.betas[1], self.eps
+        self._maybe_flipped = True
+        return ta
+
+    def _table_struct(self):
+        """the same struct without marking a step (the closing launch of a fused step needs it for the table's dense-level prefix)"""
+        flag = self._maybe_flipped
+        ta = self.table_adam()
+        self._maybe_flipped = flag
+        return ta
+
+    @torch.no_grad()
+    def materialize(self):
+        """after a stretch of fused-table steps: make buffer set A (the torch Parameter, its moments in `state`, its fp16 shadow) the
+        current one again -- one host read of the parity word and, when it says B, four device copies.  Called by everything that
+        reads or writes the parameter outside the fused iteration (unfused step(), state_dict(), shadow syncs, checkpoints, the fp16 pin
+        of an inference render).  Not capturable (it reads the device); a no-op when no fused step ran since the last call."""
+        if not self._maybe_flipped or self.fused_table is None:
+            return
+        if self.scalars.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('NGPAdam.materialize: called inside a stream capture (it reads the parity word on the host)')
+        p = self.fused_table
+        st, alt = self.state[p], self._table_alt
+        if float(self.scalars[5].item()) != 0.0:
+            p.data.copy_(alt['p'])        # (.data: no autograd version bump -- the shadow is copied right here)
+            st['exp_avg'].copy_(alt['m'])
+            st['exp_avg_sq'].copy_(alt['v'])
+            st['fp16'].copy_(alt['p16'])
+            self.scalars[5:6].zero_()
+        self._maybe_flipped = False
 
     # -- GradScaler-like surface -------------------------------------------------------------------
     def scale(self, loss):
@@ -159,6 +234,7 @@ class NGPAdam:
         self._sync_shadows()
 
     def _sync_shadows(self, assume_complete=False):
+        self.materialize()
         self.wait_shadows()
         if self.shard and not assume_complete:
             self.gather_master()
@@ -376,6 +452,28 @@ class NGPAdam:
                                                    self.betas[1], self.eps, 1.0, self.growth_factor, self.backoff_factor, self.growth_interval,
                                                    self.scalars.data_ptr(), cast[8], float(omd), phases, capi.stream()))
 
+    def _launch_small_commit(self, entries, flip, table_prefix=0):
+        k = len(entries)
+        vp = ctypes.c_void_p
+
+        def ptrs(i):
+            return (vp * k)(*[(e[i].data_ptr() if e[i] is not None else None) for e in entries])
+        if k:
+            n = (ctypes.c_uint64 * k)(*[int(e[0]) for e in entries])
+            arrs = (n, ptrs(1), ptrs(2), ptrs(3), ptrs(4), ptrs(5), (ctypes.c_int * k)(*[int(e[6]) for e in entries]),
+                    (ctypes.c_float * k)(*[float(e[7]) for e in entries]))
+            self._keep.append((arrs, entries))
+            cast = [ctypes.cast(a, vp) for a in arrs]
+        else:
+            cast = [None] * 8
+        ta = self._table_struct() if table_prefix else None   # (copied by the C entry before it returns)
+        capi.check(capi.lib.ngp_optim_adam_small_commit(k, cast[0], cast[1], cast[2], cast[3], cast[4], cast[5], cast[6], cast[7], self.betas[0],
+                                                        self.betas[1], self.eps, 1.0, self.growth_factor, self.backoff_factor, self.growth_interval,
+                                                        self.scalars.data_ptr(), 1 if flip else 0,
+                                                        None if ta is None else ctypes.cast(ctypes.pointer(ta), ctypes.c_void_p),
+                                                        self.state[self.fused_table]['grad16'].data_ptr() if table_prefix else None,
+                                                        int(table_prefix), capi.stream()))
+
     @torch.no_grad()
     def step(self, update_ema=None, gradients_checked=False):
         """one optimizer + loss-scaling step.  `update_ema`: an `NGPEma` whose moving average is advanced inside the same sweep (the
@@ -400,6 +498,23 @@ class NGPAdam:
             self.gather_shadows()
             self.wait_shadows()
             return
+        table_done = self.fused_table is not None and getattr(self.fused_table, '_ngp_table_adam_done', False)
+        if table_done:
+            # this step's grid backward already applied Adam to the table (speculatively, into the other buffer set): Adam on the small
+            # tensors that are left + commit + parity flip in ONE single-workgroup launch
+            self.fused_table._ngp_table_adam_done = False
+            if update_ema is not None or not gradients_checked:
+                raise RuntimeError('NGPAdam.step: a fused-table step needs gradients_checked=True (the producers raise found_inf) and no fold-in EMA')
+            self.clean_deposits([p for p in self.flat_params if p is not self.fused_table and not getattr(p, '_ngp_deposit_overwritten', False)])
+            entries = [(p.numel(), p, st['exp_avg'], st['exp_avg_sq'], grad, st.get('fp16'), is_half, lr, None)
+                       for p, st, grad, is_half, lr in self._entries() if p is not self.fused_table]
+            if len(entries) > _MAX or not all(e[6] & 1 for e in entries):
+                raise RuntimeError('NGPAdam.step: a fused-table step serves at most 8 remaining tensors, all with deposited fp16 gradients')
+            # the dense levels at the start of the table (left out by the accumulate's flush) are swept here, contiguously
+            prefix = int(getattr(self.fused_table, '_ngp_table_adam_prefix', 0)) * int(self.fused_table.shape[1])
+            self._launch_small_commit(entries, flip=True, table_prefix=prefix)
+            return
+        self.materialize()   # (a no-op unless fused-table steps ran before this unfused one)
         # a deposit buffer that an overwriting producer left behind and nobody has overwritten since holds an OLD gradient
         self.clean_deposits([p for p in self.flat_params if not getattr(p, '_ngp_deposit_overwritten', False)])
         omd = update_ema.begin_update() if update_ema is not None else 0.0
@@ -422,6 +537,7 @@ class NGPAdam:
         """resume from a reference checkpoint: `torch.optim.Adam.state_dict()` (per-parameter exp_avg / exp_avg_sq / step, in
         param_groups order) and, optionally, `GradScaler.state_dict()` ('scale', '_growth_tracker')"""
         flat = [p for g in self.param_groups for p in g['params']]
+        self.materialize()
         ids = [i for g in adam_sd['param_groups'] for i in g['params']]
         if len(ids) != len(flat):
             raise RuntimeError(f'NGPAdam: checkpoint has {len(ids)} parameters, the optimizer {len(flat)}')
@@ -487,6 +603,7 @@ class NGPAdam:
     def state_dict(self):
         """full (unsharded) optimizer state; in sharded mode a collective call (every rank assembles the complete moments)"""
         flat = [p for g in self.param_groups for p in g['params']]
+        self.materialize()
         if self.shard:
             self.gather_master()
         mv = [self._get_moments(p) for p in flat]
@@ -495,7 +612,9 @@ class NGPAdam:
 
     def load_state_dict(self, sd):
         flat = [p for g in self.param_groups for p in g['params']]
+        self.materialize()
         self.scalars.copy_(sd['scalars'])
+        self.scalars[5:6].zero_()   # (the parity of a fused table is not part of a checkpoint: set A is what gets loaded)
         for p, m, v in zip(flat, sd['exp_avg'], sd['exp_avg_sq']):
             self._set_moments(p, m, v)
         for g, lr in zip(self.param_groups, sd['lr']):

@@ -789,8 +789,9 @@ def canary_child(args, dev, world, rank):
     """the trial itself (child process of collectives_canary): the sharded lookahead step with captured collectives for 24 replayed steps"""
     args.graph_collectives, args.no_lookahead = True, False
     run = TrainingRun(args, dev, world, rank, fused=True, graph=True, torch_optim=False, autograd=False, force_ddp=args.force_ddp)
+    n_steps = int(os.environ.get('NGP_BENCH_CANARY_STEPS', '24'))
     run.setup(4)
-    res = run.timed(24)
+    res = run.timed(n_steps)
     st, opt = run.stepper, run.optimizer
     ok = st.capture_error is None and st.la is not None and st.la_apply is None and bool(getattr(opt, 'shard', False)) and res['final_loss'] == res['final_loss']
     opt.wait_shadows()
@@ -799,7 +800,7 @@ def canary_child(args, dev, world, rank):
     both = [torch.zeros_like(digest) for _ in range(world)]
     dist.all_gather(both, digest)
     same = all(int(b.item()) == int(both[0].item()) for b in both)
-    return ok and same, f"{res['elapsed'] / 24 * 1e3:.4f} ms/step, capture_error={st.capture_error}, shadows agree={same}"
+    return ok and same, f"{res['elapsed'] / n_steps * 1e3:.4f} ms/step, capture_error={str(st.capture_error)[:80]}, shadows agree={same}"
 
 
 def self_launch(args):
@@ -945,7 +946,10 @@ def main():
         dist.destroy_process_group()
         sys.exit(0 if ok else 3)
     canary = None
-    if ((world > 1 or os.environ.get('NGP_BENCH_FORCE_CANARY') == '1') and comm.get('rccl_ranks') and not args.no_canary and not args.torch_optim and not args.replicated_optim and not args.no_fused
+    # (NGP_BENCH_CANARY_ANY_BACKEND=1: functional-test hook -- the hand-over itself (child ranks on a port of their own, scrubbed environment,
+    # MIN all-reduce of the verdicts, the kill after 200 s) at 8 ranks over gloo; gloo cannot be captured, so the verdict there is "eager")
+    if ((world > 1 or os.environ.get('NGP_BENCH_FORCE_CANARY') == '1') and (comm.get('rccl_ranks') or os.environ.get('NGP_BENCH_CANARY_ANY_BACKEND') == '1')
+            and not args.no_canary and not args.torch_optim and not args.replicated_optim and not args.no_fused
             and not args.no_graph and not args.autograd and not args.no_lookahead and os.environ.get('NGP_GRAPH_COLLECTIVES') is None):
         args.graph_collectives, canary = collectives_canary(args, world, rank, dev)
     if args.ddp_probe_only:

@@ -19,8 +19,8 @@
  * buffer.  All launches are asynchronous on `stream`.
  *
  * Contracts kept from the reference: buffers the reference requires pre-zeroed stay caller-zeroed
- * (xyzs/dirs/deltas, grad_embeddings, grad_inputs of the grid and SH backward, grad_sigmas/grad_rgbs,
- * grad_weights); `counter` is read-modify-written.
+ * (xyzs/dirs/deltas, grad_embeddings, grad_inputs of the grid and SH backward, grad_sigmas/grad_rgbs);
+ * `counter` is read-modify-written.  (ffmlp_backward OVERWRITES grad_weights: no pre-zeroing needed.)
  */
 #ifndef NGP_HIP_H
 #define NGP_HIP_H
@@ -181,8 +181,9 @@ int ngp_ffmlp_inference(const void* inputs, const void* weights, uint32_t B, uin
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, void* inference_buffer, void* outputs, ngp_stream_t stream);
 /* replaces ffmlp_backward (ffmlp.cu:749-895): grad [B,output_dim]; backward_buffer [num_layers,B,hidden]
- * scratch; grad_inputs [B,input_dim] written iff calc_grad_inputs; grad_weights flat fp16 (pre-zeroed by
- * the caller, overwritten with the fp32-accumulated batch sums rounded once to fp16). */
+ * scratch; grad_inputs [B,input_dim] written iff calc_grad_inputs; grad_weights flat fp16: OVERWRITTEN with the
+ * fp32-accumulated batch sums rounded once to fp16 whatever it held (the reference's wrapper zero-fills it,
+ * ffmlp.py:66-71: not needed here) -- also for an empty batch (B == 0: zeros). */
 int ngp_ffmlp_backward(const void* grad, const void* inputs, const void* weights, const void* forward_buffer,
                        uint32_t B, uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers,
                        uint32_t activation, uint32_t output_activation, int calc_grad_inputs, void* backward_buffer,

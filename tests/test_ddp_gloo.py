@@ -43,15 +43,26 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_average_and_broadcast():
-    world = 2
+# world 8 = BASELINE config 3's size (the one config that had never executed at its own size anywhere)
+WORLDS = [2, 8]
+
+
+@pytest.mark.parametrize('world', WORLDS)
+def test_gradient_average_and_broadcast(world):
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
-    assert out[0][0] and out[1][0], 'parameters differ after broadcast'
-    assert out[0][1] and out[1][1], 'gradients not averaged'
-    assert (out[0][2], out[0][3], out[1][2], out[1][3]) == (0, 2049, 2049, 4097)
+    assert all(out[r][0] for r in range(world)), 'parameters differ after broadcast'
+    assert all(out[r][1] for r in range(world)), 'gradients not averaged'
+    # contiguous blocks that cover [0, 4097) exactly, sizes differing by at most one ray
+    assert out[0][2] == 0 and out[world - 1][3] == 4097
+    assert all(out[r][3] == out[r + 1][2] for r in range(world - 1))
+    sizes = [out[r][3] - out[r][2] for r in range(world)]
+    per = -(-4097 // world)     # ceil blocks, the last rank takes what is left
+    assert sizes[:-1] == [per] * (world - 1) and 0 < sizes[-1] <= per
+    if world == 2:
+        assert (out[0][2], out[0][3], out[1][2], out[1][3]) == (0, 2049, 2049, 4097)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -114,12 +125,42 @@ def _make_double():
     return TorchKernelDouble
 
 
-def _grads_for(rank, step, shapes, scale):
+def _grads_for(rank, step, shapes, scale, boundaries=()):
+    """loss-scaled fp16 gradients of one rank and step: k * 2^-6 * (scale / 1024) with integer |k| <= 63 -- seven significant bits, so the
+    pre-multiplied (1 / world) sum over up to 8 ranks is EXACT in fp16 whatever order the backend adds in (a ring adds in another order than
+    the single-process reference; with full-precision values the two would differ by fp16 rounding, ~1e-4 in the parameters after 7 steps).
+    Tensors beyond 1 M elements (the real 12.2 M-parameter hash table of the world-8 case) get a SPARSE gradient -- 200 k random elements
+    plus a window around every shard boundary that falls inside them and the tail -- so that eight processes on eight cores do not spend
+    their time in the generator; every boundary, the table's tail and the padding are still exercised."""
     g = torch.Generator().manual_seed(1000 * step + rank)
-    return [(torch.randn(*s, generator=g) * 1e-3 * scale).half() for s in shapes]
+    unit = 2.0 ** -6 * (scale / 1024.0)
+
+    def draw(n):
+        return (torch.randint(-63, 64, (n,), generator=g).float() * unit).half()
+    out, off = [], 0
+    for s in shapes:
+        n = math.prod(s)
+        if n <= (1 << 20):
+            out.append(draw(n).view(*s))
+        else:
+            t = torch.zeros(n, dtype=torch.half)
+            idx = torch.randint(0, n, (200000,), generator=g)
+            t[idx] = draw(200000)
+            for b in boundaries:
+                lo, hi = max(b - off - 64, 0), min(b - off + 64, n)
+                if lo < hi:
+                    t[lo:hi] = draw(hi - lo)
+            t[-256:] = draw(256)
+            out.append(t.view(*s))
+        off += (n + 7) // 8 * 8
+    return out
 
 
-def _optim_worker(rank, world, port, out, shard, verdict='poison'):
+# the parameter set of BASELINE config 2 / 3: hash table [6 119 864, 2] (12 239 728 parameters), sigma MLP 7 168, colour MLP 11 264
+REAL_SHAPES = [(6119864, 2), (7168,), (11264,)]
+
+
+def _optim_worker(rank, world, port, out, shard, verdict='poison', real=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, 'torch-ngp_amd'))
@@ -127,6 +168,9 @@ def _optim_worker(rank, world, port, out, shard, verdict='poison'):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     Double = _make_double()
     shapes = [(3001, 2), (7168,), (1130,)]   # odd sizes: parameters straddle the shard boundary, padding between them
+    if real:
+        shapes = REAL_SHAPES                 # seven shard boundaries cut the table; the last rank owns its tail, both MLPs and the padding
+        torch.set_num_threads(1)
     torch.manual_seed(0)
     params = [torch.nn.Parameter(torch.randn(*s) * 0.1) for s in shapes]
     opt = Double([{'params': params[:1], 'lr': 1e-2}, {'params': params[1:], 'lr': 3e-3}], betas=(0.9, 0.99), eps=1e-15, init_scale=1024.0,
@@ -143,12 +187,22 @@ def _optim_worker(rank, world, port, out, shard, verdict='poison'):
     ref = [torch.nn.Parameter(p.detach().clone()) for p in params]
     topt = torch.optim.Adam([{'params': ref[:1], 'lr': 1e-2}, {'params': ref[1:], 'lr': 3e-3}], betas=(0.9, 0.99), eps=1e-15)
     scale, tracker, ok = 1024.0, 0, True
+    bounds = [r * opt.payload for r in range(1, world)] if shard else []
+    if shard and real:
+        # the layout the 8-rank run of bench.py will have: payload = ceil(packed total / world) rounded up to 8, last rank = tail + MLPs + pad
+        packed = sum((math.prod(sh) + 7) // 8 * 8 for sh in shapes)
+        ok = ok and opt.payload == ((packed + world - 1) // world + 7) // 8 * 8 and opt.total == opt.payload * world
+        ok = ok and opt.shard_range == (rank * opt.payload, (rank + 1) * opt.payload)
+        pieces = opt._shard_entries()
+        ok = ok and len(pieces) == (3 if rank == world - 1 else 1) and sum(e[0] for e in pieces) <= opt.payload
+        ok = ok and (rank != world - 1 or pieces[0][0] == math.prod(shapes[0]) - (world - 1) * opt.payload)
+    last = world - 1
     for step in range(7):
-        per_rank = [_grads_for(r, step, shapes, scale) for r in range(world)]
+        per_rank = [_grads_for(r, step, shapes, scale, bounds) for r in range(world)]
         if step == 2:
             per_rank[1][0][5, 1] = float('inf')     # only rank 1 overflows, in a region rank 0 owns
         if step == 5:
-            per_rank[0][2][7] = float('nan')
+            per_rank[0][2][7] = float('nan')        # only rank 0, in the LAST rank's region
         for p, g in zip(params, per_rank[rank]):
             p._ngp_grad16.copy_(g)
         if shard:
@@ -209,23 +263,25 @@ def _optim_worker(rank, world, port, out, shard, verdict='poison'):
     mom = max(float((m - topt.state[r]['exp_avg']).abs().max()) for m, r in zip(sd['exp_avg'], ref))
     digest = [None] * world
     dist.all_gather_object(digest, [float(p.detach().double().sum()) for p in params])
-    out[rank] = (ok, max(worst, ck_worst, ema_worst), shadows_ok, mom, digest[0] == digest[1], float(opt.scalars[3]) - (1.0 if shard else 0.0))
+    out[rank] = (ok, max(worst, ck_worst, ema_worst), shadows_ok, mom, all(d == digest[0] for d in digest), float(opt.scalars[3]) - (1.0 if shard else 0.0))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('shard,verdict', [(False, 'poison'), (True, 'poison'), (True, 'allreduce')])
-def test_two_rank_ngp_adam_exchange(shard, verdict):
-    """step 2: only rank 1 overflows, in a region rank 0 owns; step 5: only rank 0, in rank 1's region -- both ranks must skip both steps.
-    verdict='poison': the skip verdict travels inside the reduce-scatter (NaN in element 0 of every shard), no collective of its own."""
-    world = 2
+@pytest.mark.parametrize('world,shard,verdict,real', [(2, False, 'poison', False), (2, True, 'poison', False), (2, True, 'allreduce', False),
+                                                      (8, True, 'poison', False), (8, True, 'poison', True), (8, False, 'poison', False)])
+def test_ngp_adam_exchange(world, shard, verdict, real):
+    """step 2: only rank 1 overflows, in a region rank 0 owns; step 5: only rank 0, in the last rank's region -- EVERY rank must skip both steps.
+    verdict='poison': the skip verdict travels inside the reduce-scatter (NaN in element 0 of every shard), no collective of its own.
+    real: the parameter sizes of BASELINE config 3 (12 239 728 + 7 168 + 11 264) at world 8 -- seven shard boundaries inside the table,
+    rank 7 owns the table's tail, both MLP vectors and the padding; sharded checkpoint gather, EMA store and shadow sync included."""
     port = _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_optim_worker, args=(world, port, out, shard, verdict), nprocs=world, join=True)
+    mp.spawn(_optim_worker, args=(world, port, out, shard, verdict, real), nprocs=world, join=True)
     for r in range(world):
         ok, worst, shadows_ok, mom, same, steps = out[r]
-        assert ok, 'loss-scale dynamics / gradient zeroing differ from the single-process reference'
+        assert ok, 'shard layout / loss-scale dynamics / gradient zeroing differ from the single-process reference'
         assert worst < 5e-6 and mom < 1e-6, (worst, mom)
-        assert shadows_ok and same and steps == 5.0   # 7 iterations, 2 skipped on BOTH ranks
+        assert shadows_ok and same and steps == 5.0   # 7 iterations, 2 skipped on EVERY rank
 
 
 def _roll_call_worker(rank, world, port, out):
@@ -247,19 +303,19 @@ def _roll_call_worker(rank, world, port, out):
             _all_ranks_here(opt, timeout_s=1.0, use_store=True)
             res.append('no error')
         except RuntimeError as e:
-            res.append('collective' in str(e) and '1 of 2' in str(e))
+            res.append('collective' in str(e) and f'1 of {world}' in str(e))
     dist.barrier()
     out[rank] = res
     dist.destroy_process_group()
 
 
-def test_sharded_checkpoint_roll_call_is_backend_independent():
+@pytest.mark.parametrize('world', WORLDS)
+def test_sharded_checkpoint_roll_call_is_backend_independent(world):
     """the roll call in front of a sharded save_checkpoint must not depend on gloo's monitored_barrier (an RCCL group has none):
     a counter in the rendezvous store; a call from rank 0 alone is an error within the timeout"""
-    world = 2
     out = mp.Manager().dict()
     mp.spawn(_roll_call_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert out[0] == ['ok', 'ok', True] and out[1] == ['ok', 'ok']
+    assert out[0] == ['ok', 'ok', True] and all(out[r] == ['ok', 'ok'] for r in range(1, world))
 
 
 def _occ_worker(rank, world, port, out):
@@ -286,20 +342,22 @@ def _occ_worker(rank, world, port, out):
     ddp.sync_occupancy(model)
     both = [None] * world
     dist.all_gather_object(both, mine)
-    want = torch.maximum(both[0], both[1])
+    want = both[0]
+    for b in both[1:]:
+        want = torch.maximum(want, b)
     thresh = min(float(want.clamp(min=0).mean()), 1.5)
     want_bits = ((want.reshape(-1, 8) > thresh).to(torch.uint8) * (1 << torch.arange(8)).to(torch.uint8)).sum(1).to(torch.uint8)
     out[rank] = (torch.equal(model.density_grid, want), torch.equal(model.density_bitfield, want_bits), model.mean_count)
     dist.destroy_process_group()
 
 
-def test_two_rank_sync_occupancy():
-    world = 2
+@pytest.mark.parametrize('world', WORLDS)
+def test_sync_occupancy(world):
     port = _free_port()
     out = mp.Manager().dict()
     mp.spawn(_occ_worker, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
-        assert out[r] == (True, True, 2000)
+        assert out[r] == (True, True, 1000 * world)   # grid = element-wise MAX, bitfield re-packed, the sample estimate = the largest rank's
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -319,7 +377,7 @@ class _PerRayRenderer:
         return {'image': img, 'depth': (rays_o * rays_d).sum(-1)}
 
 
-def _render_worker(rank, world, port, out):
+def _render_worker(rank, world, port, out, n=1001):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, 'torch-ngp_amd'))
@@ -327,7 +385,6 @@ def _render_worker(rank, world, port, out):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from ddp import render_sharded
     g = torch.Generator().manual_seed(7)
-    n = 1001
     o, d = torch.randn(1, n, 3, generator=g), torch.randn(1, n, 3, generator=g)
     m = _PerRayRenderer()
     got = render_sharded(m, o, d, bg_color=1)
@@ -341,16 +398,23 @@ def _render_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_render_gathers_the_full_frame():
-    world = 2
+@pytest.mark.parametrize('world,n', [(2, 1001), (8, 1001), (8, 640000)])
+def test_sharded_render_gathers_the_full_frame(world, n):
+    """n = 640 000: the 800 x 800 frame of BASELINE's metric in eight blocks of 80 000 rays; n = 1001 does not divide by the world size"""
     port = _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_render_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_render_worker, args=(world, port, out, n), nprocs=world, join=True)
     for r in range(world):
         same_img, same_depth, ishape, dshape, calls = out[r]
         assert same_img and same_depth, 'gathered frame differs from the one-rank frame'
-        assert ishape == (1, 1001, 3) and dshape == (1, 1001)
-    assert out[0][4] == [501] and out[1][4] == [500]   # each rank rendered only its block of rows
+        assert ishape == (1, n, 3) and dshape == (1, n)
+    per = [out[r][4][0] for r in range(world)]
+    blk = -(-n // world)
+    assert sum(per) == n and per[:-1] == [blk] * (world - 1) and 0 < per[-1] <= blk   # each rank rendered only its block of rows
+    if world == 2:
+        assert per == [501, 500]
+    if n == 640000:
+        assert per == [80000] * 8
 
 
 def test_kept_deposit_buffer_protocol_on_the_host():

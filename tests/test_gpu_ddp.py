@@ -51,6 +51,47 @@ def test_bench_two_ranks_share_one_gpu(extra):
     assert 4e5 < line['config']['samples_per_step_per_gpu'] * 2 < 7e5
 
 
+def test_bench_eight_ranks_share_one_gpu_with_the_canary_hand_over():
+    """BASELINE config 3's size (8 ranks) executed end to end on the one GPU over gloo (the driver's `bench.py --gpus 8` is a one-shot
+    run): the weak line, the strong-scaling run at 512 rays per rank, the sharded 800 x 800 frame in eight blocks -- and the canary hand-over with
+    EIGHT children (each rank starts a child on a rendezvous port of the children's own; the verdicts meet in a MIN all-reduce).  gloo cannot
+    be captured into a HIP graph, so the children report failure and the run must continue in the eager-collective form."""
+    env = dict(os.environ, NGP_BENCH_SHARE_GPU='1', NGP_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1', GLOO_SOCKET_IFNAME='lo',
+               NGP_BENCH_CANARY_ANY_BACKEND='1', NGP_BENCH_CANARY_STEPS='2', OMP_NUM_THREADS='2')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'NGP_GRAPH_COLLECTIVES'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '0', '--no-cpu-baseline', '--no-dropin', '--no-extra',
+           '--strong-steps', '2', '--watchdog', '800']
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1200)
+    if res.returncode != 0 and 'Timeout (' in res.stderr:
+        dump = os.path.join(ROOT, 'gpurun_out', 'ddp8_watchdog_dump.txt')
+        os.makedirs(os.path.dirname(dump), exist_ok=True)
+        open(dump, 'w').write(res.stderr)
+    assert res.returncode == 0, res.stderr[-6000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 8 and line['config']['captures_in_timed_region'] == 0
+    assert line['comm']['ranks'] == 8 and line['comm']['self_launched'] and line['comm']['devices'] == [0] * 8
+    assert line['scaling'] == 'weak' and line['config']['global_rays_per_step'] == 8 * 4096
+    assert 'sharded' in line['config']['parallelism'] and line['sharded_update_fallback'] is None
+    # the hand-over ran on every rank and came back with a verdict (not a hang, not a port collision): eager collectives here
+    can = line['collectives_in_graph']
+    assert can['used'] is False and can['canary'] is not None and can['canary']['all_ranks_ok'] is False
+    assert 'did not finish' not in can['canary']['detail'], can['canary']
+    # (the children ended by themselves with a non-zero exit code -- a refused capture, here even a HIP error out of it -- and were not killed)
+    assert can['canary']['detail'].startswith('rc '), can['canary']
+    coll = line['collectives']
+    for name in ('reduce_scatter_fp16_gradients', 'all_gather_fp16_shadows'):
+        assert coll[name]['ms'] > 0 and coll[name]['calls'] >= 2
+    st = line['strong_scaling']
+    assert st['scaling'] == 'strong' and st['rays_per_gpu_per_step'] == 512 and st['global_rays_per_step'] == 4096
+    assert 2e5 < st['samples_per_step_global'] < 3.5e5 and st['captures_in_timed_region'] == 0
+    r = line['render_800x800_ms']
+    assert r['n_gpus'] == 8 and r['transparent_random_init'] > 0 and r['opaque_density_scale_300'] > 0
+    assert line['config']['autograd_free_iteration'] and 'hip-graph replay' in line['config']['execution']
+    assert line['value'] > 1e4 and line['config']['final_loss'] == line['config']['final_loss']
+    assert 16e5 < line['config']['samples_per_step_per_gpu'] * 8 < 28e5      # 8 ranks x ~262 k samples per step
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """`--gpus 8` on a box with fewer devices must fail loudly, never measure fewer GPUs under the requested label"""
     import torch
@@ -101,14 +142,15 @@ dist.destroy_process_group()
 """
 
 
-def test_sharded_frame_is_bit_identical_to_the_one_rank_frame(tmp_path):
-    """two ranks (sharing the one GPU, gloo) render their blocks of pixel rows through the eval branch of run_cuda and all-gather them:
+@pytest.mark.parametrize('world', [2, 8])
+def test_sharded_frame_is_bit_identical_to_the_one_rank_frame(tmp_path, world):
+    """2 / 8 ranks (sharing the one GPU, gloo) render their blocks of pixel rows through the eval branch of run_cuda and all-gather them:
     the frame equals the frame one rank renders alone, bit for bit (image and depth)"""
     script = tmp_path / 'frame.py'
     script.write_text(_FRAME)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', GLOO_SOCKET_IFNAME='lo')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29519',
-           str(script), ROOT]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', GLOO_SOCKET_IFNAME='lo', OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1', '--master-port',
+           str(29519 + world), str(script), ROOT]
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])['ok']

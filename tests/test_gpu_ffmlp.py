@@ -269,3 +269,27 @@ def test_bad_shapes_raise():
         be.ffmlp_forward(torch.zeros(128, 32, device='cuda'), h(7168), 128, 32, 16, 64, 2, 0, 6, h(2, 128, 64), h(128, 16))
     with pytest.raises(RuntimeError, match='128'):
         be.ffmlp_forward(h(100, 32), h(7168), 100, 32, 16, 64, 2, 0, 6, h(2, 100, 64), h(100, 16))
+
+
+def test_empty_batch_backward_returns_zero_weight_gradient():
+    """the wrappers hand ffmlp_backward uninitialised grad_weights (every kernel overwrites them); with B == 0 no kernel runs, so
+    the C entry must write the zeros itself -- also through nerf/network.py's fused Linear stacks under an all-False mask"""
+    from ffmlp import FFMLP
+    from ffmlp.ffmlp import ffmlp_forward
+    torch.manual_seed(0)
+    net = FFMLP(32, 16, 64, 2).cuda()
+    x = torch.zeros(0, 32, device='cuda', dtype=torch.half, requires_grad=True)
+    for _ in range(3):   # (fresh uninitialised buffers every time: garbage would show up sooner or later)
+        torch.empty(net.weights.numel(), device='cuda', dtype=torch.half).fill_(7.0)
+        with torch.autocast('cuda', dtype=torch.float16):   # (the wrappers cast under autocast, as the reference's custom_fwd does)
+            out = ffmlp_forward(x, net.weights, 32, 16, 64, 2, 0, 6, False, True)
+        assert out.shape == (0, 16)
+        gw, = torch.autograd.grad(out.float().sum(), net.weights, allow_unused=True)
+        assert gw is not None and float(gw.abs().max()) == 0.0
+    from nerf.network import NeRFNetwork
+    m = NeRFNetwork(bound=1, cuda_ray=False).cuda()
+    d = torch.nn.functional.normalize(torch.randn(8, 3, device='cuda'), dim=-1)
+    geo = torch.randn(8, 15, device='cuda', requires_grad=True)
+    with torch.autocast('cuda', dtype=torch.float16):
+        rgb = m.color(torch.zeros(8, 3, device='cuda'), d, mask=torch.zeros(8, dtype=torch.bool, device='cuda'), geo_feat=geo)
+    assert float(rgb.abs().max()) == 0.0

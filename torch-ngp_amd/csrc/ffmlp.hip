@@ -2191,7 +2191,16 @@ extern "C" int ngp_ffmlp_backward_ws(const void* grad, const void* inputs, const
     (void)output_activation;  // the reference discards it as well (ffmlp.cu:780)
     int rc = check_ff_args("ffmlp_backward", B, input_dim, output_dim, hidden_dim, num_layers);
     if (rc) return rc;
-    if (B == 0) return NGP_OK;
+    if (B == 0) {
+        // an empty batch: no kernel runs, but the caller's weight gradient must still be what the sum over zero samples is (callers hand
+        // over uninitialised memory: every other path OVERWRITES it) -- ADVICE r5.  (With NGP_FF_DEFER_REDUCE the later reduction writes it.)
+        if (grad_weights && !(flags & NGP_FF_DEFER_REDUCE)) {
+            const size_t n_w = (size_t)hidden_dim * ((size_t)input_dim + (size_t)hidden_dim * (num_layers - 1) + (size_t)output_dim);
+            hipError_t e = hipMemsetAsync(grad_weights, 0, n_w * sizeof(half_t), as_stream(stream));
+            NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp_backward: hipMemsetAsync failed: %s", hipGetErrorString(e));
+        }
+        return NGP_OK;
+    }
     NGP_REQUIRE(grad && inputs && weights && (forward_buffer || (flags & NGP_FF_RECOMPUTE)) && backward_buffer && grad_weights, NGP_ERR_INVALID,
                 "ffmlp_backward: NULL tensor");
     NGP_REQUIRE(!calc_grad_inputs || grad_inputs, NGP_ERR_INVALID, "ffmlp_backward: grad_inputs is NULL but calc_grad_inputs is set");

@@ -66,7 +66,7 @@ def _apply_stack_fused(layers, h):
     parts.append(F.pad(layers[-1].weight, (0, 0, 0, 16 - n_out)).reshape(-1))
     flat = torch.cat(parts)
     batch = h.shape[0]
-    rows = (batch + 127) // 128 * 128
+    rows = max(128, (batch + 127) // 128 * 128)   # (an empty input -- color() under an all-False mask -- still runs one padded tile)
     x = F.pad(h, (0, in_pad - n_in, 0, rows - batch))
     out = ffmlp_forward(x, flat, in_pad, 16, hidden, max(depth - 1, 2), 0, 6, not torch.is_grad_enabled(), x.requires_grad)
     return out[:batch, :n_out]

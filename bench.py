@@ -76,7 +76,7 @@ TIMED = {
     'ngp_grid_encode_backward_checked_slabs': ('grid_encode_backward', 5, lambda a: 1100.0 + 26.0 * _table_adam_params(a) / max(int(a[5]), 1),
                                                lambda a: 0.0, 'point'),
     # what is left of the optimizer step when the table is updated in the grid backward: Adam on the MLP weights + commit, one workgroup
-    'ngp_optim_adam_small_commit': ('k_adam_small_commit (MLP weights + scaler commit + parity flip)', lambda a: _small_params(a), lambda a: 30.0,
+    'ngp_optim_adam_small_commit': ('k_adam_small_commit (dense table levels + MLP weights + scaler commit + parity flip)', lambda a: _small_params(a), lambda a: 28.0,
                                     lambda a: 0.0, 'parameter'),
     'ngp_ffmlp_forward_ex': ('ffmlp_forward', 2, lambda a: _ff_fwd_bytes(a[6]), lambda a: _ff_flops(a[6]), 'sample'),
     # the whole network behind the encoder in one launch: enc 64 B + dir 12 B in, both forward buffers (when they are stored: not with the
@@ -117,9 +117,9 @@ def _small_params(a):
     import ctypes
     k = int(a[0])
     if k == 0 or not a[1]:
-        return 0
+        return int(a[20] or 0)
     n = ctypes.cast(a[1], ctypes.POINTER(ctypes.c_uint64))
-    return int(sum(n[i] for i in range(k)))
+    return int(sum(n[i] for i in range(k))) + int(a[20] or 0)   # (+ the dense-level prefix of the double-buffered table)
 
 
 def _adam_bytes(a):
@@ -200,6 +200,15 @@ class KernelTimers:
                 row['mfma'] = {'achieved': round(tf, 2), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 5)}
             if traffic and label in traffic:
                 row['traffic'] = traffic[label]
+            if label.startswith('grid_encode_forward'):
+                # what actually bounds the encoder (profiles/r03_grid_forward_pmc.json: L1 hit 69 %, L2 hit 91 %, 37 MB from HBM): the L1's
+                # line rate.  Line requests per point of k_grid_forward_fast on the L16 table: 4 per level (hashed: the x-pair shares an
+                # aligned 64-byte block; dense: four 8-byte loads) + ~4 for the positions re-read per level and the output rows = 68;
+                # ceiling = one line per clock and CU: 256 CUs x 2.4 GHz.
+                lines = 68.0 * float(units.mean())
+                floor_ms = lines / (256 * 2.4e9) * 1e3
+                row['l1'] = {'bound': 'l1', 'lines_per_point': 68.0, 'peak_lines_per_s': 256 * 2.4e9, 'floor_ms': round(floor_ms, 4),
+                             'frac': round(floor_ms / max(float(ms.mean()), 1e-9), 4)}
             out.append(row)
         out.sort(key=lambda r: -r['total_ms'])
         return out
@@ -315,6 +324,19 @@ def load_pmc_traffic():
         return json.load(open(files[-1]))['per_launch'], os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+def load_march_pmc():
+    """SQ_INSTS_VALU of k_march_rays per opaque 800x800 frame from the newest committed counter pass (profiles/*_march_rays_pmc.json)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_march_rays_pmc.json')))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return {'valu_insts_per_frame': float(d['valu_insts_per_frame']), 'source': os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
 
 
 RING_BLOCK = 8         # steps between snapshots of the model's 16-slot sample-counter ring (see TrainingRun.train_step)
@@ -1091,15 +1113,44 @@ def main():
             # the inference kernels of one more opaque frame with HIP-event pairs (encoder and fused network launches of the eval loop; the
             # march / composite / compaction kernels of the loop are in the committed rocprofv3 summary, profiles/)
             model.density_scale = 300.0
-            timers.suffix, timers.enabled, timers.step = ' (800x800 render, opaque frame)', True, 1 << 30
-            with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
-                model.render(ro, rd, **rkw)   # rank 0 alone, the whole frame: no collective in here
+            timers.suffix, timers.enabled = ' (800x800 render, opaque frame)', True
+            # units per launch = the sample rows the iteration really EMITTED (rows with dt > 0, counted on the device right behind the march),
+            # not the rows launched and not alive x n_step (VERDICT r5 "What's weak" 7: the launched rows inflated these rows by 1.4x)
+            emitted = []
+
+            def count_rows(deltas):
+                timers.step = len(emitted)
+                emitted.append((deltas[:, 0] > 0).sum())
+            model._loop_iter_hook = count_rows
+            try:
+                with torch.no_grad(), torch.autocast('cuda', dtype=torch.float16):
+                    model.render(ro, rd, **rkw)   # rank 0 alone, the whole frame: no collective in here
+            finally:
+                model._loop_iter_hook = None
             torch.cuda.synchronize()
             timers.suffix, timers.enabled = '', False
-            for r in timers.summary():
+            emitted = [max(int(e.item()), 1) for e in emitted]
+            for r in timers.summary(marched=emitted):
                 if r['kernel'].endswith('opaque frame)'):
                     r['traffic_source'] = None
+                    r['units'] = 'sample rows emitted by the march of the same iteration (device count of rows with dt > 0)'
+                    r['rows_emitted_in_frame'] = int(sum(emitted))
                     roofs.append(r)
+            # k_march_rays (the largest kernel of the opaque frame) says nothing against HBM: it is bound by its instruction stream.  Row:
+            # the stage's HIP-event time of the probed frame above against the issue floor of its vector instructions -- SQ_INSTS_VALU per
+            # frame from the committed rocprofv3 --pmc pass (profiles/*_march_rays_pmc.json, tools/bench_render.py under the counter) x 4
+            # cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz).
+            st = render.get('stages_opaque_density_scale_300', {})
+            march = [x for x in st.get('stages', []) if x['stage'] == 'march_rays'] if isinstance(st, dict) else []
+            pmc = load_march_pmc()
+            if march and pmc:
+                floor_ms = pmc['valu_insts_per_frame'] * 4.0 / (1024 * 2.4e9) * 1e3
+                roofs.append({'kernel': 'k_march_rays (800x800 render, opaque frame: all iterations)', 'bound': 'issue', 'achieved': round(floor_ms, 4),
+                              'peak': march[0]['ms'], 'unit': 'ms of pure VALU issue vs ms measured', 'frac': round(floor_ms / max(march[0]['ms'], 1e-9), 4),
+                              'traffic': None, 'avg_kernel_ms': round(march[0]['ms'] / max(march[0]['launch_groups'], 1), 4),
+                              'launches': march[0]['launch_groups'], 'total_ms': march[0]['ms'], 'valu_insts_per_frame': pmc['valu_insts_per_frame'],
+                              'hbm_frac': march[0]['frac_of_hbm_peak'], 'source': pmc['source'],
+                              'note': 'frac = issue floor / measured stage time (1.0 = nothing but its own vector instructions); HBM says nothing here'})
         model.density_scale = 1
         model.train()
 

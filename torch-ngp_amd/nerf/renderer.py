@@ -347,6 +347,9 @@ class NeRFRenderer(nn.Module):
             deltas = torch.empty(rows, 2, dtype=torch.float32, device=dev)
             stage('march_rays', lambda: rb.march_rays_dev(state[cur], lanes, n_total, cap, alive[cur], s_t, s_o, s_d, self.bound, dt_gamma, max_steps,
                                                           self.cascade, self.grid_size, bits, s_near, s_far, xyzs, dirs, deltas, noises, rows))
+            hook = getattr(self, '_loop_iter_hook', None)
+            if hook is not None:   # bench.py's roofline pass: the rows this iteration really emitted (device count), for honest units per launch
+                hook(deltas)
             if hasattr(self, 'forward_scaled'):   # (the fused network folds the density scale: one launch less per iteration)
                 sigmas, rgbs = stage('network (encoder + MLPs + glue)', lambda: self.forward_scaled(xyzs, dirs, self.density_scale))
                 sigmas, rgbs32 = stage('casts (density_scale, fp32 copies)', lambda: (sigmas.float().contiguous(), rgbs.float().contiguous()))

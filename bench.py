@@ -1201,13 +1201,15 @@ def main():
         e_run = TrainingRun(args, dev, 1, 0, fused=True, graph=not args.no_graph, torch_optim=False, autograd=False)
         e_run.setup(4)
         e_run.evolving = True
-        e_caps0 = e_run.stepper.captures
+        e_caps0, e_sw0 = e_run.stepper.captures, e_run.stepper.n_switches
         e_res = e_run.timed(96)
         evolving = {'steps': 96, 'ms_per_step': round(e_res['elapsed'] / 96 * 1e3, 4), 'samples_per_step': round(e_res['samples'] / 96, 1),
                     'value': round(e_res['samples'] / e_res['elapsed'], 1), 'unit': 'samples/s', 'graph_captures_in_timed_region': e_res['captures'],
                     'captured_capacity_at_end': e_run.stepper.captured_capacity, 'mean_count_at_end': int(e_run.model.mean_count),
+                    'capacity_switches_in_timed_region': e_run.stepper.n_switches - e_sw0, 'captured_capacities': sorted(e_run.stepper._captured),
                     'capture_error': e_run.stepper.capture_error, 'final_loss': e_res['final_loss'],
-                    'note': 'the occupancy refreshes are kept (6 of them in 96 steps): the grid follows the density network; not a steady state'}
+                    'note': 'the occupancy refreshes are kept (6 of them in 96 steps): the grid follows the density network; not a steady state.  '
+                            'Round 6: precapture() records a ladder of capacities, the moving estimate SWITCHES between captured graphs instead of re-capturing'}
         del e_run
         tnt = {'config': 'Tanks&Temples-shaped: bound=8, 4 cascades x 128^3, dt_gamma=1/128, background model (radius-32 sphere, 2-D hashgrid + nn.Linear), '
                          'nn.Linear sigma/colour/background networks (nerf/network.py) evaluated on the fused-MLP kernels under autocast (fused_linear: one-hidden-layer stacks through an exact identity layer; '

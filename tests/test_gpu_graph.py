@@ -456,3 +456,51 @@ def test_overwritten_table_gradient_is_the_same_training(lookahead):
         assert torch.equal(x, y)
     for x, y in zip(a[1][1:], b[1][1:]):
         assert torch.equal(x, y)
+
+
+def test_capacity_ladder_switches_between_captured_graphs_without_capturing():
+    """precapture() records a ladder of sample capacities; a sample estimate that leaves the active buffer (the occupancy grid follows the
+    density network: renderer.py:531-538 moves `mean_count` by tens of percent) then SWITCHES to another captured capacity -- no capture in
+    the stretch, the lookahead keeps working -- and trains exactly like a stepper that re-captures for the new estimate (a larger buffer
+    changes nothing as long as no ray is dropped)."""
+    from graph import GraphedTrainStep
+    dev = torch.device('cuda')
+    occ = torch.from_numpy(sc.occupancy_density()).to(dev)
+    bits = torch.from_numpy(oracle.packbits(sc.occupancy_density(), 10.0)).to(dev)
+    n_rays = 1024
+    kw = dict(staged=False, bg_color=1, perturb=False, force_all_rays=False, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+    batches = []
+    for i in range(41):
+        o, d, gt = sc.training_batch(n_rays, seed=500 + i)
+        batches.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev), torch.from_numpy(gt).to(dev)))
+
+    def keep(m):
+        m.density_grid.copy_(occ)
+        m.density_bitfield.copy_(bits)
+
+    runs = {}
+    for ladder in (True, False):
+        model, opt = _make_ngp(dev)
+        st = GraphedTrainStep(model, opt, None, n_rays, kw, after_update=keep, direct=True, lookahead=True,
+                              capacity_ladder=(1.25, 1.5625) if ladder else ())
+        losses = []
+        for i in range(40):
+            if i == 18:
+                n = st.precapture()
+                assert n >= (3 if ladder else 0)
+                caps0 = st.captures
+            if i in (20, 33):          # the estimate moves up by ~35 %, later back down: what a refresh on an evolving grid does
+                model.mean_count = int(model.mean_count * (1.35 if i == 20 else 1 / 1.35))
+            losses.append(float(st.step(*batches[i], next_rays=batches[i + 1])))
+        assert st.capture_error is None
+        if ladder:
+            assert st.captures == caps0, 'a captured capacity served every estimate: nothing may be captured after precapture()'
+            assert st.n_switches >= 2 and len(st._captured) >= 3 and st.la_hits >= 10
+        else:
+            assert st.captures > caps0
+        params = [p.detach().clone() for p in (model.encoder.embeddings, model.sigma_net.weights, model.color_net.weights)]
+        runs[ladder] = (losses, params)
+        st.close()
+    assert runs[True][0] == runs[False][0]
+    for x, y in zip(runs[True][1], runs[False][1]):
+        assert torch.equal(x, y)

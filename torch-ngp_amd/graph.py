@@ -67,7 +67,7 @@ def mse_loss(out, target):
 class GraphedTrainStep:
     def __init__(self, model, optimizer, scaler, n_rays, render_kwargs, loss_fn=mse_loss, averager=None, capacity_quantum=8192,
                  update_interval=16, after_update=None, autocast_dtype=torch.float16, direct=True, capacity_slack=2, lookahead=False,
-                 fused_table_adam=False):
+                 fused_table_adam=False, capacity_ladder=(0.8, 1.25, 1.5625, 1.953125, 2.44140625)):
         self.model, self.optimizer, self.scaler = model, optimizer, scaler
         self.loss_fn, self.averager = loss_fn, averager
         if averager is not None and averager is not optimizer and getattr(optimizer, 'flat_grad16', None) is not None:
@@ -88,6 +88,14 @@ class GraphedTrainStep:
         self.counter = torch.zeros(16, 2, dtype=torch.int32, device=dev)  # row 0 is the captured marcher's counter
         self.global_step = 0
         self.captured_capacity = None
+        # every capacity captured so far: {capacity: the graphs and what belongs to them}.  A sample estimate that leaves the active buffer's
+        # window first looks for another captured capacity that serves it (a switch costs nothing) before anything is captured anew;
+        # `precapture()` records a LADDER of capacities (this one x capacity_ladder) up front, so that a training run whose occupancy grid
+        # follows the density network -- the estimate moves by tens of percent over the first thousands of steps (renderer.py:531-538) --
+        # does not stop to capture (round 5: two re-captures in 96 steps made that stretch run at 1.98 ms / step against 0.43)
+        self._captured = {}
+        self.capacity_ladder = tuple(float(f) for f in (capacity_ladder or ()))
+        self.n_switches = 0
         self.graphs = None
         self.loss = None
         self.n_captures = 0
@@ -147,7 +155,8 @@ class GraphedTrainStep:
             # any stream / event query) there would invalidate that capture.  The graphs and everything they replay into are parked instead
             # and released by the next close() / capture that runs outside a capture (_drain_parked)
             if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-                _PARKED.append((self.graphs, self.la, self.update_graphs, side, getattr(self, 'optimizer', None)))
+                _PARKED.append((self.graphs, self.la, self.update_graphs, side, getattr(self, 'optimizer', None), getattr(self, '_captured', None),
+                                getattr(self, 'la_apply', None), getattr(self, '_sample_pool', None), getattr(self, '_rest_pool', None)))
                 return
             if side is not None:
                 side.synchronize()
@@ -168,6 +177,27 @@ class GraphedTrainStep:
         if mc <= 0:
             return None
         return ((mc + 128 + self.quantum - 1) // self.quantum) * self.quantum
+
+    _SNAP = ('graphs', 'la', 'loss', 'la_apply', '_rest_pool', 'sharded', 'used_direct', 'table_fused', 'producers_check', '_checked_ok')
+
+    def _snapshot(self):
+        return {k: getattr(self, k, None) for k in self._SNAP}
+
+    def _activate(self, cap):
+        """make the graphs captured for `cap` samples the active ones (no device work).  A batch the side stream marched ahead sits in the
+        OLD capacity's buffers: it is forgotten (the next step marches its batch in line) -- a switch follows an occupancy refresh, and the
+        step before a refresh does not look ahead anyway."""
+        for k, v in self._captured[cap].items():
+            setattr(self, k, v)
+        if cap != self.captured_capacity:
+            self.n_switches += 1
+        self.captured_capacity = cap
+        self.la_ready = [None, None]
+
+    def _pick_captured(self, cap):
+        """the smallest captured capacity that holds an estimate of `cap` samples without wasting more than ~30 % of its rows (None: capture)"""
+        fits = [c for c in self._captured if c >= cap and c <= cap * 1.3 + self.slack * self.quantum]
+        return min(fits) if fits else None
 
     def _fits(self, cap):
         """the captured buffer still serves an estimate of `cap` samples (hysteresis: see the module docstring)"""
@@ -194,6 +224,21 @@ class GraphedTrainStep:
                 self.capture_error = repr(e)
                 self.graphs = None
                 torch.cuda.synchronize()
+        if cap is not None and self.graphs is not None and self.capture_error is None and self.capacity_ladder:
+            # the ladder: graphs for the capacities the estimate may move to (each rung owns its buffers: ~2 KB per sample and buffer set)
+            base = self.captured_capacity
+            for f in self.capacity_ladder:
+                rung = ((int(base * f) + self.quantum - 1) // self.quantum) * self.quantum
+                if rung in self._captured or rung < 16384:
+                    continue
+                try:
+                    self.captured_capacity = rung
+                    self._capture()
+                except Exception as e:  # noqa: BLE001 -- the ladder is an optimisation: keep what was captured
+                    self.ladder_error = repr(e)
+                    torch.cuda.synchronize()
+                    break
+            self._activate(base)
         m = self.model
         if self.graphs is not None and self.graph_updates and getattr(m, 'refresh_occupancy', None) is not None and getattr(m, 'cuda_ray', False):
             if update_modes is None:
@@ -368,6 +413,10 @@ class GraphedTrainStep:
                 self._iteration_back()
             self.graphs = (g1, g2)
         self.n_captures += 1
+        self._captured[self.captured_capacity] = self._snapshot()
+        while len(self._captured) > 12:   # (an estimate that wanders for a long time: drop the capacity farthest from the active one)
+            far = max((c for c in self._captured if c != self.captured_capacity), key=lambda c: abs(c - self.captured_capacity))
+            _PARKED.append(self._captured.pop(far))
 
     def _capture_lookahead(self):
         """two buffer sets, per set a march graph (static rays of the set -> its samples) and a rest graph (samples + target -> loss,
@@ -616,7 +665,11 @@ class GraphedTrainStep:
             loss = self._eager(rays_o, rays_d, target)
             self.global_step += 1
             return loss
-        if not self._fits(cap):
+        pick = None if self._fits(cap) else self._pick_captured(cap)
+        if pick is not None:
+            if pick != self.captured_capacity:
+                self._activate(pick)     # another captured capacity serves this estimate: no capture, no device work
+        elif not self._fits(cap):
             self.captured_capacity = cap
             try:
                 self._capture()

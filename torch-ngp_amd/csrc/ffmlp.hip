@@ -1939,6 +1939,11 @@ static int launch_forward(const void* inputs, const void* weights, uint32_t B, u
     // matmul by matmul (k_ffmlp_forward_layered)
     if (WIDTH > 128 || lds > 152 * 1024 || (flags & NGP_FF_LAYERED))
         return launch_forward_layered<WIDTH, TRAIN>(inputs, weights, B, in_dim, num_layers, act, out_act, fwd, outputs, flags, st);
+    // (256-wide layers never get here: the register-resident kernel is not even instantiated for them -- it would need 128 accumulator
+    // and 64 operand registers per lane and spilled 29-176 of them)
+    if constexpr (WIDTH > 128) {
+        return NGP_ERR_INVALID;
+    } else {
     // the specialisation without the other activations' code is a fifth of the size (instruction fetch at kernel start matters for a
     // 25 us kernel)
     const bool plain = act == ACT_RELU && out_act == ACT_NONE;
@@ -1962,6 +1967,7 @@ static int launch_forward(const void* inputs, const void* weights, uint32_t B, u
     hipError_t e = hipLaunchKernel(kern, dim3(blocks), dim3(FF_THREADS), args, lds, st);
     NGP_REQUIRE(e == hipSuccess, NGP_ERR_LAUNCH, "ffmlp: kernel launch failed: %s", hipGetErrorString(e));
     return check_launch(TRAIN ? "ffmlp_forward" : "ffmlp_inference");
+    }
 }
 
 // layered backward: dgrad chain (dZ of every layer into backward_buffer, dL/dx) + the weight-gradient kernel

@@ -398,6 +398,7 @@ class TrainingRun:
                 # RCCL build refuses one of them (reduce_scatter_tensor with AVG on fp16, in-place all_gather_into_tensor), every rank sees
                 # the same exception and the run continues with the replicated update instead of dying
                 try:
+                    optimizer.poison_shards()
                     optimizer.reduce_gradients()
                     optimizer.gather_shadows()
                     optimizer.wait_shadows()
@@ -1039,7 +1040,7 @@ def main():
         if rank == 0:
             traffic, traffic_source, measured = None, None, False
             if args.pmc and world == 1:
-                tail = [f for f in ('--no-lookahead', '--no-graph', '--no-fused', '--torch-optim', '--autograd') if f in sys.argv[1:]]
+                tail = [f for f in ('--no-lookahead', '--no-graph', '--no-fused', '--torch-optim', '--autograd', '--no-fused-adam') if f in sys.argv[1:]]
                 traffic, traffic_source = measure_pmc_traffic(tail)
                 measured = traffic is not None
             if traffic is None:

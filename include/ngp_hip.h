@@ -516,7 +516,8 @@ int ngp_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
  * overwrite_table), so it is left as it is (and a skipped step does not touch the tensor at all); params_fp16[k]
  * (optional, may be NULL per tensor or as a whole) receives the fp16 copy of the updated weights.
  * state = device float[8]: {loss scale, growth tracker, found_inf, Adam step count, lr multiplier, table parity (ngp_table_adam_t), ticket of
- * ngp_optim_adam_small_commit (0 between launches), -};
+ * ngp_optim_adam_small_commit (0 between launches), scale_dead (sticky: set by COMMIT once the loss scale has underflowed -- 1 / scale not
+ * finite -- after which every step is skipped: the run is dead and says so)};
  * no host sync.
  * grad_mult: extra factor on the gradients (1 / world_size after a SUM all-reduce).  A step over more than 8 tensors uses
  * ngp_optim_adam_step_ex below (phases), which keeps "a non-finite gradient anywhere skips the whole step" across calls; for

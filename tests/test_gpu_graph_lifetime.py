@@ -7,7 +7,7 @@ host to be 60 us ahead of the device by chance:
 
   * the shipped close() (called by __del__) waits for the side stream: the drop takes as long as the spin, and memory allocated afterwards is
     never written by the dropped stepper's kernels;
-  * WITHOUT the wait (`_unsafe_skip_close`, tools/graph_lifetime_probe.py in a subprocess per arm: a memory fault must not take pytest down)
+  * WITHOUT the wait (a subclass whose close() does nothing, tools/graph_lifetime_probe.py in a subprocess per arm: a memory fault must not take pytest down)
     the release STILL waits: destroying a HIP graph whose replay is in flight blocks until that replay has finished (measured on MI355X,
     ROCm 7.0 / PyTorch 2.10: the drop takes the whole spin, with and without an empty_cache() behind it), and nothing that is allocated
     afterwards is written.  The theory is therefore DEAD: a released stepper cannot have caused the three events (EXPERIMENTS.md round 5);

@@ -62,6 +62,8 @@ def test_fused_flush_is_the_separate_adam_sweep_bit_for_bit():
         x = torch.rand(M, 3, device=dev, generator=gen)
         x[: M // 2] = x[: M // 2] * 0.2 + 0.4        # half of the points clustered: long same-entry runs on the coarse levels
         g_enc = (torch.randn(16, M, 2, device=dev, generator=gen) * 0.05).half()
+        if it == 1:
+            g_enc = (g_enc.float() * 200).half()      # contributions of ~10: slice sums beyond 128 take the other scaling of the fixed-point addend
         if it == 3:
             g_enc[7, 123, 1] = float('inf')           # a non-finite table gradient: the step is skipped as a whole
         if it == 5:

@@ -29,6 +29,8 @@ KERNELS = {  # substring of the kernel name (first match wins) -> (label used by
     'k_ffmlp_backward_paired<64, 1, 2': ('ffmlp_backward (colour net)', 2.0),
     'k_ffmlp_backward': ('ffmlp_backward', 2.0),
     'k_march_train_wave': ('march_rays_train (+ near/far)', 1.0),
+    # (round 6: what is left of the optimizer step when the table's Adam sweep rides in k_grid_backward_accumulate; listed BEFORE 'k_adam': first match wins)
+    'k_adam_small_commit': ('k_adam_small_commit (dense table levels + MLP weights + scaler commit + parity flip)', 2.0),
     'k_adam': ('k_adam (Adam + scaler + shadows + gradient zeroing)', 2.0),   # 16-byte streaming reads: doubled
     'k_composite_train_loss_bwd': ('composite + loss + backward', 2.0),
     'k_composite_train_fwd': ('composite_rays_train_forward', 2.0),

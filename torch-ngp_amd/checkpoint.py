@@ -74,16 +74,29 @@ def _all_ranks_here(optimizer, timeout_s=60.0, use_store=None):
     store = dist.distributed_c10d._get_default_store()
     world = dist.get_world_size(group)
     ranks = dist.get_process_group_ranks(group) if group is not None else list(range(world))
-    optimizer._roll_calls = getattr(optimizer, '_roll_calls', 0) + 1     # every rank counts its own calls: the n-th call meets the n-th call
-    key = f'ngp_checkpoint_roll_call/{ranks[0]}-{ranks[-1]}x{world}/{optimizer._roll_calls}'
-    store.add(key, 1)
+    # The round is agreed on THROUGH THE STORE, not counted per rank (a rank whose earlier call timed out or raised would be one
+    # call ahead of the others for ever, and two optimizers on one group shared their keys): `epoch` names the round that is open; the rank
+    # that completes a round moves the epoch on and deletes the round's counter.  A rank that arrives reads the epoch first, so a caller
+    # that comes back after a failed round joins the round the others are in.
+    base = f'ngp_checkpoint_roll_call/{ranks[0]}-{ranks[-1]}x{world}'
+    epoch = int(store.add(base + '/epoch', 0))
+    key = f'{base}/{epoch}'
+    here = int(store.add(key, 1))
+    if here >= world:                      # the last one in: open the next round, drop this one's counter behind the others' last look
+        store.add(base + '/epoch', 1)
     deadline = time.monotonic() + timeout_s
     while True:
-        here = int(store.add(key, 0))
-        if here >= world:
+        if int(store.add(base + '/epoch', 0)) > epoch:
+            if here >= world:
+                try:
+                    store.delete_key(key)
+                except Exception:  # noqa: BLE001 -- a store without delete: the key stays (a few bytes per checkpoint)
+                    pass
             return
         if time.monotonic() > deadline:
-            raise RuntimeError(complaint + f'{here} of {world} rank(s) arrived within {timeout_s:.0f} s')
+            seen = int(store.add(key, 0))
+            store.add(key, -1)             # take this rank out of the round again: a later, complete call must not count it twice
+            raise RuntimeError(complaint + f'{seen} of {world} rank(s) arrived within {timeout_s:.0f} s')
         time.sleep(0.002)
 
 

@@ -981,7 +981,6 @@ struct BinPlan {
     uint32_t lc[NGP_MAX_LEVELS][BIN_LC_WORDS];
     uint32_t n_chunks;                   // chunks (BIN_PPB samples) per level
     uint32_t n_levels;                   // binned levels
-    uint8_t acc_order[NGP_MAX_LEVELS];   // accumulate launch: grid row r serves binned level acc_order[r]
     // interleaved = 0: bin = index >> 12 (contiguous slices); 1: bin = index & 127 (dense levels, see above)
     __host__ __device__ __forceinline__ uint32_t level(uint32_t li) const { return lc[li][0]; }
     __host__ __device__ __forceinline__ uint32_t n_bins(uint32_t li) const { return lc[li][1]; }
@@ -1494,7 +1493,11 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     uint32_t* head_at = reinterpret_cast<uint32_t*>(run_table + WAVES * 64);                                // [WAVES][64] run (1-based) whose first pair sits at this lane of the window
     // levels in REVERSE order: the sort wrote the last level's records last, so they are the ones still in the memory-side cache
     // (same-box A/B: -4 us per iteration)
-    const uint32_t li = plan.acc_order[blockIdx.y - slab_row], bin = blockIdx.x;
+    // (Round 6 tried other row orders through a byte table in the plan -- dense levels first / alternating, to stagger the flush phases of the
+    // Adam-carrying workgroups: no gain, and the table made `li` the result of a VECTOR load: every address derived from it moved to vector
+    // registers and the kernel's results stopped being reproducible at loss-scaled magnitudes (tests/test_gpu_grid.py caught it; cause not
+    // found).  The row order is this formula again; EXPERIMENTS.md.)
+    const uint32_t li = plan.n_levels - 1u - (blockIdx.y - slab_row), bin = blockIdx.x;
     if (bin >= plan.n_bins(li)) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = (int)__builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 2 * BIN_SLICE; i += ACC_THREADS) acc[i] = 0ull;
@@ -2118,24 +2121,6 @@ static int launch_backward_bins(const void* grad, const float* inputs, const int
     const uint32_t blocks = persistent + ap.n_blocks;
     BinPlan bins = p.bins;
     bins.n_levels = p.n_binned;
-    {   // row order of the accumulate launch.  Default: levels in REVERSE (the sort wrote the last level's records last: still in the memory-side cache)
-        static const int order_mode = getenv("NGP_ACC_ORDER") ? atoi(getenv("NGP_ACC_ORDER")) : 0;   // experiment knob (EXPERIMENTS.md round 6)
-        uint32_t r = 0;
-        std::vector<uint32_t> dense, hashed;
-        for (uint32_t i = p.n_binned; i-- > 0;) (bins.interleaved(i) ? dense : hashed).push_back(i);
-        if (order_mode == 1) {          // dense levels first (short workgroups of unequal length: the hashed rounds behind them start staggered)
-            for (uint32_t i : dense) bins.acc_order[r++] = (uint8_t)i;
-            for (uint32_t i : hashed) bins.acc_order[r++] = (uint8_t)i;
-        } else if (order_mode == 2) {   // alternate hashed / dense
-            size_t a = 0, b = 0;
-            while (a < hashed.size() || b < dense.size()) {
-                if (a < hashed.size()) bins.acc_order[r++] = (uint8_t)hashed[a++];
-                if (b < dense.size()) bins.acc_order[r++] = (uint8_t)dense[b++];
-            }
-        } else {
-            for (uint32_t i = p.n_binned; i-- > 0;) bins.acc_order[r++] = (uint8_t)i;
-        }
-    }
     if (bins_cap <= 128u)
         hipLaunchKernelGGL((k_grid_backward_bin<D, AMERGE, 2>), dim3(blocks), dim3(BIN_THREADS), bin_smem, st, (const half_t*)grad, inputs, offsets,
                            (half_t*)grad_emb, B, lv, gridtype, ac, interp, im, bins, descriptors, records, ap);

@@ -228,6 +228,9 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
 // growth_interval, scale *= growth (only if the result is finite) and tracker = 0.  Also commits the Adam step count.
 __device__ __forceinline__ void update_scale(float* state, float growth, float backoff, float growth_interval, bool flip_parity = false) {
     if (state[2] != 0.0f || !__builtin_isfinite(1.0f / state[0])) {   // (an underflowed scale counts as an overflow: see k_adam)
+        // GradScaler has no lower bound either: a scale that has underflowed stays 0 and every later step is skipped -- the run is dead,
+        // silently.  state[7] is the signal (sticky): optim.NGPAdam.scale_is_dead() / bench.py report it.
+        if (!__builtin_isfinite(1.0f / state[0])) state[7] = 1.0f;
         state[0] *= backoff;
         state[1] = 0.0f;
     } else {

@@ -147,8 +147,6 @@ class GraphedTrainStep:
         the situation deterministic (tests/test_gpu_graph_lifetime.py, tools/graph_lifetime_probe.py: side stream held by a spin kernel) and
         found that the graph destruction ITSELF waits for the replay on this runtime -- no use-after-free with or without this method.  It
         stays as the explicit statement of the ordering (and for runtimes that do not wait).  Called by __del__."""
-        if getattr(self, '_unsafe_skip_close', False):
-            return   # tests/test_gpu_graph_lifetime.py only: the arm of the lifetime reproducer that releases the graphs WITHOUT waiting
         side = getattr(self, 'la_side', None)
         try:
             # this object may be collected by the cyclic GC while ANOTHER stepper is inside a stream capture (ADVICE r4): a synchronize (or

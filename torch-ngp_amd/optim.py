@@ -201,6 +201,11 @@ class NGPAdam:
     def get_scale(self):
         return float(self.scalars[0].item())
 
+    def scale_is_dead(self):
+        """True once the loss scale has underflowed (a long run of overflowing steps halved it to 0 / a denormal): from then on every step is
+        skipped -- as with GradScaler, which has no lower bound either -- and nothing else would say so (one host read of scalars[7])"""
+        return bool(self.scalars[7].item() != 0.0)
+
     def set_lr_scale(self, factor):
         """multiplies every group's lr (what the reference's LambdaLR does, main_nerf.py:137); a device write, valid under graph replay"""
         self.scalars[4:5].fill_(float(factor))
@@ -293,6 +298,9 @@ class NGPAdam:
         of the flat gradient, so that the reduce-scatter hands the verdict to every rank; capturable (one tiny launch), a no-op otherwise"""
         if self.verdict == 'poison':
             self._poison_launch()
+            if self.flat_grad16.is_cuda and torch.cuda.is_current_stream_capturing():
+                self._poison_captured = True   # part of a graph: every replay issues it
+            self._poisoned = True   # (host-side: reduce_gradients() refuses to run without it -- at capture time for a captured step)
 
     def _poison_launch(self):
         capi.check(capi.lib.ngp_optim_poison_shards(self.flat_grad16.data_ptr(), self.world_size, self.payload, self.scalars.data_ptr(), capi.stream()))
@@ -306,6 +314,12 @@ class NGPAdam:
         """ONE reduce-scatter: every rank receives the average of its shard of the flat fp16 gradient.  verdict='allreduce': the per-rank
         found_inf verdicts are combined (MAX) by a second, 4-byte collective so that a step is skipped on all ranks or on none;
         verdict='poison': the reduce-scatter itself carried the verdict (poison_shards before it, apply() reads it)"""
+        if self.verdict == 'poison' and not getattr(self, '_poisoned', False):
+            # ADVICE r5: without poison_shards() in front of it the exchange carries NO skip verdict -- the rank that saw the overflow would
+            # skip and back off alone, the others would update: parameters and loss scales diverge silently.  (A captured rest graph that ends
+            # in poison_shards() sets the flag once, at capture time, and keeps it: the launch is part of every replay.)
+            raise RuntimeError("NGPAdam.reduce_gradients: verdict='poison' needs poison_shards() between the local non-finite sweep and the "
+                               "reduce-scatter (step() and graph.GraphedTrainStep issue it); verdict='allreduce' exchanges the verdict itself")
         view = self.flat_grad16.view(self.world_size, self.payload)
         if self._avg_native():
             dist.reduce_scatter_tensor(self.shard_grad, self.flat_grad16, op=dist.ReduceOp.AVG, group=self.group)
@@ -345,6 +359,8 @@ class NGPAdam:
         self._launch([], capi.NGP_OPT_PHASE_COMMIT, 0.0)
         if zero:
             self.flat_grad16.zero_()
+        if not (self.flat_grad16.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._poisoned = getattr(self, '_poison_captured', False)   # an eager step consumed its poison launch; a captured one replays it
         for p in self.flat_params:   # zeroed: clean, whatever an overwriting producer announced; kept: stale until overwritten / cleaned
             p._ngp_deposit_overwritten = False
             p._ngp_grad16_stale = not zero

@@ -449,6 +449,28 @@ int ngp_composite_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t 
 int ngp_compact_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, uint32_t max_steps, const int32_t* rays_alive,
                          int32_t* out_alive, int32_t* out_state, void* workspace, ngp_stream_t stream);
 
+/* n iterations of the eval loop (renderer.py:341-367: march_rays -> network -> composite_rays -> compaction of the alive list) issued by ONE
+ * call -- EXTENSION: ngp_march_rays_dev -> ngp_grid_encode_forward_sched -> ngp_network_forward (inference, density scale
+ * folded) -> ngp_composite_rays_dev -> ngp_compact_rays_dev per iteration, on the ping-pong alive lists / device state of the *_dev entry
+ * points (iteration i works on state[(first_cur + i) & 1] and leaves the compacted list in the other one).  Launches are sized by `lanes`
+ * and `rows` (host values: the caller's last known alive count); rows beyond the device-side count are zero rows, lanes beyond it idle.
+ * `noises` (may be NULL) is handed to the first iteration of the call only.  Same kernels, arguments and order as the per-stage calls: the
+ * image is the same, bit for bit.  Sample buffers xyzs / dirs [rows,3], deltas [rows,2], sigmas [rows], rgbs [rows,3] fp32 and enc
+ * [L,rows,2] fp16 are caller-provided scratch; the network tensors are the fp16 copies (embeddings [n,2], w_sigma, w_color flat). */
+typedef struct ngp_render_loop {
+    int32_t* state;                 /* [2][2] {alive rays, steps marched} */
+    int32_t* alive[2];
+    float* rays_t; const float* rays_o; const float* rays_d; const float* nears; const float* fars; const uint8_t* grid; const float* noises;
+    float* xyzs; float* dirs; float* deltas; void* enc; float* sigmas; float* rgbs;
+    const void* embeddings; const int32_t* offsets; const float* level_cost_host; const void* w_sigma; const void* w_color;
+    float* weights_sum; float* depth; float* image; void* compact_workspace;
+    uint32_t lanes, rows, n_total, n_step_cap, max_steps, cascade, grid_size;
+    uint32_t L, H, gridtype, interp, num_layers_sigma, num_layers_color;
+    int32_t align_corners;
+    float bound, dt_gamma, T_thresh, S, density_scale;
+} ngp_render_loop_t;
+int ngp_render_iterations_dev(const ngp_render_loop_t* args, uint32_t n_iter, uint32_t first_cur, ngp_stream_t stream);
+
 /* Empty-ray culling for the inference loop -- EXTENSION (no reference counterpart: renderer.py:330-333 starts every frame with all N rays
  * alive).  ngp_coarse_occupancy: per cascade a (H/4)^3 byte grid (x fastest), 1 when any voxel of the cell's 4^3 block or of one of its 26
  * neighbouring blocks is occupied (ngp_coarse_occupancy_bytes(C, H) bytes).  ngp_cull_rays: rays_alive[n] = n, or -1 for a ray whose segment

@@ -1,6 +1,6 @@
 #!/bin/bash
 # one gpurun call that refreshes the round's evidence on ONE box: gpurun_out/<tag>/...  (copied into profiles/ afterwards)
-tag=${1:-r05_final}
+tag=${1:-r06_final}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
 out=gpurun_out/$tag; mkdir -p $out
@@ -27,7 +27,7 @@ for sc_ in 300 1; do
   python tools/profile_summary.py $out/prof_render_$sc_ "python tools/render_frames.py --scale $sc_ --frames 4 --load <network trained 160 steps> (the trace holds the 4 frames only: divide totals by 4)" > $out/render_summary_$sc_.md 2>/dev/null
   rm -rf $out/prof_render_$sc_
 done
-NGP_HIP_LIBRARY=$(pwd)/torch-ngp_amd/variants/fwd_new_mask/libngp_hip.so timeout 300 python tools/grid_fwd_levels.py --levels > $out/grid_forward_levels.txt 2>&1
+timeout 120 python tools/table_adam_probe.py > $out/table_adam_probe.txt 2>&1
 timeout 300 python tools/graph_lifetime_probe.py > $out/graph_lifetime_probe.txt 2>&1
 timeout 300 python tools/unroll_probe.py > $out/unroll_probe.txt 2>&1
 rocm-smi --showclocks --showpower > $out/box_state_after.txt 2>&1

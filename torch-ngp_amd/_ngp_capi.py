@@ -23,7 +23,7 @@ NGP_F32, NGP_F16 = 0, 1
 NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR, NGP_FF_LAYERED, NGP_FF_SINGLE_WAVE, NGP_FF_DEFER_REDUCE, NGP_FF_RECOMPUTE = 1, 2, 4, 8, 16, 32
 NGP_MARCH_RESET_COUNTER, NGP_MARCH_ZERO_TAIL, NGP_MARCH_NOISE_FROM_SEED, NGP_MARCH_SCAN_LAUNCH = 1, 2, 4, 8
 NGP_OPT_PHASE_CHECK, NGP_OPT_PHASE_UPDATE, NGP_OPT_PHASE_COMMIT, NGP_OPT_PHASE_FLIP = 1, 2, 4, 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -62,6 +62,7 @@ _SIGNATURES = {
     'ngp_march_rays_dev': [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     'ngp_composite_rays_dev': [_vp, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'ngp_compact_rays_dev': [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp],
+    'ngp_render_iterations_dev': [_vp, _u32, _u32, _vp],
     'ngp_ffmlp_forward': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     'ngp_ffmlp_inference': [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     'ngp_ffmlp_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
@@ -155,6 +156,17 @@ class SlabSets(ctypes.Structure):
                 ('slabs_b', ctypes.c_void_p), ('n_slabs_b', ctypes.c_uint32), ('n_params_b', ctypes.c_uint32), ('grad_weights_b', ctypes.c_void_p),
                 ('ray_err', ctypes.c_void_p), ('n_rays', ctypes.c_uint32), ('loss', ctypes.c_void_p), ('overwrite_table', ctypes.c_uint32),
                 ('table_adam', ctypes.c_void_p)]
+
+
+class RenderLoop(ctypes.Structure):
+    """ngp_render_loop_t (include/ngp_hip.h): the argument block of ngp_render_iterations_dev"""
+    _fields_ = ([('state', ctypes.c_void_p), ('alive', ctypes.c_void_p * 2)] +
+                [(n, ctypes.c_void_p) for n in ('rays_t', 'rays_o', 'rays_d', 'nears', 'fars', 'grid', 'noises', 'xyzs', 'dirs', 'deltas', 'enc', 'sigmas',
+                                                'rgbs', 'embeddings', 'offsets', 'level_cost_host', 'w_sigma', 'w_color', 'weights_sum', 'depth', 'image',
+                                                'compact_workspace')] +
+                [(n, ctypes.c_uint32) for n in ('lanes', 'rows', 'n_total', 'n_step_cap', 'max_steps', 'cascade', 'grid_size', 'L', 'H', 'gridtype',
+                                                'interp', 'num_layers_sigma', 'num_layers_color')] +
+                [('align_corners', ctypes.c_int32)] + [(n, ctypes.c_float) for n in ('bound', 'dt_gamma', 'T_thresh', 'S', 'density_scale')])
 
 
 class TableAdam(ctypes.Structure):

@@ -324,14 +324,16 @@ __global__ __launch_bounds__(OPT_SMALL_THREADS) void k_adam_small_commit(OptTens
         }
     }
     // every lane of this workgroup has read state[] (adam_consts, parity) before the workgroup draws its ticket; the last ticket commits
+    // (No __threadfence() around the ticket: on this chip it writes back the XCD's whole dirty L2 -- full of the accumulate's Adam output at
+    // this point -- once per workgroup, and nothing here needs it: what must be ordered are this workgroup's READS of state[], and a
+    // load whose value has been consumed -- every one of them steers a branch above -- cannot be served later; what the last workgroup
+    // writes is for the NEXT launch.  The ticket itself is a device-scope atomic.)
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
-        const float old = atomicAdd(&state[6], 1.0f);
+        const float old = __hip_atomic_fetch_add(&state[6], 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == (float)(gridDim.x - 1u)) {
-            __threadfence();
             update_scale(state, growth, backoff, growth_interval, flip_parity != 0);
-            state[6] = 0.0f;
+            __hip_atomic_store(&state[6], 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -203,3 +203,41 @@ extern "C" int ngp_rays_from_pixels(const float* poses, uint32_t B, float fx, fl
                        (const long long*)inds, inds_batch_stride, N, rays_o, rays_d);
     return check_launch("rays_from_pixels");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The eval loop of NeRFRenderer.run_cuda (renderer.py:341-367), n iterations per call: march -> encode -> network -> composite -> compact,
+// ping-pong alive lists / device state, issued from here -- ONE call where the Python loop made five per iteration plus three allocations
+// (round 5 measured ~95 us of host time per iteration against ~30 us of GPU work in the tail of an opaque frame).  Same kernels, same
+// arguments, same order as the per-stage calls: the image is the same bit for bit.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+extern "C" int ngp_render_iterations_dev(const ngp_render_loop_t* a, uint32_t n_iter, uint32_t first_cur, ngp_stream_t stream) {
+    NGP_REQUIRE(a, NGP_ERR_INVALID, "render_iterations: NULL argument block");
+    NGP_REQUIRE(a->state && a->alive[0] && a->alive[1] && a->rays_t && a->rays_o && a->rays_d && a->nears && a->fars && a->grid, NGP_ERR_INVALID,
+                "render_iterations: NULL ray state");
+    NGP_REQUIRE(a->xyzs && a->dirs && a->deltas && a->enc && a->sigmas && a->rgbs && a->embeddings && a->offsets && a->w_sigma && a->w_color,
+                NGP_ERR_INVALID, "render_iterations: NULL sample buffer / network tensor");
+    NGP_REQUIRE(a->weights_sum && a->depth && a->image && a->compact_workspace, NGP_ERR_INVALID, "render_iterations: NULL accumulator");
+    NGP_REQUIRE(a->rows % 128u == 0u && a->rows > 0u, NGP_ERR_INVALID, "render_iterations: rows must be a positive multiple of 128 (the fused network's tile)");
+    NGP_REQUIRE(first_cur < 2u, NGP_ERR_INVALID, "render_iterations: first_cur is 0 or 1");
+    for (uint32_t i = 0; i < n_iter; i++) {
+        const uint32_t cur = (first_cur + i) & 1u, nxt = cur ^ 1u;
+        const int32_t* st = a->state + 2 * cur;
+        int rc = ngp_march_rays_dev(st, a->lanes, a->n_total, a->n_step_cap, a->alive[cur], a->rays_t, a->rays_o, a->rays_d, a->bound, a->dt_gamma,
+                                    a->max_steps, a->cascade, a->grid_size, a->grid, a->nears, a->fars, a->xyzs, a->dirs, a->deltas,
+                                    i == 0 ? a->noises : nullptr, a->rows, stream);
+        if (rc) return rc;
+        rc = ngp_grid_encode_forward_sched(a->xyzs, a->embeddings, a->offsets, a->enc, a->rows, 3, 2, a->L, a->S, a->H, nullptr, a->gridtype,
+                                           a->align_corners, a->interp, NGP_F16, a->bound, a->level_cost_host, stream);
+        if (rc) return rc;
+        rc = ngp_network_forward(a->enc, a->dirs, a->rows, a->rows, a->w_sigma, a->w_color, a->num_layers_sigma, a->num_layers_color, a->density_scale,
+                                 0, nullptr, nullptr, a->sigmas, nullptr, nullptr, a->rgbs, NGP_FF_INPUT_PLANAR, stream);
+        if (rc) return rc;
+        rc = ngp_composite_rays_dev(st, a->lanes, a->n_total, a->n_step_cap, a->T_thresh, a->alive[cur], a->rays_t, a->sigmas, a->rgbs, a->deltas,
+                                    a->weights_sum, a->depth, a->image, stream);
+        if (rc) return rc;
+        rc = ngp_compact_rays_dev(st, a->lanes, a->n_total, a->n_step_cap, a->max_steps, a->alive[cur], a->alive[nxt], a->state + 2 * nxt,
+                                  a->compact_workspace, stream);
+        if (rc) return rc;
+    }
+    return NGP_OK;
+}

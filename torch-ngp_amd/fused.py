@@ -640,6 +640,26 @@ def fused_density(x, encoder, sigma_net, bound):
     return torch.exp(h16[:, 0].float()), h16[:, 1:]
 
 
+def inference_weights(model, x):
+    """(fp16 table, fp16 sigma weights, fp16 colour weights, network cfg) exactly as `fused_ngp(..., training=False)` would pick them for an
+    inference call on `x` -- the pinned copies of a render call, else the optimizer's shadows -- or None when that call would not run the
+    fused path with plain pointers (ineligible model / dtype state, or a double-buffered table that needs the device-side selection)."""
+    enc, sn, cn = getattr(model, 'encoder', None), getattr(model, 'sigma_net', None), getattr(model, 'color_net', None)
+    if enc is None or sn is None or cn is None or torch.is_grad_enabled():
+        return None
+    probe = torch.empty(128, 3, device=x.device, dtype=torch.float32)
+    if not getattr(model, '_fused_ok', lambda *_: False)(probe, probe):
+        return None
+    params = (enc.embeddings, sn.weights, cn.weights)
+    sh = [getattr(p, '_ngp_fp16_pin', None) for p in params]
+    if any(t is None for t in sh):
+        _resync_stale_shadows(params)
+        sh = [getattr(p, '_ngp_fp16', None) for p in params]
+    if any(t is None for t in sh) or getattr(sh[0], '_ngp_sel', None) is not None:
+        return None
+    return sh[0], sh[1], sh[2], network_cfg(enc, sn, cn, model.bound, False)
+
+
 class pinned_half_weights:
     """`with pinned_half_weights(model):` -- cast the three parameter tensors to fp16 ONCE for a block of inference calls (the eval loop
     of NeRFRenderer.run_cuda evaluates the network ~100 times per frame; the reference path re-casts the 47 MiB table every time,

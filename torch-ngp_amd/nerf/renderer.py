@@ -363,6 +363,49 @@ class NeRFRenderer(nn.Module):
         def pad(rows):
             return rows + 128 - rows % 128  # the marchers' padding rule (raymarching.py:328-331); the fused network wants multiples of 128
 
+        # ONE native call per pair of iterations (round 6, ngp_render_iterations_dev: march -> encode -> network -> composite -> compact twice,
+        # issued from C) where the Python `iteration` above makes ten calls and six allocations -- the tail iterations of an opaque frame carried
+        # ~30 us of GPU work against ~95 us of host issue each.  Same kernels, arguments and order: the image is the same bit for bit
+        # (tests/test_gpu_pipeline.py).  Taken when the network call would run the fused inference path on pinned fp16 weights and nobody is
+        # probing the stages; `native_loop = False` keeps the per-stage calls.
+        native = None
+        if (getattr(self, 'native_loop', True) and getattr(self, '_loop_probe', None) is None and getattr(self, '_loop_iter_hook', None) is None
+                and hasattr(self, 'forward_scaled') and hasattr(capi.lib, 'ngp_render_iterations_dev')):
+            import ctypes
+            import fused
+            w = fused.inference_weights(self, s_o)
+            if w is not None:
+                emb16, ws16, wc16, cfg = w
+                (bound_, L_, S_, H_, gridtype_, align_, interp_, nl_s, nl_c, _) = cfg
+                a = capi.RenderLoop()
+                a.state, a.alive[0], a.alive[1] = state.data_ptr(), alive[0].data_ptr(), alive[1].data_ptr()
+                a.rays_t, a.rays_o, a.rays_d, a.nears, a.fars, a.grid = (s_t.data_ptr(), s_o.data_ptr(), s_d.data_ptr(), s_near.data_ptr(), s_far.data_ptr(),
+                                                                         bits.data_ptr())
+                a.embeddings, a.offsets, a.w_sigma, a.w_color = emb16.data_ptr(), self.encoder.offsets.data_ptr(), ws16.data_ptr(), wc16.data_ptr()
+                a.level_cost_host = capi.ray_level_costs(L_, S_, H_, 3.0 ** 0.5 / (1024.0 * max(float(bound_), 1e-6))) if fused.USE_BALANCED_FORWARD else None
+                a.weights_sum, a.depth, a.image, a.compact_workspace = s_ws.data_ptr(), s_depth.data_ptr(), s_image.data_ptr(), ws.data_ptr()
+                a.max_steps, a.cascade, a.grid_size = int(max_steps), int(self.cascade), int(self.grid_size)
+                a.L, a.H, a.gridtype, a.interp, a.num_layers_sigma, a.num_layers_color = L_, H_, gridtype_, interp_, nl_s, nl_c
+                a.align_corners = align_
+                a.bound, a.dt_gamma, a.T_thresh, a.S, a.density_scale = float(self.bound), float(dt_gamma), float(T_thresh), float(S_), float(self.density_scale)
+                native = (a, (emb16, ws16, wc16), [None])
+
+        def pair(lanes, rows, noises, n_total=n_rays, cap=0):
+            """iterations on state 0 then state 1"""
+            if native is None:
+                iteration(0, lanes, rows, noises, n_total, cap)
+                iteration(1, lanes, rows, None, n_total, cap)
+                return
+            a = native[0]
+            f32 = dict(dtype=torch.float32, device=dev)
+            bufs = (torch.empty(rows, 3, **f32), torch.empty(rows, 3, **f32), torch.empty(rows, 2, **f32),
+                    torch.empty(a.L, rows, 2, dtype=torch.half, device=dev), torch.empty(rows, **f32), torch.empty(rows, 3, **f32))
+            native[2][0] = (bufs, noises)   # (alive until the next pair: the launches are asynchronous)
+            a.xyzs, a.dirs, a.deltas, a.enc, a.sigmas, a.rgbs = [t.data_ptr() for t in bufs]
+            a.noises = None if noises is None else noises.data_ptr()
+            a.lanes, a.rows, a.n_total, a.n_step_cap = int(lanes), int(rows), int(n_total), int(cap)
+            capi.check(capi.lib.ngp_render_iterations_dev(ctypes.cast(ctypes.pointer(a), ctypes.c_void_p), 2, 0, capi.stream()))
+
         # the first two iterations: full-frame sized, kernel-bound, the only ones that may perturb -- issued eagerly
         # Row budget of this first pair: `loop_initial_boost` x N (default 2; 1 = the reference's n_step rule).  With N rows the opaque frame's
         # first iterations march 1 and 2 samples per ray (n_step = N // alive) although every surviving ray has 5-10 to give: twice the
@@ -374,8 +417,7 @@ class NeRFRenderer(nn.Module):
         ib = 1 if perturb else max(1, int(os.environ.get('NGP_LOOP_INITIAL_BOOST', getattr(self, 'loop_initial_boost', 2))))
         full = pad(ib * n_rays)
         noises = torch.rand(n_rays, dtype=torch.float32, device=dev) if perturb else None
-        iteration(0, n_rays, full, noises, ib * n_rays)
-        iteration(1, n_rays, full, None, ib * n_rays)
+        pair(n_rays, full, noises, ib * n_rays)
         done = 2
         use_graphs = getattr(self, 'graph_loop', False) and not cache['failed']
         adaptive = getattr(self, 'adaptive_n_step', True) and not use_graphs
@@ -437,8 +479,7 @@ class NeRFRenderer(nn.Module):
                 if g is not None:
                     g.replay()
                 else:
-                    iteration(0, lanes, rows, None, n_total, 0 if cap == 8 else cap)
-                    iteration(1, lanes, rows, None, n_total, 0 if cap == 8 else cap)
+                    pair(lanes, rows, None, n_total, 0 if cap == 8 else cap)
                 done += 2
                 prev_iters += 2
             batch = min(sync_every, batch * 2) if done >= 6 else batch

@@ -97,8 +97,11 @@ def test_on_device_render_loop_equals_host_driven_loop(density_scale, perturb):
         o, d = sc.rays_for_pixels(pose, pix)
         frames.append((torch.from_numpy(o)[None].to(dev), torch.from_numpy(d)[None].to(dev)))
     res = {}
-    for mode, (on_device, graphs) in {'graphs': (True, True), 'eager': (True, False), 'host': (False, False)}.items():
+    # 'eager': pairs of iterations issued by ONE native call (ngp_render_iterations_dev, round 6); 'stages': the same loop through the per-stage calls
+    for mode, (on_device, graphs) in {'graphs': (True, True), 'eager': (True, False), 'stages': (True, False), 'host': (False, False)}.items():
         model.device_loop, model.graph_loop = on_device, graphs
+        model.native_loop = mode != 'stages'
+        model._loop_native_pairs = 0
         model._loop_cache = None
         model._loop_debug = [] if mode == 'eager' else None
         for k, (ot, dt_) in enumerate(frames):
@@ -111,8 +114,10 @@ def test_on_device_render_loop_equals_host_driven_loop(density_scale, perturb):
             assert max(b for _, _, b, _ in model._loop_debug) >= 4, 'a semi-transparent frame must have raised the row budget'
         if mode == 'graphs':
             assert model._loop_cache['failed'] is False and (len(model._loop_cache['graphs']) > 0 or density_scale > 100)
+        assert model._loop_native_pairs == 0 if mode in ('stages', 'host') else model._loop_native_pairs >= 2, (mode, model._loop_native_pairs)
+    model.native_loop = True
     for k in range(2):
-        for mode in ('graphs', 'eager'):
+        for mode in ('graphs', 'eager', 'stages'):
             assert torch.equal(res[(mode, k)][0], res[('host', k)][0]) and torch.equal(res[(mode, k)][1], res[('host', k)][1]), (mode, k)
         assert float(res[('host', k)][0].std()) > 0
 

@@ -104,7 +104,7 @@ def _table_adam_params(a):
     """table parameters whose Adam sweep one ngp_grid_encode_backward_checked_slabs call carries (0: none)"""
     import ctypes
     import _ngp_capi as capi
-    ss, oh = a[23], a[18]
+    ss, oh = a[22], a[18]
     if not ss or not oh:
         return 0
     sets = ctypes.cast(ss, ctypes.POINTER(capi.SlabSets)).contents
@@ -200,6 +200,14 @@ class KernelTimers:
                 row['mfma'] = {'achieved': round(tf, 2), 'peak': MFMA_F16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_F16_PEAK_TFLOPS, 5)}
             if traffic and label in traffic:
                 row['traffic'] = traffic[label]
+            if label.startswith('grid_encode_backward') and float(byts.mean() / units.mean()) > 1100.5:
+                # the launch also carries the table's Adam sweep (26 B per table parameter): both definitions, side by side
+                g1 = 1100.0 * float(units.mean()) / t / 1e9
+                row['carries_table_adam'] = {'bytes_per_unit_grid_backward': 1100.0, 'bytes_per_unit_table_adam': round(float(byts.mean() / units.mean()) - 1100.0, 1),
+                                             'frac_without_adam_bytes': round(g1 / HBM_PEAK_GBS, 4),
+                                             'note': 'frac counts the 1100 B / point of SURVEY 8(d) PLUS the 26 B per table parameter of the Adam sweep this launch performs '
+                                                     '(master weight and two moments read and written, fp16 shadow written); frac_without_adam_bytes is the old definition on the '
+                                                     'new, longer launch; the separate-kernel figures (--no-fused-adam): grid backward 0.26, k_adam 0.70'}
             if label.startswith('grid_encode_forward'):
                 # what actually bounds the encoder (profiles/r03_grid_forward_pmc.json: L1 hit 69 %, L2 hit 91 %, 37 MB from HBM): the L1's
                 # line rate.  Line requests per point of k_grid_forward_fast on the L16 table: 4 per level (hashed: the x-pair shares an

@@ -490,7 +490,7 @@ extern "C" int ngp_optim_adam_small_commit(int count, const uint64_t* n, float* 
                 "ngp_optim_adam_step_ex", (unsigned long long)total);
     // (every workgroup ends with one atomic on the ticket word: ~100 of them keep that queue short)
     uint32_t blocks = (uint32_t)cdiv64(total, (uint64_t)OPT_SMALL_THREADS * 8);
-    static const uint32_t max_blocks = getenv("NGP_SMALL_COMMIT_BLOCKS") ? (uint32_t)atoi(getenv("NGP_SMALL_COMMIT_BLOCKS")) : 128u;   // experiment knob
+    constexpr uint32_t max_blocks = 128u;   // (swept 88 ... 352 in the training step: 0.416-0.420 ms, no trend)
     blocks = blocks < 1u ? 1u : (blocks > max_blocks ? max_blocks : blocks);
     hipLaunchKernelGGL(k_adam_small_commit, dim3(blocks), dim3(OPT_SMALL_THREADS), 0, as_stream(stream), ts, state, beta1, beta2, eps, grad_mult,
                        growth_factor, backoff_factor, growth_interval, flip_parity, ta, reinterpret_cast<const half_t*>(table_grad_fp16),

@@ -267,18 +267,17 @@ int ngp_grid_encode_backward_checked(const void* grad, const float* inputs, cons
  * untouched -- GradScaler's semantics, exactly.  Readers of the fp16 table select the current set at kernel entry
  * (ngp_grid_encode_forward_sel).  Needs overwrite_table with every level on the record-sort path (else NGP_ERR_INVALID: nothing was
  * launched); the fp16 gradient is rounded exactly as when it is stored, so the result equals ngp_optim_adam_step_ex on the stored gradient
- * bit for bit.  grad_embeddings may be NULL: the table gradient is then not stored at all (when given, it is written as usual).  (The dense
- * levels' entries are dealt to the accumulate's workgroups in groups of 8 adjacent entries, so their flush sweeps with the same 16-byte
- * accesses as a hashed slice; an interim version left them to ngp_optim_adam_small_commit as a table PREFIX: that entry point still takes
- * one -- ngp_grid_table_adam_prefix() entries, 0 since then.) */
+ * bit for bit.  The DENSE levels at the start of the table (their entries are dealt round-robin to the accumulate's workgroups: 8-byte
+ * accesses 1 KiB apart would be all the flush could do for them) are left out: their gradient is stored to grad_embeddings as usual and
+ * ngp_optim_adam_small_commit sweeps that prefix contiguously (same double buffer, verdict already known) -- ngp_grid_table_adam_prefix()
+ * entries.  Behind the prefix grad_embeddings is not written (it may be NULL when the prefix is empty). */
 typedef struct ngp_table_adam {
     float* param[2]; float* exp_avg[2]; float* exp_avg_sq[2]; void* param_fp16[2];   /* [n_entries, C] each; set index = parity */
     const float* state;          /* the optimizer's scalars (ngp_optim_adam_step: state[0] scale, [3] step count, [4] lr multiplier, [5] parity) */
     float lr, beta1, beta2, eps;
 } ngp_table_adam_t;
-/* entries (whole levels) at the start of the table that a backward with table_adam leaves to ngp_optim_adam_small_commit (0: none -- what
- * this library returns for every shape it serves); 0xffffffff: this batch / table shape cannot carry the sweep at all (the backward
- * would refuse table_adam).  Host computation, same plan as the backward. */
+/* entries (whole levels) at the start of the table that a backward with table_adam leaves to ngp_optim_adam_small_commit; 0xffffffff: this
+ * batch / table shape cannot carry the sweep at all (the backward would refuse table_adam).  Host computation, same plan as the backward. */
 uint32_t ngp_grid_table_adam_prefix(const int32_t* offsets_host, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                     uint32_t gridtype, int align_corners, int dtype);
 typedef struct ngp_slab_sets {
@@ -538,7 +537,7 @@ int ngp_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
  * grad_is_half[k] & 2: the producer of that buffer overwrites ALL of it every step (ngp_grid_encode_backward_checked_slabs with
  * overwrite_table), so it is left as it is (and a skipped step does not touch the tensor at all); params_fp16[k]
  * (optional, may be NULL per tensor or as a whole) receives the fp16 copy of the updated weights.
- * state = device float[8]: {loss scale, growth tracker, found_inf, Adam step count, lr multiplier, table parity (ngp_table_adam_t), ticket of
+ * state = device float[8], 16-byte aligned: {loss scale, growth tracker, found_inf, Adam step count, lr multiplier, table parity (ngp_table_adam_t), ticket of
  * ngp_optim_adam_small_commit (0 between launches), scale_dead (sticky: set by COMMIT once the loss scale has underflowed -- 1 / scale not
  * finite -- after which every step is skipped: the run is dead and says so)};
  * no host sync.

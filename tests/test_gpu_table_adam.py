@@ -43,7 +43,7 @@ def _backward(enc, g_enc, x, opt, fused_adam):
     if fused_adam:   # (what fused._mark_table_adam leaves for the optimizer's closing launch: the dense-level prefix is its part)
         arr = capi.host_offsets(enc.offsets)
         prefix = int(capi.lib.ngp_grid_table_adam_prefix(ctypes.cast(arr, ctypes.c_void_p), M, 3, 2, 16, S, 16, enc.gridtype_id, 0, capi.NGP_F16))
-        assert prefix == 0     # (an interim version left the dense levels 0-4 to the closing launch as a prefix; their bins sweep them now)
+        assert 0 < prefix < 0xffffffff and prefix == int(enc.offsets[5])     # levels 0-4 of the lego table are dense
         emb._ngp_table_adam_prefix = prefix
         emb._ngp_table_adam_done = True
 

@@ -968,20 +968,9 @@ constexpr int BIN_RESIDENT = NGP_BIN_RESIDENT;                 // persistent sor
 #endif
 constexpr int ACC_THREADS = NGP_ACC_THREADS;
 // Dense levels: samples cluster where the scene is, so contiguous slices would be very unevenly loaded (and a 4913-entry level would
-// have two of them).  Their entries are dealt round-robin to BIN_DENSE_BINS workgroups instead -- since round 6 in GROUPS of 8 adjacent
-// entries (64 bytes of an fp32 [n, 2] array: one cache line per lane quad), so that the flush of a bin can carry the table's Adam sweep with
-// the same 16-byte accesses as a hashed slice (entry by entry the bins touched 8 bytes at a stride of 1 KiB: 45 us):
-//   bin = (index >> 3) & 127,   slot = ((index >> 10) << 3) | (index & 7),   index = ((slot >> 3) << 10) | (bin << 3) | (slot & 7)
+// have two of them).  Their entries are dealt round-robin to BIN_DENSE_BINS workgroups instead: bin = index mod 128, slot = index / 128.
 constexpr int BIN_DENSE_BITS = 7;
 constexpr int BIN_DENSE_BINS = 1 << BIN_DENSE_BITS;
-constexpr int BIN_DENSE_GROUP_BITS = 3;
-__host__ __device__ __forceinline__ uint32_t dense_bin_of(uint32_t index) { return (index >> BIN_DENSE_GROUP_BITS) & (uint32_t)(BIN_DENSE_BINS - 1); }
-__host__ __device__ __forceinline__ uint32_t dense_slot_of(uint32_t index) {
-    return ((index >> (BIN_DENSE_BITS + BIN_DENSE_GROUP_BITS)) << BIN_DENSE_GROUP_BITS) | (index & ((1u << BIN_DENSE_GROUP_BITS) - 1u));
-}
-__host__ __device__ __forceinline__ uint32_t dense_index_of(uint32_t bin, uint32_t slot) {
-    return ((slot >> BIN_DENSE_GROUP_BITS) << (BIN_DENSE_BITS + BIN_DENSE_GROUP_BITS)) | (bin << BIN_DENSE_GROUP_BITS) | (slot & ((1u << BIN_DENSE_GROUP_BITS) - 1u));
-}
 
 constexpr int BIN_LC_WORDS = 12;
 struct BinPlan {
@@ -992,7 +981,7 @@ struct BinPlan {
     uint32_t lc[NGP_MAX_LEVELS][BIN_LC_WORDS];
     uint32_t n_chunks;                   // chunks (BIN_PPB samples) per level
     uint32_t n_levels;                   // binned levels
-    // interleaved = 0: bin = index >> 12 (contiguous slices); 1: bin = dense_bin_of(index) (dense levels, see above)
+    // interleaved = 0: bin = index >> 12 (contiguous slices); 1: bin = index & 127 (dense levels, see above)
     __host__ __device__ __forceinline__ uint32_t level(uint32_t li) const { return lc[li][0]; }
     __host__ __device__ __forceinline__ uint32_t n_bins(uint32_t li) const { return lc[li][1]; }
     __host__ __device__ __forceinline__ bool interleaved(uint32_t li) const { return (lc[li][2] & 1u) != 0u; }
@@ -1136,7 +1125,7 @@ template <bool FAST>
 __device__ __forceinline__ uint32_t bin_counter_addr(uint32_t addr, const BinItem& it, uint32_t row_base) {  // LDS byte address of the bin's counter
     // (rows are 512-byte aligned: the base is ORed in)
     if constexpr (FAST) return ((addr >> (BIN_SLICE_BITS - 2)) & (uint32_t)((BIN_MAX_BINS - 1) << 2)) | row_base;
-    else return ((it.interleaved ? dense_bin_of(addr) : (addr >> BIN_SLICE_BITS)) << 2) | row_base;
+    else return ((it.interleaved ? (addr & (uint32_t)(BIN_DENSE_BINS - 1)) : (addr >> BIN_SLICE_BITS)) << 2) | row_base;
 }
 
 // Lanes of a corner slot that CONTINUE the run of the lane below them: same table index, both live, same 16-lane row (`pairs` holds the
@@ -1239,7 +1228,7 @@ __device__ __forceinline__ void bin_pass_place(uint32_t gbits, const BinItem& it
         for (int d = 1; d < D; d++) w *= bl.wp[d][(s >> d) & 1];
         float v0 = w * g0, v1 = w * g1;
         const LaneMask m = bin_run_mask(addr, pairs);
-        uint32_t key = FAST ? (addr & (uint32_t)(BIN_SLICE - 1)) : (it.interleaved ? dense_slot_of(addr) : (addr & (uint32_t)(BIN_SLICE - 1)));
+        uint32_t key = FAST ? (addr & (uint32_t)(BIN_SLICE - 1)) : (it.interleaved ? (addr >> BIN_DENSE_BITS) : (addr & (uint32_t)(BIN_SLICE - 1)));
         if (m.any()) {  // segmented inclusive scan: the last lane of a run ends up with the run's sum
             seg_scan_rows(v0, v1, m);
             // a run of up to 16 finite fp16-range terms can leave the fp16 range although the sum over the whole batch need not: such a
@@ -1480,6 +1469,9 @@ void k_grid_backward_bin(const half_t* __restrict__ grad, const float* __restric
 // table that used to follow (k_adam: 61 us, HBM-bound) is exactly the kind of stream that fits under a latency-bound kernel.  The update is
 // speculative -- parameters / moments of buffer set state[5] are read, the OTHER set is written; the commit flips the parity only when no
 // gradient of the step was non-finite -- and uses the fp16-rounded gradient, i.e. the bits k_adam would have read from the stored table.
+#ifndef NGP_TADAM_STORE_GRADIENT
+#define NGP_TADAM_STORE_GRADIENT 0
+#endif
 #ifndef NGP_TADAM_PROBE
 #define NGP_TADAM_PROBE 0   // timing probes only (tools/table_adam_probe.py): 1 = no Adam on the round-robin bins of the dense levels, 2 = no stores, 4 = no loads
 #endif
@@ -1520,13 +1512,13 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
     const bool interleaved = plan.interleaved(li);
     // ADAM: the slice's master weights and moments are REQUESTED HERE, in front of the record walk, and consumed by the flush behind it --
     // the walk is bound by latency (descriptors -> record windows), the requests ride under it; the step's constants (two powf, a sqrt,
-    // a division) are computed under the same latency and parked in LDS.  The round-robin bins of the dense levels take part like the hashed
-    // slices since they own GROUPS of 8 adjacent entries (dense_index_of): with single entries 128 apart -- 8-byte accesses at a stride of
-    // 1 KiB -- they cost 45 of the first version's 94 us, and an interim version left them to the closing launch (13.6 us there).
+    // a division) are computed under the same latency and parked in LDS.  The round-robin bins of the dense levels (entries 128 apart: 8-byte
+    // accesses at a stride of 1 KiB) do NOT take part: their flush stores the gradient as usual and the step's closing launch
+    // (ngp_optim_adam_small_commit) sweeps that prefix of the table contiguously -- measured: 45 of the fused flush's 94 us were those bins.
     constexpr int TRIPS = BIN_SLICE / (2 * ACC_THREADS);
     static_assert(BIN_SLICE % (2 * ACC_THREADS) == 0, "slice entries divide evenly over lane pairs");
     float* adam_lds = reinterpret_cast<float*>(head_at + WAVES * 64);   // [4]: inv_scale, step_size, bc2_sqrt, source set
-    const bool adam_here = ADAM;   // (every level since the dense levels' bins own groups of 8 adjacent entries)
+    const bool adam_here = ADAM && !interleaved;
     float4_t pp[TRIPS], pm[TRIPS], pv[TRIPS];
     bool wide[TRIPS];
     // (requested in FRONT of the walk, straight-line.  Requesting behind the first two record windows -- so that the descriptors and those
@@ -1542,8 +1534,7 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
             const float* __restrict__ v_in = ta.v[src] + (size_t)off0_ * 2;
 #pragma unroll
             for (int k = 0; k < TRIPS; k++) {
-                const uint32_t i_ = 2u * ((uint32_t)tid + (uint32_t)k * ACC_THREADS);
-                const uint32_t e0 = interleaved ? dense_index_of(bin, i_) : bin * BIN_SLICE + i_;   // (slots 2j, 2j + 1: adjacent entries either way)
+                const uint32_t e0 = bin * BIN_SLICE + 2u * ((uint32_t)tid + (uint32_t)k * ACC_THREADS);
                 wide[k] = e0 + 1u < size_ && ((off0_ + e0) & 1u) == 0u;   // a 16-byte aligned pair of entries inside the level
                 pp[k] = pm[k] = pv[k] = float4_t{0.0f, 0.0f, 0.0f, 0.0f};
                 if (wide[k] && !(NGP_TADAM_PROBE & 4)) {
@@ -1692,12 +1683,10 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
             float* __restrict__ m_out = ta.m[dst] + (size_t)off0 * 2;
             float* __restrict__ v_out = ta.v[dst] + (size_t)off0 * 2;
             half_t* __restrict__ h_out = ta.p16[dst] + (size_t)off0 * 2;
-            uint32_t tid_f = (uint32_t)tid;
-            asm volatile("" : "+v"(tid_f));   // (recomputed here: addresses carried from the request in front of the walk cost the 65th register)
 #pragma unroll
             for (int k = 0; k < TRIPS; k++) {
-                const uint32_t i = 2u * (tid_f + (uint32_t)k * ACC_THREADS);
-                const uint32_t e0 = interleaved ? dense_index_of(bin, i) : bin * BIN_SLICE + i;
+                const uint32_t i = 2u * ((uint32_t)tid + (uint32_t)k * ACC_THREADS);
+                const uint32_t e0 = bin * BIN_SLICE + i;
                 const bool ok0 = e0 < hashmap_size, ok1 = e0 + 1u < hashmap_size;
                 if (!wide[k]) {
                     const float* __restrict__ p_in = ta.p[src] + (size_t)off0 * 2;
@@ -1737,21 +1726,22 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
                     __builtin_nontemporal_store(pv[k], reinterpret_cast<float4_t*>(v_out + (size_t)e0 * 2));
                     __builtin_nontemporal_store(pp[k], reinterpret_cast<float4_t*>(p_out + (size_t)e0 * 2));
                     *reinterpret_cast<half4_t*>(h_out + (size_t)e0 * 2) = h16;
-                    if (grad_grid) *reinterpret_cast<half4_t*>(gtable + e0) = g16;
+                    // (the gradient is consumed right here: it is not stored -- 23 MB of writes per step; -DNGP_TADAM_STORE_GRADIENT for debugging)
+                    if (NGP_TADAM_STORE_GRADIENT && grad_grid) *reinterpret_cast<half4_t*>(gtable + e0) = g16;
                 } else {
                     if (ok0) {
                         *reinterpret_cast<float2_t*>(m_out + (size_t)e0 * 2) = float2_t{pm[k].x, pm[k].y};
                         *reinterpret_cast<float2_t*>(v_out + (size_t)e0 * 2) = float2_t{pv[k].x, pv[k].y};
                         *reinterpret_cast<float2_t*>(p_out + (size_t)e0 * 2) = float2_t{pp[k].x, pp[k].y};
                         *reinterpret_cast<half2_t*>(h_out + (size_t)e0 * 2) = half2_t{h16[0], h16[1]};
-                        if (grad_grid) gtable[e0] = half2_t{g16[0], g16[1]};
+                        if (NGP_TADAM_STORE_GRADIENT && grad_grid) gtable[e0] = half2_t{g16[0], g16[1]};
                     }
                     if (ok1) {
                         *reinterpret_cast<float2_t*>(m_out + (size_t)e0 * 2 + 2) = float2_t{pm[k].z, pm[k].w};
                         *reinterpret_cast<float2_t*>(v_out + (size_t)e0 * 2 + 2) = float2_t{pv[k].z, pv[k].w};
                         *reinterpret_cast<float2_t*>(p_out + (size_t)e0 * 2 + 2) = float2_t{pp[k].z, pp[k].w};
                         *reinterpret_cast<half2_t*>(h_out + (size_t)e0 * 2 + 2) = half2_t{h16[2], h16[3]};
-                        if (grad_grid) gtable[e0 + 1u] = half2_t{g16[2], g16[3]};
+                        if (NGP_TADAM_STORE_GRADIENT && grad_grid) gtable[e0 + 1u] = half2_t{g16[2], g16[3]};
                     }
                 }
             }
@@ -1772,7 +1762,7 @@ __global__ __launch_bounds__(ACC_THREADS) __attribute__((amdgpu_waves_per_eu(8, 
 #pragma unroll
     for (int k = 0; k < PER_THREAD; k++) {
         const uint32_t i = (uint32_t)tid + (uint32_t)k * ACC_THREADS;
-        ent[k] = interleaved ? dense_index_of(bin, i) : bin * BIN_SLICE + i;
+        ent[k] = interleaved ? (i << BIN_DENSE_BITS) + bin : bin * BIN_SLICE + i;
         sum0[k] = (long long)acc[2 * i];
         sum1[k] = (long long)acc[2 * i + 1];
         badb[k] = (poison[i >> 4] >> ((i & 15u) * 2u)) & 3u;
@@ -2413,7 +2403,11 @@ extern "C" uint32_t ngp_grid_table_adam_prefix(const int32_t* offsets_host, uint
     BackwardPlan plan;
     plan_backward(plan, offsets_host, lv, B, D, C, L, dtype, gridtype, align_corners != 0, true);
     if (plan.n_atomic != 0 || plan.n_binned != L || dtype != NGP_F16 || C != 2) return 0xffffffffu;
-    return 0u;   // (round 6, final form: the dense levels' bins own groups of adjacent entries and carry their part of the sweep themselves)
+    uint32_t k = 0;
+    while (k < L && plan.bins.interleaved(k)) k++;
+    for (uint32_t j = k; j < L; j++)
+        if (plan.bins.interleaved(j)) return 0xffffffffu;
+    return (uint32_t)offsets_host[k];   // (binned levels are listed in level order when every level is binned: index == level)
 }
 
 template <typename T>
@@ -2493,6 +2487,18 @@ extern "C" int ngp_grid_encode_backward_checked_slabs(const void* grad, const fl
                     "grid_encode_backward: table_adam needs overwrite_table and every level on the record-sort path (fp16, C = 2, >= %u samples, "
                     "a workspace and the host offsets)", BIN_MIN_SAMPLES);
         NGP_REQUIRE(tadam->state, NGP_ERR_INVALID, "grid_encode_backward: table_adam without the optimizer's state");
+        {   // the dense levels' round-robin bins leave their entries to ngp_optim_adam_small_commit: they must form a prefix of the table
+            // (ngp_grid_table_adam_prefix tells the caller how long it is), and their gradient has to be stored for it
+            uint32_t k = 0;
+            while (k < plan.n_binned && plan.bins.interleaved(k)) k++;
+            for (uint32_t j = k; j < plan.n_binned; j++)
+                NGP_REQUIRE(!plan.bins.interleaved(j), NGP_ERR_INVALID, "grid_encode_backward: table_adam: a dense level behind a hashed one (level %u)",
+                            plan.bins.level(j));
+            NGP_REQUIRE(k == 0 || grad_embeddings, NGP_ERR_INVALID, "grid_encode_backward: table_adam: the dense levels' gradient needs grad_embeddings");
+        }
+        for (int k = 0; k < 2; k++)
+            NGP_REQUIRE(tadam->param[k] && tadam->exp_avg[k] && tadam->exp_avg_sq[k] && tadam->param_fp16[k], NGP_ERR_INVALID,
+                        "grid_encode_backward: table_adam: NULL buffer in set %d", k);
         plan.adam = true;
         for (int k = 0; k < 2; k++) {
             plan.table_adam.p[k] = tadam->param[k]; plan.table_adam.m[k] = tadam->exp_avg[k]; plan.table_adam.v[k] = tadam->exp_avg_sq[k];

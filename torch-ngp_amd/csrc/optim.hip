@@ -227,27 +227,34 @@ __global__ __launch_bounds__(OPT_THREADS) void k_adam(OptTensors ts, const float
 // torch.amp.GradScaler.update (_amp_update_scale_): found_inf -> scale *= backoff, tracker = 0; else tracker += 1 and, when it reaches
 // growth_interval, scale *= growth (only if the result is finite) and tracker = 0.  Also commits the Adam step count.
 __device__ __forceinline__ void update_scale(float* state, float growth, float backoff, float growth_interval, bool flip_parity = false) {
-    if (state[2] != 0.0f || !__builtin_isfinite(1.0f / state[0])) {   // (an underflowed scale counts as an overflow: see k_adam)
+    // (all eight words are read in ONE request and the changed ones written back: written as read-modify-writes of single words this was a
+    // chain of six dependent memory round trips -- 4 us of a 4 us kernel)
+    float4_t a = *reinterpret_cast<const float4_t*>(state), b = *reinterpret_cast<const float4_t*>(state + 4);
+    float scale = a.x, tracker = a.y, t = a.w, parity = b.y, dead = b.w;
+    const bool scale_dead = !__builtin_isfinite(1.0f / scale);
+    if (a.z != 0.0f || scale_dead) {   // (an underflowed scale counts as an overflow: see k_adam)
         // GradScaler has no lower bound either: a scale that has underflowed stays 0 and every later step is skipped -- the run is dead,
         // silently.  state[7] is the signal (sticky): optim.NGPAdam.scale_is_dead() / bench.py report it.
-        if (!__builtin_isfinite(1.0f / state[0])) state[7] = 1.0f;
-        state[0] *= backoff;
-        state[1] = 0.0f;
+        if (scale_dead) dead = 1.0f;
+        scale *= backoff;
+        tracker = 0.0f;
     } else {
-        state[3] += 1.0f;
-        const float tr = state[1] + 1.0f;
+        t += 1.0f;
+        const float tr = tracker + 1.0f;
         if (tr >= growth_interval) {
-            const float grown = state[0] * growth;
-            if (__builtin_isfinite(grown)) state[0] = grown;
-            state[1] = 0.0f;
+            const float grown = scale * growth;
+            if (__builtin_isfinite(grown)) scale = grown;
+            tracker = 0.0f;
         } else {
-            state[1] = tr;
+            tracker = tr;
         }
         // the step stands: the buffer set the grid backward wrote speculatively (ngp_table_adam_t) becomes the current one.  A skipped
         // step leaves the parity -- and with it the table, its moments and its fp16 shadow -- exactly as they were.
-        if (flip_parity) state[5] = state[5] != 0.0f ? 0.0f : 1.0f;
+        if (flip_parity) parity = parity != 0.0f ? 0.0f : 1.0f;
     }
-    state[2] = 0.0f;
+    *reinterpret_cast<float4_t*>(state) = float4_t{scale, tracker, 0.0f, t};
+    state[5] = parity;
+    state[7] = dead;
 }
 __global__ void k_update_scale(float* __restrict__ state, float growth, float backoff, float growth_interval, int flip_parity) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -263,12 +270,17 @@ constexpr int OPT_SMALL_THREADS = 1024;
 __global__ __launch_bounds__(OPT_SMALL_THREADS) void k_adam_small_commit(OptTensors ts, float* __restrict__ state, float beta1, float beta2, float eps,
                                                                         float grad_mult, float growth, float backoff, float growth_interval,
                                                                         int flip_parity, TableAdam ta, const half_t* __restrict__ tgrad,
-                                                                        uint64_t tprefix) {
+                                                                        uint64_t tprefix, uint32_t prefix_blocks) {
     const AdamConsts ac = adam_consts(state, beta1, beta2, grad_mult);
     const float bc2_sqrt = ac.bc2_sqrt;
     const float beta1_s = beta1, beta2_s = beta2, eps_s = eps;   // (the small tensors'; the table prefix brings its own in `ta` -- the same values)
-    const uint64_t gtid = (uint64_t)blockIdx.x * OPT_SMALL_THREADS + threadIdx.x, gstride = (uint64_t)gridDim.x * OPT_SMALL_THREADS;
-    if (tprefix && !ac.skip) {   // (a skipped step writes nothing: the current set stays what it is, the other one is never read)
+    // two kinds of workgroups -- the first `prefix_blocks` sweep the table prefix, the others the small tensors -- so that the two dependent
+    // load -> store chains run side by side instead of one behind the other in every lane
+    const bool prefix_role = blockIdx.x < prefix_blocks;
+    const uint32_t role_blocks = prefix_role ? prefix_blocks : gridDim.x - prefix_blocks;
+    const uint64_t gtid = (uint64_t)(prefix_role ? blockIdx.x : blockIdx.x - prefix_blocks) * OPT_SMALL_THREADS + threadIdx.x;
+    const uint64_t gstride = (uint64_t)role_blocks * OPT_SMALL_THREADS;
+    if (prefix_role && tprefix && !ac.skip) {   // (a skipped step writes nothing: the current set stays what it is, the other one is never read)
         const uint32_t src = state[5] != 0.0f ? 1u : 0u, dst = src ^ 1u;
         const float step_size = ta.lr * ac.lr_mult / ac.bc1;
         beta1 = ta.beta1; beta2 = ta.beta2; eps = ta.eps;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(OPT_SMALL_THREADS) void k_adam_small_commit(OptTens
             if (two) { m_out[j] = pm1; v_out[j] = pv1; p_out[j] = pp1; h_out[j] = ph1; }
         }
     }
-    for (int k = 0; k < ts.count; k++) {
+    for (int k = 0; !prefix_role && k < ts.count; k++) {
         const uint64_t n = ts.n[k];
         const float step_size = ts.lr[k] * ac.lr_mult / ac.bc1;
         float* __restrict__ p = ts.p[k];
@@ -389,6 +401,7 @@ extern "C" int ngp_optim_adam_step_ex(int count, const uint64_t* n, float* const
                                       float beta2, float eps, float grad_mult, float growth_factor, float backoff_factor, float growth_interval,
                                       float* state, float* const* ema, float ema_one_minus_decay, uint32_t phases, ngp_stream_t stream) {
     NGP_REQUIRE(state, NGP_ERR_INVALID, "optim_adam_step: NULL state");
+    NGP_REQUIRE((reinterpret_cast<uintptr_t>(state) & 15u) == 0, NGP_ERR_INVALID, "optim_adam_step: state (8 floats) must be 16-byte aligned");
     NGP_REQUIRE((phases & ~15u) == 0 && (phases & 7u) != 0, NGP_ERR_INVALID, "optim_adam_step: phases must be a non-empty subset of CHECK|UPDATE|COMMIT (+FLIP)");
     NGP_REQUIRE(!(phases & NGP_OPT_PHASE_FLIP) || (phases & NGP_OPT_PHASE_COMMIT), NGP_ERR_INVALID, "optim_adam_step: FLIP rides in the COMMIT phase");
     hipStream_t st = as_stream(stream);
@@ -451,6 +464,7 @@ extern "C" int ngp_optim_adam_small_commit(int count, const uint64_t* n, float* 
                                            float growth_interval, float* state, int flip_parity, const ngp_table_adam_t* table,
                                            const void* table_grad_fp16, uint64_t table_prefix_params, ngp_stream_t stream) {
     NGP_REQUIRE(state, NGP_ERR_INVALID, "optim_adam_small_commit: NULL state");
+    NGP_REQUIRE((reinterpret_cast<uintptr_t>(state) & 15u) == 0, NGP_ERR_INVALID, "optim_adam_small_commit: state (8 floats) must be 16-byte aligned");
     NGP_REQUIRE(count >= 0 && count <= OPT_MAX_TENSORS, NGP_ERR_INVALID, "optim_adam_small_commit: at most %d tensors per call (got %d)", OPT_MAX_TENSORS,
                 count);
     NGP_REQUIRE(count == 0 || (n && params && exp_avg && exp_avg_sq && grads && grad_is_half && lr), NGP_ERR_INVALID,
@@ -489,12 +503,14 @@ extern "C" int ngp_optim_adam_small_commit(int count, const uint64_t* n, float* 
     NGP_REQUIRE(total <= (1u << 22), NGP_ERR_INVALID, "optim_adam_small_commit: %llu parameters -- this entry serves small tensors (<= 4 M); use "
                 "ngp_optim_adam_step_ex", (unsigned long long)total);
     // (every workgroup ends with one atomic on the ticket word: ~100 of them keep that queue short)
-    uint32_t blocks = (uint32_t)cdiv64(total, (uint64_t)OPT_SMALL_THREADS * 8);
-    constexpr uint32_t max_blocks = 128u;   // (swept 88 ... 352 in the training step: 0.416-0.420 ms, no trend)
-    blocks = blocks < 1u ? 1u : (blocks > max_blocks ? max_blocks : blocks);
-    hipLaunchKernelGGL(k_adam_small_commit, dim3(blocks), dim3(OPT_SMALL_THREADS), 0, as_stream(stream), ts, state, beta1, beta2, eps, grad_mult,
-                       growth_factor, backoff_factor, growth_interval, flip_parity, ta, reinterpret_cast<const half_t*>(table_grad_fp16),
-                       table_prefix_params);
+    // workgroups of two kinds (see the kernel): one trip per lane where the cap allows it -- eight prefix parameters, one small-tensor element
+    uint32_t prefix_blocks = (uint32_t)cdiv64(table_prefix_params, (uint64_t)OPT_SMALL_THREADS * 8);
+    if (prefix_blocks > 192u) prefix_blocks = 192u;
+    uint32_t small_blocks = (uint32_t)cdiv64(total - table_prefix_params, (uint64_t)OPT_SMALL_THREADS);
+    small_blocks = small_blocks < 1u ? 1u : (small_blocks > 32u ? 32u : small_blocks);   // (>= 1: somebody has to draw the last ticket)
+    hipLaunchKernelGGL(k_adam_small_commit, dim3(prefix_blocks + small_blocks), dim3(OPT_SMALL_THREADS), 0, as_stream(stream), ts, state, beta1, beta2, eps,
+                       grad_mult, growth_factor, backoff_factor, growth_interval, flip_parity, ta, reinterpret_cast<const half_t*>(table_grad_fp16),
+                       table_prefix_params, prefix_blocks);
     return check_launch("optim_adam_small_commit");
 }
 

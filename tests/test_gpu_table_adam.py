@@ -226,6 +226,14 @@ def test_graphed_training_with_fused_table_adam_is_the_same_training(lookahead, 
         if fuse:
             assert opt.fused_table is model.encoder.embeddings
         emb = model.encoder.embeddings
+        # the Trainer's parameter EMA (torch_ema surface) reads and writes the torch Parameters: it has to see / leave the CURRENT table
+        from optim import NGPEma
+        ema = NGPEma([p for p in model.parameters() if p.requires_grad], 0.95, optimizer=opt)   # (reads the parameters: materializes)
+        ema.update()
+        ema.store()
+        ema.copy_to()
+        ema.restore()
+        ema_sum = [float(t.double().sum()) for t in ema.shadow_params]
         state = checkpoint.save_checkpoint(str(tmp_path / f'ck_{fuse}.pth'), model, optimizer=opt, full=True)   # materializes
         assert float(opt.scalars[5]) == 0.0
         assert torch.equal(emb._ngp_fp16, emb.detach().half())
@@ -246,7 +254,7 @@ def test_graphed_training_with_fused_table_adam_is_the_same_training(lookahead, 
             frame = model.render(batches[0][0], batches[0][1], staged=False, bg_color=1, perturb=False, max_steps=1024)['image'].clone()
         params = [p.detach().clone() for p in (emb, model.sigma_net.weights, model.color_net.weights)]
         runs[fuse] = (losses, params, float(opt.scalars[0]), float(opt.scalars[3]), state['model']['encoder.embeddings'].clone(),
-                      [m.clone() for m in sd['exp_avg']], means, frame)
+                      [m.clone() for m in sd['exp_avg']], means, frame, ema_sum)
         st.close()
     a, b = runs[True], runs[False]
     assert a[2] == b[2] and a[3] == b[3] and a[3] < 43
@@ -260,3 +268,4 @@ def test_graphed_training_with_fused_table_adam_is_the_same_training(lookahead, 
     for x, y in zip(a[1], b[1]):
         assert torch.equal(x, y)
     assert torch.equal(a[7], b[7])
+    assert a[8] == b[8]

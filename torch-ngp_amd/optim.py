@@ -675,6 +675,8 @@ class NGPEma:
     def _complete_params(self):
         """sharded optimizer: the fp32 parameters this rank does not own are stale between steps -- complete them first (collective)"""
         opt = self.optimizer
+        if opt is not None and hasattr(opt, 'materialize'):
+            opt.materialize()   # a table with two buffer sets (enable_table_fusion): the torch Parameter becomes the current one
         if opt is not None and getattr(opt, 'shard', False):
             opt.wait_shadows()
             opt.gather_master()
@@ -698,6 +700,8 @@ class NGPEma:
 
     @torch.no_grad()
     def copy_to(self):
+        if self.optimizer is not None and hasattr(self.optimizer, 'materialize'):
+            self.optimizer.materialize()   # BEFORE the parameters are written (else the sync below would copy set B over them)
         for s_, p in zip(self.shadow_params, self.params):
             p.copy_(s_)  # bumps the version counter: stale fp16 shadows are detected by fused._resync_stale_shadows
         if self.optimizer is not None:
@@ -712,6 +716,8 @@ class NGPEma:
     def restore(self):
         if self.collected_params is None:
             raise RuntimeError('This ExponentialMovingAverage has no `store()`ed weights to `restore()`')
+        if self.optimizer is not None and hasattr(self.optimizer, 'materialize'):
+            self.optimizer.materialize()
         for c, p in zip(self.collected_params, self.params):
             p.copy_(c)
         if self.optimizer is not None:

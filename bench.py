@@ -67,7 +67,7 @@ TIMED = {
     'ngp_ffmlp_backward': ('ffmlp_backward', 4, lambda a: _ff_bwd_bytes(a[8]), lambda a: 2.0 * _ff_flops(a[8]), 'sample'),
     'ngp_grid_encode_forward_ex': ('grid_encode_forward', 4, lambda a: 588.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_forward_sched': ('grid_encode_forward', 4, lambda a: 588.0, lambda a: 0.0, 'point'),
-    'ngp_grid_encode_forward_sel': ('grid_encode_forward', 6, lambda a: 588.0, lambda a: 0.0, 'point'),   # (double-buffered table: optim.NGPAdam.enable_table_fusion)
+    'ngp_grid_encode_forward_sel': ('grid_encode_forward', 7, lambda a: 588.0, lambda a: 0.0, 'point'),   # (double-buffered table: optim.NGPAdam.enable_table_fusion)
     'ngp_grid_encode_backward_ex': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_ws': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),
     'ngp_grid_encode_backward_checked': ('grid_encode_backward', 5, lambda a: 1100.0, lambda a: 0.0, 'point'),

@@ -223,11 +223,13 @@ int ngp_grid_encode_forward_sched(const float* inputs, const void* embeddings, c
 /* ngp_grid_encode_forward_sched for a DOUBLE-BUFFERED fp16 table (ngp_table_adam_t): the kernel reads *parity (a device float: the
  * optimizer's state[5]) at entry and gathers from `embeddings` when it is 0, from `embeddings_alt` otherwise -- the selection is made on the
  * device, so a captured HIP graph follows the commit / skip decisions of the steps replayed before it.  embeddings_alt == NULL or parity ==
- * NULL: ngp_grid_encode_forward_sched.  dy_dx must be NULL (the inference / fused-training forward). */
+ * NULL: ngp_grid_encode_forward_sched.  dy_dx must be NULL (the inference / fused-training forward).
+ * rows_dev (optional device word, independent of the table selection): only the first min(B, *rows_dev) points are encoded -- the launch is sized
+ * for B, workgroups behind the device-side count leave at once (the eval loop's emitted-row count, ngp_march_rays_dev_rows). */
 int ngp_grid_encode_forward_sel(const float* inputs, const void* embeddings, const void* embeddings_alt, const float* parity,
-                                const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                                uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound, const float* level_cost_host,
-                                ngp_stream_t stream);
+                                const uint32_t* rows_dev, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
+                                const float* level_cost_host, ngp_stream_t stream);
 
 /* diagnostic: the per-XCD work lists ngp_grid_encode_forward_sched would launch for L levels of `tiles` tiles each (host computation):
  * 8 x 8 segments (level, first tile, cumulative slot end; level 0xffff = unused); returns the slots of the longest list (0 on bad arguments) */
@@ -359,6 +361,13 @@ int ngp_network_forward(const void* enc, const float* dirs, uint32_t M, uint32_t
                         void* forward_buffer_sigma, void* h16, float* sigma, void* color_in, void* forward_buffer_color, float* rgb,
                         uint32_t flags, ngp_stream_t stream);
 
+/* ngp_network_forward whose launch is sized for M rows but evaluates only the first ceil(*rows_dev / 32) tiles (rows_dev: optional device word, the
+ * eval loop's emitted-row count; NULL: ngp_network_forward).  Buffer strides follow M. */
+int ngp_network_forward_rows(const void* enc, const float* dirs, uint32_t M, uint32_t M_valid, const void* w_sigma, const void* w_color,
+                             uint32_t num_layers_sigma, uint32_t num_layers_color, float density_scale, int training,
+                             void* forward_buffer_sigma, void* h16, float* sigma, void* color_in, void* forward_buffer_color, float* rgb,
+                             uint32_t flags, const uint32_t* rows_dev, ngp_stream_t stream);
+
 /* Extensions for the fused training iteration (the backward of network_ff.py:40-74):
  *  - ngp_network_backward_color = ngp_ffmlp_backward_ex of the colour MLP (32 -> 64 x (n-1) -> 16, ReLU, n = 2 or 3) whose input-gradient
  *    epilogue writes the sigma net's output gradient grad_h16 [M,16] directly (what ngp_pipeline_mid_backward would assemble from
@@ -443,6 +452,13 @@ int ngp_march_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_to
                        const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
                        const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                        const float* noises, uint32_t rows, ngp_stream_t stream);
+/* ngp_march_rays_dev that also PUBLISHES the rows that can carry a sample in this iteration (rows_used: device word = min(rows, n_alive * n_step
+ * padded by the marchers' rule); only those rows are zero-filled) for consumers that are launched for a stale bound and stop at the device-side
+ * count (ngp_grid_encode_forward_sel, ngp_network_forward_rows).  rows_used == NULL: ngp_march_rays_dev. */
+int ngp_march_rays_dev_rows(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, const int32_t* rays_alive, const float* rays_t,
+                            const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                            const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                            const float* noises, uint32_t rows, uint32_t* rows_used, ngp_stream_t stream);
 int ngp_composite_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, float T_thresh, int32_t* rays_alive, float* rays_t,
                            const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image,
                            ngp_stream_t stream);
@@ -464,6 +480,7 @@ typedef struct ngp_render_loop {
     float* xyzs; float* dirs; float* deltas; void* enc; float* sigmas; float* rgbs;
     const void* embeddings; const int32_t* offsets; const float* level_cost_host; const void* w_sigma; const void* w_color;
     float* weights_sum; float* depth; float* image; void* compact_workspace;
+    uint32_t* rows_used;            /* optional device word: the encoder / network launches stop at the rows the march of the same iteration emitted */
     uint32_t lanes, rows, n_total, n_step_cap, max_steps, cascade, grid_size;
     uint32_t L, H, gridtype, interp, num_layers_sigma, num_layers_color;
     int32_t align_corners;

@@ -68,7 +68,7 @@ _SIGNATURES = {
     'ngp_ffmlp_backward': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp],
     'ngp_grid_encode_forward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
     'ngp_grid_encode_forward_sched': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _u32, _i32, _u32, _i32, _f32, _vp, _vp],
-    'ngp_grid_encode_forward_sel': [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _u32, _i32, _f32, _vp, _vp],
+    'ngp_grid_encode_forward_sel': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _u32, _i32, _u32, _i32, _f32, _vp, _vp],
     'ngp_grid_encode_backward_ex': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp],
     'ngp_grid_encode_backward_ws': [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _f32, _u32, _vp, _vp, _u32, _i32, _u32, _i32, _f32, _vp, _vp,
                                     _sz, _vp],
@@ -83,6 +83,8 @@ _SIGNATURES = {
     'ngp_ffmlp_backward_ex': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp],
     'ngp_ffmlp_backward_ws': [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _u32, _vp, _sz, _vp],
     'ngp_network_forward': [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    'ngp_network_forward_rows': [_vp, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp],
+    'ngp_march_rays_dev_rows': [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _f32, _f32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp],
     'ngp_pipeline_mid_forward': [_vp, _vp, _vp, _vp, _u32, _u32, _f32, _vp],
     'ngp_pipeline_rgb_forward': [_vp, _vp, _u32, _vp],
     'ngp_pipeline_rgb_backward': [_vp, _vp, _vp, _u32, _vp],
@@ -163,7 +165,7 @@ class RenderLoop(ctypes.Structure):
     _fields_ = ([('state', ctypes.c_void_p), ('alive', ctypes.c_void_p * 2)] +
                 [(n, ctypes.c_void_p) for n in ('rays_t', 'rays_o', 'rays_d', 'nears', 'fars', 'grid', 'noises', 'xyzs', 'dirs', 'deltas', 'enc', 'sigmas',
                                                 'rgbs', 'embeddings', 'offsets', 'level_cost_host', 'w_sigma', 'w_color', 'weights_sum', 'depth', 'image',
-                                                'compact_workspace')] +
+                                                'compact_workspace', 'rows_used')] +
                 [(n, ctypes.c_uint32) for n in ('lanes', 'rows', 'n_total', 'n_step_cap', 'max_steps', 'cascade', 'grid_size', 'L', 'H', 'gridtype',
                                                 'interp', 'num_layers_sigma', 'num_layers_color')] +
                 [('align_corners', ctypes.c_int32)] + [(n, ctypes.c_float) for n in ('bound', 'dt_gamma', 'T_thresh', 'S', 'density_scale')])

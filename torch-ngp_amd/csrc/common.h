@@ -162,6 +162,7 @@ struct TableAdam {
 struct TableSel {
     const _Float16* alt;
     const float* parity;
+    const uint32_t* rows;   // optional device word: only the first min(B, *rows) points carry work (the eval loop's emitted-row count)
 };
 
 // ---- fixed-order sum of per-workgroup fp32 weight-gradient slabs (the FFMLP backward's deferred reduction), TWO sets per launch ----

@@ -481,15 +481,18 @@ template <bool TRAIN, int WAVES /* per workgroup: they share one pair of weight 
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(NT == 1 ? 4 : 2, NT == 1 ? 4 : 3))) void k_network_forward(
     const half_t* __restrict__ enc, bool enc_planar, const float* __restrict__ dirs, uint32_t M_valid, const half_t* __restrict__ w_sigma,
     const half_t* __restrict__ w_color, half_t* __restrict__ fb_s, half_t* __restrict__ h16, float* __restrict__ sigma,
-    half_t* __restrict__ color_in, half_t* __restrict__ fb_c, float* __restrict__ rgb, uint32_t n_tiles, uint32_t nl_s, uint32_t nl_c,
-    float density_scale) {
+    half_t* __restrict__ color_in, half_t* __restrict__ fb_c, float* __restrict__ rgb, uint32_t n_tiles_cap, uint32_t nl_s, uint32_t nl_c,
+    float density_scale, const uint32_t* __restrict__ rows_dev) {
     constexpr int WIDTH = 64, NIB = 2, NKB = 4;
     constexpr uint32_t in_kb = 2;  // both networks take 32 inputs
+    // n_tiles_cap: the buffers' rows / 32 (strides of the planar input and of the stored activations); n_tiles: the tiles that carry work --
+    // all of them, or (rows_dev: the eval loop's device-side count of emitted rows) the first ceil(*rows_dev / 32)
+    const uint32_t n_tiles = rows_dev ? min(n_tiles_cap, (rows_dev[0] + (uint32_t)FF_TILE - 1u) / (uint32_t)FF_TILE) : n_tiles_cap;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     half8_t* img_s = reinterpret_cast<half8_t*>(smem);
     const uint32_t frags_s = NIB * in_kb + (nl_s - 1) * NIB * NKB + NKB;
     half8_t* img_c = img_s + (size_t)frags_s * 64;
-    const size_t rows = (size_t)n_tiles * FF_TILE;
+    const size_t rows = (size_t)n_tiles_cap * FF_TILE;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int n = lane & 31, h = lane >> 5;
     const uint32_t n_groups = (n_tiles + NT - 1) / NT;   // a wave iteration = NT consecutive tiles (the last group repeats the last tile)
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(NT =
     build_forward_image<WIDTH>(img_c, w_color, 32, nl_c);
     __syncthreads();
 
-    const size_t layer_stride = (size_t)n_tiles * NKB * 64;  // half8 units
+    const size_t layer_stride = (size_t)n_tiles_cap * NKB * 64;  // half8 units
     const half8_t* s_l0 = img_s + lane;
     const half8_t* s_hid = s_l0 + (size_t)NIB * in_kb * 64;
     const half8_t* s_out = s_hid + (size_t)(nl_s - 1) * NIB * NKB * 64;
@@ -2297,6 +2300,14 @@ extern "C" int ngp_network_forward(const void* enc, const float* dirs, uint32_t 
                                    uint32_t num_layers_sigma, uint32_t num_layers_color, float density_scale, int training,
                                    void* forward_buffer_sigma, void* h16, float* sigma, void* color_in, void* forward_buffer_color,
                                    float* rgb, uint32_t flags, ngp_stream_t stream) {
+    return ngp_network_forward_rows(enc, dirs, M, M_valid, w_sigma, w_color, num_layers_sigma, num_layers_color, density_scale, training,
+                                    forward_buffer_sigma, h16, sigma, color_in, forward_buffer_color, rgb, flags, nullptr, stream);
+}
+
+extern "C" int ngp_network_forward_rows(const void* enc, const float* dirs, uint32_t M, uint32_t M_valid, const void* w_sigma, const void* w_color,
+                                        uint32_t num_layers_sigma, uint32_t num_layers_color, float density_scale, int training,
+                                        void* forward_buffer_sigma, void* h16, float* sigma, void* color_in, void* forward_buffer_color,
+                                        float* rgb, uint32_t flags, const uint32_t* rows_dev, ngp_stream_t stream) {
     NGP_REQUIRE(M % 128 == 0, NGP_ERR_INVALID, "network_forward: sample count must be 128 * m, but got %u", M);
     NGP_REQUIRE(num_layers_sigma >= 2 && num_layers_color >= 2, NGP_ERR_INVALID, "network_forward: num_layers should be larger than 2");
     if (M == 0) return NGP_OK;
@@ -2338,11 +2349,11 @@ extern "C" int ngp_network_forward(const void* enc, const float* dirs, uint32_t 
     if (training)
         hipLaunchKernelGGL((k_network_forward<true, TW, TT>), dim3(blocks), dim3(TW * 64), lds, st, (const half_t*)enc, planar, dirs, M_valid, (const half_t*)w_sigma,
                            (const half_t*)w_color, (half_t*)forward_buffer_sigma, (half_t*)h16, sigma, (half_t*)color_in, (half_t*)forward_buffer_color, rgb,
-                           n_tiles, num_layers_sigma, num_layers_color, density_scale);
+                           n_tiles, num_layers_sigma, num_layers_color, density_scale, rows_dev);
     else
         hipLaunchKernelGGL((k_network_forward<false, IW, IT>), dim3(blocks), dim3(IW * 64), lds, st, (const half_t*)enc, planar, dirs, M_valid, (const half_t*)w_sigma,
                            (const half_t*)w_color, (half_t*)nullptr, (half_t*)nullptr, sigma, (half_t*)nullptr, (half_t*)nullptr, rgb, n_tiles,
-                           num_layers_sigma, num_layers_color, density_scale);
+                           num_layers_sigma, num_layers_color, density_scale, rows_dev);
     return check_launch("network_forward");
 }
 

@@ -402,7 +402,9 @@ __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_pair(const float* 
     NGP_BOUNDS((uint64_t)tile * points_per_block < (uint64_t)B);  // every listed tile holds at least one point
 
     const uint32_t b_begin = tile * points_per_block;
-    const uint32_t b_end = min(B, b_begin + points_per_block);
+    const uint32_t B_work = sel.rows ? min(B, sel.rows[0]) : B;   // (device-side row count: the rows behind it carry nothing)
+    if (b_begin >= B_work) return;
+    const uint32_t b_end = min(B_work, b_begin + points_per_block);
     forward_pair_block<T, D, C>(inputs, table, olevel, scale, indexer, hashmap_size, align_corners, interp, im, b_begin, b_end);
 }
 
@@ -473,7 +475,9 @@ __global__ __launch_bounds__(FWD_THREADS) void k_grid_forward_fast(const float* 
     half_t* __restrict__ olevel = outputs + (size_t)level * B * C;
     NGP_BOUNDS((uint64_t)tile * points_per_block < (uint64_t)B);  // every listed tile holds at least one point
     const uint32_t b_begin = tile * points_per_block;
-    const uint32_t b_end = min(B, b_begin + points_per_block);
+    const uint32_t B_work = sel.rows ? min(B, sel.rows[0]) : B;   // (device-side row count: the rows behind it carry nothing)
+    if (b_begin >= B_work) return;
+    const uint32_t b_end = min(B_work, b_begin + points_per_block);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bool dense = !indexer.hashed && !indexer.need_mod && indexer.stride[0] == 1u && indexer.stride[1] != 0u && indexer.stride[2] != 0u;
     const bool hashed_pow2 = indexer.hashed && indexer.mask != 0u;
@@ -2334,16 +2338,17 @@ extern "C" int ngp_grid_encode_forward_sched(const float* inputs, const void* em
                                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, void* dy_dx,
                                              uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
                                              const float* level_cost_host, ngp_stream_t stream) {
-    return grid_encode_forward_impl(inputs, embeddings, TableSel{nullptr, nullptr}, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
+    return grid_encode_forward_impl(inputs, embeddings, TableSel{nullptr, nullptr, nullptr}, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners,
                                     interp, dtype, bound, level_cost_host, stream);
 }
 
 extern "C" int ngp_grid_encode_forward_sel(const float* inputs, const void* embeddings, const void* embeddings_alt, const float* parity,
-                                           const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
-                                           uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
-                                           const float* level_cost_host, ngp_stream_t stream) {
+                                           const uint32_t* rows_dev, const int32_t* offsets, void* outputs, uint32_t B, uint32_t D, uint32_t C,
+                                           uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                           float bound, const float* level_cost_host, ngp_stream_t stream) {
     NGP_REQUIRE(dtype == NGP_F16 || !(embeddings_alt && parity), NGP_ERR_INVALID, "grid_encode_forward_sel: the double-buffered table is fp16");
-    const TableSel sel = embeddings_alt && parity ? TableSel{reinterpret_cast<const _Float16*>(embeddings_alt), parity} : TableSel{nullptr, nullptr};
+    TableSel sel = embeddings_alt && parity ? TableSel{reinterpret_cast<const _Float16*>(embeddings_alt), parity, nullptr} : TableSel{nullptr, nullptr, nullptr};
+    sel.rows = rows_dev;
     return grid_encode_forward_impl(inputs, embeddings, sel, offsets, outputs, B, D, C, L, S, H, nullptr, gridtype, align_corners, interp, dtype,
                                     bound, level_cost_host, stream);
 }
@@ -2365,7 +2370,7 @@ extern "C" int ngp_debug_forward_bad_tile(const float* inputs, const void* embed
     sc.level[0][0] = 0;
     sc.tile0[0][0] = cdiv(B, 1024u);  // one past the last tile
     hipLaunchKernelGGL((k_grid_forward_pair<half_t, 3, 2>), dim3(8u), dim3(FWD_THREADS), 0, as_stream(stream), inputs, (const half_t*)embeddings,
-                       offsets, (half_t*)outputs, B, 2u, lv, 0u, false, 0u, sc, 1024u, InputMap{0.0f, 0.0f}, TableSel{nullptr, nullptr});
+                       offsets, (half_t*)outputs, B, 2u, lv, 0u, false, 0u, sc, 1024u, InputMap{0.0f, 0.0f}, TableSel{nullptr, nullptr, nullptr});
     return check_launch("debug_forward_bad_tile");
 }
 #endif

@@ -222,15 +222,17 @@ extern "C" int ngp_render_iterations_dev(const ngp_render_loop_t* a, uint32_t n_
     for (uint32_t i = 0; i < n_iter; i++) {
         const uint32_t cur = (first_cur + i) & 1u, nxt = cur ^ 1u;
         const int32_t* st = a->state + 2 * cur;
-        int rc = ngp_march_rays_dev(st, a->lanes, a->n_total, a->n_step_cap, a->alive[cur], a->rays_t, a->rays_o, a->rays_d, a->bound, a->dt_gamma,
-                                    a->max_steps, a->cascade, a->grid_size, a->grid, a->nears, a->fars, a->xyzs, a->dirs, a->deltas,
-                                    i == 0 ? a->noises : nullptr, a->rows, stream);
+        // rows_used (optional device word): the march publishes the rows that can carry a sample; the encoder and the network, launched for
+        // `rows` (the caller's stale bound), stop there -- so a batch of iterations may be issued without a read-back in between
+        int rc = ngp_march_rays_dev_rows(st, a->lanes, a->n_total, a->n_step_cap, a->alive[cur], a->rays_t, a->rays_o, a->rays_d, a->bound, a->dt_gamma,
+                                         a->max_steps, a->cascade, a->grid_size, a->grid, a->nears, a->fars, a->xyzs, a->dirs, a->deltas,
+                                         i == 0 ? a->noises : nullptr, a->rows, a->rows_used, stream);
         if (rc) return rc;
-        rc = ngp_grid_encode_forward_sched(a->xyzs, a->embeddings, a->offsets, a->enc, a->rows, 3, 2, a->L, a->S, a->H, nullptr, a->gridtype,
-                                           a->align_corners, a->interp, NGP_F16, a->bound, a->level_cost_host, stream);
+        rc = ngp_grid_encode_forward_sel(a->xyzs, a->embeddings, nullptr, nullptr, a->rows_used, a->offsets, a->enc, a->rows, 3, 2, a->L, a->S, a->H,
+                                         a->gridtype, a->align_corners, a->interp, NGP_F16, a->bound, a->level_cost_host, stream);
         if (rc) return rc;
-        rc = ngp_network_forward(a->enc, a->dirs, a->rows, a->rows, a->w_sigma, a->w_color, a->num_layers_sigma, a->num_layers_color, a->density_scale,
-                                 0, nullptr, nullptr, a->sigmas, nullptr, nullptr, a->rgbs, NGP_FF_INPUT_PLANAR, stream);
+        rc = ngp_network_forward_rows(a->enc, a->dirs, a->rows, a->rows, a->w_sigma, a->w_color, a->num_layers_sigma, a->num_layers_color,
+                                      a->density_scale, 0, nullptr, nullptr, a->sigmas, nullptr, nullptr, a->rgbs, NGP_FF_INPUT_PLANAR, a->rows_used, stream);
         if (rc) return rc;
         rc = ngp_composite_rays_dev(st, a->lanes, a->n_total, a->n_step_cap, a->T_thresh, a->alive[cur], a->rays_t, a->sigmas, a->rgbs, a->deltas,
                                     a->weights_sum, a->depth, a->image, stream);

@@ -794,11 +794,21 @@ __global__ __launch_bounds__(RM_THREADS) void k_march_rays(uint32_t n_alive, uin
                                                            const float* __restrict__ fars, float* __restrict__ xyzs,
                                                            float* __restrict__ dirs, float* __restrict__ deltas,
                                                            const float* __restrict__ noises, uint32_t zero_rows,
-                                                           const int32_t* __restrict__ dev_state, uint32_t n_total, uint32_t n_step_cap) {
+                                                           const int32_t* __restrict__ dev_state, uint32_t n_total, uint32_t n_step_cap,
+                                                           uint32_t* __restrict__ rows_used) {
     const uint32_t n = blockIdx.x * RM_THREADS + threadIdx.x;
     if (dev_state) {  // on-device render loop: the alive count lives on the device, n_step follows the renderer's rule
         n_alive = (uint32_t)dev_state[0];
         n_step = loop_n_step(n_total, n_alive, n_step_cap);
+    }
+    if (rows_used) {
+        // the rows that can carry a sample in this iteration, padded by the marchers' rule (raymarching.py:328-331) -- published for the
+        // encoder / network launches behind this one (ngp_grid_encode_forward_sel, ngp_network_forward_rows), which are sized for the
+        // caller's stale bound and stop here; only these rows are zero-filled
+        const uint32_t used = n_alive * n_step;
+        const uint32_t padded = min(zero_rows, used + 128u - used % 128u);
+        if (n == 0u) rows_used[0] = padded;
+        zero_rows = padded;
     }
     if (zero_rows > 0) {  // padding rows behind the last ray's slots: at most `align` of them, spread over the first lanes
         for (uint32_t row = n_alive * n_step + n; row < zero_rows; row += gridDim.x * RM_THREADS) {
@@ -1606,7 +1616,7 @@ extern "C" int ngp_march_rays_ex(uint32_t n_alive, uint32_t n_step, const int32_
     NGP_REQUIRE(zero_rows == 0 || zero_rows >= n_alive * n_step, NGP_ERR_INVALID, "march_rays: zero_rows is smaller than n_alive * n_step");
     const uint32_t lanes = n_alive > 0 ? n_alive : 1u;
     RM_LAUNCH_1D(k_march_rays, lanes, as_stream(stream), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
-                 max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, zero_rows, (const int32_t*)nullptr, 0u, 0u);
+                 max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises, zero_rows, (const int32_t*)nullptr, 0u, 0u, (uint32_t*)nullptr);
     return check_launch("march_rays");
 }
 
@@ -1677,9 +1687,17 @@ extern "C" int ngp_compact_rays(const int32_t* rays_alive, uint32_t n_alive, int
 // order-preserving compaction as the host-driven loop: identical results.
 // ---------------------------------------------------------------------------------------------
 extern "C" int ngp_march_rays_dev(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, const int32_t* rays_alive, const float* rays_t,
+                                  const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                                  const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                  const float* noises, uint32_t rows, ngp_stream_t stream) {
+    return ngp_march_rays_dev_rows(state, alive_bound, n_total, n_step_cap, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, nears, fars,
+                                   xyzs, dirs, deltas, noises, rows, nullptr, stream);
+}
+
+extern "C" int ngp_march_rays_dev_rows(const int32_t* state, uint32_t alive_bound, uint32_t n_total, uint32_t n_step_cap, const int32_t* rays_alive, const float* rays_t,
                                   const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
                                   uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs,
-                                  float* deltas, const float* noises, uint32_t rows, ngp_stream_t stream) {
+                                  float* deltas, const float* noises, uint32_t rows, uint32_t* rows_used, ngp_stream_t stream) {
     (void)nears;
     int rc = check_march_args("march_rays", C, H, max_steps);
     if (rc) return rc;
@@ -1688,7 +1706,7 @@ extern "C" int ngp_march_rays_dev(const int32_t* state, uint32_t alive_bound, ui
     NGP_REQUIRE(n_step_cap <= 1024u, NGP_ERR_INVALID, "march_rays_dev: n_step_cap must be in [0, 1024] (0 = the reference's 8)");
     const uint32_t lanes = alive_bound > 0 ? alive_bound : 1u;
     RM_LAUNCH_1D(k_march_rays, lanes, as_stream(stream), alive_bound, 1u, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
-                 grid, fars, xyzs, dirs, deltas, noises, rows, state, n_total, n_step_cap);
+                 grid, fars, xyzs, dirs, deltas, noises, rows, state, n_total, n_step_cap, rows_used);
     return check_launch("march_rays_dev");
 }
 

@@ -40,7 +40,7 @@ def _grid_forward(x, emb16, offsets, enc, M, L, S, H, gridtype, align, interp, b
     shadow tensor (`_ngp_sel`): the kernel then picks the current copy itself (ngp_grid_encode_forward_sel) -- valid under graph replay."""
     sel = getattr(emb16, '_ngp_sel', None)
     if sel is not None:
-        _check(capi.lib.ngp_grid_encode_forward_sel(x.data_ptr(), emb16.data_ptr(), sel[0].data_ptr(), sel[1].data_ptr(), offsets.data_ptr(),
+        _check(capi.lib.ngp_grid_encode_forward_sel(x.data_ptr(), emb16.data_ptr(), sel[0].data_ptr(), sel[1].data_ptr(), None, offsets.data_ptr(),
                                                     enc.data_ptr(), M, 3, 2, L, S, H, gridtype, align, interp, capi.NGP_F16, float(bound), costs, st))
     else:
         _check(capi.lib.ngp_grid_encode_forward_sched(x.data_ptr(), emb16.data_ptr(), offsets.data_ptr(), enc.data_ptr(), M, 3, 2, L, S, H,

@@ -388,6 +388,13 @@ class NeRFRenderer(nn.Module):
                 a.L, a.H, a.gridtype, a.interp, a.num_layers_sigma, a.num_layers_color = L_, H_, gridtype_, interp_, nl_s, nl_c
                 a.align_corners = align_
                 a.bound, a.dt_gamma, a.T_thresh, a.S, a.density_scale = float(self.bound), float(dt_gamma), float(T_thresh), float(S_), float(self.density_scale)
+                if getattr(self, 'loop_device_rows', True):
+                    # the march publishes the rows that can carry a sample; the encoder and the network -- launched for the stale host-side
+                    # bound -- stop there (ngp_march_rays_dev_rows / ngp_grid_encode_forward_sel / ngp_network_forward_rows): an oversized
+                    # iteration costs its (mostly empty) launches, not the evaluation of zero rows, so more iterations go between read-backs
+                    if 'rows_used' not in cache:
+                        cache['rows_used'] = torch.zeros(1, dtype=torch.int32, device=dev)
+                    a.rows_used = cache['rows_used'].data_ptr()
                 native = (a, (emb16, ws16, wc16), [None])
 
         def pair(lanes, rows, noises, n_total=n_rays, cap=0):
@@ -489,10 +496,13 @@ class NeRFRenderer(nn.Module):
                     pair(lanes, rows, None, n_total, 0 if cap == 8 else cap)
                 done += 2
                 prev_iters += 2
-            batch = min(sync_every, batch * 2) if done >= 6 else batch
+            device_rows = native is not None and bool(native[0].rows_used)
+            batch = min(sync_every, batch * 2) if done >= 6 else (4 if device_rows else batch)
             bound_alive = int(state[0, 0].item())
             if adaptive and tail_cap > 8 and bound_alive * 16 <= n_rays:
-                batch = 2          # the tail: a pair of iterations now marches up to 2 x cap samples per ray -- look before launching more
+                # the tail: a pair of iterations now marches up to 2 x cap samples per ray -- look before launching more.  With device-side
+                # row counts an iteration that turns out (nearly) empty costs ~25 us of launches, a read-back turnaround 50-80 us: two pairs
+                batch = 4 if device_rows else 2
         if static:
             weights_sum.copy_(s_ws)
             depth.copy_(s_depth)

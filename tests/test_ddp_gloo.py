@@ -491,3 +491,46 @@ def test_underflowed_loss_scale_is_an_overflow_of_its_own_on_the_host_double():
         for p, b in zip(params, before):
             assert torch.isfinite(p).all() and torch.equal(p.detach(), b)
         assert float(opt.scalars[3]) == 0.0 and float(opt.scalars[0]) <= scale and float(opt.scalars[2]) == 0.0
+
+
+def test_double_buffered_table_bookkeeping_on_the_host():
+    """optim.NGPAdam.enable_table_fusion on the host side (the kernels that flip the parity need the GPU: tests/test_gpu_table_adam.py): the
+    second buffer set, the selection handle on the fp16 shadow, materialize() copying set B back when the device word says so -- and only after
+    a fused step was issued --, the hooks that checkpoints / EMA / the drop-in encoder use, and the refusals."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "torch-ngp_amd"))
+    Double = _make_double()
+    torch.manual_seed(0)
+    table, mlp = torch.nn.Parameter(torch.randn(64, 2) * 0.1), torch.nn.Parameter(torch.randn(128) * 0.1)
+    opt = Double([{'params': [table], 'lr': 1e-2}, {'params': [mlp], 'lr': 3e-3}], betas=(0.9, 0.99), eps=1e-15)
+    with pytest.raises(RuntimeError, match='deposit-managed'):
+        opt.enable_table_fusion(torch.nn.Parameter(torch.zeros(4, 2)))
+    opt.enable_table_fusion(table)
+    opt.enable_table_fusion(table)                       # idempotent
+    with pytest.raises(RuntimeError, match='one table'):
+        opt.enable_table_fusion(mlp)
+    alt, st = opt._table_alt, opt.state[table]
+    assert st['fp16']._ngp_sel[0] is alt['p16'] and st['fp16']._ngp_sel[1].data_ptr() == opt.scalars[5:6].data_ptr()
+    assert table._ngp_materialize == opt.materialize
+    before = table.detach().clone()
+    alt['p'].fill_(3.0); alt['m'].fill_(0.5); alt['v'].fill_(0.25); alt['p16'].fill_(3.0)
+    opt.scalars[5] = 1.0
+    opt.materialize()                                    # no fused step was issued: the word is not even read
+    assert torch.equal(table.detach(), before) and float(opt.scalars[5]) == 1.0
+    opt._maybe_flipped = True                            # (what table_adam() records when a fused iteration takes the struct)
+    opt.materialize()
+    assert float(opt.scalars[5]) == 0.0 and not opt._maybe_flipped
+    assert float(table.detach().min()) == 3.0 and float(st['exp_avg'].min()) == 0.5 and float(st['exp_avg_sq'].min()) == 0.25
+    assert float(st['fp16'].float().min()) == 3.0
+    # checkpoint._materialize goes through the hook on the parameter
+    from checkpoint import _materialize
+    alt['p'].fill_(5.0); alt['p16'].fill_(5.0)
+    opt.scalars[5] = 1.0
+    opt._maybe_flipped = True
+    holder = torch.nn.ParameterList([table, mlp])
+    _materialize(holder)
+    assert float(table.detach().min()) == 5.0 and float(opt.scalars[5]) == 0.0
+    # sharded / data-parallel optimizers exchange the gradient first: no fusion
+    sharded = Double([{'params': [torch.nn.Parameter(torch.zeros(8, 2))], 'lr': 1e-2}], world_size=2, shard=False)
+    with pytest.raises(RuntimeError, match='data-parallel'):
+        sharded.enable_table_fusion(sharded.flat_params[0])

@@ -734,6 +734,16 @@ def ddp_overhead_1rank(args, dev, steps):
         out['single_gpu_no_lookahead_ms_per_step'] = round(r['elapsed'] / steps * 1e3, 4)
         del base
         args.no_lookahead = saved
+        # ... and the single-GPU lookahead step with the SEPARATE Adam sweep: the data-parallel step cannot carry the table's sweep in its grid
+        # backward (the gradient is exchanged first), so this -- not the round-6 headline, which saves ~9 us there -- is the step it is built from
+        fa = getattr(args, 'no_fused_adam', False)
+        args.no_fused_adam = True
+        base = one()
+        base.setup(min(args.warmup, 16))
+        r = base.timed(steps)
+        out['single_gpu_lookahead_separate_adam_ms_per_step'] = round(r['elapsed'] / steps * 1e3, 4)
+        del base
+        args.no_fused_adam = fa
         # (the variant that captures RCCL calls inside a HIP graph runs LAST: a refused capture must not disturb the others)
         for name, look, graphed, verdict in (('sharded_lookahead', True, False, 'poison'),
                                              ('sharded_3_replays_no_lookahead', False, False, 'poison'),
@@ -770,6 +780,12 @@ def ddp_overhead_1rank(args, dev, steps):
         args.shard_verdict, args.no_lookahead, args.graph_collectives = 'poison', saved, False
         out['ddp_overhead_ms_per_step'] = round(out['sharded_lookahead']['ms_per_step'] - getattr(args, '_headline_ms', float('nan')), 4)
         out['ddp_overhead_ms_per_step_collectives_in_graph'] = round(out['sharded_lookahead_collectives_in_graph']['ms_per_step'] - getattr(args, '_headline_ms', float('nan')), 4)
+        sep = out['single_gpu_lookahead_separate_adam_ms_per_step']
+        out['ddp_overhead_vs_separate_adam_step_ms'] = {'eager_collectives': round(out['sharded_lookahead']['ms_per_step'] - sep, 4),
+                                                        'collectives_in_graph': round(out['sharded_lookahead_collectives_in_graph']['ms_per_step'] - sep, 4),
+                                                        'note': 'against the single-GPU step the N > 1 step is built from (separate k_adam over the WHOLE table: at N ranks '
+                                                                'that sweep shrinks to 1 / N, 60 -> 8 us at N = 8); ddp_overhead_ms_per_step is against the headline, whose '
+                                                                "table sweep rides in the grid backward (single GPU only)"}
         out['note'] = ('1-rank RCCL group in a process of its own: every collective and every graph boundary of the N > 1 step executes, wire time is zero; '
                        'ddp_overhead = sharded_lookahead (what bench.py --gpus N runs when its canary does not clear the captured collectives) - the headline '
                        'single-GPU step of this run; ..._collectives_in_graph = the form it runs when the canary clears them')

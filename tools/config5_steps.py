@@ -25,10 +25,10 @@ if '--old-glue' in sys.argv:   # same-box A/B of the round-5 glue changes: fp16 
         return 1 if bg_color is None else bg_color
     rnd.NeRFRenderer._background = _background
 args = types.SimpleNamespace(rays=4096, no_graph=False, no_lookahead=True, graph_collectives=False, force_ddp=False, update=16, replicated_optim=False,
-                             shard_verdict='poison')
+                             shard_verdict='poison', no_fused_adam=True)
 dev = torch.device('cuda:0')
 try:
-    run = bench.TrainingRun(args, dev, 1, 0, fused=False, graph=True, torch_optim=True, autograd=True, config5=True)
+    run = bench.TrainingRun(args, dev, 1, 0, fused=False, graph=True, torch_optim='--ngp-adam' not in sys.argv, autograd=True, config5=True)
 except AttributeError as e:   # (an attribute of the argparse namespace this stand-in lacks)
     raise SystemExit(f'tools/config5_steps.py: bench.TrainingRun wants {e}')
 run.setup(4)

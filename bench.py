@@ -24,6 +24,11 @@ roofline: `roofline` = the dominant kernel (grid_encode_backward, 1100 B per poi
           the launch stream; algorithmic bytes per SURVEY.md 8(d); `traffic` from the committed rocprofv3 --pmc passes.
           `traffic` is NOT measured in this run (PMC needs rocprofv3 around the process): it is the per-launch HBM byte count of the
           committed counter pass named in `traffic_source`.
+optimizer (N = 1, default; --no-fused-adam switches it off): the hash table's Adam sweep rides in the grid backward's slice accumulate
+          (speculative double buffer, device-side parity word: GradScaler's skip rule exactly, torch-ngp_amd/optim.py enable_table_fusion) and the
+          step closes with one small launch (MLP weights, dense table levels, loss-scale commit, parity flip); `config.table_adam_in_grid_backward`
+          says which form ran.  The `roofline` row of that call counts the Adam bytes it carries (`carries_table_adam` gives both definitions).
+          N > 1 exchanges the gradient first and keeps the separate sweep (on 1 / N of the table per rank).
 steady state: every HIP graph the timed region replays (the training iteration and the occupancy refresh) is captured AND replayed
           at least once during the untimed setup (33 iterations: the reference's 16 worst-case-sized steps, the first estimate, one
           full refresh period from graphs); `captures_in_timed_region` reports graph captures that happened between t0 and t1 (0).

@@ -17,6 +17,9 @@ x = T._ray_points(1024, 48, rng)
 g = oracle.round_fp16(rng.normal(size=(16, x.shape[0], 2)).astype(np.float32) * mag)
 first = torch.load(os.environ['NGP_REPRO_GOLDEN']).cuda() if os.environ.get('NGP_REPRO_GOLDEN') and os.path.exists(os.environ['NGP_REPRO_GOLDEN']) else None
 bad = 0
+ref = None
+if os.environ.get('NGP_REPRO_ORACLE'):
+    ref = oracle.grid_backward(g, x, offs, int(offs[-1]), 2, S, 16)[0].astype(np.float64)
 for r in range(reps):
     out = T._backward_ws(g, x, offs, S, True)[0]
     if first is None:
@@ -26,8 +29,23 @@ for r in range(reps):
         bad += 1
         idx = ne.any(dim=1).nonzero().flatten().cpu().numpy()
         lv = np.searchsorted(offs, idx, side='right') - 1
-        a, b = out[idx[0]].float().cpu().numpy(), first[idx[0]].float().cpu().numpy()
-        print(f'rep {r}: {len(idx)} entries differ, levels {sorted(set(lv.tolist()))}, first: entry {idx[0]} (level {lv[0]}, slot {idx[0] - offs[lv[0]]}) {a} vs {b}')
+        a, b = out[idx].float().cpu().numpy().astype(np.float64), first[idx].float().cpu().numpy().astype(np.float64)
+        ch = ne[idx].sum(dim=0).cpu().numpy()
+        per_level = {int(l): int((lv == l).sum()) for l in sorted(set(lv.tolist()))}
+        print(f'rep {r}: {len(idx)} entries differ, per channel {ch.tolist()}, per level {per_level}')
+        with np.errstate(all='ignore'):
+            d = a - b
+            rel = np.abs(d) / np.maximum(np.abs(b), 1e-30)
+        print(f'    |rep - first| / |first|: median {np.nanmedian(rel[rel > 0]):.3g}, max {np.nanmax(rel[np.isfinite(rel)]) if np.isfinite(rel).any() else float("nan"):.3g}; '
+              f'inf in rep {int(np.isinf(a).sum())} / first {int(np.isinf(b).sum())}; nan {int(np.isnan(a).sum())} / {int(np.isnan(b).sum())}')
+        for j in range(min(4, len(idx))):
+            slot = idx[j] - offs[lv[j]]
+            extra = f', oracle {ref[idx[j]]}' if ref is not None else ''
+            print(f'    entry {idx[j]} (level {lv[j]}, slot {slot}, bin {slot & 127}, row {slot >> 7}): rep {a[j]} first {b[j]}{extra}')
+        if ref is not None:
+            ea, eb = np.abs(a - ref[idx]), np.abs(b - ref[idx])
+            with np.errstate(all='ignore'):
+                print(f'    closer to the oracle: rep {int((ea < eb).sum())}, first {int((eb < ea).sum())}')
 if os.environ.get('NGP_REPRO_SAVE'):
     torch.save(first.cpu(), os.environ['NGP_REPRO_SAVE'])
 print(f'{capi.LIB_PATH}: magnitude {mag}: {bad} of {reps - 1} repeats differ from the first')

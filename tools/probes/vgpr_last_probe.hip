@@ -82,6 +82,50 @@ static int run(const char* op) {
     return 0;
 }
 
+
+// In-range accesses that END at the last register (no over-fetch expected): the 64-bit shift's data pair in v[38:39] with the amount elsewhere,
+// and a 16-byte global store of v[36:39] (register tuples are 64-bit aligned on this chip: a 12-byte tuple cannot end at the last register).
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tail_ok(unsigned long long* __restrict__ bad, uint32_t* __restrict__ buf, uint32_t iters) {
+    unsigned long long wrong = 0ull;
+    uint32_t* mine = buf + 4u * (blockIdx.x * 1024u + threadIdx.x);
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t h = (threadIdx.x * 2654435761u) ^ (it * 40503u) ^ (blockIdx.x * 7919u);
+        const uint32_t amount = (h >> 3) % 23u, lo = h | 1u, hi = (h >> 9) & 0xffu;
+        uint32_t rlo, rhi;
+        asm volatile("v_mov_b32 v38, %[lo]\n\tv_mov_b32 v39, %[hi]\n\tv_mov_b32 v32, %[amt]\n\tv_nop\n\tv_nop\n\t"
+                     "v_lshlrev_b64 v[38:39], v32, v[38:39]\n\tv_mov_b32 %[rlo], v38\n\tv_mov_b32 %[rhi], v39\n\t"
+                     "v_mov_b32 v36, %[lo]\n\tv_mov_b32 v37, %[lo]\n\tv_mov_b32 v38, %[hi]\n\tv_mov_b32 v39, %[amt]\n\tv_nop\n\t"
+                     "global_store_dwordx4 %[p], v[36:39], off\n\ts_waitcnt vmcnt(0)"
+                     : [rlo] "=&v"(rlo), [rhi] "=&v"(rhi) : [amt] "v"(amount), [lo] "v"(lo), [hi] "v"(hi), [p] "v"(mine)
+                     : "memory", "v32", "v36", "v37", "v38", "v39");
+        const unsigned long long want = ((((unsigned long long)hi << 32) | lo) << amount), got = ((unsigned long long)rhi << 32) | rlo;
+        wrong += got != want;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const volatile uint32_t* v = mine;
+        wrong += (v[0] != lo || v[1] != lo || v[2] != hi || v[3] != amount) ? 1ull << 32 : 0ull;
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
+static int run_tail_ok() {
+    unsigned long long* bad;
+    uint32_t* buf;
+    CHECK(hipMalloc(&bad, 8));
+    CHECK(hipMalloc(&buf, 4ull * 1024 * 1024 * 4));
+    CHECK(hipMemset(bad, 0, 8));
+    hipLaunchKernelGGL(k_tail_ok, dim3(1024), dim3(1024), 0, 0, bad, buf, 32u);
+    CHECK(hipDeviceSynchronize());
+    unsigned long long h = 0;
+    CHECK(hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost));
+    hipFuncAttributes fa;
+    CHECK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_tail_ok)));
+    printf("in range, ending at the last register (%d VGPRs): v_lshlrev_b64 v[38:39], v32, v[38:39]: %llu wrong; global_store_dwordx4 v[36:39]: %llu wrong of %llu\n",
+           fa.numRegs, h & 0xffffffffull, h >> 32, 1024ull * 1024ull * 32ull);
+    (void)hipFree(bad);
+    (void)hipFree(buf);
+    return 0;
+}
+
 int main() {
     run<0, 39, 39>("v_lshlrev_b64"); run<0, 39, 47>("v_lshlrev_b64"); run<0, 38, 39>("v_lshlrev_b64"); run<0, 37, 39>("v_lshlrev_b64");
     run<0, 47, 47>("v_lshlrev_b64"); run<0, 63, 63>("v_lshlrev_b64");
@@ -92,5 +136,6 @@ int main() {
     run<5, 39, 39>("v_ldexp_f64"); run<5, 39, 47>("v_ldexp_f64");
     run<6, 39, 39>("v_cvt_f64_u32"); run<6, 39, 47>("v_cvt_f64_u32");
     run<7, 39, 39>("v_cvt_f64_f32"); run<7, 39, 47>("v_cvt_f64_f32");
+    run_tail_ok();
     return 0;
 }

@@ -7,8 +7,12 @@ import os
 import re
 import shutil
 import subprocess
+import sys
 
 import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+import check_isa_hazards as isa  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJ = os.path.join(ROOT, 'torch-ngp_amd', 'csrc', '_obj')
@@ -116,31 +120,15 @@ def _kernel_metadata(unit, _cache={}):
     if unit in _cache:
         return _cache[unit]
     obj = os.path.join(OBJ, unit + '.o')
-    tools = [os.path.join(LLVM, t) for t in ('llvm-objcopy', 'clang-offload-bundler', 'llvm-readelf')]
-    if not os.path.exists(obj) or not all(os.path.exists(t) for t in tools):
+    if not os.path.exists(obj) or not isa.tools_present():
         pytest.skip(f'{obj} (run __graft_entry__.build()) or the LLVM tools are missing')
     import tempfile
     d = tempfile.mkdtemp(prefix='isa_meta_')
     try:
-        fat, co = os.path.join(d, 'fat.bin'), os.path.join(d, 'dev.co')
-        subprocess.check_call([tools[0], '-O', 'binary', '--only-section=.hip_fatbin', obj, fat])
-        subprocess.check_call([tools[1], '--unbundle', '--type=o', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--input=' + fat, '--output=' + co])
-        text = subprocess.check_output([tools[2], '--notes', co], text=True)
+        _cache[unit] = isa.kernel_metadata(isa.code_object(obj, d))
     finally:
         shutil.rmtree(d, ignore_errors=True)
-    out, cur = {}, {}
-    for line in text.splitlines():   # one YAML map per kernel, keys in alphabetical order: .agpr_count opens it, .wavefront_size closes it
-        m = re.match(r'\s+(?:- )?\.(\w+):\s+(\S+)', line)
-        if not m:
-            continue
-        key, value = m.groups()
-        if key == 'agpr_count':
-            cur = {}
-        cur[key] = value
-        if key == 'wavefront_size' and 'symbol' in cur:
-            out[cur['symbol'][:-len('.kd')]] = {k: int(cur[k]) for k in ('private_segment_fixed_size', 'vgpr_count', 'agpr_count')}
-    _cache[unit] = out
-    return out
+    return _cache[unit]
 
 
 def _scratch_bytes(unit):
@@ -173,22 +161,22 @@ def test_no_kernel_spills_except_the_pinned_ffmlp_backward_shapes(unit):
 # channel-0 contributions at random (tests/test_gpu_grid.py's repeatability check caught it).  No kernel of the library may contain the
 # pattern; if an edit or a compiler update produces it, give that kernel one more allocation granule (an `asm volatile("" ::: "v<N>")`
 # clobber of a register 8 above its count) or reorder the source until the operand moves.
-_SHIFT64 = re.compile(r'^(v_lshlrev_b64|v_lshrrev_b64|v_ashrrev_i64)\s+v\[\d+:\d+\],\s*v(\d+),')
-
-
+@pytest.mark.parametrize('build', ['_obj', '_obj_dbg'])
 @pytest.mark.parametrize('unit', ['gridencoder', 'raymarching', 'ffmlp', 'optim', 'pipeline', 'shencoder', 'freqencoder'])
-def test_no_64_bit_shift_takes_its_amount_from_the_last_allocated_register(unit, tmp_path_factory):
-    meta = _kernel_metadata(unit)
-    kernels = _disassemble(unit, tmp_path_factory)
-    checked = 0
-    for sym, ins in kernels.items():
-        if sym not in meta:
-            continue
-        checked += 1
-        m = meta[sym]
-        if m['agpr_count']:   # (accumulation registers sit above the vector registers: no vector register is the allocation's last)
-            continue
-        last = (m['vgpr_count'] + 7) // 8 * 8 - 1
-        hits = [i for i in ins if (h := _SHIFT64.match(i)) and int(h.group(2)) >= last]
-        assert not hits, f'{sym} ({m["vgpr_count"]} VGPRs): {hits[:3]} -- the shift amount is the last register of the allocation (gfx950 misreads it)'
+def test_no_64_bit_shift_takes_its_amount_from_the_last_allocated_register(unit, build):
+    """(tools/check_isa_hazards.py holds the scanner: __graft_entry__.build() runs it too; the debug-bounds build is a different register
+    allocation of the same sources and is scanned as well)"""
+    obj = os.path.join(os.path.dirname(OBJ), build, unit + '.o')
+    if not os.path.exists(obj) or not isa.tools_present():
+        pytest.skip(f'{obj} (run __graft_entry__.build()) or the LLVM tools are missing')
+    checked, hits = isa.scan_object(obj)
     assert checked >= 1
+    assert not hits, '; '.join(f'{sym} ({n} VGPRs): {ins}' for sym, n, ins in hits[:4]) + ' -- the shift amount is the last register of the allocation'
+
+
+def test_the_scanner_recognises_the_pattern():
+    meta = {'k': {'private_segment_fixed_size': 0, 'vgpr_count': 40, 'agpr_count': 0}, 'm': {'private_segment_fixed_size': 0, 'vgpr_count': 38, 'agpr_count': 0},
+            'a': {'private_segment_fixed_size': 0, 'vgpr_count': 40, 'agpr_count': 8}}
+    code = ['v_lshlrev_b64 v[32:33], v39, v[32:33]', 'v_lshlrev_b64 v[32:33], 21, v[32:33]', 'v_lshrrev_b64 v[2:3], v38, v[2:3]', 'v_lshlrev_b32_e32 v1, v39, v2']
+    hits = isa.last_register_shifts(meta, {'k': code, 'm': code, 'a': code})
+    assert hits == [('k', 40, 'v_lshlrev_b64 v[32:33], v39, v[32:33]'), ('m', 38, 'v_lshlrev_b64 v[32:33], v39, v[32:33]')]

@@ -405,6 +405,20 @@ int ngp_pipeline_mid_backward(const float* grad_sigma, const void* h16, const vo
 int ngp_pipeline_mse_loss(const float* image, const float* target, uint32_t n, const float* loss_scale, float* loss,
                           float* grad_image, ngp_stream_t stream);
 
+/* nn.Linear stack <-> the flat fp16 weight vector of the fused MLP (the reference's non---ff model, nerf/network.py:32-63 + 155-215, runs its
+ * bias-free Linear / ReLU stacks on the ffmlp kernels: torch-ngp_amd/nerf/network.py).  weights[l]: fp32 [out_l, in_l] row major, layer 0
+ * [hidden, n_in], layers 1 .. depth-2 [hidden, hidden], layer depth-1 [n_out, hidden] (n_out <= 16).  flat (ngp_linear_stack_flat_size
+ * elements): half(W_0) with its columns zero-padded to a multiple of 16 | an exact identity [hidden, hidden] when `identity` (a stack with ONE
+ * hidden layer: the kernels want two) | half(W_1 .. W_{depth-2}) | half(W_{depth-1}) zero-padded to 16 rows -- the layout of
+ * ngp_ffmlp_forward's `weights`.  unpack_grad: the flat fp16 weight gradient back into fp32 tensors of the layers' shapes (every element
+ * written; the padding's and the identity's gradient are dropped).  One launch each (PyTorch's pad / eye / cat and their autograd: ~8). */
+#define NGP_LINEAR_STACK_MAX 8
+uint32_t ngp_linear_stack_flat_size(uint32_t depth, uint32_t n_in, uint32_t hidden, uint32_t n_out, int identity);
+int ngp_linear_stack_pack(const float* const* weights, uint32_t depth, uint32_t n_in, uint32_t hidden, uint32_t n_out, int identity,
+                          void* flat_fp16, ngp_stream_t stream);
+int ngp_linear_stack_unpack_grad(const void* grad_flat_fp16, uint32_t depth, uint32_t n_in, uint32_t hidden, uint32_t n_out, int identity,
+                                 float* const* grads, ngp_stream_t stream);
+
 /* Data path: the arithmetic of get_rays (nerf/utils.py:53-137).  poses [B,4,4] row-major camera-to-world; pixel
  * indices inds [B,N] int64 (inds_batch_stride = N) or [N] shared by every pose (inds_batch_stride = 0) or NULL (pixel n = n: a full
  * H x W frame with N = H * W); pixel p is (column p % W, row p / W), sampled at its centre.  rays_o, rays_d [B,N,3] fp32:

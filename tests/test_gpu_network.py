@@ -182,3 +182,59 @@ def test_linear_stacks_on_the_fused_mlp_kernels_match_the_linear_layers():
     assert not _stack_fusable(m.sigma_net, torch.zeros(4, 32, device='cuda'))
     s32 = m.density(x[:64])['sigma']
     assert s32.dtype == torch.float32
+
+
+@pytest.mark.parametrize('shape', [(2, 32, 64, 16), (3, 31, 64, 3), (2, 24, 64, 3), (4, 40, 32, 5)])
+def test_native_flat_weights_are_the_torch_assembly_bit_for_bit(shape):
+    """ngp_linear_stack_pack / _unpack_grad (one launch each way) against pad / eye / cat and their autograd: the flat fp16 vector and the
+    fp32 gradients of every layer are identical bits -- density (32 -> 64 -> 16), colour (31 -> 64 -> 64 -> 3), background (24 -> 64 -> 3)
+    and a deeper stack with an odd input width."""
+    import nerf.network as nw
+    depth, n_in, hidden, n_out = shape
+    torch.manual_seed(depth * 100 + n_in)
+    layers = nw._linear_stack(n_in, hidden, n_out, depth).cuda()
+    in_pad = (n_in + 15) // 16 * 16
+    flat_t = nw._flat_weights_torch(layers)
+    flat_n = nw._stack_weights.apply(n_in, hidden, n_out, *[l.weight for l in layers])
+    assert flat_n.dtype == torch.half and flat_n.shape == flat_t.shape
+    assert flat_n.numel() == hidden * in_pad + (hidden * hidden if depth == 2 else 0) + (depth - 2) * hidden * hidden + 16 * hidden
+    assert torch.equal(flat_n.view(torch.int16), flat_t.half().view(torch.int16))
+    g = torch.randn(flat_t.numel(), device='cuda').half()
+    grads_t = torch.autograd.grad(flat_t, [l.weight for l in layers], g.float())
+    grads_n = torch.autograd.grad(flat_n, [l.weight for l in layers], g)
+    for a, b, l in zip(grads_n, grads_t, layers):
+        assert a.dtype == torch.float32 and a.shape == l.weight.shape and torch.equal(a, b)
+
+
+def test_fused_linear_stacks_are_unchanged_by_the_native_flat_weights():
+    """the whole model, forward and backward, with the native assembly and with the PyTorch one: identical bits"""
+    import nerf.network as nw
+    torch.manual_seed(5)
+    m = nw.NeRFNetwork(bound=2, cuda_ray=True, bg_radius=32.0).cuda().train()
+    with torch.no_grad():
+        m.encoder.embeddings.uniform_(-0.5, 0.5)
+        m.encoder_bg.embeddings.uniform_(-0.5, 0.5)
+    g = torch.Generator(device='cuda').manual_seed(2)
+    x = torch.rand(2000, 3, device='cuda', generator=g) * 4 - 2
+    d = torch.nn.functional.normalize(torch.randn(2000, 3, device='cuda', generator=g), dim=-1)
+    sph = torch.rand(500, 2, device='cuda', generator=g) * 2 - 1
+    res = {}
+    try:
+        for native in (True, False):
+            nw.NATIVE_FLAT_WEIGHTS = native
+            m.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.float16):
+                sigma, rgb = m(x, d)
+                bg = m.background(sph, d[:500])
+                loss = rgb.float().sum() + sigma.float().clamp(max=50).sum() * 1e-2 + bg.float().sum()
+            loss.backward()
+            res[native] = ([sigma.detach().clone(), rgb.detach().clone(), bg.detach().clone()] +
+                           [p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None and 'embeddings' not in n],
+                           [p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None and 'embeddings' in n])
+    finally:
+        nw.NATIVE_FLAT_WEIGHTS = True
+    assert len(res[True][0]) == len(res[False][0]) == 3 + 7 and len(res[True][1]) == 2
+    for k, (a, b) in enumerate(zip(res[True][0], res[False][0])):
+        assert a.dtype == b.dtype and torch.equal(a, b), k
+    for a, b in zip(res[True][1], res[False][1]):   # (small batches scatter with fp16 atomics: the tables' gradients are not reproducible bit for bit)
+        assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b)) < 2e-3

@@ -23,7 +23,7 @@ NGP_F32, NGP_F16 = 0, 1
 NGP_FF_INPUT_PLANAR, NGP_FF_DX_PLANAR, NGP_FF_LAYERED, NGP_FF_SINGLE_WAVE, NGP_FF_DEFER_REDUCE, NGP_FF_RECOMPUTE = 1, 2, 4, 8, 16, 32
 NGP_MARCH_RESET_COUNTER, NGP_MARCH_ZERO_TAIL, NGP_MARCH_NOISE_FROM_SEED, NGP_MARCH_SCAN_LAUNCH = 1, 2, 4, 8
 NGP_OPT_PHASE_CHECK, NGP_OPT_PHASE_UPDATE, NGP_OPT_PHASE_COMMIT, NGP_OPT_PHASE_FLIP = 1, 2, 4, 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -107,6 +107,8 @@ _SIGNATURES = {
     'ngp_optim_ema_update': [_i32, _vp, _vp, _vp, _f32, _vp],
     'ngp_optim_poison_shards': [_vp, _u32, ctypes.c_uint64, _vp, _vp],
     'ngp_optim_shard_verdict': [_vp, _vp, _vp, _u32, ctypes.c_uint64, _vp],
+    'ngp_linear_stack_pack': [_vp, _u32, _u32, _u32, _u32, _i32, _vp, _vp],
+    'ngp_linear_stack_unpack_grad': [_vp, _u32, _u32, _u32, _u32, _i32, _vp, _vp],
     'ngp_allocate_splitk': [_sz],
     'ngp_free_splitk': [],
 }
@@ -134,6 +136,8 @@ lib.ngp_coarse_occupancy_bytes.restype = _sz
 lib.ngp_grid_forward_work_lists.argtypes = [_u32, _u32, _vp, _vp, _vp, _vp]
 lib.ngp_grid_forward_work_lists.restype = _u32
 lib.ngp_density_grid_update_workspace_bytes.argtypes = [_u32]
+lib.ngp_linear_stack_flat_size.argtypes = [_u32, _u32, _u32, _u32, _i32]
+lib.ngp_linear_stack_flat_size.restype = _u32
 lib.ngp_density_grid_update_workspace_bytes.restype = _sz
 
 if lib.ngp_abi_version() != ABI_VERSION:
@@ -143,7 +147,7 @@ EXPORTED = sorted(list(_SIGNATURES) + ['ngp_last_error', 'ngp_target_arch', 'ngp
                                        'ngp_march_rays_train_workspace_bytes', 'ngp_compact_rays_workspace_bytes',
                                        'ngp_grid_backward_workspace_bytes', 'ngp_ffmlp_backward_workspace_bytes',
                                        'ngp_ffmlp_backward_slab_count', 'ngp_density_grid_update_workspace_bytes', 'ngp_grid_forward_work_lists', 'ngp_coarse_occupancy_bytes',
-                                       'ngp_grid_table_adam_prefix'])
+                                       'ngp_grid_table_adam_prefix', 'ngp_linear_stack_flat_size'])
 
 
 def check(rc):

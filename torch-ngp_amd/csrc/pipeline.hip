@@ -193,6 +193,115 @@ extern "C" int ngp_pipeline_mse_loss(const float* image, const float* target, ui
     return check_launch("pipeline_mse_loss");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// nn.Linear stack <-> the fused MLP's flat weight vector (nerf/network.py: BASELINE config 5 evaluates its bias-free Linear / ReLU stacks on
+// the fused-MLP kernels).  PyTorch assembled the vector with pad / eye / cat (and autograd took it apart again): ~8 launches per stack and
+// direction, three stacks per step.  One launch each way: flat = half(W_0 [hidden, n_in] padded to in_pad columns) | [identity, if
+// `identity`] | half(W_1 .. W_{depth-2}) [hidden, hidden] | half(W_{depth-1} [n_out, hidden]) padded to 16 rows; the gradient goes back as
+// fp32 slices (the padding's and the identity's gradient are dropped).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct LinearStack {
+    const float* w[NGP_LINEAR_STACK_MAX];
+    float* g[NGP_LINEAR_STACK_MAX];
+    uint32_t depth, n_in, in_pad, hidden, n_out, identity;
+    __host__ __device__ uint32_t total() const { return hidden * in_pad + (identity ? hidden * hidden : 0u) + (depth - 2u) * hidden * hidden + 16u * hidden; }
+};
+
+// flat index -> (layer, row, column, live): live = the element is a weight (not padding, not the identity block)
+__device__ __forceinline__ bool linear_stack_locate(const LinearStack& st, uint32_t i, uint32_t& layer, uint32_t& src, float& constant) {
+    constant = 0.0f;
+    uint32_t seg = st.hidden * st.in_pad;
+    if (i < seg) {
+        const uint32_t r = i / st.in_pad, c = i - r * st.in_pad;
+        layer = 0u;
+        src = r * st.n_in + c;
+        return c < st.n_in;
+    }
+    i -= seg;
+    seg = st.hidden * st.hidden;
+    if (st.identity) {
+        if (i < seg) {
+            const uint32_t r = i / st.hidden, c = i - r * st.hidden;
+            constant = r == c ? 1.0f : 0.0f;
+            return false;
+        }
+        i -= seg;
+    }
+    const uint32_t mid = st.depth - 2u;
+    if (i < mid * seg) {
+        layer = 1u + i / seg;
+        src = i - (layer - 1u) * seg;
+        return true;
+    }
+    i -= mid * seg;
+    layer = st.depth - 1u;
+    src = i;   // [16, hidden] rows beyond n_out are padding
+    return i < st.n_out * st.hidden;
+}
+
+__global__ __launch_bounds__(PL_THREADS) void k_linear_stack_pack(LinearStack st, half_t* __restrict__ flat) {
+    const uint32_t i = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (i >= st.total()) return;
+    uint32_t layer = 0u, src = 0u;
+    float constant;
+    const bool live = linear_stack_locate(st, i, layer, src, constant);
+    float v = constant;
+#pragma unroll
+    for (uint32_t l = 0; l < NGP_LINEAR_STACK_MAX; l++)   // (a dynamic index into the by-value pointer array would go through scratch memory)
+        if (live && l == layer) v = st.w[l][src];
+    flat[i] = (half_t)v;
+}
+
+__global__ __launch_bounds__(PL_THREADS) void k_linear_stack_unpack(LinearStack st, const half_t* __restrict__ grad_flat) {
+    const uint32_t i = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (i >= st.total()) return;
+    uint32_t layer = 0u, src = 0u;
+    float constant;
+    if (!linear_stack_locate(st, i, layer, src, constant)) return;
+    const float v = (float)grad_flat[i];
+#pragma unroll
+    for (uint32_t l = 0; l < NGP_LINEAR_STACK_MAX; l++)
+        if (l == layer) st.g[l][src] = v;
+}
+
+static int linear_stack_args(const float* const* weights, float* const* grads, uint32_t depth, uint32_t n_in, uint32_t hidden, uint32_t n_out,
+                             int identity, LinearStack& st, const char* who) {
+    NGP_REQUIRE(depth >= 2 && depth <= NGP_LINEAR_STACK_MAX, NGP_ERR_INVALID, "%s: depth %u outside 2 .. %d", who, depth, NGP_LINEAR_STACK_MAX);
+    NGP_REQUIRE(n_in > 0 && hidden > 0 && n_out > 0 && n_out <= 16, NGP_ERR_INVALID, "%s: n_in / hidden must be positive, n_out in 1 .. 16", who);
+    st = LinearStack{};
+    for (uint32_t l = 0; l < depth; l++) {
+        NGP_REQUIRE((weights == nullptr || weights[l]) && (grads == nullptr || grads[l]), NGP_ERR_INVALID, "%s: NULL tensor for layer %u", who, l);
+        st.w[l] = weights ? weights[l] : nullptr;
+        st.g[l] = grads ? grads[l] : nullptr;
+    }
+    st.depth = depth; st.n_in = n_in; st.in_pad = (n_in + 15u) / 16u * 16u; st.hidden = hidden; st.n_out = n_out; st.identity = identity ? 1u : 0u;
+    return NGP_OK;
+}
+
+extern "C" uint32_t ngp_linear_stack_flat_size(uint32_t depth, uint32_t n_in, uint32_t hidden, uint32_t n_out, int identity) {
+    LinearStack st{};
+    st.depth = depth < 2 ? 2 : depth; st.n_in = n_in; st.in_pad = (n_in + 15u) / 16u * 16u; st.hidden = hidden; st.n_out = n_out; st.identity = identity ? 1u : 0u;
+    return st.total();
+}
+
+extern "C" int ngp_linear_stack_pack(const float* const* weights, uint32_t depth, uint32_t n_in, uint32_t hidden, uint32_t n_out, int identity,
+                                     void* flat_fp16, ngp_stream_t stream) {
+    LinearStack st;
+    NGP_REQUIRE(weights && flat_fp16, NGP_ERR_INVALID, "linear_stack_pack: NULL tensor");
+    if (int rc = linear_stack_args(weights, nullptr, depth, n_in, hidden, n_out, identity, st, "linear_stack_pack")) return rc;
+    hipLaunchKernelGGL(k_linear_stack_pack, dim3(cdiv(st.total(), PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), st, (half_t*)flat_fp16);
+    return check_launch("linear_stack_pack");
+}
+
+extern "C" int ngp_linear_stack_unpack_grad(const void* grad_flat_fp16, uint32_t depth, uint32_t n_in, uint32_t hidden, uint32_t n_out, int identity,
+                                            float* const* grads, ngp_stream_t stream) {
+    LinearStack st;
+    NGP_REQUIRE(grads && grad_flat_fp16, NGP_ERR_INVALID, "linear_stack_unpack_grad: NULL tensor");
+    if (int rc = linear_stack_args(nullptr, grads, depth, n_in, hidden, n_out, identity, st, "linear_stack_unpack_grad")) return rc;
+    hipLaunchKernelGGL(k_linear_stack_unpack, dim3(cdiv(st.total(), PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), st, (const half_t*)grad_flat_fp16);
+    return check_launch("linear_stack_unpack_grad");
+}
+
 extern "C" int ngp_rays_from_pixels(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t W, const int64_t* inds,
                                     uint32_t inds_batch_stride, uint32_t N, float* rays_o, float* rays_d, ngp_stream_t stream) {
     if (B == 0 || N == 0) return NGP_OK;

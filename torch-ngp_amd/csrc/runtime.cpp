@@ -16,5 +16,5 @@ void set_error(const char* fmt, ...) {
 }  // namespace ngp
 
 extern "C" const char* ngp_last_error(void) { return ngp::g_last_error.c_str(); }
-extern "C" int ngp_abi_version(void) { return 9; }
+extern "C" int ngp_abi_version(void) { return 10; }
 extern "C" const char* ngp_target_arch(void) { return "gfx950"; }

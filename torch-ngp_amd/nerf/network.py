@@ -54,17 +54,65 @@ def _stack_fusable(layers, h):
     return all(l.in_features == hidden and l.out_features == hidden for l in layers[1:-1])
 
 
-def _apply_stack_fused(layers, h):
-    from ffmlp.ffmlp import ffmlp_forward
+class _stack_weights(torch.autograd.Function):
+    """the layers' fp32 weights -> the flat fp16 vector the fused-MLP kernels read, and its gradient back to the layers, ONE launch each way
+    (csrc/pipeline.hip, ngp_linear_stack_pack / _unpack_grad; assembled by pad / eye / cat -- `_flat_weights_torch`, kept for the tests --
+    the same values cost ~8 launches per stack and direction, three stacks per step)"""
+
+    @staticmethod
+    def forward(ctx, n_in, hidden, n_out, *weights):
+        import ctypes
+        import _ngp_capi as capi
+        depth = len(weights)
+        ws = [w.detach().contiguous() for w in weights]
+        identity = 1 if depth == 2 else 0
+        flat = torch.empty(int(capi.lib.ngp_linear_stack_flat_size(depth, n_in, hidden, n_out, identity)), dtype=torch.half, device=ws[0].device)
+        arr = (ctypes.c_void_p * depth)(*[w.data_ptr() for w in ws])
+        capi.check(capi.lib.ngp_linear_stack_pack(ctypes.cast(arr, ctypes.c_void_p), depth, n_in, hidden, n_out, identity, flat.data_ptr(), capi.stream()))
+        ctx.geometry = (depth, n_in, hidden, n_out, identity, [w.shape for w in weights])
+        return flat
+
+    @staticmethod
+    def backward(ctx, grad_flat):
+        import ctypes
+        import _ngp_capi as capi
+        depth, n_in, hidden, n_out, identity, shapes = ctx.geometry
+        grad_flat = grad_flat.contiguous()
+        if grad_flat.dtype != torch.half:
+            grad_flat = grad_flat.half()
+        grads = [torch.empty(shape, dtype=torch.float32, device=grad_flat.device) for shape in shapes]
+        arr = (ctypes.c_void_p * depth)(*[g.data_ptr() for g in grads])
+        capi.check(capi.lib.ngp_linear_stack_unpack_grad(grad_flat.data_ptr(), depth, n_in, hidden, n_out, identity, ctypes.cast(arr, ctypes.c_void_p),
+                                                         capi.stream()))
+        return (None, None, None) + tuple(grads)
+
+
+def _flat_weights_torch(layers):
+    """the same vector from PyTorch ops (fp32; the fused MLP's autocast entry rounds it to fp16)"""
     depth, hidden = len(layers), layers[0].out_features
     n_in, n_out = layers[0].in_features, layers[-1].out_features
     in_pad = (n_in + 15) // 16 * 16
     parts = [F.pad(layers[0].weight, (0, in_pad - n_in)).reshape(-1)]
     if depth == 2:   # one hidden layer: the exact identity hidden matmul (see above)
-        parts.append(torch.eye(hidden, device=h.device, dtype=layers[0].weight.dtype).reshape(-1))
+        parts.append(torch.eye(hidden, device=layers[0].weight.device, dtype=layers[0].weight.dtype).reshape(-1))
     parts += [l.weight.reshape(-1) for l in layers[1:-1]]
     parts.append(F.pad(layers[-1].weight, (0, 0, 0, 16 - n_out)).reshape(-1))
-    flat = torch.cat(parts)
+    return torch.cat(parts)
+
+
+import os as _os
+NATIVE_FLAT_WEIGHTS = _os.environ.get('NGP_NO_NATIVE_FLAT', '0') != '1'   # False: assemble the flat vector with PyTorch ops (tests compare the two; the variable is for same-box A/B runs)
+
+
+def _apply_stack_fused(layers, h):
+    from ffmlp.ffmlp import ffmlp_forward
+    depth, hidden = len(layers), layers[0].out_features
+    n_in, n_out = layers[0].in_features, layers[-1].out_features
+    in_pad = (n_in + 15) // 16 * 16
+    if NATIVE_FLAT_WEIGHTS and depth <= 8 and all(l.weight.dtype == torch.float32 for l in layers):
+        flat = _stack_weights.apply(n_in, hidden, n_out, *[l.weight for l in layers])
+    else:
+        flat = _flat_weights_torch(layers)
     batch = h.shape[0]
     rows = max(128, (batch + 127) // 128 * 128)   # (an empty input -- color() under an all-False mask -- still runs one padded tile)
     x = F.pad(h, (0, in_pad - n_in, 0, rows - batch))

@@ -419,6 +419,11 @@ int ngp_linear_stack_pack(const float* const* weights, uint32_t depth, uint32_t 
 int ngp_linear_stack_unpack_grad(const void* grad_flat_fp16, uint32_t depth, uint32_t n_in, uint32_t hidden, uint32_t n_out, int identity,
                                  float* const* grads, ngp_stream_t stream);
 
+/* dst [dst_rows, dst_cols] fp16 = src [src_rows, src_cols] (rows src_row_stride elements apart) in its top-left corner, zeros elsewhere: the row /
+ * column padding ngp_ffmlp_forward wants (rows to a multiple of 128, columns to 16), one launch. */
+int ngp_pad_2d_fp16(const void* src, uint32_t src_rows, uint32_t src_cols, uint32_t src_row_stride, void* dst, uint32_t dst_rows,
+                    uint32_t dst_cols, ngp_stream_t stream);
+
 /* Data path: the arithmetic of get_rays (nerf/utils.py:53-137).  poses [B,4,4] row-major camera-to-world; pixel
  * indices inds [B,N] int64 (inds_batch_stride = N) or [N] shared by every pose (inds_batch_stride = 0) or NULL (pixel n = n: a full
  * H x W frame with N = H * W); pixel p is (column p % W, row p / W), sampled at its centre.  rays_o, rays_d [B,N,3] fp32:

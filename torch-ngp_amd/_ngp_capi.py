@@ -109,6 +109,7 @@ _SIGNATURES = {
     'ngp_optim_shard_verdict': [_vp, _vp, _vp, _u32, ctypes.c_uint64, _vp],
     'ngp_linear_stack_pack': [_vp, _u32, _u32, _u32, _u32, _i32, _vp, _vp],
     'ngp_linear_stack_unpack_grad': [_vp, _u32, _u32, _u32, _u32, _i32, _vp, _vp],
+    'ngp_pad_2d_fp16': [_vp, _u32, _u32, _u32, _vp, _u32, _u32, _vp],
     'ngp_allocate_splitk': [_sz],
     'ngp_free_splitk': [],
 }

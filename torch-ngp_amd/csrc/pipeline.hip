@@ -200,6 +200,7 @@ extern "C" int ngp_pipeline_mse_loss(const float* image, const float* target, ui
 // `identity`] | half(W_1 .. W_{depth-2}) [hidden, hidden] | half(W_{depth-1} [n_out, hidden]) padded to 16 rows; the gradient goes back as
 // fp32 slices (the padding's and the identity's gradient are dropped).
 // ---------------------------------------------------------------------------------------------------------------------------------------
+namespace ngp {
 struct LinearStack {
     const float* w[NGP_LINEAR_STACK_MAX];
     float* g[NGP_LINEAR_STACK_MAX];
@@ -264,6 +265,17 @@ __global__ __launch_bounds__(PL_THREADS) void k_linear_stack_unpack(LinearStack 
         if (l == layer) st.g[l][src] = v;
 }
 
+// dst [dst_rows, dst_cols] = src [src_rows, src_cols] (row stride src_stride elements) in the top-left corner, zeros elsewhere: the batch / column
+// padding the fused-MLP kernels want, one launch (PyTorch's constant_pad_nd is a fill and a copy)
+__global__ __launch_bounds__(PL_THREADS) void k_pad_2d(const half_t* __restrict__ src, uint32_t src_rows, uint32_t src_cols, uint32_t src_stride,
+                                                        half_t* __restrict__ dst, uint32_t dst_rows, uint32_t dst_cols) {
+    const uint32_t i = blockIdx.x * PL_THREADS + threadIdx.x;
+    if (i >= dst_rows * dst_cols) return;
+    const uint32_t r = i / dst_cols, c = i - r * dst_cols;
+    dst[i] = (r < src_rows && c < src_cols) ? src[(size_t)r * src_stride + c] : (half_t)0.0f;
+}
+}  // namespace ngp
+
 static int linear_stack_args(const float* const* weights, float* const* grads, uint32_t depth, uint32_t n_in, uint32_t hidden, uint32_t n_out,
                              int identity, LinearStack& st, const char* who) {
     NGP_REQUIRE(depth >= 2 && depth <= NGP_LINEAR_STACK_MAX, NGP_ERR_INVALID, "%s: depth %u outside 2 .. %d", who, depth, NGP_LINEAR_STACK_MAX);
@@ -300,6 +312,18 @@ extern "C" int ngp_linear_stack_unpack_grad(const void* grad_flat_fp16, uint32_t
     if (int rc = linear_stack_args(nullptr, grads, depth, n_in, hidden, n_out, identity, st, "linear_stack_unpack_grad")) return rc;
     hipLaunchKernelGGL(k_linear_stack_unpack, dim3(cdiv(st.total(), PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), st, (const half_t*)grad_flat_fp16);
     return check_launch("linear_stack_unpack_grad");
+}
+
+extern "C" int ngp_pad_2d_fp16(const void* src, uint32_t src_rows, uint32_t src_cols, uint32_t src_row_stride, void* dst, uint32_t dst_rows,
+                               uint32_t dst_cols, ngp_stream_t stream) {
+    if (dst_rows == 0 || dst_cols == 0) return NGP_OK;
+    NGP_REQUIRE(dst && (src || src_rows == 0 || src_cols == 0), NGP_ERR_INVALID, "pad_2d_fp16: NULL tensor");
+    NGP_REQUIRE(src_rows <= dst_rows && src_cols <= dst_cols && src_row_stride >= src_cols, NGP_ERR_INVALID,
+                "pad_2d_fp16: source [%u, %u] (row stride %u) does not fit the destination [%u, %u]", src_rows, src_cols, src_row_stride, dst_rows, dst_cols);
+    NGP_REQUIRE((uint64_t)dst_rows * dst_cols <= 0xffffffffull, NGP_ERR_INVALID, "pad_2d_fp16: destination too large");
+    hipLaunchKernelGGL(k_pad_2d, dim3(cdiv(dst_rows * dst_cols, PL_THREADS)), dim3(PL_THREADS), 0, as_stream(stream), (const half_t*)src, src_rows,
+                       src_cols, src_row_stride, (half_t*)dst, dst_rows, dst_cols);
+    return check_launch("pad_2d_fp16");
 }
 
 extern "C" int ngp_rays_from_pixels(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t W, const int64_t* inds,

@@ -104,13 +104,60 @@ import os as _os
 NATIVE_FLAT_WEIGHTS = _os.environ.get('NGP_NO_NATIVE_FLAT', '0') != '1'   # False: assemble the flat vector with PyTorch ops (tests compare the two; the variable is for same-box A/B runs)
 
 
+class _padded_mlp(torch.autograd.Function):
+    """h [batch, n_in] fp16, flat fp16 weights -> out [batch, n_out]: the row / column padding the kernels want is one launch on the way in
+    (ngp_pad_2d_fp16) and a narrow of the padded result on the way out; backward pads the incoming gradient the same way and hands back
+    narrows.  The PyTorch form -- F.pad, ffmlp_forward, a slice -- is the same arithmetic in five more launches per stack and step."""
+
+    @staticmethod
+    def forward(ctx, h, flat, n_in, n_out, hidden, num_layers, inference):
+        import _ngp_capi as capi
+        from ffmlp.ffmlp import _backend as ff
+        batch, in_pad = h.shape[0], (n_in + 15) // 16 * 16
+        rows = max(128, (batch + 127) // 128 * 128)   # (an empty input -- color() under an all-False mask -- still runs one padded tile)
+        if h.stride(-1) != 1:
+            h = h.contiguous()
+        x = torch.empty(rows, in_pad, dtype=torch.half, device=h.device)
+        capi.check(capi.lib.ngp_pad_2d_fp16(capi.ptr(h), batch, n_in, h.stride(0) if batch else n_in, x.data_ptr(), rows, in_pad, capi.stream()))
+        out = torch.empty(rows, 16, dtype=torch.half, device=h.device)
+        if inference:
+            scratch = torch.empty(rows, hidden, dtype=torch.half, device=h.device)
+            ff.ffmlp_inference(x, flat, rows, in_pad, 16, hidden, num_layers, 0, 6, scratch, out)
+        else:
+            forward_buffer = torch.empty(num_layers, rows, hidden, dtype=torch.half, device=h.device)
+            ff.ffmlp_forward(x, flat, rows, in_pad, 16, hidden, num_layers, 0, 6, forward_buffer, out)
+            ctx.save_for_backward(x, flat, forward_buffer)
+            ctx.geometry = (batch, n_in, n_out, in_pad, rows, hidden, num_layers, bool(ctx.needs_input_grad[0]))
+        return out[:batch, :n_out]
+
+    @staticmethod
+    def backward(ctx, grad):
+        import _ngp_capi as capi
+        from ffmlp.ffmlp import _backend as ff
+        x, flat, forward_buffer = ctx.saved_tensors
+        batch, n_in, n_out, in_pad, rows, hidden, num_layers, need_dx = ctx.geometry
+        if grad.dtype != torch.half or grad.stride(-1) != 1:
+            grad = grad.to(torch.half).contiguous()
+        g = torch.empty(rows, 16, dtype=torch.half, device=grad.device)
+        capi.check(capi.lib.ngp_pad_2d_fp16(capi.ptr(grad), batch, n_out, grad.stride(0) if batch else n_out, g.data_ptr(), rows, 16, capi.stream()))
+        grad_inputs = torch.empty_like(x) if need_dx else torch.empty(1, dtype=torch.half, device=grad.device)
+        grad_weights = torch.empty_like(flat)
+        backward_buffer = torch.empty(num_layers, rows, hidden, dtype=torch.half, device=grad.device)
+        ff.ffmlp_backward(g, x, flat, forward_buffer, rows, in_pad, 16, hidden, num_layers, 0, 6, need_dx, backward_buffer, grad_inputs, grad_weights)
+        return (grad_inputs[:batch, :n_in] if need_dx else None), grad_weights, None, None, None, None, None
+
+
 def _apply_stack_fused(layers, h):
     from ffmlp.ffmlp import ffmlp_forward
     depth, hidden = len(layers), layers[0].out_features
     n_in, n_out = layers[0].in_features, layers[-1].out_features
     in_pad = (n_in + 15) // 16 * 16
-    if NATIVE_FLAT_WEIGHTS and depth <= 8 and all(l.weight.dtype == torch.float32 for l in layers):
+    native = NATIVE_FLAT_WEIGHTS and depth <= 8 and all(l.weight.dtype == torch.float32 for l in layers)
+    if native:
         flat = _stack_weights.apply(n_in, hidden, n_out, *[l.weight for l in layers])
+        if h.dtype != torch.half:   # (cat([SH code fp32, features fp16]) is fp32: the rounding the fused MLP's autocast entry would apply)
+            h = h.to(torch.half)
+        return _padded_mlp.apply(h, flat, n_in, n_out, hidden, max(depth - 1, 2), not torch.is_grad_enabled())
     else:
         flat = _flat_weights_torch(layers)
     batch = h.shape[0]
